@@ -1,0 +1,142 @@
+"""Synthetic data spec in numpy — deterministic, counter-based, bit-identical to the
+C oracle (`oracle/dawn_oracle.c: orc_synth_*`) and to the on-GPU generator (`csrc/synth.hip`).
+
+Nothing here restates reference behaviour; it only defines the seeded inputs that the parity tests
+and bench.py feed to both the HIP path and the oracle.
+
+  uniform(seed, i) = (2*u + 1 - 2^24) / 2^24,  u = top 24 bits of
+                     splitmix64(splitmix64(seed) + i * 0x9E3779B97F4A7C15)
+  unit row r of stream `seed` = normalise([uniform(seed, r*384 + c) for c in 0..384]) with the
+                     reference's sequential f32 sum / sqrt / divide (src/search/vector.rs:194-197)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EM_LEN = 384
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(z: np.ndarray) -> np.ndarray:
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed: int, idx: np.ndarray) -> np.ndarray:
+    """24-bit uniform in (-1, 1), exactly representable in f32."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    key = splitmix64(np.uint64(seed))
+    with np.errstate(over="ignore"):
+        h = splitmix64(key + idx * _GOLDEN)
+    u = (h >> np.uint64(40)).astype(np.int64)
+    n = 2 * u + 1 - (1 << 24)
+    return (n.astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def _seq_sum_sq(rows: np.ndarray) -> np.ndarray:
+    """Sequential (left-to-right) f32 sum of squares per row — vector.rs:195 order."""
+    s = np.zeros(rows.shape[0], dtype=np.float32)
+    for c in range(rows.shape[1]):
+        s = (s + rows[:, c] * rows[:, c]).astype(np.float32)
+    return s
+
+
+def normalize_rows(rows: np.ndarray) -> np.ndarray:
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    length = np.sqrt(_seq_sum_sq(rows)).astype(np.float32)
+    return (rows / length[:, None]).astype(np.float32)
+
+
+def unit_rows(seed: int, first_row: int, n: int) -> np.ndarray:
+    """[n, 384] f32 unit rows of stream `seed` starting at row `first_row`."""
+    idx = (np.uint64(first_row) * np.uint64(EM_LEN)
+           + np.arange(n * EM_LEN, dtype=np.uint64)).reshape(n, EM_LEN)
+    return normalize_rows(uniform(seed, idx))
+
+
+def scaled(seed: int, n: int, scale: float, offset: float) -> np.ndarray:
+    u = uniform(seed, np.arange(n, dtype=np.uint64))
+    m = (np.float32(scale) * u).astype(np.float32)
+    return (np.float32(offset) + m).astype(np.float32)
+
+
+def planted_queries(index_seed: int, rows: np.ndarray, noise_seed: int, noise: float = 0.05) -> np.ndarray:
+    """Queries whose nearest neighbour is known: query_i = normalise(row[rows[i]] + noise * u)."""
+    out = []
+    for i, r in enumerate(np.asarray(rows, dtype=np.int64)):
+        base = unit_rows(index_seed, int(r), 1)[0]
+        u = uniform(noise_seed, np.uint64(i) * np.uint64(EM_LEN) + np.arange(EM_LEN, dtype=np.uint64))
+        out.append((base + np.float32(noise) * np.float32(1.0 / np.sqrt(EM_LEN)) * u).astype(np.float32))
+    return normalize_rows(np.stack(out))
+
+
+# ---- synthetic all-MiniLM-L6-v2-shaped weights (same list as oracle/dawn_oracle.c: orc_bert_synth) ----
+
+MINILM_CONFIG = dict(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12,
+                     intermediate_size=1536, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02,
+                     layer_norm_eps=1e-12, pad_token_id=0, model_type="bert")
+
+
+def bert_tensor_specs(cfg: dict = MINILM_CONFIG):
+    """[(name, shape, scale, offset)] in stream order (tensor t uses seed*1000 + t)."""
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    specs = [
+        ("embeddings.word_embeddings.weight", (cfg["vocab_size"], H), 0.05, 0.0),
+        ("embeddings.position_embeddings.weight", (cfg["max_position_embeddings"], H), 0.02, 0.0),
+        ("embeddings.token_type_embeddings.weight", (cfg["type_vocab_size"], H), 0.02, 0.0),
+        ("embeddings.LayerNorm.weight", (H,), 0.10, 1.0),
+        ("embeddings.LayerNorm.bias", (H,), 0.05, 0.0),
+    ]
+    for L in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{L}."
+        specs += [
+            (p + "attention.self.query.weight", (H, H), 0.08, 0.0),
+            (p + "attention.self.query.bias", (H,), 0.02, 0.0),
+            (p + "attention.self.key.weight", (H, H), 0.08, 0.0),
+            (p + "attention.self.key.bias", (H,), 0.02, 0.0),
+            (p + "attention.self.value.weight", (H, H), 0.08, 0.0),
+            (p + "attention.self.value.bias", (H,), 0.02, 0.0),
+            (p + "attention.output.dense.weight", (H, H), 0.05, 0.0),
+            (p + "attention.output.dense.bias", (H,), 0.02, 0.0),
+            (p + "attention.output.LayerNorm.weight", (H,), 0.10, 1.0),
+            (p + "attention.output.LayerNorm.bias", (H,), 0.05, 0.0),
+            (p + "intermediate.dense.weight", (I, H), 0.05, 0.0),
+            (p + "intermediate.dense.bias", (I,), 0.02, 0.0),
+            (p + "output.dense.weight", (H, I), 0.03, 0.0),
+            (p + "output.dense.bias", (H,), 0.02, 0.0),
+            (p + "output.LayerNorm.weight", (H,), 0.10, 1.0),
+            (p + "output.LayerNorm.bias", (H,), 0.05, 0.0),
+        ]
+    return specs
+
+
+def bert_weights(seed: int, cfg: dict = MINILM_CONFIG) -> dict:
+    out = {}
+    for t, (name, shape, scale, offset) in enumerate(bert_tensor_specs(cfg)):
+        n = int(np.prod(shape))
+        out[name] = scaled(seed * 1000 + t, n, scale, offset).reshape(shape)
+    return out
+
+
+def token_sequences(seed: int, B: int, min_len: int = 4, max_len: int = 32):
+    """Synthetic WordPiece id sequences: [CLS]=101, ids uniform in [1000, 30521], [SEP]=102."""
+    seqs = []
+    key_len = splitmix64(np.uint64(seed))
+    key_tok = splitmix64(np.uint64(seed + 7919))
+    with np.errstate(over="ignore"):
+        for b in range(B):
+            h = splitmix64(key_len + np.uint64(b) * _GOLDEN)
+            L = min_len + int(h % np.uint64(max_len - min_len + 1))
+            body_n = max(L - 2, 0)
+            ctr = np.uint64(b) * np.uint64(1024) + np.arange(body_n, dtype=np.uint64)
+            hh = splitmix64(key_tok + ctr * _GOLDEN)
+            body = (np.uint64(1000) + hh % np.uint64(30522 - 1000)).astype(np.uint32)
+            seqs.append(np.concatenate([[101], body, [102]]).astype(np.uint32)[:max(L, 2)])
+    return seqs

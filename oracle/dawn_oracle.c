@@ -1,0 +1,572 @@
+/*
+ * dawn_oracle.c — CPU restatement of DawnSearch's embed-and-rank hot path (see dawn_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY — never linked into, imported by or executed from the product path.
+ * PARITY UNPINNED BY THE REFERENCE (no tests / golden vectors upstream); pinned instead against
+ * HF transformers + numpy in the build container, fixtures under tests/golden/.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC (oracle/Makefile).
+ * All paths below are relative to the reference repository root.
+ */
+#include "dawn_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EM ORC_EM_LEN
+
+/* ======================================================================================= */
+/* src/search/vector.rs                                                                     */
+/* ======================================================================================= */
+
+/* vector.rs:95-97  zip(self,b).map(|(a,b)| (a-b).powf(2.0)).sum()  — sequential f32 sum.
+ * powf(x, 2.0) is x*x (exact square, correctly rounded either way). */
+float orc_distance_l2sq(const float *a, const float *b) {
+    float s = 0.0f;
+    for (int i = 0; i < EM; i++) {
+        float d = a[i] - b[i];
+        s += d * d;
+    }
+    return s;
+}
+
+/* vector.rs:99-101  zip(self,b).map(|(a,b)| a*b).sum() */
+float orc_distance_ip(const float *a, const float *b) {
+    float s = 0.0f;
+    for (int i = 0; i < EM; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* vector.rs:128-134  result += a[i]*b[i]; 1.0 - result  (== USearch MetricKind::IP distance) */
+float orc_distance_cosine(const float *a, const float *b) {
+    float r = 0.0f;
+    for (int i = 0; i < EM; i++) r += a[i] * b[i];
+    return 1.0f - r;
+}
+
+/* vector.rs:181-183  v.distance(&[0.0; EM_LEN]).sqrt() */
+float orc_vector_length(const float *v) {
+    float s = 0.0f;
+    for (int i = 0; i < EM; i++) {
+        float d = v[i] - 0.0f;
+        s += d * d;
+    }
+    return sqrtf(s);
+}
+
+/* vector.rs:185-192  MAX_VECTOR_DELTA = 0.01; finite and 0.99 < l < 1.01 */
+int orc_is_normalized(const float *v) {
+    float l = orc_vector_length(v);
+    if (!isfinite(l)) return 0;
+    return l > 1.0f - 0.01f && l < 1.0f + 0.01f;
+}
+
+/* vector.rs:194-197  length = sum(x*x).sqrt(); x /= length */
+void orc_normalize(float *v, size_t n) {
+    float s = 0.0f;
+    for (size_t i = 0; i < n; i++) s += v[i] * v[i];
+    float len = sqrtf(s);
+    for (size_t i = 0; i < n; i++) v[i] /= len;
+}
+
+/* vector.rs:30-32  (x * i16::MAX as f32).round() as i16   (Rust `as` saturates) */
+int16_t orc_f32_to_i16(float x) {
+    float r = roundf(x * 32767.0f);
+    if (r != r) return 0;
+    if (r >= 32767.0f) return 32767;
+    if (r <= -32768.0f) return -32768;
+    return (int16_t)r;
+}
+
+/* vector.rs:74-86  v = (((x as f64 + 1.0)/2.0) * 0x7FFFFF as f64) as i32; 3 LE bytes */
+void orc_to24(const float *v, uint8_t *out) {
+    for (int i = 0; i < EM; i++) {
+        double t = (((double)v[i] + 1.0) / 2.0) * (double)0x7FFFFF;
+        int32_t iv;
+        /* Rust `as i32` truncates toward zero and saturates; NaN -> 0 */
+        if (t != t) iv = 0;
+        else if (t >= 2147483647.0) iv = 2147483647;
+        else if (t <= -2147483648.0) iv = (int32_t)(-2147483647 - 1);
+        else iv = (int32_t)t;
+        out[i * 3 + 0] = (uint8_t)(iv & 0xFF);
+        out[i * 3 + 1] = (uint8_t)((iv >> 8) & 0xFF);
+        out[i * 3 + 2] = (uint8_t)((iv >> 16) & 0xFF);
+    }
+}
+
+/* vector.rs:57-72  incl. the "sign extend" branch that ORs 0xFF into the LOW byte (sic) */
+int orc_from24(const uint8_t *data, float *out) {
+    for (int i = 0; i < EM; i++) {
+        int32_t v = 0;
+        v |= (int32_t)data[i * 3];
+        v |= ((int32_t)data[i * 3 + 1]) << 8;
+        v |= ((int32_t)data[i * 3 + 2]) << 16;
+        if (data[i * 3 + 2] & 0x80) v |= 0xFF;
+        out[i] = (float)((double)v / (double)0x7FFFFF * 2.0 - 1.0);
+    }
+    return orc_is_normalized(out) ? 0 : -1;
+}
+
+/* ======================================================================================= */
+/* src/search/best_results.rs                                                               */
+/* ======================================================================================= */
+
+orc_best_results *orc_best_new(size_t size) { /* :36-43 */
+    orc_best_results *b = (orc_best_results *)calloc(1, sizeof(*b));
+    b->results = (orc_node_ref *)calloc(size ? size : 1, sizeof(orc_node_ref));
+    b->len = 0;
+    b->worst_result_index = 0;
+    b->worst_distance = 0.0f; /* T::zero() until the list is full — callers see 0 (:40) */
+    b->size = size;
+    return b;
+}
+
+void orc_best_free(orc_best_results *b) {
+    if (!b) return;
+    free(b->results);
+    free(b);
+}
+
+static int best_contains(const orc_best_results *b, size_t id) { /* :67-69 */
+    for (size_t i = 0; i < b->len; i++)
+        if (b->results[i].id == id) return 1;
+    return 0;
+}
+
+static void best_update_worst(orc_best_results *b) { /* :97-107: first maximum wins (strict >) */
+    b->worst_result_index = 0;
+    b->worst_distance = b->results[0].distance;
+    for (size_t i = 1; i < b->len; i++) {
+        if (b->results[i].distance > b->worst_distance) {
+            b->worst_distance = b->results[i].distance;
+            b->worst_result_index = i;
+        }
+    }
+}
+
+int orc_best_insert(orc_best_results *b, size_t id, float d) { /* :44-65 */
+    if (b->len < b->size) {
+        if (best_contains(b, id)) return 0;
+        b->results[b->len].id = id;
+        b->results[b->len].distance = d;
+        b->len++;
+        if (b->len == b->size) best_update_worst(b);
+        return 1;
+    }
+    if (d < b->worst_distance) {
+        if (best_contains(b, id)) return 0;
+        b->results[b->worst_result_index].id = id;
+        b->results[b->worst_result_index].distance = d;
+        best_update_worst(b);
+        return 1;
+    }
+    return 0;
+}
+
+void orc_best_sort(orc_best_results *b) { /* :71-79 — Vec::sort_by is stable: insertion sort */
+    if (b->len == 0) return;
+    for (size_t i = 1; i < b->len; i++) {
+        orc_node_ref t = b->results[i];
+        size_t j = i;
+        while (j > 0 && b->results[j - 1].distance > t.distance) {
+            b->results[j] = b->results[j - 1];
+            j--;
+        }
+        b->results[j] = t;
+    }
+    b->worst_result_index = b->len - 1;
+    b->worst_distance = b->results[b->len - 1].distance;
+}
+
+float orc_best_worst_distance(const orc_best_results *b) { return b->worst_distance; } /* :93-95 */
+
+/* ======================================================================================= */
+/* Exact brute-force scan                                                                    */
+/* ======================================================================================= */
+
+typedef struct {
+    float d;
+    size_t pos;
+} cand_t;
+
+/* sorted ascending by (distance, position); strict total order */
+static inline int cand_less(float d, size_t pos, const cand_t *c) {
+    return d < c->d || (d == c->d && pos < c->pos);
+}
+
+static void topk_push(cand_t *list, size_t *len, size_t k, float d, size_t pos) {
+    if (*len == k && !cand_less(d, pos, &list[k - 1])) return;
+    size_t j = (*len < k) ? (*len)++ : k - 1;
+    while (j > 0 && cand_less(d, pos, &list[j - 1])) {
+        list[j] = list[j - 1];
+        j--;
+    }
+    list[j].d = d;
+    list[j].pos = pos;
+}
+
+size_t orc_scan_topk(const float *x, const uint64_t *ids, size_t n, const float *q, size_t k,
+                     uint64_t *out_labels, float *out_distances) {
+    if (k == 0) return 0;
+    cand_t *list = (cand_t *)malloc(sizeof(cand_t) * k);
+    size_t len = 0;
+    for (size_t r = 0; r < n; r++) {
+        float d = orc_distance_cosine(q, x + r * EM); /* vector.rs:128-134; argument order as
+                                                         search.rs:53 p.vector.distance(query) is
+                                                         symmetric for products */
+        topk_push(list, &len, k, d, r);
+    }
+    for (size_t i = 0; i < len; i++) {
+        out_labels[i] = ids ? ids[list[i].pos] : (uint64_t)list[i].pos;
+        out_distances[i] = list[i].d;
+    }
+    free(list);
+    return len;
+}
+
+size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const float *q, size_t k,
+                        uint64_t *out_labels, float *out_distances, int threads) {
+    if (k == 0) return 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+    cand_t *lists = (cand_t *)malloc(sizeof(cand_t) * k * (size_t)threads);
+    size_t *lens = (size_t *)calloc((size_t)threads, sizeof(size_t));
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+        int nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        cand_t *list = lists + (size_t)t * k;
+        size_t len = 0;
+        for (size_t r = lo; r < hi; r++) {
+            float d = orc_distance_cosine(q, x + r * EM);
+            topk_push(list, &len, k, d, r);
+        }
+        lens[t] = len;
+    }
+    cand_t *fin = (cand_t *)malloc(sizeof(cand_t) * k);
+    size_t flen = 0;
+    for (int t = 0; t < threads; t++)
+        for (size_t i = 0; i < lens[t]; i++)
+            topk_push(fin, &flen, k, lists[(size_t)t * k + i].d, lists[(size_t)t * k + i].pos);
+    for (size_t i = 0; i < flen; i++) {
+        out_labels[i] = ids ? ids[fin[i].pos] : (uint64_t)fin[i].pos;
+        out_distances[i] = fin[i].d;
+    }
+    free(fin);
+    free(lists);
+    free(lens);
+    return flen;
+}
+
+/* examples_old/search.rs:49-72 over PageEntry records (src/index/warc.rs:35-43). */
+size_t orc_scan_examples_old(const uint8_t *page_entries, size_t n_entries, const float *q,
+                             size_t *out_entry, float *out_score) {
+    size_t len = 0;
+    for (size_t e = 0; e < n_entries; e++) {
+        float vec[EM];
+        memcpy(vec, page_entries + e * 1568 + 16, sizeof(vec));
+        float score = orc_distance_l2sq(vec, q); /* search.rs:53 */
+        if (len < 10) {                          /* :55-62 */
+            out_entry[len] = e;
+            out_score[len] = score;
+            len++;
+            continue;
+        }
+        if (score < out_score[9]) { /* :63 */
+            out_entry[9] = e;
+            out_score[9] = score;
+            /* :69 stable sort ascending */
+            for (size_t i = 1; i < 10; i++) {
+                float s = out_score[i];
+                size_t en = out_entry[i];
+                size_t j = i;
+                while (j > 0 && out_score[j - 1] > s) {
+                    out_score[j] = out_score[j - 1];
+                    out_entry[j] = out_entry[j - 1];
+                    j--;
+                }
+                out_score[j] = s;
+                out_entry[j] = en;
+            }
+        }
+    }
+    return len;
+}
+
+/* ======================================================================================= */
+/* Synthetic data spec                                                        */
+/* ======================================================================================= */
+
+uint64_t orc_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* stream `seed`, element idx: h = splitmix64(splitmix64(seed) + idx * GOLDEN); top 24 bits u;
+ * value = (2u + 1 - 2^24) / 2^24  — odd integer numerator, exactly representable in f32. */
+float orc_synth_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t key = orc_splitmix64(seed);
+    uint64_t h = orc_splitmix64(key + idx * 0x9E3779B97F4A7C15ULL);
+    int32_t u = (int32_t)(h >> 40);
+    int32_t n = 2 * u + 1 - (1 << 24);
+    return (float)n * (1.0f / 16777216.0f);
+}
+
+void orc_synth_unit_row(uint64_t seed, uint64_t row, float *out) {
+    for (int c = 0; c < EM; c++) out[c] = orc_synth_uniform(seed, row * EM + (uint64_t)c);
+    orc_normalize(out, EM);
+}
+
+void orc_synth_unit_rows(uint64_t seed, uint64_t first_row, size_t n, float *out) {
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n; r++) orc_synth_unit_row(seed, first_row + r, out + r * EM);
+}
+
+void orc_synth_scaled(uint64_t seed, size_t n, float scale, float offset, float *out) {
+    for (size_t i = 0; i < n; i++) {
+        float m = scale * orc_synth_uniform(seed, i);
+        out[i] = offset + m;
+    }
+}
+
+/* ======================================================================================= */
+/* src/embedding/model.rs                                                                    */
+/* ======================================================================================= */
+
+/* model.rs:53-64  y = x·Wᵀ + b, W stored [out,in] (:188-192) */
+static void linear(const float *x, int T, int in, int out, const float *w, const float *b, float *y) {
+    for (int t = 0; t < T; t++) {
+        const float *xr = x + (size_t)t * in;
+        for (int o = 0; o < out; o++) {
+            const float *wr = w + (size_t)o * in;
+            float s = 0.0f;
+            for (int i = 0; i < in; i++) s += xr[i] * wr[i];
+            y[(size_t)t * out + o] = s + b[o];
+        }
+    }
+}
+
+/* model.rs:86-104  mean = sum/H; xc = x-mean; var = sum(xc^2)/H; xc / sqrt(var+eps) * g + b */
+static void layer_norm(float *x, int T, int H, const float *g, const float *b, float eps) {
+    for (int t = 0; t < T; t++) {
+        float *r = x + (size_t)t * H;
+        float s = 0.0f;
+        for (int i = 0; i < H; i++) s += r[i];
+        const float inv_h = (float)(1.0 / (double)H); /* candle `Tensor / f64` == affine(1/rhs, 0) */
+        float mean = s * inv_h;
+        float v = 0.0f;
+        for (int i = 0; i < H; i++) {
+            r[i] = r[i] - mean;
+            v += r[i] * r[i];
+        }
+        float var = v * inv_h;
+        float den = sqrtf(var + eps); /* (norm_x + eps)?.sqrt() — eps=1e-12 as f32 */
+        for (int i = 0; i < H; i++) r[i] = (r[i] / den) * g[i] + b[i];
+    }
+}
+
+/* model.rs:28-37 HiddenAct::Gelu => xs.gelu(): candle's tanh form ("gelu_new", see the comment at
+ * model.rs:31-34): 0.5*v*(1+tanh(sqrt(2/pi)*v*(1+0.044715*v^2))) */
+static inline float gelu_tanh(float v) {
+    const float k = 0.7978845608028654f; /* sqrt(2/pi) */
+    return 0.5f * v * (1.0f + tanhf(k * v * (1.0f + 0.044715f * v * v)));
+}
+
+void orc_bert_forward(const orc_bert_weights *w, const uint32_t *ids, int S, float *out) {
+    const orc_bert_config *c = &w->cfg;
+    const int H = c->hidden, NH = c->heads, DH = H / NH, I = c->inter;
+    float *x = out; /* [S][H] */
+    float *q = (float *)malloc(sizeof(float) * S * H);
+    float *k = (float *)malloc(sizeof(float) * S * H);
+    float *v = (float *)malloc(sizeof(float) * S * H);
+    float *ctx = (float *)malloc(sizeof(float) * S * H);
+    float *tmp = (float *)malloc(sizeof(float) * S * H);
+    float *ff = (float *)malloc(sizeof(float) * S * I);
+    float *prob = (float *)malloc(sizeof(float) * S);
+
+    /* BertEmbeddings::forward model.rs:266-281: (word + type) + pos, LayerNorm, dropout=identity */
+    for (int t = 0; t < S; t++) {
+        const float *we = w->word_emb + (size_t)ids[t] * H;
+        const float *te = w->type_emb; /* token_type_ids = zeros (embedding_service.rs:123) */
+        const float *pe = w->pos_emb + (size_t)t * H; /* position_ids = 0..S (:274) */
+        for (int i = 0; i < H; i++) x[(size_t)t * H + i] = (we[i] + te[i]) + pe[i];
+    }
+    layer_norm(x, S, H, w->emb_ln_g, w->emb_ln_b, c->ln_eps);
+
+    /* model.rs:336 scores / (head_size as f64).sqrt(): candle lowers `Tensor / f64` to
+     * affine(1/rhs, 0), i.e. a multiply by (1/sqrt(32)) rounded to f32 */
+    const float inv_scale = (float)(1.0 / sqrt((double)DH));
+    for (int L = 0; L < c->layers; L++) {
+        const orc_bert_layer *ly = &w->layer[L];
+        /* BertSelfAttention::forward model.rs:325-347 */
+        linear(x, S, H, H, ly->q_w, ly->q_b, q);
+        linear(x, S, H, H, ly->k_w, ly->k_b, k);
+        linear(x, S, H, H, ly->v_w, ly->v_b, v);
+        for (int h = 0; h < NH; h++) {
+            for (int i = 0; i < S; i++) {
+                const float *qi = q + (size_t)i * H + h * DH;
+                float mx = -INFINITY;
+                for (int j = 0; j < S; j++) {
+                    const float *kj = k + (size_t)j * H + h * DH;
+                    float s = 0.0f;
+                    for (int d = 0; d < DH; d++) s += qi[d] * kj[d];
+                    s = s * inv_scale;
+                    prob[j] = s;
+                    if (s > mx) mx = s;
+                }
+                /* candle_nn::ops::softmax: max-subtract, exp, sum, div; no mask (:338-341) */
+                float sum = 0.0f;
+                for (int j = 0; j < S; j++) {
+                    prob[j] = expf(prob[j] - mx);
+                    sum += prob[j];
+                }
+                for (int j = 0; j < S; j++) prob[j] = prob[j] / sum;
+                float *ci = ctx + (size_t)i * H + h * DH;
+                for (int d = 0; d < DH; d++) {
+                    float a = 0.0f;
+                    for (int j = 0; j < S; j++) a += prob[j] * v[(size_t)j * H + h * DH + d];
+                    ci[d] = a;
+                }
+            }
+        }
+        /* BertSelfOutput::forward model.rs:374-379: LN(dense(ctx) + x) */
+        linear(ctx, S, H, H, ly->ao_w, ly->ao_b, tmp);
+        for (int i = 0; i < S * H; i++) tmp[i] = tmp[i] + x[i];
+        layer_norm(tmp, S, H, ly->ao_ln_g, ly->ao_ln_b, c->ln_eps);
+        /* BertIntermediate::forward model.rs:425-430 */
+        linear(tmp, S, H, I, ly->i_w, ly->i_b, ff);
+        for (int i = 0; i < S * I; i++) ff[i] = gelu_tanh(ff[i]);
+        /* BertOutput::forward model.rs:458-463: LN(dense(ff) + attention_output) */
+        linear(ff, S, I, H, ly->o_w, ly->o_b, x);
+        for (int i = 0; i < S * H; i++) x[i] = x[i] + tmp[i];
+        layer_norm(x, S, H, ly->o_ln_g, ly->o_ln_b, c->ln_eps);
+    }
+    free(q);
+    free(k);
+    free(v);
+    free(ctx);
+    free(tmp);
+    free(ff);
+    free(prob);
+}
+
+/* embedding_service.rs:124-136: embeddings.sum(1) / n_tokens, then normalize (vector.rs:194-197) */
+void orc_embed(const orc_bert_weights *w, const uint32_t *ids, int S, float *out) {
+    const int H = w->cfg.hidden;
+    float *seq = (float *)malloc(sizeof(float) * S * H);
+    orc_bert_forward(w, ids, S, seq);
+    for (int i = 0; i < H; i++) {
+        float s = 0.0f;
+        for (int t = 0; t < S; t++) s += seq[(size_t)t * H + i];
+        /* embeddings.sum(1)? / (n_tokens as f64): candle affine(1/S, 0) => multiply by f32(1/S).
+         * (x*(1/S) vs x/S differ by <= 1 ulp and normalize() follows: O(1e-8) on the result.) */
+        out[i] = s * (float)(1.0 / (double)S);
+    }
+    orc_normalize(out, (size_t)H);
+    free(seq);
+}
+
+void orc_embed_padded_batch(const orc_bert_weights *w, const uint32_t *ids, const int *lens, int B,
+                            uint32_t pad_id, float *out) {
+    const int H = w->cfg.hidden;
+    int S = 0;
+    for (int b = 0; b < B; b++)
+        if (lens[b] > S) S = lens[b];
+    uint32_t *padded = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)S);
+    const uint32_t *p = ids;
+    for (int b = 0; b < B; b++) {
+        for (int t = 0; t < S; t++) padded[t] = t < lens[b] ? p[t] : pad_id;
+        orc_embed(w, padded, S, out + (size_t)b * H); /* no mask: rows are independent given S */
+        p += lens[b];
+    }
+    free(padded);
+}
+
+/* ---- synthetic weights ------------------------------------------------------------------ */
+
+size_t orc_bert_param_count(const orc_bert_config *c) {
+    size_t H = (size_t)c->hidden, I = (size_t)c->inter;
+    size_t n = (size_t)c->vocab_size * H + (size_t)c->max_pos * H + (size_t)c->type_vocab * H + 2 * H;
+    n += (size_t)c->layers * (4 * (H * H + H) + 2 * H + (I * H + I) + (H * I + H) + 2 * H);
+    return n;
+}
+
+/* Tensor t of the list below is filled by orc_synth_scaled(seed*1000 + t, n, scale, offset):
+ *   0 embeddings.word_embeddings.weight      [V,H]   0.05, 0
+ *   1 embeddings.position_embeddings.weight  [P,H]   0.02, 0
+ *   2 embeddings.token_type_embeddings.weight[2,H]   0.02, 0
+ *   3 embeddings.LayerNorm.weight            [H]     0.10, 1
+ *   4 embeddings.LayerNorm.bias              [H]     0.05, 0
+ *   per layer L, base = 5 + 16 L:
+ *   +0/+1  attention.self.query.{weight [H,H] 0.08, bias [H] 0.02}
+ *   +2/+3  attention.self.key.{weight, bias}      same
+ *   +4/+5  attention.self.value.{weight, bias}    same
+ *   +6/+7  attention.output.dense.{weight [H,H] 0.05, bias 0.02}
+ *   +8/+9  attention.output.LayerNorm.{weight 0.10+1, bias 0.05}
+ *   +10/+11 intermediate.dense.{weight [I,H] 0.05, bias [I] 0.02}
+ *   +12/+13 output.dense.{weight [H,I] 0.03, bias [H] 0.02}
+ *   +14/+15 output.LayerNorm.{weight 0.10+1, bias 0.05}
+ */
+orc_bert_weights *orc_bert_synth(uint64_t seed) {
+    orc_bert_weights *w = (orc_bert_weights *)calloc(1, sizeof(*w));
+    orc_bert_config c = {30522, 384, 6, 12, 1536, 512, 2, 1e-12f}; /* model.rs:160-180 */
+    w->cfg = c;
+    size_t total = orc_bert_param_count(&c);
+    float *blk = (float *)malloc(sizeof(float) * total);
+    float *p = blk;
+    const size_t H = 384, I = 1536;
+    int t = 0;
+#define TENSOR(field, n, scale, off)                                        \
+    do {                                                                    \
+        orc_synth_scaled(seed * 1000 + (uint64_t)t, (n), (scale), (off), p); \
+        field = p;                                                          \
+        p += (n);                                                           \
+        t++;                                                                \
+    } while (0)
+    TENSOR(w->word_emb, (size_t)c.vocab_size * H, 0.05f, 0.0f);
+    TENSOR(w->pos_emb, (size_t)c.max_pos * H, 0.02f, 0.0f);
+    TENSOR(w->type_emb, (size_t)c.type_vocab * H, 0.02f, 0.0f);
+    TENSOR(w->emb_ln_g, H, 0.10f, 1.0f);
+    TENSOR(w->emb_ln_b, H, 0.05f, 0.0f);
+    for (int L = 0; L < c.layers; L++) {
+        orc_bert_layer *ly = &w->layer[L];
+        TENSOR(ly->q_w, H * H, 0.08f, 0.0f);
+        TENSOR(ly->q_b, H, 0.02f, 0.0f);
+        TENSOR(ly->k_w, H * H, 0.08f, 0.0f);
+        TENSOR(ly->k_b, H, 0.02f, 0.0f);
+        TENSOR(ly->v_w, H * H, 0.08f, 0.0f);
+        TENSOR(ly->v_b, H, 0.02f, 0.0f);
+        TENSOR(ly->ao_w, H * H, 0.05f, 0.0f);
+        TENSOR(ly->ao_b, H, 0.02f, 0.0f);
+        TENSOR(ly->ao_ln_g, H, 0.10f, 1.0f);
+        TENSOR(ly->ao_ln_b, H, 0.05f, 0.0f);
+        TENSOR(ly->i_w, I * H, 0.05f, 0.0f);
+        TENSOR(ly->i_b, I, 0.02f, 0.0f);
+        TENSOR(ly->o_w, H * I, 0.03f, 0.0f);
+        TENSOR(ly->o_b, H, 0.02f, 0.0f);
+        TENSOR(ly->o_ln_g, H, 0.10f, 1.0f);
+        TENSOR(ly->o_ln_b, H, 0.05f, 0.0f);
+    }
+#undef TENSOR
+    return w;
+}
+
+void orc_bert_free_synth(orc_bert_weights *w) {
+    if (!w) return;
+    free((void *)w->word_emb); /* start of the single block */
+    free(w);
+}

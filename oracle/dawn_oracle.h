@@ -1,0 +1,126 @@
+/*
+ * dawn_oracle.h — CPU restatement of DawnSearch's embed-and-rank hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into it, and there only as
+ * the checker / the CPU baseline, never as the thing measured or shipped.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: dawn-search/dawnsearch has no tests, golden vectors or
+ * fixtures (.github/workflows/build.yml:32-34 "No tests yet!") and cannot be built here (Rust,
+ * un-vendored crates).  What pins this restatement instead:
+ *   - the embedder is cross-checked in the build container against HuggingFace
+ *     transformers.BertModel(hidden_act="gelu_new") on the same seeded weights and the outputs
+ *     are committed under tests/golden/ (generator: tests/golden/make_golden.py);
+ *   - the scan / top-k / codec functions are cross-checked against an independent numpy
+ *     restatement (tests/np_oracle.py) and analytical known-answer cases.
+ *
+ * Every function cites the reference file:line (relative to the reference repo root) it follows.
+ * All f32 arithmetic is done in the reference's order: sequential, un-fused (Rust never
+ * contracts a*b+c), so this file MUST be compiled with -ffp-contract=off and without -ffast-math.
+ */
+#ifndef DAWN_ORACLE_H
+#define DAWN_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_EM_LEN 384 /* src/search/vector.rs:26 */
+
+/* ---- src/search/vector.rs ------------------------------------------------------------- */
+float orc_distance_l2sq(const float *a, const float *b);    /* vector.rs:95-97  */
+float orc_distance_ip(const float *a, const float *b);      /* vector.rs:99-101 */
+float orc_distance_cosine(const float *a, const float *b);  /* vector.rs:128-134 */
+float orc_vector_length(const float *v);                    /* vector.rs:181-183 */
+int orc_is_normalized(const float *v);                      /* vector.rs:185-192 */
+void orc_normalize(float *v, size_t n);                     /* vector.rs:194-197 */
+void orc_to24(const float *v, uint8_t *out /*[1152]*/);     /* vector.rs:74-86  */
+int orc_from24(const uint8_t *data /*[1152]*/, float *out); /* vector.rs:57-72; 0 ok, -1 not normalised */
+int16_t orc_f32_to_i16(float x);                            /* vector.rs:30-32  */
+
+/* ---- src/search/best_results.rs -------------------------------------------------------- */
+typedef struct {
+    size_t id;
+    float distance;
+} orc_node_ref; /* best_results.rs:22-26 */
+
+typedef struct {
+    orc_node_ref *results; /* capacity == size */
+    size_t len;
+    size_t worst_result_index;
+    float worst_distance;
+    size_t size;
+} orc_best_results; /* best_results.rs:28-33 */
+
+orc_best_results *orc_best_new(size_t size);                 /* best_results.rs:36-43 */
+void orc_best_free(orc_best_results *b);
+int orc_best_insert(orc_best_results *b, size_t id, float d); /* best_results.rs:44-65 */
+void orc_best_sort(orc_best_results *b);                      /* best_results.rs:71-79 (stable) */
+float orc_best_worst_distance(const orc_best_results *b);     /* best_results.rs:93-95 */
+
+/* ---- exact brute-force scan (what USearch `search` approximates) ------------------------ */
+/* distance = 1 - sum(q_i*x_i) (search_provider.rs:214 with MetricKind::IP, vector.rs:128-134),
+ * ascending, ties -> earlier-added row.  x is the packed [n][384] f32 index, ids[n] the labels
+ * passed to `add` (search_provider.rs:149,284).  Returns found = min(k, n). */
+size_t orc_scan_topk(const float *x, const uint64_t *ids, size_t n, const float *q, size_t k,
+                     uint64_t *out_labels, float *out_distances);
+/* Same maths, OpenMP over row blocks + per-thread lists (CPU baseline "all cores"). */
+size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const float *q, size_t k,
+                        uint64_t *out_labels, float *out_distances, int threads);
+/* Literal restatement of examples_old/search.rs:49-72 (L2^2 score, top-10, the un-sorted-first-10
+ * quirk included) over a packed PageEntry file image (src/index/warc.rs:35-43: 1568-B records,
+ * vector at byte offset 16).  Returns number of results (<= 10). */
+size_t orc_scan_examples_old(const uint8_t *page_entries, size_t n_entries, const float *q,
+                             size_t *out_entry, float *out_score);
+
+/* ---- synthetic data spec (not reference behaviour) ------------------------- */
+uint64_t orc_splitmix64(uint64_t z);
+float orc_synth_uniform(uint64_t seed, uint64_t idx);                   /* 24-bit uniform in (-1,1) */
+void orc_synth_unit_row(uint64_t seed, uint64_t row, float *out /*[384]*/); /* normalised as vector.rs:194-197 */
+void orc_synth_unit_rows(uint64_t seed, uint64_t first_row, size_t n, float *out);
+void orc_synth_scaled(uint64_t seed, size_t n, float scale, float offset, float *out); /* offset + scale*u */
+
+/* ---- src/embedding/model.rs + embedding_service.rs --------------------------------------- */
+typedef struct {
+    int vocab_size, hidden, layers, heads, inter, max_pos, type_vocab; /* model.rs:160-180 */
+    float ln_eps;
+} orc_bert_config;
+
+typedef struct {
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;       /* attention.self.{query,key,value} */
+    const float *ao_w, *ao_b, *ao_ln_g, *ao_ln_b;         /* attention.output.{dense,LayerNorm} */
+    const float *i_w, *i_b;                               /* intermediate.dense */
+    const float *o_w, *o_b, *o_ln_g, *o_ln_b;             /* output.{dense,LayerNorm} */
+} orc_bert_layer;
+
+typedef struct {
+    orc_bert_config cfg;
+    const float *word_emb, *pos_emb, *type_emb, *emb_ln_g, *emb_ln_b; /* model.rs:235-255 */
+    orc_bert_layer layer[12];
+} orc_bert_weights;
+
+/* BertModel::forward for ONE sequence (batch 1, as every real call: embedding_service.rs:161-163).
+ * ids[S] u32, token_type_ids = 0 (embedding_service.rs:123) -> out[S][hidden]. model.rs:565-570 */
+void orc_bert_forward(const orc_bert_weights *w, const uint32_t *ids, int S, float *out);
+/* calculate_embedding minus the tokenizer: forward -> mean over S -> normalize.
+ * embedding_service.rs:124-136 */
+void orc_embed(const orc_bert_weights *w, const uint32_t *ids, int S, float *out /*[hidden]*/);
+/* Batched with BatchLongest zero-id padding and NO mask, exactly as embedding_service.rs:101-128
+ * would do for B>1 (documented deviation target: the product gives every text its batch-1 result). */
+void orc_embed_padded_batch(const orc_bert_weights *w, const uint32_t *ids, const int *lens, int B,
+                            uint32_t pad_id, float *out /*[B][hidden]*/);
+
+/* Synthetic all-MiniLM-L6-v2-shaped weights.  Allocates one block; free with
+ * orc_bert_free_synth.  Tensor order/names documented in dawn_oracle.c (same as the safetensors
+ * writer in tests/synth_weights.py). */
+orc_bert_weights *orc_bert_synth(uint64_t seed);
+void orc_bert_free_synth(orc_bert_weights *w);
+size_t orc_bert_param_count(const orc_bert_config *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
