@@ -1,0 +1,109 @@
+"""ctypes binding of libdawn_hip.so — the C ABI declared in include/dawn_hip.h.
+
+The library is the product; this module only loads it.  There is no Python/torch/CPU fallback: if the
+shared object is missing, import fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C dawnsearch_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdawn_hip.so")
+
+DAWN_OK = 0
+ERR_INVALID_ARG, ERR_NOT_NORMALIZED, ERR_HIP, ERR_IO, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6, -7
+EM_LEN = 384
+MAX_K = 64
+DTYPE_F32 = 0
+
+
+class DawnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[dawn {code}] {msg}")
+        self.code = code
+
+
+class NotNormalizedError(DawnError):
+    """`bail!("Search vector is not normalized")` — search_provider.rs:206-208,265-267."""
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. dawnsearch_amd has no fallback path; "
+            "run `make -C dawnsearch_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _sz, _u64, _i32, _i64 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_int64
+_pp = C.POINTER(C.c_void_p)
+
+_SIGS = {
+    "dawn_last_error": (C.c_char_p, []),
+    "dawn_version": (_i32, []),
+    "dawn_device_count": (_i32, [C.POINTER(_i32)]),
+    "dawn_index_create": (_i32, [_sz, _i32, _i32, _pp]),
+    "dawn_index_destroy": (None, [_vp]),
+    "dawn_index_reserve": (_i32, [_vp, _sz]),
+    "dawn_index_size": (_sz, [_vp]),
+    "dawn_index_capacity": (_sz, [_vp]),
+    "dawn_index_add": (_i32, [_vp, _u64, _vp]),
+    "dawn_index_add_batch": (_i32, [_vp, _sz, _vp, _vp]),
+    "dawn_index_search": (_i32, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_sz)]),
+    "dawn_index_search_batch": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "dawn_index_save": (_i32, [_vp, C.c_char_p]),
+    "dawn_index_load": (_i32, [_vp, C.c_char_p]),
+    "dawn_index_load_page_entries": (_i32, [_vp, C.c_char_p, _u64]),
+    "dawn_index_search_device": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "dawn_topk_merge_device": (_i32, [_i32, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dawn_index_fill_synthetic": (_i32, [_vp, _u64, _u64, _sz, _u64]),
+    "dawn_index_get_rows": (_i32, [_vp, _sz, _sz, _vp, _vp]),
+    "dawn_index_profile_enable": (_i32, [_vp, _i32]),
+    "dawn_index_profile_read": (_i32, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "dawn_index_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "dawn_index_set_option": (_i32, [_vp, C.c_char_p, _i64]),
+    "dawn_vec_is_normalized": (_i32, [_vp]),
+    "dawn_vec_normalize": (None, [_vp, _sz]),
+    "dawn_vec_to24": (None, [_vp, _vp]),
+    "dawn_vec_from24": (_i32, [_vp, _vp]),
+    "dawn_best_new": (_i32, [_sz, _pp]),
+    "dawn_best_free": (None, [_vp]),
+    "dawn_best_insert": (_i32, [_vp, _sz, C.c_float]),
+    "dawn_best_sort": (None, [_vp]),
+    "dawn_best_worst_distance": (C.c_float, [_vp]),
+    "dawn_best_len": (_sz, [_vp]),
+    "dawn_best_get": (_i32, [_vp, _sz, C.POINTER(_sz), C.POINTER(C.c_float)]),
+    "dawn_embedder_create": (_i32, [C.c_char_p, C.c_char_p, _i32, _pp]),
+    "dawn_embedder_destroy": (None, [_vp]),
+    "dawn_embedder_forward": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "dawn_embedder_forward_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "dawn_embedder_hidden_states": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+}
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return (lib.dawn_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc == DAWN_OK:
+        return
+    msg = last_error()
+    if rc == ERR_NOT_NORMALIZED:
+        raise NotNormalizedError(rc, msg)
+    raise DawnError(rc, msg)
+
+
+def device_count() -> int:
+    n = _i32(0)
+    rc = lib.dawn_device_count(C.byref(n))
+    return n.value if rc == DAWN_OK else 0

@@ -1,0 +1,499 @@
+// dawn_index.cpp — the HBM-resident packed vector index behind the dawn_index_* C ABI.
+//
+// Replaces usearch::ffi::Index as used by src/search/search_provider.rs (new_index :102, reserve
+// :133/:282, add :149/:284, search :214, size/capacity :246/:280, save/load :115-117/:178) with an
+// exact brute-force index: rows [N][384] f32 + ids [N] u64 live in one HBM allocation each, appended in
+// insertion order; search = scan_kernels.hip.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+using dawn::fail;
+
+namespace {
+constexpr size_t kMaxBatch = 256;        // queries per internal pass of the host API
+constexpr size_t kMaxProfile = 4096;     // kept event pairs
+constexpr char kMagic[8] = {'D', 'A', 'W', 'N', 'I', 'D', 'X', '1'};
+}  // namespace
+
+struct dawn_index {
+    int device = 0;
+    size_t dims = DAWN_EM_LEN;
+    hipStream_t stream = nullptr;
+
+    float* d_x = nullptr;       // [(cap_phys + ROW_PAD)][384]
+    uint64_t* d_ids = nullptr;  // [cap_phys]
+    size_t size = 0;
+    size_t cap_reported = 0;  // what reserve() promised (usearch semantics)
+    size_t cap_phys = 0;      // rows actually allocated (geometric growth)
+
+    // search workspaces
+    dawn::ScanGeom geom{512, 1024};
+    size_t ws_B = 0;
+    float* d_cand_s = nullptr;
+    uint32_t* d_cand_p = nullptr;
+    uint32_t* d_flags = nullptr;
+    // host-API staging
+    float* d_q = nullptr;
+    uint64_t* d_labels = nullptr;
+    float* d_dist = nullptr;
+    uint32_t* d_found = nullptr;
+    uint32_t* d_bad = nullptr;
+    void* h_pinned = nullptr;  // kMaxBatch * (384*4 + 64*8 + 64*4 + 4 + 4)
+    size_t h_pinned_bytes = 0;
+
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    uint64_t n_searches = 0, n_fallbacks = 0;
+    int force_fallback = 0;
+};
+
+namespace {
+
+int set_device(const dawn_index* idx) {
+    DAWN_HIP_TRY(hipSetDevice(idx->device));
+    return DAWN_OK;
+}
+
+size_t padded_rows(size_t rows) { return ((rows + dawn::ROW_PAD - 1) / dawn::ROW_PAD) * dawn::ROW_PAD + dawn::ROW_PAD; }
+
+// Make room for at least `rows` rows (physical).  Existing rows are preserved.
+int grow_phys(dawn_index* idx, size_t rows) {
+    if (rows <= idx->cap_phys) return DAWN_OK;
+    if (rows >= 0xFFFFFF00ull) return fail(DAWN_ERR_UNSUPPORTED, "index limited to 2^32-256 rows per device");
+    float* nx = nullptr;
+    uint64_t* nid = nullptr;
+    const size_t prow = padded_rows(rows);
+    DAWN_HIP_TRY(hipMalloc((void**)&nx, prow * dawn::EM * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&nid, std::max<size_t>(rows, 1) * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        (void)hipFree(nx);
+        return fail(DAWN_ERR_OOM, "hipMalloc(ids): %s", hipGetErrorString(e));
+    }
+    if (idx->size) {
+        DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, idx->size * dawn::EM * sizeof(float), hipMemcpyDeviceToDevice,
+                                    idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(nid, idx->d_ids, idx->size * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                    idx->stream));
+    }
+    // zero everything past the live rows: the scan may read (never use) up to ROW_PAD rows past size
+    DAWN_HIP_TRY(hipMemsetAsync(nx + idx->size * dawn::EM, 0, (prow - idx->size) * dawn::EM * sizeof(float),
+                                idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (idx->d_x) (void)hipFree(idx->d_x);
+    if (idx->d_ids) (void)hipFree(idx->d_ids);
+    idx->d_x = nx;
+    idx->d_ids = nid;
+    idx->cap_phys = rows;
+    return DAWN_OK;
+}
+
+int ensure_room(dawn_index* idx, size_t extra) {
+    const size_t need = idx->size + extra;
+    if (need > idx->cap_phys) {
+        size_t target = std::max(need, idx->cap_phys + idx->cap_phys / 2);
+        target = std::max<size_t>(target, 1024);
+        DAWN_TRY(grow_phys(idx, target));
+    }
+    if (need > idx->cap_reported) idx->cap_reported = need;  // usearch would have required reserve(); we grow
+    return DAWN_OK;
+}
+
+int ensure_workspace(dawn_index* idx, size_t B) {
+    if (B <= idx->ws_B) return DAWN_OK;
+    if (idx->d_cand_s) (void)hipFree(idx->d_cand_s);
+    if (idx->d_cand_p) (void)hipFree(idx->d_cand_p);
+    if (idx->d_flags) (void)hipFree(idx->d_flags);
+    idx->d_cand_s = nullptr;
+    idx->d_cand_p = nullptr;
+    idx->d_flags = nullptr;
+    idx->ws_B = 0;
+    const size_t n = B * (size_t)idx->geom.blocks * dawn::LIST;
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
+    idx->ws_B = B;
+    return DAWN_OK;
+}
+
+// The whole search as a fixed launch sequence on `stream` (no host decisions in between).
+int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
+                     uint32_t* d_found, hipStream_t stream) {
+    DAWN_TRY(ensure_workspace(idx, B));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (idx->profiling && idx->events_used < kMaxProfile) {
+        if (idx->events_used == idx->events.size()) {
+            hipEvent_t a, b;
+            DAWN_HIP_TRY(hipEventCreate(&a));
+            DAWN_HIP_TRY(hipEventCreate(&b));
+            idx->events.emplace_back(a, b);
+        }
+        e0 = idx->events[idx->events_used].first;
+        e1 = idx->events[idx->events_used].second;
+        idx->events_used++;
+    }
+    const uint32_t n = (uint32_t)idx->size;
+    dawn::launch_scan_filter(idx->d_x, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
+    dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
+                               (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, stream);
+    dawn::launch_scan_exact(idx->d_x, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
+                            stream);
+    dawn::launch_merge_exact(idx->d_ids, n, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
+                             (uint32_t)k, d_labels, d_dist, d_found, stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    return DAWN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
+    if (!out) return fail(DAWN_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (dims != DAWN_EM_LEN) return fail(DAWN_ERR_UNSUPPORTED, "dims must be %d (EM_LEN)", DAWN_EM_LEN);
+    if (dtype != DAWN_DTYPE_F32) return fail(DAWN_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
+    DAWN_TRY(dawn::require_device(device));
+    DAWN_HIP_TRY(hipSetDevice(device));
+    auto* idx = new dawn_index();
+    idx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        idx->geom.blocks = prop.multiProcessorCount * 2;  // 2 x 16 waves per CU = full occupancy
+    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(DAWN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    const size_t hb = kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8 + DAWN_MAX_K * 4 + 8);
+    if (hipHostMalloc(&idx->h_pinned, hb, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&idx->d_q, kMaxBatch * dawn::EM * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_labels, kMaxBatch * DAWN_MAX_K * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_dist, kMaxBatch * DAWN_MAX_K * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_found, kMaxBatch * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_bad, sizeof(uint32_t)) != hipSuccess) {
+        dawn_index_destroy(idx);
+        return fail(DAWN_ERR_OOM, "allocating index staging buffers failed");
+    }
+    idx->h_pinned_bytes = hb;
+    *out = idx;
+    return DAWN_OK;
+}
+
+void dawn_index_destroy(dawn_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    for (auto& ev : idx->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->d_q,
+                    idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int dawn_index_reserve(dawn_index* idx, size_t capacity) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    DAWN_TRY(set_device(idx));
+    if (capacity > idx->cap_phys) DAWN_TRY(grow_phys(idx, capacity));
+    if (capacity > idx->cap_reported) idx->cap_reported = capacity;
+    return DAWN_OK;
+}
+
+size_t dawn_index_size(const dawn_index* idx) { return idx ? idx->size : 0; }
+size_t dawn_index_capacity(const dawn_index* idx) { return idx ? idx->cap_reported : 0; }
+
+int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const float* v) {
+    if (!idx || (!ids && n) || (!v && n)) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (n == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_room(idx, n));
+    float* dst = idx->d_x + idx->size * dawn::EM;
+    // rows land past `size` (invisible to searches) and become live only after validation
+    DAWN_HIP_TRY(hipMemcpyAsync(dst, v, n * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, ids, n * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                idx->stream));
+    DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), idx->stream));
+    dawn::launch_validate_rows(dst, (uint32_t)n, idx->d_bad, idx->stream);
+    uint32_t bad = 0;
+    DAWN_HIP_TRY(hipMemcpyAsync(&bad, idx->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (bad) {
+        (void)hipMemsetAsync(dst, 0, n * dawn::EM * sizeof(float), idx->stream);
+        (void)hipStreamSynchronize(idx->stream);
+        return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized (%u of %zu rows)", bad, n);
+    }
+    idx->size += n;
+    return DAWN_OK;
+}
+
+int dawn_index_add(dawn_index* idx, uint64_t id, const float* v) {
+    if (!idx || !v) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (!dawn::host_is_normalized(v)) return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized");
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_room(idx, 1));
+    float* hp = (float*)idx->h_pinned;
+    std::memcpy(hp, v, dawn::EM * sizeof(float));
+    uint64_t* hid = (uint64_t*)(hp + dawn::EM);
+    *hid = id;
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_x + idx->size * dawn::EM, hp, dawn::EM * sizeof(float), hipMemcpyHostToDevice,
+                                idx->stream));
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, hid, sizeof(uint64_t), hipMemcpyHostToDevice, idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->size += 1;
+    return DAWN_OK;
+}
+
+int dawn_index_search_device(dawn_index* idx, const float* d_queries, size_t B, size_t count, uint64_t* d_labels,
+                             float* d_distances, uint32_t* d_found, void* stream) {
+    if (!idx || !d_queries || !d_labels || !d_distances || !d_found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (count == 0 || count > DAWN_MAX_K) return fail(DAWN_ERR_UNSUPPORTED, "count must be 1..%d", DAWN_MAX_K);
+    if (B == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    idx->n_searches += B;
+    return search_on_device(idx, d_queries, B, count, d_labels, d_distances, d_found, (hipStream_t)stream);
+}
+
+int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, size_t count, uint64_t* labels,
+                            float* distances, size_t* found) {
+    if (!idx || !queries || !labels || !distances || !found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (count == 0 || count > DAWN_MAX_K) return fail(DAWN_ERR_UNSUPPORTED, "count must be 1..%d", DAWN_MAX_K);
+    for (size_t b = 0; b < B; ++b)  // search_provider.rs:206-208
+        if (!dawn::host_is_normalized(queries + b * dawn::EM))
+            return fail(DAWN_ERR_NOT_NORMALIZED, "Search vector is not normalized");
+    DAWN_TRY(set_device(idx));
+    for (size_t b0 = 0; b0 < B; b0 += kMaxBatch) {
+        const size_t nb = std::min(kMaxBatch, B - b0);
+        char* hp = (char*)idx->h_pinned;
+        float* hq = (float*)hp;
+        uint64_t* hl = (uint64_t*)(hp + kMaxBatch * dawn::EM * 4);
+        float* hd = (float*)(hp + kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8));
+        uint32_t* hf = (uint32_t*)(hp + kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8 + DAWN_MAX_K * 4));
+        uint32_t* hflag = hf + kMaxBatch;
+        std::memcpy(hq, queries + b0 * dawn::EM, nb * dawn::EM * sizeof(float));
+        DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, hq, nb * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+        idx->n_searches += nb;
+        DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, idx->d_labels, idx->d_dist, idx->d_found, idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(hl, idx->d_labels, nb * count * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(hd, idx->d_dist, nb * count * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(hf, idx->d_found, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(hflag, idx->d_flags, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+        DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+        std::memcpy(labels + b0 * count, hl, nb * count * sizeof(uint64_t));
+        std::memcpy(distances + b0 * count, hd, nb * count * sizeof(float));
+        for (size_t b = 0; b < nb; ++b) {
+            found[b0 + b] = hf[b];
+            if (hflag[b] != dawn::FLAG_OK) idx->n_fallbacks++;
+        }
+    }
+    return DAWN_OK;
+}
+
+int dawn_index_search(dawn_index* idx, const float* query, size_t count, uint64_t* labels, float* distances,
+                      size_t* found) {
+    return dawn_index_search_batch(idx, query, 1, count, labels, distances, found);
+}
+
+int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const uint64_t* d_in_labels,
+                           const float* d_in_distances, const uint32_t* d_in_found, uint64_t* d_labels,
+                           float* d_distances, uint32_t* d_found, void* stream) {
+    if (!d_in_labels || !d_in_distances || !d_in_found || !d_labels || !d_distances || !d_found)
+        return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (G == 0 || count == 0 || G * count > 512) return fail(DAWN_ERR_UNSUPPORTED, "G*count must be 1..512");
+    DAWN_TRY(dawn::require_device(device));
+    DAWN_HIP_TRY(hipSetDevice(device));
+    if (B == 0) return DAWN_OK;
+    dawn::launch_shard_merge(G, B, count, d_in_labels, d_in_distances, d_in_found, d_labels, d_distances, d_found,
+                             (hipStream_t)stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    return DAWN_OK;
+}
+
+int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    if (n == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_room(idx, n));
+    const size_t chunk = 1u << 22;  // 4M rows per generator launch (16 MiB of row lengths)
+    float* d_len = nullptr;
+    DAWN_HIP_TRY(hipMalloc((void**)&d_len, std::min(n, chunk) * sizeof(float)));
+    for (size_t o = 0; o < n; o += chunk) {
+        const size_t m = std::min(chunk, n - o);
+        dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, idx->d_x + (idx->size + o) * dawn::EM, d_len, idx->stream);
+        dawn::launch_iota_u64(idx->d_ids + idx->size + o, first_id + o, (uint32_t)m, idx->stream);
+    }
+    hipError_t e = hipStreamSynchronize(idx->stream);
+    (void)hipFree(d_len);
+    if (e != hipSuccess) return fail(DAWN_ERR_HIP, "fill_synthetic: %s", hipGetErrorString(e));
+    idx->size += n;
+    return DAWN_OK;
+}
+
+int dawn_index_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    if (first + n > idx->size) return fail(DAWN_ERR_INVALID_ARG, "rows [%zu, %zu) out of range (size %zu)", first, first + n, idx->size);
+    if (n == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    if (out_rows) DAWN_HIP_TRY(hipMemcpy(out_rows, idx->d_x + first * dawn::EM, n * dawn::EM * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_ids) DAWN_HIP_TRY(hipMemcpy(out_ids, idx->d_ids + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return DAWN_OK;
+}
+
+// File layout: "DAWNIDX1" | u32 dims | u32 dtype | u64 n | ids[n] u64 | rows[n][384] f32 (little endian)
+int dawn_index_save(dawn_index* idx, const char* path) {
+    if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    DAWN_TRY(set_device(idx));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(DAWN_ERR_IO, "cannot open %s for writing", path);
+    const uint32_t dims = DAWN_EM_LEN, dtype = DAWN_DTYPE_F32;
+    const uint64_t n = idx->size;
+    bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(&dims, 4, 1, f) == 1 &&
+              std::fwrite(&dtype, 4, 1, f) == 1 && std::fwrite(&n, 8, 1, f) == 1;
+    const size_t chunk = 1u << 16;
+    std::vector<char> buf(chunk * dawn::EM * sizeof(float));
+    for (size_t o = 0; ok && o < n; o += chunk) {
+        const size_t m = std::min<size_t>(chunk, n - o);
+        if (hipMemcpy(buf.data(), idx->d_ids + o, m * 8, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        else ok = std::fwrite(buf.data(), 8, m, f) == m;
+    }
+    for (size_t o = 0; ok && o < n; o += chunk) {
+        const size_t m = std::min<size_t>(chunk, n - o);
+        if (hipMemcpy(buf.data(), idx->d_x + o * dawn::EM, m * dawn::EM * 4, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        else ok = std::fwrite(buf.data(), dawn::EM * 4, m, f) == m;
+    }
+    if (std::fclose(f) != 0) ok = false;
+    if (!ok) return fail(DAWN_ERR_IO, "writing %s failed", path);
+    return DAWN_OK;
+}
+
+int dawn_index_load(dawn_index* idx, const char* path) {
+    if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    DAWN_TRY(set_device(idx));
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(DAWN_ERR_IO, "cannot open %s", path);
+    char magic[8];
+    uint32_t dims = 0, dtype = 0;
+    uint64_t n = 0;
+    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kMagic, 8) != 0 || std::fread(&dims, 4, 1, f) != 1 ||
+        std::fread(&dtype, 4, 1, f) != 1 || std::fread(&n, 8, 1, f) != 1 || dims != DAWN_EM_LEN ||
+        dtype != DAWN_DTYPE_F32) {
+        std::fclose(f);
+        return fail(DAWN_ERR_IO, "%s is not a dawn index file", path);
+    }
+    std::vector<uint64_t> ids(n);
+    if (n && std::fread(ids.data(), 8, n, f) != n) {
+        std::fclose(f);
+        return fail(DAWN_ERR_IO, "%s: truncated id table", path);
+    }
+    idx->size = 0;  // load replaces the contents (usearch load semantics)
+    const size_t chunk = 1u << 16;
+    std::vector<float> buf(chunk * dawn::EM);
+    for (size_t o = 0; o < n; o += chunk) {
+        const size_t m = std::min<size_t>(chunk, n - o);
+        if (std::fread(buf.data(), dawn::EM * 4, m, f) != m) {
+            std::fclose(f);
+            return fail(DAWN_ERR_IO, "%s: truncated row data", path);
+        }
+        int rc = dawn_index_add_batch(idx, m, ids.data() + o, buf.data());
+        if (rc != DAWN_OK) {
+            std::fclose(f);
+            return rc;
+        }
+    }
+    std::fclose(f);
+    return DAWN_OK;
+}
+
+// src/index/warc.rs:35-43 PageEntry (repr(C)): u64 url_pos, u64 title_pos, f32 vector[384], u64 url_len,
+// u64 title_len = 1568 bytes; read as examples_old/document_embeddings.rs:60-71 does.
+int dawn_index_load_page_entries(dawn_index* idx, const char* emb_path, uint64_t first_id) {
+    if (!idx || !emb_path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    FILE* f = std::fopen(emb_path, "rb");
+    if (!f) return fail(DAWN_ERR_IO, "cannot open %s", emb_path);
+    constexpr size_t REC = 1568, OFF = 16;
+    const size_t chunk = 1u << 14;
+    std::vector<unsigned char> raw(chunk * REC);
+    std::vector<float> rows(chunk * dawn::EM);
+    std::vector<uint64_t> ids(chunk);
+    uint64_t next = first_id;
+    for (;;) {
+        const size_t m = std::fread(raw.data(), REC, chunk, f);  // entries() = len / size_of::<PageEntry>()
+        if (m == 0) break;
+        for (size_t i = 0; i < m; ++i) {
+            std::memcpy(rows.data() + i * dawn::EM, raw.data() + i * REC + OFF, dawn::EM * 4);
+            ids[i] = next++;
+        }
+        int rc = dawn_index_add_batch(idx, m, ids.data(), rows.data());
+        if (rc != DAWN_OK) {
+            std::fclose(f);
+            return rc;
+        }
+    }
+    std::fclose(f);
+    return DAWN_OK;
+}
+
+int dawn_index_profile_enable(dawn_index* idx, int enable) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    idx->profiling = enable != 0;
+    idx->events_used = 0;
+    return DAWN_OK;
+}
+
+int dawn_index_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms) {
+    if (!idx || !launches || !total_ms) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    DAWN_TRY(set_device(idx));
+    DAWN_HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0;
+    for (size_t i = 0; i < idx->events_used; ++i) {
+        float ms = 0.f;
+        DAWN_HIP_TRY(hipEventElapsedTime(&ms, idx->events[i].first, idx->events[i].second));
+        sum += ms;
+    }
+    *launches = idx->events_used;
+    *total_ms = sum;
+    idx->events_used = 0;
+    return DAWN_OK;
+}
+
+int dawn_index_stats(dawn_index* idx, uint64_t* searches, uint64_t* fallbacks) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    if (searches) *searches = idx->n_searches;
+    if (fallbacks) *fallbacks = idx->n_fallbacks;
+    return DAWN_OK;
+}
+
+int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
+    if (!idx || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    const std::string n(name);
+    if (n == "force_fallback") {
+        idx->force_fallback = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "scan_blocks") {
+        if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "scan_blocks out of range");
+        idx->geom.blocks = (int)value;
+        idx->ws_B = 0;  // candidate buffers are sized by the grid
+        return DAWN_OK;
+    }
+    if (n == "scan_threads") {
+        if (value != 256 && value != 512 && value != 1024) return fail(DAWN_ERR_INVALID_ARG, "scan_threads must be 256/512/1024");
+        idx->geom.threads = (int)value;
+        return DAWN_OK;
+    }
+    return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
+}
+
+}  // extern "C"

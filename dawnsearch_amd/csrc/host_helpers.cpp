@@ -1,0 +1,186 @@
+// host_helpers.cpp — host-side pieces of the C ABI: error text, device probing, and the
+// bit-compatible restatements of src/search/vector.rs and src/search/best_results.rs that the
+// reference's callers use right next to the index (normalisation gate, i24 wire codec, local+remote
+// result merge).  Compiled with -ffp-contract=off: Rust never fuses a*b+c.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace dawn {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int require_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(DAWN_ERR_NO_DEVICE, "no usable HIP device (%s); libdawn_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(DAWN_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    return DAWN_OK;
+}
+
+// vector.rs:181-192
+bool host_is_normalized(const float* v) {
+    float s = 0.0f;
+    for (int i = 0; i < DAWN_EM_LEN; ++i) {
+        const float d = v[i] - 0.0f;
+        s += d * d;
+    }
+    const float l = std::sqrt(s);
+    if (!std::isfinite(l)) return false;
+    return l > 1.0f - 0.01f && l < 1.0f + 0.01f;
+}
+
+}  // namespace dawn
+
+using dawn::fail;
+
+extern "C" {
+
+const char* dawn_last_error(void) { return dawn::last_error().c_str(); }
+
+int dawn_version(void) { return 100; }  // 0.1.0
+
+int dawn_device_count(int* count) {
+    if (!count) return fail(DAWN_ERR_INVALID_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(DAWN_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return DAWN_OK;
+}
+
+// ---- src/search/vector.rs --------------------------------------------------------------------
+
+int dawn_vec_is_normalized(const float* v) { return (v && dawn::host_is_normalized(v)) ? 1 : 0; }
+
+// vector.rs:194-197
+void dawn_vec_normalize(float* v, size_t n) {
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) s += v[i] * v[i];
+    const float len = std::sqrt(s);
+    for (size_t i = 0; i < n; ++i) v[i] /= len;
+}
+
+// vector.rs:74-86: (((x as f64 + 1.0) / 2.0) * I24_MAX as f64) as i32 -> 3 little-endian bytes
+void dawn_vec_to24(const float* v, uint8_t* out) {
+    for (int i = 0; i < DAWN_EM_LEN; ++i) {
+        const double t = (((double)v[i] + 1.0) / 2.0) * (double)0x7FFFFF;
+        int32_t iv;
+        if (t != t) iv = 0;  // Rust float->int `as`: NaN -> 0, saturating
+        else if (t >= 2147483647.0) iv = INT32_MAX;
+        else if (t <= -2147483648.0) iv = INT32_MIN;
+        else iv = (int32_t)t;
+        out[i * 3 + 0] = (uint8_t)(iv & 0xFF);
+        out[i * 3 + 1] = (uint8_t)((iv >> 8) & 0xFF);
+        out[i * 3 + 2] = (uint8_t)((iv >> 16) & 0xFF);
+    }
+}
+
+// vector.rs:57-72 (the `v |= 0xFF` "sign extend" of the low byte is reproduced as written)
+int dawn_vec_from24(const uint8_t* in, float* out) {
+    for (int i = 0; i < DAWN_EM_LEN; ++i) {
+        int32_t v = 0;
+        v |= (int32_t)in[i * 3];
+        v |= ((int32_t)in[i * 3 + 1]) << 8;
+        v |= ((int32_t)in[i * 3 + 2]) << 16;
+        if (in[i * 3 + 2] & 0x80) v |= 0xFF;
+        out[i] = (float)((double)v / (double)0x7FFFFF * 2.0 - 1.0);
+    }
+    if (!dawn::host_is_normalized(out)) return fail(DAWN_ERR_NOT_NORMALIZED, "Embedding is not normalized");
+    return DAWN_OK;
+}
+
+// ---- src/search/best_results.rs ----------------------------------------------------------------
+
+struct dawn_best_results {
+    struct Node {
+        size_t id;
+        float distance;
+    };
+    std::vector<Node> results;
+    size_t worst_result_index = 0;
+    float worst_distance = 0.0f;  // T::zero() until full (:40)
+    size_t size = 0;
+
+    bool contains_id(size_t id) const {  // :67-69
+        for (const Node& n : results)
+            if (n.id == id) return true;
+        return false;
+    }
+    void update_worst() {  // :97-107
+        worst_result_index = 0;
+        worst_distance = results[0].distance;
+        for (size_t i = 1; i < results.size(); ++i) {
+            if (results[i].distance > worst_distance) {
+                worst_distance = results[i].distance;
+                worst_result_index = i;
+            }
+        }
+    }
+};
+
+int dawn_best_new(size_t size, dawn_best_results** out) {
+    if (!out) return fail(DAWN_ERR_INVALID_ARG, "out is NULL");
+    auto* b = new dawn_best_results();
+    b->size = size;
+    b->results.reserve(size);
+    *out = b;
+    return DAWN_OK;
+}
+
+void dawn_best_free(dawn_best_results* b) { delete b; }
+
+int dawn_best_insert(dawn_best_results* b, size_t id, float distance) {  // :44-65
+    if (b->results.size() < b->size) {
+        if (b->contains_id(id)) return 0;
+        b->results.push_back({id, distance});
+        if (b->results.size() == b->size) b->update_worst();
+        return 1;
+    }
+    if (distance < b->worst_distance) {
+        if (b->contains_id(id)) return 0;
+        b->results[b->worst_result_index] = {id, distance};
+        b->update_worst();
+        return 1;
+    }
+    return 0;
+}
+
+void dawn_best_sort(dawn_best_results* b) {  // :71-79, stable like Vec::sort_by
+    if (b->results.empty()) return;
+    for (size_t i = 1; i < b->results.size(); ++i) {
+        auto t = b->results[i];
+        size_t j = i;
+        while (j > 0 && b->results[j - 1].distance > t.distance) {
+            b->results[j] = b->results[j - 1];
+            --j;
+        }
+        b->results[j] = t;
+    }
+    b->worst_result_index = b->results.size() - 1;
+    b->worst_distance = b->results.back().distance;
+}
+
+float dawn_best_worst_distance(const dawn_best_results* b) { return b->worst_distance; }
+size_t dawn_best_len(const dawn_best_results* b) { return b->results.size(); }
+
+int dawn_best_get(const dawn_best_results* b, size_t i, size_t* id, float* distance) {
+    if (i >= b->results.size()) return fail(DAWN_ERR_INVALID_ARG, "index %zu out of range", i);
+    if (id) *id = b->results[i].id;
+    if (distance) *distance = b->results[i].distance;
+    return DAWN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,607 @@
+// scan_kernels.hip — brute-force cosine scan + wavefront top-k for gfx950 (MI355X).
+//
+// Replaces the vector-index search the reference delegates to usearch (src/search/search_provider.rs:214)
+// with the EXACT computation that search approximates: distance = 1 - sum(q_i*x_i)
+// (src/search/vector.rs:128-134), ascending, ties -> earlier-added row.
+//
+// Structure:
+//   1. scan_filter_kernel   HBM-bound stream over the packed [N][384] f32 index.  Coalesced 16-B/lane
+//                           non-temporal loads, 2 rows per 3 wave-loads, DPP wave reduction, per-wave
+//                           sorted top-64 list held one entry per lane (insertion only on a threshold
+//                           hit), per-block bitonic merge.  Scores here are f32 in a tree order.
+//   2. merge_rescore_kernel merges the per-block lists, recomputes the 64 survivors' distances in the
+//                           reference's sequential un-fused f32 order (bit-for-bit), sorts by
+//                           (distance, row), and certifies that no row outside the shortlist can reach
+//                           the top-k (rigorous bound FILTER_EPS_F32).
+//   3. scan_exact_kernel / merge_exact_kernel: the always-exact (slower, lane-per-row) pass, run only for
+//                           queries whose certificate failed (predicated on a device flag: no host
+//                           round trip).
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf, and
+// the exact paths use separate multiply and add as the reference (Rust) does.
+#include "kernels.hpp"
+
+namespace dawn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NEG_INF (-__builtin_inff())
+#define POS_INF (__builtin_inff())
+constexpr uint32_t NO_POS = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------------------
+// wave-level primitives (64-wide wavefront)
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                                 BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes; the total is valid in lane 63 (rows 3's lanes).  6 DPP adds, no LDS.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_mov<0xB1, 0xf, 0xf, true>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, 0xf, true>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf, 0xf, true>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf, 0xf, true>(v);   // row_mirror       -> every lane of a 16-row holds the row sum
+    v += dpp_mov<0x142, 0xa, 0xf, false>(v);  // row_bcast15 into rows 1,3
+    v += dpp_mov<0x143, 0xc, 0xf, false>(v);  // row_bcast31 into rows 2,3 -> row 3 holds the total
+    return v;
+}
+
+__device__ __forceinline__ float read_lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// (score desc, row asc) strict order; fillers are (-inf, NO_POS).
+__device__ __forceinline__ bool better(float s, uint32_t p, float s2, uint32_t p2) {
+    return s > s2 || (s == s2 && p < p2);
+}
+
+// Insert a wave-uniform candidate into the wave's descending list (one entry per lane).
+__device__ __forceinline__ void wave_insert(float& ls, uint32_t& lp, float s, uint32_t p, int lane) {
+    const bool ahead = better(ls, lp, s, p);
+    const int pos = __popcll(__ballot(ahead));
+    const float ps = __shfl_up(ls, 1);
+    const uint32_t pp = __shfl_up(lp, 1);
+    if (lane > pos) {
+        ls = ps;
+        lp = pp;
+    } else if (lane == pos) {
+        ls = s;
+        lp = p;
+    }
+}
+
+// Merge another descending list (given REVERSED: lane i holds other[63-i]) into mine; result = top 64 of
+// the union, descending.  Bitonic half-cleaner + 6 compare-exchange stages.
+__device__ __forceinline__ void merge64(float& s, uint32_t& p, float os_rev, uint32_t op_rev, int lane) {
+    if (better(os_rev, op_rev, s, p)) {
+        s = os_rev;
+        p = op_rev;
+    }
+#pragma unroll
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        const float s2 = __shfl_xor(s, stride);
+        const uint32_t p2 = __shfl_xor(p, stride);
+        const bool lower = (lane & stride) == 0;
+        const bool other_better = better(s2, p2, s, p);
+        if (lower == other_better) {
+            s = s2;
+            p = p2;
+        }
+    }
+}
+
+// Block-level tree merge of per-wave lists through LDS; result in wave 0.  nwaves is a power of two.
+__device__ __forceinline__ void block_merge(float& s, uint32_t& p, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST],
+                                            int wave, int lane, int nwaves) {
+    for (int stride = nwaves >> 1; stride >= 1; stride >>= 1) {
+        if (wave >= stride && wave < 2 * stride) {
+            sh_s[wave][lane] = s;
+            sh_p[wave][lane] = p;
+        }
+        __syncthreads();
+        if (wave < stride) {
+            const float os = sh_s[wave + stride][63 - lane];
+            const uint32_t op = sh_p[wave + stride][63 - lane];
+            merge64(s, p, os, op, lane);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float dot4_fma(const f32x4& a, const f32x4& b, float acc) {
+    acc = __builtin_fmaf(a.x, b.x, acc);
+    acc = __builtin_fmaf(a.y, b.y, acc);
+    acc = __builtin_fmaf(a.z, b.z, acc);
+    acc = __builtin_fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ f32x4 nt_load(const f32x4* p) { return __builtin_nontemporal_load(p); }
+
+// ------------------------------------------------------------------------------------------------
+// 1. filter scan
+// ------------------------------------------------------------------------------------------------
+// Work unit of a wave: a "pair" = 2 consecutive rows = 3072 contiguous bytes = 3 wave-wide 16-B loads.
+//   load 0: row 0, f32x4 chunks 0..63         load 1: lanes 0..31 -> row 0 chunks 64..95,
+//   load 2: row 1, chunks 32..95                        lanes 32..63 -> row 1 chunks 0..31
+// A wave handles U pairs per iteration (U*3 KiB in flight) and strides over the index with all other
+// waves of the grid, so that at any moment the chip reads one contiguous window of HBM.
+template <int QB, int U>
+__global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+                                                           const float* __restrict__ q,
+                                                           float* __restrict__ out_s,
+                                                           uint32_t* __restrict__ out_p, uint32_t q_stride_lists) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * nwaves + wave;
+    const uint32_t total_waves = gridDim.x * nwaves;
+    const uint32_t n_pairs = (n_rows + 1u) >> 1;
+    const uint32_t n_chunks = (n_pairs + U - 1) / U;
+
+    f32x4 qa[QB], qb[QB], qc[QB];
+    float ls[QB], tau[QB];
+    uint32_t lp[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const f32x4* qq = reinterpret_cast<const f32x4*>(q + b * EM);
+        qa[b] = qq[lane];
+        qb[b] = qq[lane < 32 ? 64 + lane : lane - 32];
+        qc[b] = qq[32 + lane];
+        ls[b] = NEG_INF;
+        lp[b] = NO_POS;
+        tau[b] = NEG_INF;
+    }
+    const bool lo_half = lane < 32;
+
+    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
+        const f32x4* p = x + (size_t)c * (U * 192) + lane;
+        f32x4 v[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u][0] = nt_load(p + u * 192);
+            v[u][1] = nt_load(p + u * 192 + 64);
+            v[u][2] = nt_load(p + u * 192 + 128);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r0 = (c * U + u) * 2u;
+            const uint32_t r1 = r0 + 1u;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const float d1 = dot4_fma(v[u][1], qb[b], 0.f);
+                float p0 = dot4_fma(v[u][0], qa[b], lo_half ? d1 : 0.f);
+                float p1 = dot4_fma(v[u][2], qc[b], lo_half ? 0.f : d1);
+                float s0 = read_lane63(wave_sum_lane63(p0));
+                float s1 = read_lane63(wave_sum_lane63(p1));
+                // rows past the end (padding) and non-finite garbage never enter a list
+                s0 = (r0 < n_rows && s0 == s0) ? s0 : NEG_INF;
+                s1 = (r1 < n_rows && s1 == s1) ? s1 : NEG_INF;
+                if (s0 > tau[b]) {
+                    wave_insert(ls[b], lp[b], s0, r0, lane);
+                    tau[b] = read_lane63(ls[b]);
+                }
+                if (s1 > tau[b]) {
+                    wave_insert(ls[b], lp[b], s1, r1, lane);
+                    tau[b] = read_lane63(ls[b]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+        if (wave == 0) {
+            const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
+            out_s[o] = ls[b];
+            out_p[o] = lp[b];
+        }
+    }
+}
+
+template <int QB>
+static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
+                             const ScanGeom& g, hipStream_t stream) {
+    constexpr int U = 2;
+    hipLaunchKernelGGL((scan_filter_kernel<QB, U>), dim3(g.blocks), dim3(g.threads), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, cand_s, cand_p, (uint32_t)g.blocks);
+}
+
+void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int B, float* cand_s, uint32_t* cand_p,
+                        const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    int b = 0;
+    const size_t per_q = (size_t)g.blocks * LIST;
+    while (b < B) {
+        const int rem = B - b;
+        const float* q = d_q + (size_t)b * EM;
+        float* cs = cand_s + (size_t)b * per_q;
+        uint32_t* cp = cand_p + (size_t)b * per_q;
+        if (rem >= 4) {
+            launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
+            b += 4;
+        } else if (rem >= 2) {
+            launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
+            b += 2;
+        } else {
+            launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
+            b += 1;
+        }
+    }
+    if (ev1) (void)hipEventRecord(ev1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. merge + exact rescore + certificate
+// ------------------------------------------------------------------------------------------------
+// Sequential, un-fused f32 dot in the reference's order (vector.rs:128-134): result += a[i]*b[i].
+__device__ __forceinline__ float exact_dot_seq(const float* __restrict__ qv, const f32x4* __restrict__ row) {
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int c = 0; c < ROW_F4; ++c) {
+        const f32x4 xv = row[c];
+        const f32x4 qq = reinterpret_cast<const f32x4*>(qv)[c];
+        acc = __fadd_rn(acc, __fmul_rn(qq.x, xv.x));
+        acc = __fadd_rn(acc, __fmul_rn(qq.y, xv.y));
+        acc = __fadd_rn(acc, __fmul_rn(qq.z, xv.z));
+        acc = __fadd_rn(acc, __fmul_rn(qq.w, xv.w));
+    }
+    return acc;
+}
+
+// (distance asc, row asc)
+__device__ __forceinline__ bool less_dp(float d, uint32_t p, float d2, uint32_t p2) {
+    return d < d2 || (d == d2 && p < p2);
+}
+
+// Full bitonic sort of one (d, p) per lane, ascending.
+__device__ __forceinline__ void sort64_asc(float& d, uint32_t& p, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            const float d2 = __shfl_xor(d, j);
+            const uint32_t p2 = __shfl_xor(p, j);
+            const bool asc = (lane & k2) == 0;
+            const bool lower = (lane & j) == 0;
+            const bool keep_small = (lower == asc);
+            const bool other_less = less_dp(d2, p2, d, p);
+            const bool other_greater = less_dp(d, p, d2, p2);
+            if (keep_small ? other_less : other_greater) {
+                d = d2;
+                p = p2;
+            }
+        }
+    }
+}
+
+// smallest float >= t (t finite, double)
+__device__ __forceinline__ float round_up_f32(double t) {
+    float f = (float)t;
+    if ((double)f < t) {
+        if (f == 0.0f) return 1.0e-45f;
+        int bits = __builtin_bit_cast(int, f);
+        bits += (f > 0.0f) ? 1 : -1;
+        f = __builtin_bit_cast(float, bits);
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(1024) void merge_rescore_kernel(
+    const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
+    const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
+    uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
+    uint32_t* __restrict__ out_flags, int force_fallback) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+
+    float s = NEG_INF;
+    uint32_t p = NO_POS;
+    const float* cs = cand_s + (size_t)b * n_lists * LIST;
+    const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
+    for (int l = wave; l < n_lists; l += nwaves) {
+        const float os = cs[(size_t)l * LIST + 63 - lane];
+        const uint32_t op = cp[(size_t)l * LIST + 63 - lane];
+        merge64(s, p, os, op, lane);
+    }
+    block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+    if (wave != 0) return;
+
+    // shortlist: 64 best rows by filter score.  m = the worst filter score that made it.
+    const float m = read_lane63(s);
+    const bool valid = p != NO_POS;
+    float d = POS_INF;
+    if (valid) {
+        const float dot = exact_dot_seq(q + (size_t)b * EM, x + (size_t)p * ROW_F4);
+        d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+    }
+    sort64_asc(d, p, lane);
+
+    const uint32_t found = n_rows < k ? n_rows : k;
+    uint32_t flag = FLAG_OK;
+    if (n_rows > LIST && found > 0) {
+        // Any row r outside the shortlist has filter score <= m, hence exact dot <= m + eps, hence
+        // distance fl(1 - dot_r) >= fl(1 - up(m + eps)) =: d_bound.  If d_bound > d_k (strictly, so that
+        // not even a tie on the rounded distance is possible) the exact top-k lies inside the shortlist.
+        const float t = round_up_f32((double)m + (double)FILTER_EPS_F32);
+        const float d_bound = __fsub_rn(1.0f, t);
+        const float dk = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
+        if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+    }
+    if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
+    if ((uint32_t)lane < found) {
+        out_labels[(size_t)b * k + lane] = ids[p];
+        out_dist[(size_t)b * k + lane] = d;
+    }
+    if (lane == 0) {
+        out_found[b] = found;
+        out_flags[b] = flag;
+    }
+}
+
+void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+                          const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
+                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(merge_rescore_kernel, dim3(B), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_x),
+                       d_ids, n_rows, d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags,
+                       force_fallback);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. exact fallback: lane-per-row, reference summation order, key = -distance
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_exact_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+                                                        const float* __restrict__ q,
+                                                        const uint32_t* __restrict__ flags,
+                                                        float* __restrict__ out_s, uint32_t* __restrict__ out_p,
+                                                        uint32_t n_lists) {
+    __shared__ float sh_s[4][LIST];
+    __shared__ uint32_t sh_p[4][LIST];
+    const int b = blockIdx.y;
+    if (flags[b] != FLAG_FALLBACK) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * nwaves + wave;
+    const uint32_t total_waves = gridDim.x * nwaves;
+    const float* qv = q + (size_t)b * EM;
+
+    float ls = NEG_INF, tau = NEG_INF;
+    uint32_t lp = NO_POS;
+    const uint32_t n_groups = (n_rows + 63u) >> 6;
+    for (uint32_t g = gwave; g < n_groups; g += total_waves) {
+        const uint32_t r = g * 64u + lane;
+        float key = NEG_INF;
+        if (r < n_rows) {
+            const float dot = exact_dot_seq(qv, x + (size_t)r * ROW_F4);
+            const float d = __fsub_rn(1.0f, dot);
+            key = (d == d) ? -d : NEG_INF;
+        }
+        // rows of this group arrive in ascending row order; insert the lanes that beat the threshold
+        unsigned long long hits = __ballot(key > tau);
+        while (hits) {
+            const int src = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
+            if (ks > tau) {
+                wave_insert(ls, lp, ks, g * 64u + (uint32_t)src, lane);
+                tau = read_lane63(ls);
+            }
+        }
+    }
+    block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
+    if (wave == 0) {
+        const size_t o = ((size_t)b * n_lists + blockIdx.x) * LIST + lane;
+        out_s[o] = ls;
+        out_p[o] = lp;
+    }
+}
+
+__global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __restrict__ ids, uint32_t n_rows,
+                                                          const uint32_t* __restrict__ flags,
+                                                          const float* __restrict__ cand_s,
+                                                          const uint32_t* __restrict__ cand_p, int n_lists,
+                                                          uint32_t k, uint64_t* __restrict__ out_labels,
+                                                          float* __restrict__ out_dist,
+                                                          uint32_t* __restrict__ out_found) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int b = blockIdx.x;
+    if (flags[b] != FLAG_FALLBACK) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    float s = NEG_INF;
+    uint32_t p = NO_POS;
+    const float* cs = cand_s + (size_t)b * n_lists * LIST;
+    const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
+    for (int l = wave; l < n_lists; l += nwaves) {
+        merge64(s, p, cs[(size_t)l * LIST + 63 - lane], cp[(size_t)l * LIST + 63 - lane], lane);
+    }
+    block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+    if (wave != 0) return;
+    const uint32_t found = n_rows < k ? n_rows : k;
+    if ((uint32_t)lane < found) {
+        out_labels[(size_t)b * k + lane] = ids[p];
+        out_dist[(size_t)b * k + lane] = -s;
+    }
+    if (lane == 0) out_found[b] = found;
+}
+
+void launch_scan_exact(const float* d_x, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
+                       float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_exact_kernel, dim3(n_lists, B), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, d_flags, cand_s, cand_p, (uint32_t)n_lists);
+}
+
+void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags, const float* cand_s,
+                        const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist,
+                        uint32_t* d_found, hipStream_t stream) {
+    hipLaunchKernelGGL(merge_exact_kernel, dim3(B), dim3(1024), 0, stream, d_ids, n_rows, d_flags, cand_s, cand_p,
+                       n_lists, k, d_labels, d_dist, d_found);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: stable G-way merge of per-shard (distance-ascending) results
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B, uint32_t k,
+                                                         const uint64_t* __restrict__ in_labels,
+                                                         const float* __restrict__ in_dist,
+                                                         const uint32_t* __restrict__ in_found,
+                                                         uint64_t* __restrict__ out_labels,
+                                                         float* __restrict__ out_dist,
+                                                         uint32_t* __restrict__ out_found) {
+    __shared__ float sh_d[512];
+    const uint32_t b = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    const uint32_t total = G * k;  // <= 512
+    uint32_t g = t / k, i = t % k;
+    float d = POS_INF;
+    uint64_t label = 0;
+    bool valid = false;
+    if (t < total) {
+        valid = i < in_found[(size_t)g * B + b];
+        if (valid) {
+            d = in_dist[((size_t)g * B + b) * k + i];
+            label = in_labels[((size_t)g * B + b) * k + i];
+        }
+    }
+    sh_d[t] = d;
+    __syncthreads();
+    if (valid) {
+        // rank = number of candidates ordered before (d, g, i); t = g*k+i is that lexicographic index
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < total; ++o) {
+            const float od = sh_d[o];
+            rank += (od < d || (od == d && o < t)) ? 1u : 0u;
+        }
+        if (rank < k) {
+            out_labels[(size_t)b * k + rank] = label;
+            out_dist[(size_t)b * k + rank] = d;
+        }
+    }
+    if (t == 0) {
+        uint32_t sum = 0;
+        for (uint32_t gg = 0; gg < G; ++gg) sum += in_found[(size_t)gg * B + b];
+        out_found[b] = sum < k ? sum : k;
+    }
+}
+
+void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
+                        const uint32_t* in_found, uint64_t* out_labels, float* out_dist, uint32_t* out_found,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(shard_merge_kernel, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
+                       (uint32_t)k, in_labels, in_dist, in_found, out_labels, out_dist, out_found);
+}
+
+// ------------------------------------------------------------------------------------------------
+// validation + synthetic generator
+// ------------------------------------------------------------------------------------------------
+// vector.rs:181-192: l = sqrt(sum((v_i - 0)^2)) sequential; finite and 0.99 < l < 1.01
+__global__ void validate_rows_kernel(const float* __restrict__ rows, uint32_t n, uint32_t* __restrict__ bad) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* v = rows + (size_t)r * EM;
+    float s = 0.0f;
+    for (int i = 0; i < EM; ++i) {
+        const float dlt = __fsub_rn(v[i], 0.0f);
+        s = __fadd_rn(s, __fmul_rn(dlt, dlt));
+    }
+    const float l = sqrtf(s);  // correctly rounded (HIP default)
+    const bool ok = __builtin_isfinite(l) && l > (1.0f - 0.01f) && l < (1.0f + 0.01f);
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(validate_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rows, n, d_bad_count);
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float synth_uniform(uint64_t key, uint64_t idx) {
+    const uint64_t h = splitmix64(key + idx * 0x9E3779B97F4A7C15ULL);
+    const int u = (int)(h >> 40);
+    const int nn = 2 * u + 1 - (1 << 24);
+    return __fmul_rn((float)nn, 1.0f / 16777216.0f);
+}
+
+// pass 1: per-row length, sequential sum of squares (vector.rs:195)
+__global__ void synth_len_kernel(uint64_t key, uint64_t first_row, uint32_t n, float* __restrict__ len) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t base = (first_row + r) * (uint64_t)EM;
+    float s = 0.0f;
+    for (int c = 0; c < EM; ++c) {
+        const float v = synth_uniform(key, base + c);
+        s = __fadd_rn(s, __fmul_rn(v, v));
+    }
+    len[r] = sqrtf(s);
+}
+
+// pass 2: coalesced write of v / len (vector.rs:196)
+__global__ void synth_write_kernel(uint64_t key, uint64_t first_row, uint32_t n, const float* __restrict__ len,
+                                   f32x4* __restrict__ out) {
+    const size_t total = (size_t)n * ROW_F4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / ROW_F4);
+        const uint32_t c = (uint32_t)(i % ROW_F4);
+        const uint64_t base = (first_row + r) * (uint64_t)EM + c * 4u;
+        const float l = len[r];
+        f32x4 v;
+        v.x = synth_uniform(key, base + 0) / l;
+        v.y = synth_uniform(key, base + 1) / l;
+        v.z = synth_uniform(key, base + 2) / l;
+        v.w = synth_uniform(key, base + 3) / l;
+        out[i] = v;
+    }
+}
+
+static uint64_t host_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_out, float* d_len,
+                       hipStream_t stream) {
+    if (n == 0) return;
+    const uint64_t key = host_splitmix64(seed);
+    hipLaunchKernelGGL(synth_len_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, first_row, n, d_len);
+    const size_t total = (size_t)n * ROW_F4;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(synth_write_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, key, first_row, n, d_len,
+                       reinterpret_cast<f32x4*>(d_out));
+}
+
+__global__ void iota_u64_kernel(uint64_t* out, uint64_t first, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first + i;
+}
+
+void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(iota_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_out, first, n);
+}
+
+}  // namespace dawn

@@ -1,0 +1,183 @@
+"""Thin Python handles over the dawn_index_* / dawn_best_* / dawn_vec_* C ABI (host-side plumbing for
+tests and bench.py; the Rust/C++ callers bind the same symbols directly — see INTEGRATION.md)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EM_LEN, MAX_K, check, lib
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class VectorIndex:
+    """usearch::ffi::Index replacement (search_provider.rs:102-284) living in HBM on one MI355X."""
+
+    def __init__(self, device: int = 0, dims: int = EM_LEN):
+        h = C.c_void_p()
+        check(lib.dawn_index_create(dims, _lib.DTYPE_F32, device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dawn_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- usearch surface ----------------------------------------------------------------------
+    def reserve(self, n: int):
+        check(lib.dawn_index_reserve(self._h, n))
+
+    def size(self) -> int:
+        return lib.dawn_index_size(self._h)
+
+    def capacity(self) -> int:
+        return lib.dawn_index_capacity(self._h)
+
+    def add(self, id_: int, v: np.ndarray):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert v.shape == (EM_LEN,)
+        check(lib.dawn_index_add(self._h, id_, _ptr(v)))
+
+    def add_batch(self, ids: np.ndarray, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        assert rows.ndim == 2 and rows.shape[1] == EM_LEN and ids.shape == (rows.shape[0],)
+        check(lib.dawn_index_add_batch(self._h, rows.shape[0], _ptr(ids), _ptr(rows)))
+
+    def search(self, q: np.ndarray, count: int):
+        """-> (labels u64[found], distances f32[found]) ascending by distance."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        labels = np.zeros(count, dtype=np.uint64)
+        dist = np.zeros(count, dtype=np.float32)
+        found = C.c_size_t(0)
+        check(lib.dawn_index_search(self._h, _ptr(q), count, _ptr(labels), _ptr(dist), C.byref(found)))
+        return labels[:found.value], dist[:found.value]
+
+    def search_batch(self, Q: np.ndarray, count: int):
+        """-> (labels [B,count], distances [B,count], found [B])."""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        B = Q.shape[0]
+        labels = np.zeros((B, count), dtype=np.uint64)
+        dist = np.zeros((B, count), dtype=np.float32)
+        found = np.zeros(B, dtype=np.uintp)
+        check(lib.dawn_index_search_batch(self._h, _ptr(Q), B, count, _ptr(labels), _ptr(dist), _ptr(found)))
+        return labels, dist, found.astype(np.int64)
+
+    def save(self, path: str):
+        check(lib.dawn_index_save(self._h, path.encode()))
+
+    def load(self, path: str):
+        check(lib.dawn_index_load(self._h, path.encode()))
+
+    def load_page_entries(self, emb_path: str, first_id: int = 1):
+        check(lib.dawn_index_load_page_entries(self._h, emb_path.encode(), first_id))
+
+    # -- device-resident forms (raw device pointers as ints) ------------------------------------
+    def search_device(self, d_queries: int, B: int, count: int, d_labels: int, d_distances: int, d_found: int,
+                      stream: int = 0):
+        check(lib.dawn_index_search_device(self._h, d_queries, B, count, d_labels, d_distances, d_found, stream))
+
+    # -- bench / test utilities -----------------------------------------------------------------
+    def fill_synthetic(self, seed: int, first_row: int, n: int, first_id: int = 1):
+        check(lib.dawn_index_fill_synthetic(self._h, seed, first_row, n, first_id))
+
+    def get_rows(self, first: int, n: int):
+        rows = np.empty((n, EM_LEN), dtype=np.float32)
+        ids = np.empty(n, dtype=np.uint64)
+        check(lib.dawn_index_get_rows(self._h, first, n, _ptr(rows), _ptr(ids)))
+        return rows, ids
+
+    def profile_enable(self, on: bool = True):
+        check(lib.dawn_index_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        n = C.c_uint64(0)
+        ms = C.c_double(0.0)
+        check(lib.dawn_index_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def stats(self):
+        s = C.c_uint64(0)
+        f = C.c_uint64(0)
+        check(lib.dawn_index_stats(self._h, C.byref(s), C.byref(f)))
+        return {"searches": s.value, "fallbacks": f.value}
+
+    def set_option(self, name: str, value: int):
+        check(lib.dawn_index_set_option(self._h, name.encode(), value))
+
+
+def topk_merge_device(device: int, G: int, B: int, count: int, d_in_labels: int, d_in_dist: int, d_in_found: int,
+                      d_labels: int, d_dist: int, d_found: int, stream: int = 0):
+    check(lib.dawn_topk_merge_device(device, G, B, count, d_in_labels, d_in_dist, d_in_found, d_labels, d_dist,
+                                     d_found, stream))
+
+
+# ---- src/search/vector.rs ---------------------------------------------------------------------
+
+def is_normalized(v: np.ndarray) -> bool:
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    assert v.shape == (EM_LEN,)
+    return bool(lib.dawn_vec_is_normalized(_ptr(v)))
+
+
+def normalize(v: np.ndarray) -> np.ndarray:
+    v = np.array(v, dtype=np.float32, copy=True)
+    lib.dawn_vec_normalize(_ptr(v), v.size)
+    return v
+
+
+def to24(v: np.ndarray) -> bytes:
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.zeros(EM_LEN * 3, dtype=np.uint8)
+    lib.dawn_vec_to24(_ptr(v), _ptr(out))
+    return out.tobytes()
+
+
+def from24(data: bytes) -> np.ndarray:
+    a = np.frombuffer(data, dtype=np.uint8).copy()
+    assert a.size == EM_LEN * 3
+    out = np.zeros(EM_LEN, dtype=np.float32)
+    check(lib.dawn_vec_from24(_ptr(a), _ptr(out)))
+    return out
+
+
+class BestResults:
+    """src/search/best_results.rs:28-107."""
+
+    def __init__(self, size: int):
+        h = C.c_void_p()
+        check(lib.dawn_best_new(size, C.byref(h)))
+        self._h = h
+
+    def insert(self, id_: int, distance: float) -> bool:
+        return bool(lib.dawn_best_insert(self._h, id_, float(np.float32(distance))))
+
+    def sort(self):
+        lib.dawn_best_sort(self._h)
+
+    def worst_distance(self) -> float:
+        return float(lib.dawn_best_worst_distance(self._h))
+
+    def __len__(self):
+        return lib.dawn_best_len(self._h)
+
+    def results(self):
+        out = []
+        for i in range(len(self)):
+            id_ = C.c_size_t(0)
+            d = C.c_float(0)
+            check(lib.dawn_best_get(self._h, i, C.byref(id_), C.byref(d)))
+            out.append((id_.value, d.value))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.dawn_best_free(self._h)
+            self._h = None

@@ -1,0 +1,163 @@
+/*
+ * dawn_hip.h — C ABI of libdawn_hip.so: the MI355X (gfx950) drop-in for DawnSearch's
+ * embed-and-rank hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * dawn-search/dawnsearch repository).  The reference reaches its vector index through
+ * `usearch::ffi` (cxx bridge) and its embedder through `EmbeddingProvider`; a Rust `extern "C"`
+ * block binding exactly these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns DAWN_OK (0) or a negative DAWN_ERR_* code; dawn_last_error() returns a
+ *     thread-local message for the last failing call on this thread (the reference surfaces
+ *     `cxx::Exception` / `anyhow::Error` text the same way);
+ *   - the caller owns every host buffer; the library owns all device memory;
+ *   - a handle is used from one thread at a time (the reference drives each provider from one
+ *     dedicated blocking thread: src/bin/dawnsearch.rs:63-66,76-78); distinct handles are independent;
+ *   - there is NO CPU fallback: without a usable HIP device every create call fails with
+ *     DAWN_ERR_NO_DEVICE.
+ */
+#ifndef DAWN_HIP_H
+#define DAWN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAWN_OK 0
+#define DAWN_ERR_INVALID_ARG (-1)
+#define DAWN_ERR_NOT_NORMALIZED (-2) /* "Search vector is not normalized" search_provider.rs:206-208,265-267 */
+#define DAWN_ERR_HIP (-3)
+#define DAWN_ERR_IO (-4)
+#define DAWN_ERR_NO_DEVICE (-5)
+#define DAWN_ERR_UNSUPPORTED (-6)
+#define DAWN_ERR_OOM (-7)
+
+#define DAWN_EM_LEN 384 /* src/search/vector.rs:26 */
+#define DAWN_MAX_K 64   /* largest `count` of one search call (reference uses 20: search_provider.rs:214) */
+
+#define DAWN_DTYPE_F32 0 /* ScalarKind::F32, search_provider.rs:38 */
+
+const char *dawn_last_error(void);
+int dawn_version(void);
+int dawn_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Vector index — replaces usearch::ffi::Index as used by src/search/search_provider.rs          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct dawn_index dawn_index;
+
+/* new_index(&INDEX_OPTIONS) — search_provider.rs:35-42,102.  dims must be 384, metric is IP
+ * (distance = 1 - sum(q_i*x_i)), dtype DAWN_DTYPE_F32.  `device` = HIP device ordinal. */
+int dawn_index_create(size_t dims, int dtype, int device, dawn_index **out);
+void dawn_index_destroy(dawn_index *idx); /* drop of UniquePtr<Index> */
+
+int dawn_index_reserve(dawn_index *idx, size_t capacity);      /* index.reserve(n)  :133,282 */
+size_t dawn_index_size(const dawn_index *idx);                 /* index.size()      :246,280 */
+size_t dawn_index_capacity(const dawn_index *idx);             /* index.capacity()  :280     */
+
+/* index.add(id, &q) :149,284.  v = 384 f32, must pass is_normalized (vector.rs:185-192) — the
+ * reference checks this right before every add (:147 bytes_to_embedding, :265-267). Grows like
+ * usearch after an explicit reserve; also grows on its own when full. */
+int dawn_index_add(dawn_index *idx, uint64_t id, const float *v);
+/* Bulk form of fill_index_from_db's loop (:135-150): n rows in one transfer + one validation kernel.
+ * On a non-normalised row nothing is added and DAWN_ERR_NOT_NORMALIZED is returned. */
+int dawn_index_add_batch(dawn_index *idx, size_t n, const uint64_t *ids, const float *v);
+
+/* index.search(query, count) -> Matches{labels, distances} :214.  Exact: distances[i] =
+ * 1.0f - (sequential f32 sum of q_i*x_i) bit-for-bit as vector.rs:128-134, ascending, ties ->
+ * earlier-added row.  *found = min(count, size).  count <= DAWN_MAX_K.  The query must pass
+ * is_normalized (:206-208). */
+int dawn_index_search(dawn_index *idx, const float *query, size_t count, uint64_t *labels,
+                      float *distances, size_t *found);
+/* B queries in one call (the reference has no batching; this is what a batching caller binds).
+ * queries [B][384]; labels/distances [B][count]; found [B]. */
+int dawn_index_search_batch(dawn_index *idx, const float *queries, size_t B, size_t count,
+                            uint64_t *labels, float *distances, size_t *found);
+
+int dawn_index_save(dawn_index *idx, const char *path); /* index.save(path) :117,178 */
+int dawn_index_load(dawn_index *idx, const char *path); /* index.load(path) :115     */
+/* Bulk-load the packed PageEntry file of src/index/warc.rs:35-43 (1568-B records, vector at
+ * byte 16) as read by examples_old/document_embeddings.rs:56-71; ids = first_id + record index. */
+int dawn_index_load_page_entries(dawn_index *idx, const char *emb_path, uint64_t first_id);
+
+/* ---- device-resident forms (queries/results already in HBM; nothing is synchronised) -------- */
+/* d_queries [B][384] f32, d_labels [B][count] u64, d_distances [B][count] f32, d_found [B] u32 are
+ * DEVICE pointers on the index's device; `stream` is a hipStream_t (NULL = default stream).
+ * Queries are assumed validated.  Launch-only: graph-capturable, no host round trip. */
+int dawn_index_search_device(dawn_index *idx, const float *d_queries, size_t B, size_t count,
+                             uint64_t *d_labels, float *d_distances, uint32_t *d_found, void *stream);
+/* Stable G-way merge of per-shard results (each ascending by (distance, shard-local order)) —
+ * the multi-GPU counterpart of search_service.rs:214-263 (BestResults merge of local + remote).
+ * d_in_labels/d_in_distances [G][B][count] (e.g. the all-gather output), d_in_found [G][B];
+ * outputs [B][count] / [B].  Ties -> lower shard, then shard-local order. */
+int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const uint64_t *d_in_labels,
+                           const float *d_in_distances, const uint32_t *d_in_found, uint64_t *d_labels,
+                           float *d_distances, uint32_t *d_found, void *stream);
+
+/* Fill rows [size, size+n) with the synthetic unit rows of DESIGN.md §5 (stream `seed`, rows
+ * first_row..) generated on the GPU, ids = first_id + i.  Bench / test input only. */
+int dawn_index_fill_synthetic(dawn_index *idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id);
+/* Copy rows [first, first+n) back to the host (tests: generator parity, save/load). */
+int dawn_index_get_rows(dawn_index *idx, size_t first, size_t n, float *out_rows, uint64_t *out_ids);
+
+/* Kernel-level timing of the dominant (scan) kernel with HIP events recorded on the launch
+ * stream.  enable=1 starts recording (at most 4096 launches are kept), read returns the launch
+ * count and summed milliseconds since the last reset and resets. Synchronises the device. */
+int dawn_index_profile_enable(dawn_index *idx, int enable);
+int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_ms);
+/* Counters: searches that needed the exact fallback pass (certificate failed). */
+int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
+/* Tuning knobs (tests sweep them; defaults are the tuned values): name in
+ * {"scan_blocks_per_cu","force_fallback"}. */
+int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/search/vector.rs + best_results.rs host helpers (bit-compatible with the reference)      */
+/* ------------------------------------------------------------------------------------------ */
+int dawn_vec_is_normalized(const float *v /*[384]*/);       /* vector.rs:185-192 -> 1/0 */
+void dawn_vec_normalize(float *v, size_t n);                /* vector.rs:194-197 */
+void dawn_vec_to24(const float *v, uint8_t *out /*[1152]*/);/* vector.rs:74-86  */
+int dawn_vec_from24(const uint8_t *in, float *out);         /* vector.rs:57-72; DAWN_ERR_NOT_NORMALIZED */
+
+typedef struct dawn_best_results dawn_best_results;          /* best_results.rs:28-33 */
+int dawn_best_new(size_t size, dawn_best_results **out);     /* :36-43 */
+void dawn_best_free(dawn_best_results *b);
+int dawn_best_insert(dawn_best_results *b, size_t id, float distance); /* :44-65 -> 1 inserted / 0 */
+void dawn_best_sort(dawn_best_results *b);                   /* :71-79 */
+float dawn_best_worst_distance(const dawn_best_results *b);  /* :93-95 (0 until full) */
+size_t dawn_best_len(const dawn_best_results *b);            /* :85-87 */
+int dawn_best_get(const dawn_best_results *b, size_t i, size_t *id, float *distance);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Embedder — replaces EmbeddingProvider (src/embedding/embedding_service.rs:49-139) minus the   */
+/* tokenizer: token ids cross the boundary.                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct dawn_embedder dawn_embedder;
+
+/* EmbeddingProvider::new (:55-95): weights from a safetensors file with the tensor names of
+ * src/embedding/model.rs:235-255,301-303,359-363,417,443-447 (optional "bert." prefix :543-547,
+ * LayerNorm gamma/beta fallback :210-222); config_json as model.rs:115-133 (NULL = all-MiniLM-L6-v2). */
+int dawn_embedder_create(const char *safetensors_path, const char *config_json_path, int device,
+                         dawn_embedder **out);
+void dawn_embedder_destroy(dawn_embedder *e);
+/* calculate_embedding (:97-139) for B token sequences packed back to back: token_ids[seq_offsets[B]],
+ * sequence b = token_ids[seq_offsets[b] .. seq_offsets[b+1]).  Every sequence gets its batch-1
+ * result (no padding tokens exist).  out [B][384] unit vectors. */
+int dawn_embedder_forward(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,
+                          int B, float *out);
+/* Device-resident form: d_token_ids/d_seq_offsets/d_out on the embedder's device. total_tokens and
+ * max_len are host-known launch geometry. */
+int dawn_embedder_forward_device(dawn_embedder *e, const uint32_t *d_token_ids, const int32_t *d_seq_offsets,
+                                 int B, int total_tokens, int max_len, float *d_out, void *stream);
+/* BertModel::forward hidden states (model.rs:565-570) for tests: out [total_tokens][384]. */
+int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,
+                                int B, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

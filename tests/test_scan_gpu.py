@@ -1,0 +1,224 @@
+"""GPU parity tests for the cosine scan + top-k (configs[1] of BASELINE.json and its edge cases).
+
+The HIP path (through the C ABI) is compared with the CPU oracle (oracle/dawn_oracle.c, a restatement of
+src/search/vector.rs:128-134 + exact top-k) on identical seeded inputs.  Bar: BIT-EXACT distances and
+identical label order — the library rescoring is done in the reference's summation order, so no
+tolerance is needed (north_star allows 1e-5; we assert 0).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+
+def _mk_index(dawn, n, seed=1, first_id=1):
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(seed, 0, n, first_id)
+    return idx
+
+
+def _assert_same(lab, dist, olab, odist):
+    assert len(lab) == len(olab)
+    assert np.array_equal(lab, olab), (lab, olab)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), (dist, odist)
+
+
+def test_generator_matches_oracle(dawn, oracle):
+    n = 3000
+    idx = _mk_index(dawn, n)
+    rows, ids = idx.get_rows(0, n)
+    ref = oracle.unit_rows(1, 0, n)
+    assert np.array_equal(rows.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(ids, np.arange(1, n + 1, dtype=np.uint64))
+    assert np.array_equal(rows.view(np.uint32), synth.unit_rows(1, 0, n).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 1000, 4097, 100_003])
+@pytest.mark.parametrize("k", [1, 10, 20, 64])
+def test_scan_matches_oracle_sizes(dawn, oracle, n, k):
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 3)
+    for q in Q:
+        lab, dist = idx.search(q, k)
+        olab, odist = oracle.scan_topk(x, ids, q, k)
+        assert len(lab) == min(k, n)
+        _assert_same(lab, dist, olab, odist)
+    assert idx.stats()["searches"] == 3
+
+
+def test_scan_1m_batch1_and_batch(dawn, oracle):
+    """configs[1]: 1M x 384 f32, batch=1 (and a small batch through the batched entry point)."""
+    n = 1_000_000
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 5), synth.planted_queries(1, [0, 12345, n - 1], 9)])
+    labels, dist, found = idx.search_batch(Q, 10)
+    for b, q in enumerate(Q):
+        olab, odist = oracle.scan_topk(x, ids, q, 10, threads=8)
+        assert found[b] == 10
+        _assert_same(labels[b], dist[b], olab, odist)
+    # planted queries: the planted row is the nearest neighbour
+    assert labels[5][0] == 1 and labels[6][0] == 12346 and labels[7][0] == n
+    lab1, d1 = idx.search(Q[0], 20)
+    olab, odist = oracle.scan_topk(x, ids, Q[0], 20, threads=8)
+    _assert_same(lab1, d1, olab, odist)
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_exact_fallback_path_agrees(dawn, oracle):
+    """Force the certificate to fail: the always-exact pass must give the same answer."""
+    n = 50_000
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 4)
+    want = [oracle.scan_topk(x, ids, q, 20) for q in Q]
+    idx.set_option("force_fallback", 1)
+    labels, dist, found = idx.search_batch(Q, 20)
+    for b in range(4):
+        _assert_same(labels[b], dist[b], *want[b])
+    assert idx.stats()["fallbacks"] == 4
+
+
+def test_duplicates_and_ties(dawn, oracle):
+    """Duplicate rows => equal distances => earlier-added row first (KAT from SURVEY §8c).
+    200 copies of the best row overflow the 64-entry shortlist band, so the certificate fails and the
+    exact pass decides — results must still equal the oracle."""
+    base = synth.unit_rows(1, 0, 500)
+    q = synth.planted_queries(1, [7], 3)[0]
+    rows = np.concatenate([base, np.repeat(base[7:8], 200, axis=0), base[:100]])
+    ids = np.arange(1000, 1000 + len(rows), dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids, rows)
+    lab, dist = idx.search(q, 20)
+    olab, odist = oracle.scan_topk(rows, ids, q, 20)
+    _assert_same(lab, dist, olab, odist)
+    assert lab[0] == 1007 and list(lab[1:5]) == [1500, 1501, 1502, 1503]
+    assert idx.stats()["fallbacks"] == 1
+    # few duplicates: stays on the fast path
+    rows2 = np.concatenate([base, base[7:8], base[7:8]])
+    ids2 = np.arange(1, len(rows2) + 1, dtype=np.uint64)
+    idx2 = dawn.VectorIndex(0)
+    idx2.add_batch(ids2, rows2)
+    lab, dist = idx2.search(q, 10)
+    _assert_same(lab, dist, *oracle.scan_topk(rows2, ids2, q, 10))
+    assert list(lab[:3]) == [8, 501, 502]
+    assert idx2.stats()["fallbacks"] == 0
+
+
+def test_known_answers(dawn):
+    """query = row => distance ~ 0 and rank 0; antipodal => 2; orthogonal => 1."""
+    e = np.zeros((4, 384), dtype=np.float32)
+    e[0, 0] = 1.0
+    e[1, 1] = 1.0
+    e[2, 0] = -1.0
+    e[3, 0] = 0.6
+    e[3, 1] = 0.8
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(np.array([10, 11, 12, 13], dtype=np.uint64), e)
+    lab, dist = idx.search(e[0], 4)
+    assert list(lab) == [10, 13, 11, 12]
+    assert dist[0] == 0.0 and dist[2] == 1.0 and dist[3] == 2.0
+    assert dist[1] == np.float32(1.0) - np.float32(0.6)
+
+
+def test_errors_and_empty(dawn):
+    idx = dawn.VectorIndex(0)
+    q = synth.unit_rows(2, 0, 1)[0]
+    lab, dist = idx.search(q, 10)  # empty index: found = 0
+    assert len(lab) == 0
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.search(q * 1.5, 10)
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.add(1, q * 0.5)
+    bad = synth.unit_rows(1, 0, 10)
+    bad[4] *= 2.0
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.add_batch(np.arange(10, dtype=np.uint64), bad)
+    assert idx.size() == 0  # nothing added on failure
+    nanq = q.copy()
+    nanq[3] = np.nan
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.search(nanq, 10)
+    with pytest.raises(dawn.DawnError):
+        idx.search(q, 65)
+    # boundary of the 0.01 tolerance (vector.rs:185-192)
+    assert dawn.is_normalized(q * np.float32(1.009))
+    assert not dawn.is_normalized(q * np.float32(1.011))
+
+
+def test_add_reserve_growth_and_save_load(dawn, oracle, tmp_path):
+    idx = dawn.VectorIndex(0)
+    rows = synth.unit_rows(5, 0, 3000)
+    assert idx.capacity() == 0
+    idx.reserve(10)
+    assert idx.capacity() == 10 and idx.size() == 0
+    for i in range(40):  # single adds across several growth steps (search_provider.rs:280-284)
+        if idx.size() == idx.capacity():
+            idx.reserve(idx.size() + 16)
+        idx.add(100 + i, rows[i])
+    idx.add_batch(np.arange(140, 140 + 2960, dtype=np.uint64), rows[40:])
+    assert idx.size() == 3000
+    got, ids = idx.get_rows(0, 3000)
+    assert np.array_equal(got, rows) and np.array_equal(ids, np.arange(100, 3100, dtype=np.uint64))
+    q = synth.unit_rows(2, 3, 1)[0]
+    want = oracle.scan_topk(rows, ids, q, 20)
+    _assert_same(*idx.search(q, 20), *want)
+    p = str(tmp_path / "index.dawn")
+    idx.save(p)
+    idx2 = dawn.VectorIndex(0)
+    idx2.load(p)
+    assert idx2.size() == 3000
+    _assert_same(*idx2.search(q, 20), *want)
+    with pytest.raises(dawn.DawnError):
+        idx2.load(str(tmp_path / "missing.dawn"))
+
+
+def test_page_entry_file_loader(dawn, oracle, tmp_path):
+    """Packed PageEntry records (src/index/warc.rs:35-43): 1568 B, vector at byte 16."""
+    n = 777
+    rows = synth.unit_rows(6, 0, n)
+    rec = np.zeros((n, 1568), dtype=np.uint8)
+    rec[:, :8] = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)  # url_pos
+    rec[:, 16:16 + 1536] = rows.view(np.uint8).reshape(n, 1536)
+    rec[:, 1552:1560] = 33  # url_len garbage
+    p = str(tmp_path / "x.warc.emb")
+    rec.tofile(p)
+    idx = dawn.VectorIndex(0)
+    idx.load_page_entries(p, first_id=1)
+    assert idx.size() == n
+    q = synth.unit_rows(2, 0, 1)[0]
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    _assert_same(*idx.search(q, 10), *oracle.scan_topk(rows, ids, q, 10))
+    # the reference's own brute-force loop (examples_old/search.rs:49-72) ranks by L2^2 = 2*(1-dot):
+    # same first hit
+    import ctypes
+    ent = np.zeros(10, dtype=np.uintp)
+    sc = np.zeros(10, dtype=np.float32)
+    m = oracle.lib().orc_scan_examples_old(rec.reshape(-1), n, q, ent, sc)
+    assert m == 10
+
+
+def test_search_provider_mirror(dawn, oracle):
+    sp = dawn.SearchProvider(0)
+    rows = synth.unit_rows(7, 0, 300)
+    for i, r in enumerate(rows):
+        sp.insert(dawn.ExtractedPage(url=f"http://x/{i}", title=f"t{i}", text=f"body {i}"), r)
+    sp.insert(dawn.ExtractedPage(url="http://x/5"), rows[5])  # duplicate URL: ignored (:254-263)
+    assert sp.page_count() == 300 and sp.index.size() == 300
+    q = synth.planted_queries(7, [42], 1)[0]
+    res = sp.search_embedding(q)
+    assert res.pages_searched == 300 and len(res.pages) == 20
+    assert res.pages[0].page_id == 43 and res.pages[0].url == "http://x/42"
+    olab, odist = oracle.scan_topk(rows, np.arange(1, 301, dtype=np.uint64), q, 20)
+    assert [p.page_id for p in res.pages] == [int(v) for v in olab]
+    assert np.array_equal(np.array([p.distance for p in res.pages], dtype=np.float32), odist)
+    like = sp.search_like(43)
+    assert like.pages[0].page_id == 43 and like.pages[0].distance < 0.001  # web.rs:339 "same page"
+    with pytest.raises(dawn.NotNormalizedError):
+        sp.search_embedding(q * 3)
