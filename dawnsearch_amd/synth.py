@@ -1,5 +1,5 @@
 """Synthetic data spec in numpy — deterministic, counter-based, bit-identical to the
-C oracle (`oracle/dawn_oracle.c: orc_synth_*`) and to the on-GPU generator (`csrc/synth.hip`).
+CPU checker's C implementation and to the on-GPU generator (`csrc/scan_kernels.hip: synth_*_kernel`).
 
 Nothing here restates reference behaviour; it only defines the seeded inputs that the parity tests
 and bench.py feed to both the HIP path and the oracle.
@@ -76,7 +76,7 @@ def planted_queries(index_seed: int, rows: np.ndarray, noise_seed: int, noise: f
     return normalize_rows(np.stack(out))
 
 
-# ---- synthetic all-MiniLM-L6-v2-shaped weights (same list as oracle/dawn_oracle.c: orc_bert_synth) ----
+# ---- synthetic all-MiniLM-L6-v2-shaped weights (tensor list documented in DESIGN.md §5) ----
 
 MINILM_CONFIG = dict(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12,
                      intermediate_size=1536, hidden_act="gelu", hidden_dropout_prob=0.1,
