@@ -62,7 +62,7 @@ def cpu_baseline(sample_rows: int, k: int, total_rows: int):
     t1 = time.time() - t0
     rows_per_s = nq * sample_rows / t1
     # all-cores variant (OpenMP) for reference
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 64)
     t0 = time.time()
     nq2 = 0
     while nq2 < 64 and (time.time() - t0 < 5.0 or nq2 < 2):
