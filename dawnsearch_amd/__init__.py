@@ -8,3 +8,4 @@ from ._lib import (DawnError, NotNormalizedError, EM_LEN, MAX_K, LIB_PATH, devic
 from .index import (VectorIndex, BestResults, is_normalized, normalize, to24, from24, topk_merge_device)  # noqa: F401
 from .search_provider import (SearchProvider, SearchResult, FoundPage, ExtractedPage, SearchStats,  # noqa: F401
                               search_remote_merge)
+from .embedding_provider import EmbeddingProvider, write_synthetic_model  # noqa: F401,E402

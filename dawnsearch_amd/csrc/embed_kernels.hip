@@ -1,2 +1,298 @@
-// embed_kernels.hip — MiniLM-L6-v2 forward kernels (placeholder translation unit; filled in below).
-#include "kernels.hpp"
+// embed_kernels.hip — all-MiniLM-L6-v2 forward for gfx950, f32 end to end.
+//
+// Restates BertModel::forward (src/embedding/model.rs:565-570) + the pool/normalise tail of
+// EmbeddingProvider::calculate_embedding (src/embedding/embedding_service.rs:124-136) on PACKED
+// variable-length sequences: token t of sequence b lives at row seq_offsets[b] + t, there are no padding
+// tokens, attention never crosses a sequence and the mean is over the sequence's own tokens — so every text
+// gets exactly its batch-1 result (the reference only ever embeds one text per call, :161-163).
+//
+//   embed_ln_kernel       word[id] + type[0] + pos[t]  -> LayerNorm            (model.rs:266-281, 86-104)
+//   gemm_nt_kernel<ACT>   Y = X·Wᵀ + b (+ tanh-GELU / ReLU), W stored [out,in] (model.rs:53-64, 28-37)
+//                         v_mfma_f32_32x32x2_f32: exact f32, k-ordered FMA chain
+//   attention_kernel      per (sequence, head): softmax(QKᵀ/√32)·V, no mask     (model.rs:325-347)
+//   add_ln_kernel         LayerNorm(dense_out + residual)                       (model.rs:374-379, 458-463)
+//   pool_norm_kernel      mean over the sequence's tokens, then x/√Σx²          (embedding_service.rs:126-136)
+#include "embed_kernels.hpp"
+
+namespace dawn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int H = 384;   // hidden_size
+constexpr int DH = 32;   // attention_head_size
+constexpr int NH = 12;   // num_attention_heads
+
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LayerNorm of one 384-wide row held as 6 values per lane (element d = lane + 64*i). model.rs:86-104:
+// mean = sum/H ; xc = x - mean ; var = sum(xc^2)/H (biased) ; xc / sqrt(var + eps) * gamma + beta
+__device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __restrict__ g,
+                                               const float* __restrict__ b, float eps, int lane,
+                                               float* __restrict__ out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += v[i];
+    const float inv_h = 1.0f / (float)H;  // candle: Tensor / f64 == affine(1/rhs, 0)
+    const float mean = wave_allreduce_sum(s) * inv_h;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float var = wave_allreduce_sum(q) * inv_h;
+    const float den = sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = lane + 64 * i;
+        out[d] = (v[i] / den) * g[d] + b[d];
+    }
+}
+
+// one wave per token
+__global__ __launch_bounds__(256) void embed_ln_kernel(const uint32_t* __restrict__ ids,
+                                                      const int* __restrict__ tok_pos, int T,
+                                                      const float* __restrict__ word,
+                                                      const float* __restrict__ pos,
+                                                      const float* __restrict__ type0,
+                                                      const float* __restrict__ g, const float* __restrict__ b,
+                                                      float eps, float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* we = word + (size_t)ids[t] * H;
+    const float* pe = pos + (size_t)tok_pos[t] * H;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = lane + 64 * i;
+        v[i] = (we[d] + type0[d]) + pe[d];  // model.rs:269-276 order
+    }
+    row_layer_norm(v, g, b, eps, lane, x + (size_t)t * H);
+}
+
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                    int T, const float* __restrict__ g,
+                                                    const float* __restrict__ b, float eps,
+                                                    float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = lane + 64 * i;
+        v[i] = a[(size_t)t * H + d] + r[(size_t)t * H + d];
+    }
+    row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y[M,N] = X[M,K] · W[N,K]ᵀ + bias (+ activation).  64x64 block tile, 4 waves of 32x32 (one
+// v_mfma_f32_32x32x2_f32 accumulator each), K-step 32, register-prefetched LDS staging.
+// N % 64 == 0 and K % 32 == 0 for every MiniLM shape (384, 1152, 1536).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) {  // candle gelu = tanh form (model.rs:31-35)
+        const float k = 0.7978845608028654f;
+        return 0.5f * v * (1.0f + tanhf(k * v * (1.0f + 0.044715f * v * v)));
+    }
+    if (act == 2) return v > 0.f ? v : 0.f;  // HiddenAct::Relu
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ Y,
+                                                     int M, int N, int K) {
+    __shared__ float As[64][33];
+    __shared__ float Bs[64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: rows lr, lr+32 ; cols lc..lc+3
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = lr + 32 * j;
+            const int m = m0 + r;
+            ra[j] = (m < M) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k0 + lc);
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = lr + 32 * j;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                As[r][lc + c] = ra[j][c];
+                Bs[r][lc + c] = rb[j][c];
+            }
+        }
+        __syncthreads();
+        if (k0 + 32 < K) gload(k0 + 32);
+        const int ar = wm + (lane & 31), br = wn + (lane & 31), kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            const float a = As[ar][kk + kh];
+            const float b = Bs[br][kk + kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int n = n0 + wn + (lane & 31);
+    const float bv = bias[n];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm + row;
+        if (m < M) Y[(size_t)m * N + n] = act_apply(acc[reg] + bv, ACT);
+    }
+}
+
+void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                    hipStream_t s) {
+    if (M <= 0) return;
+    dim3 grid(N / 64, (M + 63) / 64), block(256);
+    if (act == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, s, A, W, bias, Y, M, N, K);
+    else if (act == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, s, A, W, bias, Y, M, N, K);
+    else hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, block, 0, s, A, W, bias, Y, M, N, K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention: one block per (head, sequence); K and V of the head staged in LDS (S*256 B <= 128 KiB at
+// S = 512); one thread per query row, two passes over the keys (max, then exp/sum/PV) = the
+// max-subtract softmax of candle_nn::ops::softmax.  No mask inside a sequence; nothing outside it exists.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void attention_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+                                                       const int* __restrict__ seq_offsets,
+                                                       float* __restrict__ ctx /*[T][384]*/) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    float* Ks = sm;
+    float* Vs = sm + (size_t)S * DH;
+    for (int i = threadIdx.x; i < S * (DH / 4); i += blockDim.x) {
+        const int j = i >> 3, c = (i & 7) * 4;
+        const float* row = qkv + (size_t)(start + j) * (3 * H) + h * DH + c;
+        *reinterpret_cast<f32x4*>(Ks + j * DH + c) = *reinterpret_cast<const f32x4*>(row + H);
+        *reinterpret_cast<f32x4*>(Vs + j * DH + c) = *reinterpret_cast<const f32x4*>(row + 2 * H);
+    }
+    __syncthreads();
+    const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        float q[DH];
+        const float* qr = qkv + (size_t)(start + i) * (3 * H) + h * DH;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qr + d);
+            q[d] = t.x;
+            q[d + 1] = t.y;
+            q[d + 2] = t.z;
+            q[d + 3] = t.w;
+        }
+        float mx = -__builtin_inff();
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) s = __builtin_fmaf(q[d], Ks[j * DH + d], s);
+            s *= inv_scale;
+            mx = s > mx ? s : mx;
+        }
+        float sum = 0.f;
+        float acc[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) s = __builtin_fmaf(q[d], Ks[j * DH + d], s);
+            const float p = expf(s * inv_scale - mx);
+            sum += p;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(p, Vs[j * DH + d], acc[d]);
+        }
+        float* o = ctx + (size_t)(start + i) * H + h * DH;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) {
+            f32x4 t = {acc[d] / sum, acc[d + 1] / sum, acc[d + 2] / sum, acc[d + 3] / sum};
+            *reinterpret_cast<f32x4*>(o + d) = t;
+        }
+    }
+}
+
+// one block (384 threads) per sequence: mean over its tokens, then L2 normalise (vector.rs:194-197)
+__global__ __launch_bounds__(384) void pool_norm_kernel(const float* __restrict__ x, const int* __restrict__ seq_offsets,
+                                                       float* __restrict__ out) {
+    __shared__ float red[6];
+    const int b = blockIdx.x, d = threadIdx.x;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += x[(size_t)(start + t) * H + d];
+    const float m = s * (float)(1.0 / (double)S);  // sum(1) / (n_tokens as f64): affine(1/S, 0)
+    float sq = wave_allreduce_sum(m * m);
+    if ((d & 63) == 0) red[d >> 6] = sq;
+    __syncthreads();
+    const float tot = ((red[0] + red[1]) + (red[2] + red[3])) + (red[4] + red[5]);
+    out[(size_t)b * H + d] = m / sqrtf(tot);
+}
+
+void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
+                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, tok_pos, T, word, pos, type0, g, b,
+                       eps, x);
+}
+
+void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
+                   hipStream_t s) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out);
+}
+
+void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s) {
+    if (B <= 0) return;
+    const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
+    hipLaunchKernelGGL(attention_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
+}
+
+void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(384), 0, s, x, seq_offsets, out);
+}
+
+// token -> position-in-sequence (position_ids restart at 0 per sequence, model.rs:274)
+__global__ void tok_pos_kernel(const int* __restrict__ seq_offsets, int B, int* __restrict__ tok_pos) {
+    const int b = blockIdx.x;
+    const int start = seq_offsets[b], end = seq_offsets[b + 1];
+    for (int t = start + threadIdx.x; t < end; t += blockDim.x) tok_pos[t] = t - start;
+}
+
+void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(tok_pos_kernel, dim3(B), dim3(128), 0, s, seq_offsets, B, tok_pos);
+}
+
+int attention_set_max_lds() {
+    // S = 512 needs 128 KiB of dynamic LDS: raise the kernel's limit once
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 512 * DH * 2 * (int)sizeof(float));
+}
+
+}  // namespace dawn

@@ -1,0 +1,18 @@
+// embed_kernels.hpp — launchers of the MiniLM forward kernels (embed_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dawn {
+void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s);
+void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
+                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s);
+void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
+                   hipStream_t s);
+// Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.
+void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                    hipStream_t s);
+void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s);
+void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s);
+int attention_set_max_lds();
+}  // namespace dawn

@@ -1,14 +1,513 @@
-// embedder.cpp — dawn_embedder_* C ABI (src/embedding/embedding_service.rs:49-139).
+// embedder.cpp — dawn_embedder_* C ABI: the MI355X replacement of EmbeddingProvider
+// (src/embedding/embedding_service.rs:49-139) minus the tokenizer.
+//
+// create  = EmbeddingProvider::new (:55-95) without the hub download: read config.json + model.safetensors
+//           from disk, resolve the tensor names BertModel::load asks for (src/embedding/model.rs:235-255,
+//           301-303,359-363,417,443-447,510,538-546 incl. the "bert." prefix retry :543-547 and the
+//           LayerNorm gamma/beta fallback :210-222), upload to HBM.
+// forward = calculate_embedding (:97-139) for packed token-id sequences.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
 #include "common.hpp"
+#include "embed_kernels.hpp"
+
 using dawn::fail;
-struct dawn_embedder { int device; };
+
+namespace {
+
+// ---- minimal JSON (objects / arrays / strings / numbers / literals) — enough for safetensors headers
+// and HF config.json ----------------------------------------------------------------------------
+struct JVal {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const std::string& k) const {
+        for (auto& kv : obj)
+            if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p;
+    const char* end;
+    bool ok = true;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool lit(const char* s) {
+        size_t n = std::strlen(s);
+        if ((size_t)(end - p) >= n && std::memcmp(p, s, n) == 0) {
+            p += n;
+            return true;
+        }
+        return false;
+    }
+    std::string parse_string() {
+        std::string out;
+        if (p >= end || *p != '"') {
+            ok = false;
+            return out;
+        }
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u':  // keep BMP escapes as '?': names we care about are ASCII
+                        out += '?';
+                        p += std::min<ptrdiff_t>(4, end - p - 1);
+                        break;
+                    default: out += *p;
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) ok = false;
+        else ++p;
+        return out;
+    }
+    JVal parse() {
+        JVal v;
+        ws();
+        if (p >= end) {
+            ok = false;
+            return v;
+        }
+        if (*p == '{') {
+            v.kind = JVal::Obj;
+            ++p;
+            ws();
+            if (p < end && *p == '}') {
+                ++p;
+                return v;
+            }
+            while (ok) {
+                ws();
+                std::string k = parse_string();
+                ws();
+                if (p >= end || *p != ':') {
+                    ok = false;
+                    break;
+                }
+                ++p;
+                v.obj.emplace_back(k, parse());
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == '}') {
+                    ++p;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (*p == '[') {
+            v.kind = JVal::Arr;
+            ++p;
+            ws();
+            if (p < end && *p == ']') {
+                ++p;
+                return v;
+            }
+            while (ok) {
+                v.arr.push_back(parse());
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == ']') {
+                    ++p;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (*p == '"') {
+            v.kind = JVal::Str;
+            v.str = parse_string();
+        } else if (lit("true")) {
+            v.kind = JVal::Bool;
+            v.b = true;
+        } else if (lit("false")) {
+            v.kind = JVal::Bool;
+        } else if (lit("null")) {
+            v.kind = JVal::Null;
+        } else {
+            char* e = nullptr;
+            v.kind = JVal::Num;
+            v.num = std::strtod(p, &e);
+            if (e == p || e > end) ok = false;
+            else p = e;
+        }
+        return v;
+    }
+};
+
+bool read_file(const char* path, std::vector<char>& out) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (n < 0) {
+        std::fclose(f);
+        return false;
+    }
+    out.resize((size_t)n);
+    bool ok = n == 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok;
+}
+
+struct Config {  // model.rs:115-133 ; defaults = Config::_all_mini_lm_l6_v2 (:160-180)
+    int vocab_size = 30522, hidden_size = 384, num_hidden_layers = 6, num_attention_heads = 12;
+    int intermediate_size = 1536, max_position_embeddings = 512, type_vocab_size = 2;
+    int act = 1;  // 1 = gelu (tanh form), 2 = relu
+    double layer_norm_eps = 1e-12;
+    std::string model_type = "bert";
+};
+
+struct TensorRef {
+    std::vector<int64_t> shape;
+    size_t begin = 0, end = 0;
+};
+
+struct LayerW {
+    float *qkv_w, *qkv_b, *ao_w, *ao_b, *ao_g, *ao_beta, *i_w, *i_b, *o_w, *o_b, *o_g, *o_beta;
+};
+
+}  // namespace
+
+struct dawn_embedder {
+    int device = 0;
+    Config cfg;
+    hipStream_t stream = nullptr;
+    float* d_weights = nullptr;  // one block
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<LayerW> layers;
+    // workspaces (grown on demand)
+    int cap_T = 0, cap_B = 0;
+    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *attn = nullptr, *ff = nullptr;
+    uint32_t* d_ids = nullptr;
+    int *d_off = nullptr, *d_pos = nullptr;
+    float* d_out = nullptr;
+};
+
+namespace {
+
+int ensure_ws(dawn_embedder* e, int T, int B) {
+    if (T > e->cap_T) {
+        float** bufs[] = {&e->x, &e->qkv, &e->ctx, &e->tmp, &e->attn, &e->ff};
+        for (float** b : bufs)
+            if (*b) {
+                (void)hipFree(*b);
+                *b = nullptr;
+            }
+        if (e->d_ids) (void)hipFree(e->d_ids);
+        if (e->d_pos) (void)hipFree(e->d_pos);
+        e->d_ids = nullptr;
+        e->d_pos = nullptr;
+        e->cap_T = 0;
+        const int cap = std::max(T, 256);
+        const size_t H = e->cfg.hidden_size, I = e->cfg.intermediate_size;
+        DAWN_HIP_TRY(hipMalloc((void**)&e->x, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->qkv, cap * 3 * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->tmp, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->attn, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->ff, cap * I * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->d_ids, cap * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->d_pos, cap * sizeof(int)));
+        e->cap_T = cap;
+    }
+    if (B > e->cap_B) {
+        if (e->d_off) (void)hipFree(e->d_off);
+        if (e->d_out) (void)hipFree(e->d_out);
+        e->d_off = nullptr;
+        e->d_out = nullptr;
+        e->cap_B = 0;
+        const int cap = std::max(B, 64);
+        DAWN_HIP_TRY(hipMalloc((void**)&e->d_off, (cap + 1) * sizeof(int)));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->d_out, (size_t)cap * e->cfg.hidden_size * 4));
+        e->cap_B = cap;
+    }
+    return DAWN_OK;
+}
+
+// BertModel::forward on packed tokens already on the device; result (last hidden states) in e->x.
+void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, int B, int T, int max_len,
+                     hipStream_t s) {
+    const Config& c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    const float eps = (float)c.layer_norm_eps;
+    dawn::launch_tok_pos(d_off, B, e->d_pos, s);
+    dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s);
+    for (const LayerW& L : e->layers) {  // BertLayer::forward model.rs:487-498
+        dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s);          // :327-329 (Q|K|V fused)
+        dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s);                      // :331-346
+        dawn::launch_gemm_nt(e->ctx, L.ao_w, L.ao_b, e->tmp, T, H, H, 0, s);               // :376
+        dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s);          // :378
+        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s);             // :427-428
+        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp, T, H, I, 0, s);                  // :460
+        dawn::launch_add_ln(e->tmp, e->attn, T, L.o_g, L.o_beta, eps, e->x, s);            // :462
+    }
+}
+
+int check_sequences(const dawn_embedder* e, const uint32_t* ids, const int32_t* off, int B, int* T_out, int* max_len) {
+    if (off[0] != 0) return fail(DAWN_ERR_INVALID_ARG, "seq_offsets[0] must be 0");
+    int mx = 0;
+    for (int b = 0; b < B; ++b) {
+        const int len = off[b + 1] - off[b];
+        if (len < 1) return fail(DAWN_ERR_INVALID_ARG, "sequence %d is empty", b);
+        if (len > e->cfg.max_position_embeddings)
+            return fail(DAWN_ERR_INVALID_ARG, "sequence %d has %d tokens > max_position_embeddings %d", b, len,
+                        e->cfg.max_position_embeddings);
+        mx = std::max(mx, len);
+    }
+    const int T = off[B];
+    for (int t = 0; t < T; ++t)
+        if (ids[t] >= (uint32_t)e->cfg.vocab_size)
+            return fail(DAWN_ERR_INVALID_ARG, "token id %u at %d >= vocab_size %d", ids[t], t, e->cfg.vocab_size);
+    *T_out = T;
+    *max_len = mx;
+    return DAWN_OK;
+}
+
+int upload_inputs(dawn_embedder* e, const uint32_t* ids, const int32_t* off, int B, int T) {
+    DAWN_TRY(ensure_ws(e, T, B));
+    DAWN_HIP_TRY(hipMemcpyAsync(e->d_ids, ids, (size_t)T * 4, hipMemcpyHostToDevice, e->stream));
+    DAWN_HIP_TRY(hipMemcpyAsync(e->d_off, off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    return DAWN_OK;
+}
+
+}  // namespace
+
 extern "C" {
-int dawn_embedder_create(const char*, const char*, int, dawn_embedder** out) {
-    if (out) *out = nullptr;
-    return fail(DAWN_ERR_UNSUPPORTED, "embedder not built yet");
+
+int dawn_embedder_create(const char* safetensors_path, const char* config_json_path, int device,
+                         dawn_embedder** out) {
+    if (!out || !safetensors_path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    DAWN_TRY(dawn::require_device(device));
+    DAWN_HIP_TRY(hipSetDevice(device));
+
+    Config cfg;
+    if (config_json_path) {
+        std::vector<char> txt;
+        if (!read_file(config_json_path, txt)) return fail(DAWN_ERR_IO, "cannot read %s", config_json_path);
+        JParser jp{txt.data(), txt.data() + txt.size()};
+        JVal j = jp.parse();
+        if (!jp.ok || j.kind != JVal::Obj) return fail(DAWN_ERR_IO, "%s: invalid JSON", config_json_path);
+        auto geti = [&](const char* k, int& dst) {
+            if (const JVal* v = j.get(k))
+                if (v->kind == JVal::Num) dst = (int)v->num;
+        };
+        geti("vocab_size", cfg.vocab_size);
+        geti("hidden_size", cfg.hidden_size);
+        geti("num_hidden_layers", cfg.num_hidden_layers);
+        geti("num_attention_heads", cfg.num_attention_heads);
+        geti("intermediate_size", cfg.intermediate_size);
+        geti("max_position_embeddings", cfg.max_position_embeddings);
+        geti("type_vocab_size", cfg.type_vocab_size);
+        if (const JVal* v = j.get("layer_norm_eps"))
+            if (v->kind == JVal::Num) cfg.layer_norm_eps = v->num;
+        if (const JVal* v = j.get("model_type"))
+            if (v->kind == JVal::Str) cfg.model_type = v->str;
+        if (const JVal* v = j.get("hidden_act")) {  // enum HiddenAct { Gelu, Relu } model.rs:10-15
+            if (v->kind == JVal::Str && v->str == "gelu") cfg.act = 1;
+            else if (v->kind == JVal::Str && v->str == "relu") cfg.act = 2;
+            else return fail(DAWN_ERR_UNSUPPORTED, "hidden_act must be \"gelu\" or \"relu\"");
+        }
+    }
+    if (cfg.hidden_size != 384 || cfg.num_attention_heads != 12 || cfg.intermediate_size % 64 != 0 ||
+        cfg.num_hidden_layers < 1 || cfg.num_hidden_layers > 48 || cfg.max_position_embeddings > 512)
+        return fail(DAWN_ERR_UNSUPPORTED,
+                    "kernels are built for hidden 384 / 12 heads / intermediate %%64 / <=512 positions (all-MiniLM-L6-v2)");
+
+    std::vector<char> file;
+    if (!read_file(safetensors_path, file) || file.size() < 8) return fail(DAWN_ERR_IO, "cannot read %s", safetensors_path);
+    uint64_t hlen = 0;
+    std::memcpy(&hlen, file.data(), 8);
+    if (hlen > file.size() - 8) return fail(DAWN_ERR_IO, "%s: bad safetensors header length", safetensors_path);
+    JParser jp{file.data() + 8, file.data() + 8 + hlen};
+    JVal hdr = jp.parse();
+    if (!jp.ok || hdr.kind != JVal::Obj) return fail(DAWN_ERR_IO, "%s: invalid safetensors header", safetensors_path);
+    const char* data = file.data() + 8 + hlen;
+    const size_t data_len = file.size() - 8 - hlen;
+    std::map<std::string, TensorRef> tensors;
+    for (auto& kv : hdr.obj) {
+        if (kv.first == "__metadata__") continue;
+        const JVal* dt = kv.second.get("dtype");
+        const JVal* sh = kv.second.get("shape");
+        const JVal* off = kv.second.get("data_offsets");
+        if (!dt || !sh || !off || off->arr.size() != 2) return fail(DAWN_ERR_IO, "tensor %s: malformed entry", kv.first.c_str());
+        if (dt->str != "F32") continue;  // DTYPE = F32 (model.rs:8); other dtypes are not used by this model
+        TensorRef t;
+        for (auto& d : sh->arr) t.shape.push_back((int64_t)d.num);
+        t.begin = (size_t)off->arr[0].num;
+        t.end = (size_t)off->arr[1].num;
+        if (t.end > data_len || t.begin > t.end) return fail(DAWN_ERR_IO, "tensor %s: data out of range", kv.first.c_str());
+        tensors[kv.first] = t;
+    }
+
+    // name resolution: plain, then "{model_type}." prefix (model.rs:538-556)
+    std::string prefix;
+    auto has = [&](const std::string& n) { return tensors.count(n) != 0; };
+    if (!has("embeddings.word_embeddings.weight")) {
+        prefix = cfg.model_type + ".";
+        if (!has(prefix + "embeddings.word_embeddings.weight"))
+            return fail(DAWN_ERR_IO, "cannot find tensor embeddings.word_embeddings.weight (also tried prefix %s)", prefix.c_str());
+    }
+    const int H = cfg.hidden_size, I = cfg.intermediate_size, NL = cfg.num_hidden_layers;
+    size_t total = (size_t)cfg.vocab_size * H + (size_t)cfg.max_position_embeddings * H + (size_t)cfg.type_vocab_size * H + 2 * H;
+    total += (size_t)NL * ((size_t)3 * H * H + 3 * H + (size_t)H * H + H + 2 * H + (size_t)I * H + I + (size_t)H * I + H + 2 * H);
+    std::vector<float> host(total);
+    size_t cur = 0;
+    std::string err;
+    auto take = [&](const std::string& name, std::vector<int64_t> shape, const std::string& alt = "") -> size_t {
+        std::string full = prefix + name;
+        auto it = tensors.find(full);
+        if (it == tensors.end() && !alt.empty()) it = tensors.find(prefix + alt);
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        const size_t at = cur;
+        cur += n;
+        if (it == tensors.end()) {
+            if (err.empty()) err = "cannot find tensor " + full;
+            return at;
+        }
+        if (it->second.shape != shape || it->second.end - it->second.begin != n * 4) {
+            if (err.empty()) err = "shape mismatch for tensor " + full;
+            return at;
+        }
+        std::memcpy(host.data() + at, data + it->second.begin, n * 4);
+        return at;
+    };
+    auto ln = [&](const std::string& base, size_t& g, size_t& b) {  // weight/bias, fallback gamma/beta (:210-222)
+        g = take(base + ".weight", {H}, base + ".gamma");
+        b = take(base + ".bias", {H}, base + ".beta");
+    };
+    struct LOff {
+        size_t qw, kw, vw, qb, kb, vb, aow, aob, aog, aobeta, iw, ib, ow, ob, og, obeta;
+    };
+    size_t o_word = take("embeddings.word_embeddings.weight", {cfg.vocab_size, H});
+    size_t o_pos = take("embeddings.position_embeddings.weight", {cfg.max_position_embeddings, H});
+    size_t o_type = take("embeddings.token_type_embeddings.weight", {cfg.type_vocab_size, H});
+    size_t o_eg, o_eb;
+    ln("embeddings.LayerNorm", o_eg, o_eb);
+    std::vector<LOff> lo(NL);
+    for (int L = 0; L < NL; ++L) {
+        const std::string p = "encoder.layer." + std::to_string(L) + ".";
+        // Q|K|V weights and biases are laid out back to back so one GEMM produces [T][1152]
+        lo[L].qw = take(p + "attention.self.query.weight", {H, H});
+        lo[L].kw = take(p + "attention.self.key.weight", {H, H});
+        lo[L].vw = take(p + "attention.self.value.weight", {H, H});
+        lo[L].qb = take(p + "attention.self.query.bias", {H});
+        lo[L].kb = take(p + "attention.self.key.bias", {H});
+        lo[L].vb = take(p + "attention.self.value.bias", {H});
+        lo[L].aow = take(p + "attention.output.dense.weight", {H, H});
+        lo[L].aob = take(p + "attention.output.dense.bias", {H});
+        ln(p + "attention.output.LayerNorm", lo[L].aog, lo[L].aobeta);
+        lo[L].iw = take(p + "intermediate.dense.weight", {I, H});
+        lo[L].ib = take(p + "intermediate.dense.bias", {I});
+        lo[L].ow = take(p + "output.dense.weight", {H, I});
+        lo[L].ob = take(p + "output.dense.bias", {H});
+        ln(p + "output.LayerNorm", lo[L].og, lo[L].obeta);
+    }
+    if (!err.empty()) return fail(DAWN_ERR_IO, "%s: %s", safetensors_path, err.c_str());
+
+    auto* e = new dawn_embedder();
+    e->device = device;
+    e->cfg = cfg;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&e->d_weights, total * 4) != hipSuccess ||
+        hipMemcpy(e->d_weights, host.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        dawn_embedder_destroy(e);
+        return fail(DAWN_ERR_OOM, "uploading %zu weight bytes failed", total * 4);
+    }
+    (void)dawn::attention_set_max_lds();
+    float* W = e->d_weights;
+    e->word = W + o_word;
+    e->pos = W + o_pos;
+    e->type0 = W + o_type;  // token_type_ids are all zero (embedding_service.rs:123): row 0
+    e->emb_g = W + o_eg;
+    e->emb_b = W + o_eb;
+    for (int L = 0; L < NL; ++L)
+        e->layers.push_back({W + lo[L].qw, W + lo[L].qb, W + lo[L].aow, W + lo[L].aob, W + lo[L].aog, W + lo[L].aobeta,
+                             W + lo[L].iw, W + lo[L].ib, W + lo[L].ow, W + lo[L].ob, W + lo[L].og, W + lo[L].obeta});
+    *out = e;
+    return DAWN_OK;
 }
-void dawn_embedder_destroy(dawn_embedder* e) { delete e; }
-int dawn_embedder_forward(dawn_embedder*, const uint32_t*, const int32_t*, int, float*) { return fail(DAWN_ERR_UNSUPPORTED, "embedder not built yet"); }
-int dawn_embedder_forward_device(dawn_embedder*, const uint32_t*, const int32_t*, int, int, int, float*, void*) { return fail(DAWN_ERR_UNSUPPORTED, "embedder not built yet"); }
-int dawn_embedder_hidden_states(dawn_embedder*, const uint32_t*, const int32_t*, int, float*) { return fail(DAWN_ERR_UNSUPPORTED, "embedder not built yet"); }
+
+void dawn_embedder_destroy(dawn_embedder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* ptrs[] = {e->d_weights, e->x, e->qkv, e->ctx, e->tmp, e->attn, e->ff, e->d_ids, e->d_off, e->d_pos, e->d_out};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
 }
+
+int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, const int32_t* d_seq_offsets, int B,
+                                 int total_tokens, int max_len, float* d_out, void* stream) {
+    if (!e || !d_token_ids || !d_seq_offsets || !d_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0 || total_tokens <= 0) return DAWN_OK;
+    if (max_len < 1 || max_len > e->cfg.max_position_embeddings) return fail(DAWN_ERR_INVALID_ARG, "max_len out of range");
+    DAWN_HIP_TRY(hipSetDevice(e->device));
+    DAWN_TRY(ensure_ws(e, total_tokens, B));
+    hipStream_t s = (hipStream_t)stream;
+    encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s);
+    dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);  // embedding_service.rs:126-136
+    DAWN_HIP_TRY(hipGetLastError());
+    return DAWN_OK;
+}
+
+int dawn_embedder_forward(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B, float* out) {
+    if (!e || !token_ids || !seq_offsets || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0) return DAWN_OK;
+    int T = 0, max_len = 0;
+    DAWN_TRY(check_sequences(e, token_ids, seq_offsets, B, &T, &max_len));
+    DAWN_HIP_TRY(hipSetDevice(e->device));
+    DAWN_TRY(upload_inputs(e, token_ids, seq_offsets, B, T));
+    DAWN_TRY(dawn_embedder_forward_device(e, e->d_ids, e->d_off, B, T, max_len, e->d_out, e->stream));
+    DAWN_HIP_TRY(hipMemcpyAsync(out, e->d_out, (size_t)B * e->cfg.hidden_size * 4, hipMemcpyDeviceToHost, e->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(e->stream));
+    return DAWN_OK;
+}
+
+int dawn_embedder_hidden_states(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B,
+                                float* out) {
+    if (!e || !token_ids || !seq_offsets || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0) return DAWN_OK;
+    int T = 0, max_len = 0;
+    DAWN_TRY(check_sequences(e, token_ids, seq_offsets, B, &T, &max_len));
+    DAWN_HIP_TRY(hipSetDevice(e->device));
+    DAWN_TRY(upload_inputs(e, token_ids, seq_offsets, B, T));
+    encoder_forward(e, e->d_ids, e->d_off, B, T, max_len, e->stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    DAWN_HIP_TRY(hipMemcpyAsync(out, e->x, (size_t)T * e->cfg.hidden_size * 4, hipMemcpyDeviceToHost, e->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(e->stream));
+    return DAWN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""GPU parity tests for the MiniLM-L6-v2 forward (configs[2] embed leg).
+
+HIP path (dawn_embedder_* through the C ABI) vs the CPU oracle (oracle/dawn_oracle.c restating
+src/embedding/model.rs + embedding_service.rs:124-136) and vs the committed golden vectors (HF transformers,
+tests/golden/minilm_seed3.npz).  Tolerance (north_star): unit-vector components within 1e-5 f32; hidden states
+(|x| = O(1) after LayerNorm) within 5e-5.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_EMB = 1e-5
+TOL_HID = 5e-5
+
+
+@pytest.fixture(scope="module")
+def provider(dawn, tmp_path_factory):
+    d = tmp_path_factory.mktemp("model")
+    st, cj = dawn.write_synthetic_model(str(d), seed=3)
+    ep = dawn.EmbeddingProvider(st, cj, 0)
+    yield ep
+    ep.close()
+
+
+def test_golden_vectors(provider):
+    g = np.load(os.path.join(GOLD, "minilm_seed3.npz"))
+    offs, toks = g["seq_offsets"], g["token_ids"]
+    seqs = [toks[offs[b]:offs[b + 1]] for b in range(len(offs) - 1)]
+    emb = provider.calculate_embedding(seqs)  # one packed batch, mixed lengths 4..128
+    assert emb.shape == (len(seqs), 384)
+    assert np.abs(emb - g["embeddings"]).max() < TOL_EMB
+    assert np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-6
+    hs = provider.hidden_states([seqs[0]])[0]
+    assert np.abs(hs - g["hidden_states_seq0"]).max() < TOL_HID
+
+
+def test_batch_equals_batch1_and_oracle(provider, oracle):
+    """Every text gets its batch-1 result, whatever it is batched with."""
+    sb = oracle.SynthBert(3)
+    seqs = synth.token_sequences(21, 9, 2, 40) + [np.array([101, 102], dtype=np.uint32)]
+    batch = provider.calculate_embedding(seqs)
+    for i, s in enumerate(seqs):
+        single = provider.calculate_embedding([s])[0]
+        assert np.array_equal(single, batch[i])  # bitwise: same kernels, same per-sequence arithmetic
+        ref = sb.embed(s)
+        assert np.abs(batch[i] - ref).max() < TOL_EMB
+    hs = provider.hidden_states(seqs[:3])
+    for s, h in zip(seqs[:3], hs):
+        assert np.abs(h - sb.forward(s)).max() < TOL_HID
+
+
+def test_long_sequences_and_limits(provider, oracle, dawn):
+    sb = oracle.SynthBert(3)
+    s512 = synth.token_sequences(5, 1, 512, 512)[0]
+    assert len(s512) == 512
+    e = provider.calculate_embedding([s512, s512[:200]])
+    assert np.abs(e[0] - sb.embed(s512)).max() < TOL_EMB
+    assert np.abs(e[1] - sb.embed(s512[:200])).max() < TOL_EMB
+    with pytest.raises(dawn.DawnError):
+        provider.calculate_embedding([np.zeros(513, dtype=np.uint32)])  # > max_position_embeddings
+    with pytest.raises(dawn.DawnError):
+        provider.calculate_embedding([np.array([101, 40000, 102], dtype=np.uint32)])  # id >= vocab
+    with pytest.raises(dawn.DawnError):
+        provider.calculate_embedding([np.zeros(0, dtype=np.uint32)])
+
+
+def test_weight_name_variants(dawn, oracle, tmp_path):
+    """'bert.' prefix retry (model.rs:543-547) and LayerNorm gamma/beta fallback (:210-222)."""
+    s = synth.token_sequences(3, 1, 12, 12)
+    want = oracle.SynthBert(3).embed(s[0])
+    for prefix, gb in (("bert.", False), ("", True)):
+        st, cj = dawn.write_synthetic_model(str(tmp_path / f"m{len(prefix)}{gb}"), seed=3, prefix=prefix, gamma_beta=gb)
+        ep = dawn.EmbeddingProvider(st, cj, 0)
+        assert np.abs(ep.calculate_embedding(s)[0] - want).max() < TOL_EMB
+        ep.close()
+    with pytest.raises(dawn.DawnError):
+        dawn.EmbeddingProvider(str(tmp_path / "nope.safetensors"), None, 0)
+    cfg = dict(synth.MINILM_CONFIG, hidden_size=768)
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(cfg))
+    with pytest.raises(dawn.DawnError):
+        dawn.EmbeddingProvider(st, str(bad), 0)
+
+
+def test_embed_then_rank_end_to_end(provider, dawn, oracle):
+    """configs[0]/[2] plumbing: pages embedded by the HIP forward, indexed, text query ranked — vs the
+    oracle doing the same on the CPU (oracle embed -> oracle scan)."""
+    pages = synth.token_sequences(31, 300, 8, 48)
+    emb = provider.calculate_embedding(pages)
+    ids = np.arange(1, len(pages) + 1, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids, emb)
+    qs = [pages[17][:9], pages[201]]
+    qe = provider.calculate_embedding(qs)
+    lab, dist, found = idx.search_batch(qe, 10)
+    for b in range(2):
+        ol, od = oracle.scan_topk(emb, ids, qe[b], 10)
+        assert np.array_equal(lab[b], ol) and np.array_equal(dist[b], od)
+    assert lab[1][0] == 202 and dist[1][0] < 1e-6
+    # full-CPU chain agrees on the ranking where score gaps exceed the embedding tolerance
+    sb = oracle.SynthBert(3)
+    cpu_emb = np.stack([sb.embed(p) for p in pages[:60]])
+    cl, cd = oracle.scan_topk(cpu_emb, ids[:60], sb.embed(qs[0]), 5)
+    idx2 = dawn.VectorIndex(0)
+    idx2.add_batch(ids[:60], emb[:60])
+    gl, gd = idx2.search(qe[0], 5)
+    assert np.abs(gd - cd).max() < 1e-5
+    gaps = np.diff(cd)
+    if gaps.min() > 1e-4:
+        assert np.array_equal(gl, cl)
