@@ -114,9 +114,9 @@ def main():
         d_dist = torch.zeros((Bq, k), dtype=torch.float32, device=dev)
         d_found = torch.zeros((Bq,), dtype=torch.int32, device=dev)
         if world > 1:
-            g_lab = torch.zeros((world, Bq, k), dtype=torch.int64, device=dev)
-            g_dist = torch.zeros((world, Bq, k), dtype=torch.float32, device=dev)
-            g_found = torch.zeros((world, Bq), dtype=torch.int32, device=dev)
+            g_lab = torch.zeros((world * Bq, k), dtype=torch.int64, device=dev)
+            g_dist = torch.zeros((world * Bq, k), dtype=torch.float32, device=dev)
+            g_found = torch.zeros((world * Bq,), dtype=torch.int32, device=dev)
             o_lab = torch.zeros_like(d_lab)
             o_dist = torch.zeros_like(d_dist)
             o_found = torch.zeros_like(d_found)

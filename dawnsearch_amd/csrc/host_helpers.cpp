@@ -2,6 +2,7 @@
 // bit-compatible restatements of src/search/vector.rs and src/search/best_results.rs that the
 // reference's callers use right next to the index (normalisation gate, i24 wire codec, local+remote
 // result merge).  Compiled with -ffp-contract=off: Rust never fuses a*b+c.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -99,6 +100,37 @@ int dawn_vec_from24(const uint8_t* in, float* out) {
         out[i] = (float)((double)v / (double)0x7FFFFF * 2.0 - 1.0);
     }
     if (!dawn::host_is_normalized(out)) return fail(DAWN_ERR_NOT_NORMALIZED, "Embedding is not normalized");
+    return DAWN_OK;
+}
+
+// Stable G-way merge of per-shard ascending lists: order by (distance, shard, position-in-shard).
+int dawn_topk_merge_host(size_t G, size_t B, size_t count, const uint64_t* in_labels, const float* in_distances,
+                         const uint32_t* in_found, uint64_t* labels, float* distances, uint32_t* found) {
+    if (!in_labels || !in_distances || !in_found || !labels || !distances || !found)
+        return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    std::vector<size_t> cur(G);
+    for (size_t b = 0; b < B; ++b) {
+        std::fill(cur.begin(), cur.end(), 0);
+        size_t n = 0;
+        while (n < count) {
+            size_t best = G;
+            float bd = 0.f;
+            for (size_t g = 0; g < G; ++g) {
+                if (cur[g] >= in_found[g * B + b]) continue;
+                const float d = in_distances[(g * B + b) * count + cur[g]];
+                if (best == G || d < bd) {  // strict: ties stay with the lower shard
+                    best = g;
+                    bd = d;
+                }
+            }
+            if (best == G) break;
+            labels[b * count + n] = in_labels[(best * B + b) * count + cur[best]];
+            distances[b * count + n] = bd;
+            ++cur[best];
+            ++n;
+        }
+        found[b] = (uint32_t)n;
+    }
     return DAWN_OK;
 }
 

@@ -98,6 +98,11 @@ int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const u
                            const float *d_in_distances, const uint32_t *d_in_found, uint64_t *d_labels,
                            float *d_distances, uint32_t *d_found, void *stream);
 
+/* Host form of the same stable merge (host pointers; used where the lists already sit in host memory,
+ * e.g. the reference's own local+remote merge point, and by the CPU/gloo tests of the sharded path). */
+int dawn_topk_merge_host(size_t G, size_t B, size_t count, const uint64_t *in_labels, const float *in_distances,
+                         const uint32_t *in_found, uint64_t *labels, float *distances, uint32_t *found);
+
 /* Fill rows [size, size+n) with the synthetic unit rows of DESIGN.md §5 (stream `seed`, rows
  * first_row..) generated on the GPU, ids = first_id + i.  Bench / test input only. */
 int dawn_index_fill_synthetic(dawn_index *idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id);
