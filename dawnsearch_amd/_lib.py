@@ -30,6 +30,14 @@ class NotNormalizedError(DawnError):
 
 
 def _load() -> C.CDLL:
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's); whichever is mapped first serves both, and torch reports "No HIP GPUs are available" when the
+    # system copy got in first.  torch is this package's plumbing for streams / torch.distributed, so when it is
+    # installed let it map its runtime before libdawn_hip.so resolves the SONAME.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent: libdawn_hip.so uses the system ROCm runtime
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. dawnsearch_amd has no fallback path; "

@@ -39,6 +39,9 @@ struct dawn_index {
     float* d_cand_s = nullptr;
     uint32_t* d_cand_p = nullptr;
     uint32_t* d_flags = nullptr;
+    int* d_gtau = nullptr;
+    int mfma_blocks = 256;   // one 4-wave block per CU
+    int mfma_min_batch = 9;  // B >= this goes to the matrix-core filter
     // host-API staging
     float* d_q = nullptr;
     uint64_t* d_labels = nullptr;
@@ -111,14 +114,18 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     if (idx->d_cand_s) (void)hipFree(idx->d_cand_s);
     if (idx->d_cand_p) (void)hipFree(idx->d_cand_p);
     if (idx->d_flags) (void)hipFree(idx->d_flags);
+    if (idx->d_gtau) (void)hipFree(idx->d_gtau);
     idx->d_cand_s = nullptr;
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
+    idx->d_gtau = nullptr;
     idx->ws_B = 0;
-    const size_t n = B * (size_t)idx->geom.blocks * dawn::LIST;
+    const size_t lists = std::max<size_t>(idx->geom.blocks, B >= (size_t)idx->mfma_min_batch ? idx->mfma_blocks * 4 : 0);
+    const size_t n = B * lists * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_gtau, (B + 128) * sizeof(int)));
     idx->ws_B = B;
     return DAWN_OK;
 }
@@ -140,9 +147,19 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
         idx->events_used++;
     }
     const uint32_t n = (uint32_t)idx->size;
-    dawn::launch_scan_filter(idx->d_x, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
-    dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
-                               (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, stream);
+    if ((int)B >= idx->mfma_min_batch) {
+        dawn::launch_fill_i32(idx->d_gtau, INT32_MIN, (uint32_t)(B + 128), stream);
+        dawn::launch_scan_mfma(idx->d_x, n, d_q, (int)B, idx->d_gtau, idx->d_cand_s, idx->d_cand_p, idx->mfma_blocks,
+                               stream, e0, e1);
+        dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
+                                   idx->mfma_blocks * 4, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                                   idx->force_fallback, dawn::FILTER_EPS_MFMA, idx->d_gtau, stream);
+    } else {
+        dawn::launch_scan_filter(idx->d_x, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
+        dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
+                                   idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                                   idx->force_fallback, dawn::FILTER_EPS_F32, nullptr, stream);
+    }
     dawn::launch_scan_exact(idx->d_x, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
                             stream);
     dawn::launch_merge_exact(idx->d_ids, n, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
@@ -167,6 +184,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount * 2;  // 2 x 16 waves per CU = full occupancy
+    if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete idx;
@@ -195,7 +213,7 @@ void dawn_index_destroy(dawn_index* idx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->d_q,
+    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->d_gtau, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -486,6 +504,18 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "scan_blocks out of range");
         idx->geom.blocks = (int)value;
         idx->ws_B = 0;  // candidate buffers are sized by the grid
+        return DAWN_OK;
+    }
+    if (n == "mfma_min_batch") {
+        if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
+        idx->mfma_min_batch = (int)value;
+        idx->ws_B = 0;
+        return DAWN_OK;
+    }
+    if (n == "mfma_blocks") {
+        if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
+        idx->mfma_blocks = (int)value;
+        idx->ws_B = 0;
         return DAWN_OK;
     }
     if (n == "scan_threads") {

@@ -14,6 +14,8 @@ constexpr int ROW_PAD = 64;    // index allocations are padded to a multiple of 
 // (DESIGN.md §4.3): gamma_384 * 1.0201 (sequential, un-fused reference order) + gamma_16 * 1.0201
 // (the filter's 8-deep FMA chain + 6-level tree) < 2.6e-5.
 constexpr float FILTER_EPS_F32 = 2.6e-5f;
+// MFMA filter (scan_mfma.hip): a 384-deep k-ordered FMA chain -> gamma_384 * 1.0201 on its own side.
+constexpr float FILTER_EPS_MFMA = 4.8e-5f;
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
@@ -32,7 +34,12 @@ void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int
 void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
-                          int force_fallback, hipStream_t stream);
+                          int force_fallback, float eps, const int* d_gtau, hipStream_t stream);
+// Batched filter on the matrix cores (B > 8): per-wave lists [B][blocks*4][64]; d_gtau [roundup(B,64)] must be
+// INT_MIN-initialised (launch_fill_i32) before each search.
+void launch_scan_mfma(const float* d_x, uint32_t n_rows, const float* d_q, int B, int* d_gtau, float* cand_s,
+                      uint32_t* cand_p, int blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_fill_i32(int* d, int value, uint32_t n, hipStream_t stream);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
 void launch_scan_exact(const float* d_x, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);

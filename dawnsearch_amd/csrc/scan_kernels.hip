@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
     uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
-    uint32_t* __restrict__ out_flags, int force_fallback) {
+    uint32_t* __restrict__ out_flags, int force_fallback, float eps, const int* __restrict__ gtau) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     const int lane = threadIdx.x & 63;
@@ -318,8 +318,14 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
     if (wave != 0) return;
 
-    // shortlist: 64 best rows by filter score.  m = the worst filter score that made it.
-    const float m = read_lane63(s);
+    // shortlist: 64 best rows by filter score.  m bounds the filter score of every row NOT in it: the worst
+    // score that made it, or (MFMA filter, chip-wide thresholds) the final shared threshold if that is larger.
+    float m = read_lane63(s);
+    if (gtau) {
+        const int gi = gtau[b];
+        const float gt = __builtin_bit_cast(float, gi ^ ((gi >> 31) & 0x7FFFFFFF));
+        m = gt > m ? gt : m;
+    }
     const bool valid = p != NO_POS;
     float d = POS_INF;
     if (valid) {
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
         // Any row r outside the shortlist has filter score <= m, hence exact dot <= m + eps, hence
         // distance fl(1 - dot_r) >= fl(1 - up(m + eps)) =: d_bound.  If d_bound > d_k (strictly, so that
         // not even a tie on the rounded distance is possible) the exact top-k lies inside the shortlist.
-        const float t = round_up_f32((double)m + (double)FILTER_EPS_F32);
+        const float t = round_up_f32((double)m + (double)eps);
         const float d_bound = __fsub_rn(1.0f, t);
         const float dk = __builtin_bit_cast(
             float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
@@ -353,11 +359,11 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
 
 void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
-                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
-                          hipStream_t stream) {
+                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
+                          const int* d_gtau, hipStream_t stream) {
     hipLaunchKernelGGL(merge_rescore_kernel, dim3(B), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_x),
                        d_ids, n_rows, d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags,
-                       force_fallback);
+                       force_fallback, eps, d_gtau);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,6 +603,16 @@ void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_o
 __global__ void iota_u64_kernel(uint64_t* out, uint64_t first, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = first + i;
+}
+
+__global__ void fill_i32_kernel(int* d, int v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+
+void launch_fill_i32(int* d, int value, uint32_t n, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d, value, n);
 }
 
 void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t stream) {

@@ -222,3 +222,56 @@ def test_search_provider_mirror(dawn, oracle):
     assert like.pages[0].page_id == 43 and like.pages[0].distance < 0.001  # web.rs:339 "same page"
     with pytest.raises(dawn.NotNormalizedError):
         sp.search_embedding(q * 3)
+
+
+# ---- batched (matrix-core) filter: B > 8 ----------------------------------------------------------
+
+@pytest.mark.parametrize("n,B,k", [(100_003, 9, 10), (100_003, 32, 20), (100_003, 33, 10), (50_000, 64, 64),
+                                   (50_000, 100, 20), (31, 16, 10), (64, 40, 64), (4097, 256, 20)])
+def test_mfma_batched_scan_matches_oracle(dawn, oracle, n, B, k):
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B // 2] = synth.planted_queries(1, [n // 3], 2)[0]
+    Q[B - 1] = x[n - 1]  # exact hit on the last row
+    labels, dist, found = idx.search_batch(Q, k)
+    for b in range(B):
+        olab, odist = oracle.scan_topk(x, ids, Q[b], k, threads=8)
+        assert found[b] == min(k, n)
+        _assert_same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
+    assert labels[B // 2][0] == n // 3 + 1 and labels[B - 1][0] == n
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_mfma_1m_batch256(dawn, oracle):
+    """configs[2] scan leg: 1M x 384, batch = 256 — every query checked against the oracle."""
+    n, B, k = 1_000_000, 256, 10
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    labels, dist, found = idx.search_batch(Q, k)
+    for b in range(0, B, 5):
+        olab, odist = oracle.scan_topk(x, ids, Q[b], k, threads=8)
+        _assert_same(labels[b], dist[b], olab, odist)
+    # the streaming filter (forced) and the matrix-core filter agree on all 256 queries
+    idx.set_option("mfma_min_batch", 100000)
+    l2, d2, f2 = idx.search_batch(Q, k)
+    assert np.array_equal(labels, l2) and np.array_equal(dist.view(np.uint32), d2.view(np.uint32))
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_mfma_duplicates_fall_back_and_stay_exact(dawn, oracle):
+    base = synth.unit_rows(1, 0, 3000)
+    rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])
+    ids = np.arange(1, len(rows) + 1, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids, rows)
+    Q = synth.unit_rows(2, 0, 16)
+    Q[3] = synth.planted_queries(1, [11], 8)[0]
+    labels, dist, found = idx.search_batch(Q, 20)
+    for b in range(16):
+        _assert_same(labels[b], dist[b], *oracle.scan_topk(rows, ids, Q[b], 20))
+    assert labels[3][0] == 12 and list(labels[3][1:4]) == [3001, 3002, 3003]
+    assert idx.stats()["fallbacks"] == 1
