@@ -241,7 +241,8 @@ def test_mfma_batched_scan_matches_oracle(dawn, oracle, n, B, k):
         assert found[b] == min(k, n)
         _assert_same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
     assert labels[B // 2][0] == n // 3 + 1 and labels[B - 1][0] == n
-    assert idx.stats()["fallbacks"] == 0
+    # k == shortlist length (64) leaves no margin for the certificate: those searches take the exact pass
+    assert idx.stats()["fallbacks"] == (B if k >= 64 else 0)
 
 
 def test_mfma_1m_batch256(dawn, oracle):
