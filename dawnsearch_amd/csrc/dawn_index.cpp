@@ -39,8 +39,8 @@ struct dawn_index {
     float* d_cand_s = nullptr;
     uint32_t* d_cand_p = nullptr;
     uint32_t* d_flags = nullptr;
-    int* d_gtau = nullptr;
-    int mfma_blocks = 256;   // one 4-wave block per CU
+    dawn::BatchWorkspace bws{nullptr, nullptr, nullptr, nullptr};  // matrix-core batched path
+    int mfma_blocks = 256;   // one 8-wave workgroup per CU
     int mfma_min_batch = 9;  // B >= this goes to the matrix-core filter
     // host-API staging
     float* d_q = nullptr;
@@ -110,22 +110,25 @@ int ensure_room(dawn_index* idx, size_t extra) {
 }
 
 int ensure_workspace(dawn_index* idx, size_t B) {
+    if (B >= (size_t)idx->mfma_min_batch && !idx->bws.cand) {
+        if (int e = dawn::batched_init()) return fail(DAWN_ERR_HIP, "hipFuncSetAttribute(LDS): %s", hipGetErrorString((hipError_t)e));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * dawn::EM * sizeof(_Float16)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.tau, dawn::BATCH_QT * sizeof(float)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMalloc(&idx->bws.cand, (size_t)dawn::BATCH_QT * dawn::BATCH_CAP * 8));
+    }
     if (B <= idx->ws_B) return DAWN_OK;
     if (idx->d_cand_s) (void)hipFree(idx->d_cand_s);
     if (idx->d_cand_p) (void)hipFree(idx->d_cand_p);
     if (idx->d_flags) (void)hipFree(idx->d_flags);
-    if (idx->d_gtau) (void)hipFree(idx->d_gtau);
     idx->d_cand_s = nullptr;
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
-    idx->d_gtau = nullptr;
     idx->ws_B = 0;
-    const size_t lists = std::max<size_t>(idx->geom.blocks, B >= (size_t)idx->mfma_min_batch ? idx->mfma_blocks * 4 : 0);
-    const size_t n = B * lists * dawn::LIST;
+    const size_t n = B * (size_t)idx->geom.blocks * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
-    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_gtau, (B + 128) * sizeof(int)));
     idx->ws_B = B;
     return DAWN_OK;
 }
@@ -148,17 +151,19 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
     }
     const uint32_t n = (uint32_t)idx->size;
     if ((int)B >= idx->mfma_min_batch) {
-        dawn::launch_fill_i32(idx->d_gtau, INT32_MIN, (uint32_t)(B + 128), stream);
-        dawn::launch_scan_mfma(idx->d_x, n, d_q, (int)B, idx->d_gtau, idx->d_cand_s, idx->d_cand_p, idx->mfma_blocks,
-                               stream, e0, e1);
-        dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                   idx->mfma_blocks * 4, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                                   idx->force_fallback, dawn::FILTER_EPS_MFMA, idx->d_gtau, stream);
+        // matrix-core path, BATCH_QT queries per pass over the index
+        for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
+            const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
+            dawn::launch_scan_batched(idx->d_x, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
+                                      idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
+                                      idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
+                                      b0 == 0 ? e1 : nullptr);
+        }
     } else {
         dawn::launch_scan_filter(idx->d_x, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
         dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
                                    idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                                   idx->force_fallback, dawn::FILTER_EPS_F32, nullptr, stream);
+                                   idx->force_fallback, dawn::FILTER_EPS_F32, stream);
     }
     dawn::launch_scan_exact(idx->d_x, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
                             stream);
@@ -213,8 +218,8 @@ void dawn_index_destroy(dawn_index* idx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->d_gtau, idx->d_q,
-                    idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
+    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
+                    idx->bws.cnt, idx->bws.cand, idx->d_q, idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
@@ -493,6 +498,24 @@ int dawn_index_stats(dawn_index* idx, uint64_t* searches, uint64_t* fallbacks) {
     return DAWN_OK;
 }
 
+int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t B, float* out, size_t* n_out) {
+    if (!idx || !queries || !out || !n_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (B == 0 || B > (size_t)dawn::BATCH_QT) return fail(DAWN_ERR_INVALID_ARG, "B must be 1..%d", dawn::BATCH_QT);
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_workspace(idx, std::max<size_t>(B, idx->mfma_min_batch)));
+    const size_t n = std::min<size_t>(idx->size, dawn::BATCH_CAP);
+    *n_out = n;
+    if (n == 0) return DAWN_OK;
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    dawn::launch_batched_dense_scores(idx->d_x, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
+                                      idx->stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),
+                                  n * sizeof(float), B, hipMemcpyDeviceToHost, idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return DAWN_OK;
+}
+
 int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     if (!idx || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     const std::string n(name);
@@ -509,13 +532,11 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_min_batch") {
         if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
         idx->mfma_min_batch = (int)value;
-        idx->ws_B = 0;
         return DAWN_OK;
     }
     if (n == "mfma_blocks") {
         if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
         idx->mfma_blocks = (int)value;
-        idx->ws_B = 0;
         return DAWN_OK;
     }
     if (n == "scan_threads") {

@@ -14,8 +14,17 @@ constexpr int ROW_PAD = 64;    // index allocations are padded to a multiple of 
 // (DESIGN.md §4.3): gamma_384 * 1.0201 (sequential, un-fused reference order) + gamma_16 * 1.0201
 // (the filter's 8-deep FMA chain + 6-level tree) < 2.6e-5.
 constexpr float FILTER_EPS_F32 = 2.6e-5f;
-// MFMA filter (scan_mfma.hip): a 384-deep k-ordered FMA chain -> gamma_384 * 1.0201 on its own side.
-constexpr float FILTER_EPS_MFMA = 4.8e-5f;
+// f16 matrix-core filter (scan_batched.hip).  Rows and queries are scaled by 2^8 and rounded to f16 (relative
+// error 2^-11 each, RNE): |sum(q~x~)/2^16 - sum(qx)| <= (2*2^-11 + 2^-22) * sum|q_i x_i| <= 9.97e-4 with
+// sum|q_i x_i| <= 1.0201 (is_normalized gate).  Products of two f16 are exact in f32; the 384-term f32
+// accumulation inside/between MFMAs adds <= 384 * 2^-23 * 1.0201 = 4.7e-5 (one ulp per add, any order);
+// components below 2^-22 flushed as f16 subnormals (if the hardware does) add < 1e-5; the exact side's own
+// gamma_384 * 1.0201 = 2.4e-5.  Total < 1.08e-3; 1.25e-3 is used.
+constexpr float FILTER_EPS_F16 = 1.25e-3f;
+
+constexpr int BATCH_TILE_ROWS = 64;   // rows per LDS tile of the batched scan
+constexpr int BATCH_QT = 256;         // queries per batched pass (8 waves x 32)
+constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sample size)
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
@@ -34,12 +43,29 @@ void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int
 void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
-                          int force_fallback, float eps, const int* d_gtau, hipStream_t stream);
-// Batched filter on the matrix cores (B > 8): per-wave lists [B][blocks*4][64]; d_gtau [roundup(B,64)] must be
-// INT_MIN-initialised (launch_fill_i32) before each search.
-void launch_scan_mfma(const float* d_x, uint32_t n_rows, const float* d_q, int B, int* d_gtau, float* cand_s,
-                      uint32_t* cand_p, int blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-void launch_fill_i32(int* d, int value, uint32_t n, hipStream_t stream);
+                          int force_fallback, float eps, hipStream_t stream);
+// Batched search on the matrix cores (9 <= B <= BATCH_QT): f16 MFMA filter with sampled thresholds,
+// candidate append, exact rescore + certificate (scan_batched.hip).  ev0/ev1 bracket the full pass.
+struct BatchWorkspace {
+    _Float16* qh;    // [BATCH_QT][384] scaled f16 queries
+    float* tau;      // [BATCH_QT]
+    uint32_t* cnt;   // [BATCH_QT]
+    void* cand;      // [BATCH_QT][BATCH_CAP] uint2 (score bits, row); first half doubles as dense f32 scores
+};
+struct BatchPlan {
+    bool dense_only;          // n_rows <= BATCH_CAP: one dense pass, no thresholds
+    uint32_t n_tiles_total;
+    uint32_t s1_tiles, s1_stride, m1;   // dense sample, tau = m1-th largest
+    uint32_t s2_tiles, s2_stride, m2;   // appended sample (0 = skipped), tau = m2-th largest
+};
+BatchPlan plan_batched(uint32_t n_rows);
+// Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
+void launch_batched_dense_scores(const float* d_x, uint32_t n_rows, const float* d_q, int B, const BatchWorkspace& ws,
+                                 int grid, hipStream_t stream);
+int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
+void launch_scan_batched(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k,
+                         const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
+                         uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
 void launch_scan_exact(const float* d_x, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);

@@ -1,0 +1,450 @@
+// scan_batched.hip — batched query x index contraction on the matrix cores (gfx950), B = 9..256 per pass.
+//
+// One pass over the f32 index serves up to 256 queries: the row stream stays HBM-bound (1536 B/row read
+// once), the contraction runs on v_mfma_f32_32x32x16_f16 at 1/3 of its peak.  The f16 scores are a FILTER:
+// a rigorous bound FILTER_EPS_F16 on |filter - exact| lets the tail (select_rescore_kernel) rescore a
+// 64-row shortlist in the reference's sequential f32 order (src/search/vector.rs:128-134) and certify that
+// no other row can reach the top-k; results are therefore bit-identical to the exact scan.
+//
+// Structure per search of <= 256 queries (all launches on one stream, no host decisions in between):
+//   prep_queries_kernel     q f32 -> f16(256*q), zero rows for b >= B                      [256][384] f16
+//   scan_f16_kernel<DENSE>  sample pass: scores of 8192 strided rows, stored densely       [256][8192] f32
+//   tau_select_kernel       per query: the m-th largest sample score -> threshold tau
+//   scan_f16_kernel<APPEND> (large N only: a second, larger sample, then tau again)
+//   scan_f16_kernel<APPEND> full pass: every row with score > tau is appended to the query's candidate
+//                           buffer (score, row) through an atomic counter; ~1.5k of N rows qualify
+//   select_rescore_kernel   top-64 of the candidates, exact rescore, certificate, output / fallback flag
+//
+// scan_f16_kernel: one 512-thread workgroup (8 waves, 2 per SIMD) per CU, grid-strided over 64-row tiles so
+// that the chip reads one moving contiguous window of HBM.  Wave w owns queries 32w..32w+31: their B-operand
+// fragments (24 k-steps x 8 f16) live in 96 VGPRs for the whole kernel.  A row tile is loaded once per
+// workgroup with fully coalesced 16-B/lane non-temporal loads (12 per lane, issued one tile ahead), scaled,
+// converted to f16 and written to LDS in MFMA-fragment order ([k-group g][row] 16-B slots, rows rotated by
+// g&7: conflict-free ds_write_b64 and ds_read_b128); every wave then reads the A fragments back (one
+// ds_read_b128 per MFMA).  D[row][query]: a lane holds 16 rows of ONE query, so the threshold is one VGPR.
+#include "kernels.hpp"
+#include "wave_topk.hpp"
+
+namespace dawn {
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE_ROWS = BATCH_TILE_ROWS;       // 64
+constexpr int G_STRIDE = 40 * 16;                // LDS bytes per k-group: 32 row slots + 8 (skew room)
+constexpr int SUB_BYTES = 48 * G_STRIDE;         // one 32-row f16 sub-tile: 30 KiB
+constexpr int TILE_BYTES = 2 * SUB_BYTES;        // 60 KiB
+constexpr float ROW_SCALE = 256.0f;              // rows and queries are scaled by 2^8 before f16 conversion:
+constexpr float SCORE_SCALE = 65536.0f;          // keeps small components out of the f16 subnormal range
+constexpr uint32_t STAGE_CAP = 2048;             // LDS-staged candidates per workgroup (q, score, row)
+constexpr uint32_t STAGE_FLUSH_AT = 1024;        // flush to the global per-query buffers beyond this fill
+constexpr int LDS_BYTES = 2 * TILE_BYTES + (int)STAGE_CAP * 12 + 16;
+
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int n_q,
+                                                          _Float16* __restrict__ qh) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // over BATCH_QT * EM
+    if (i >= BATCH_QT * EM) return;
+    const int b = i / EM;
+    qh[i] = (b < n_q) ? (_Float16)(q[i] * ROW_SCALE) : (_Float16)0.0f;
+}
+
+__device__ __forceinline__ half4 to_half4_scaled(const f32x4& v) {
+    half4 r;
+    r.x = (_Float16)(v.x * ROW_SCALE);  // round-to-nearest-even conversions
+    r.y = (_Float16)(v.y * ROW_SCALE);
+    r.z = (_Float16)(v.z * ROW_SCALE);
+    r.w = (_Float16)(v.w * ROW_SCALE);
+    return r;
+}
+
+// LDS byte offset (inside one tile buffer) of the 16-B slot holding f16 elements k = 8g..8g+7 of tile row `row`:
+// [sub-tile][g][row + (g & 7)].  The skew by g & 7 spreads one row's consecutive k-groups over all banks
+// (ds_write_b64 of 16 consecutive chunks is conflict-free); a k-group's 32 rows stay contiguous (ds_read_b128
+// of one MFMA operand is conflict-free).  G_STRIDE = 640 B = 5 x 128 B keeps the bank phase of every group equal.
+__device__ __forceinline__ uint32_t slot_off(uint32_t row, uint32_t g) {
+    return (row >> 5) * SUB_BYTES + g * G_STRIDE + ((row & 31u) + (g & 7u)) * 16u;
+}
+
+// Tiles visited by a pass: first_tile + i*tile_stride, i < n_tiles.  DENSE: score of sample row (i*64 + r) of
+// query b goes to dense[b][i*64 + r] (-inf past the end of the index); n_tiles*64 <= BATCH_CAP.
+template <bool DENSE>
+__global__ __launch_bounds__(512) void scan_f16_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+                                                      uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                                                      const half8* __restrict__ qh, int n_q,
+                                                      const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                      uint2* __restrict__ cand, float* __restrict__ dense) {
+    // 2 x TILE_BYTES | stage_q[STAGE_CAP] | stage_s[STAGE_CAP] | stage_r[STAGE_CAP] | count, latch[2]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint32_t* stage_q = reinterpret_cast<uint32_t*>(lds + 2 * TILE_BYTES);
+    float* stage_s = reinterpret_cast<float*>(stage_q + STAGE_CAP);
+    uint32_t* stage_r = stage_q + 2 * STAGE_CAP;
+    uint32_t* stage_n = stage_q + 3 * STAGE_CAP;  // [0] fill count, [1..2] per-iteration snapshot of it
+    if (!DENSE && threadIdx.x < 3) stage_n[threadIdx.x] = 0;
+    // Staged candidates -> global per-query buffers.  Called by every thread between two barriers during
+    // which no wave appends.
+    auto flush = [&]() {
+        uint32_t n = stage_n[0];
+        if (n > STAGE_CAP) n = STAGE_CAP;
+        for (uint32_t e = threadIdx.x; e < n; e += 512) {
+            const uint32_t q_ = stage_q[e];
+            const uint32_t slot = atomicAdd(&cnt[q_], 1u);
+            if (slot < (uint32_t)BATCH_CAP)
+                cand[(size_t)q_ * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, stage_s[e]), stage_r[e]);
+        }
+    };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const int qi = wave * 32 + (int)r;  // this lane's query
+
+    // B operand: B[k = 16s + 8h + j][col = query r], j = 0..7  ->  qh[query][2s + h]
+    half8 qf[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) qf[s] = qh[(size_t)qi * 48 + 2 * s + h];
+    float tau_s = __builtin_inff();
+    if (!DENSE && qi < n_q) tau_s = tau[qi] * SCORE_SCALE;
+
+    // producer map: wave w converts rows 8w..8w+7 of the tile = 768 consecutive 16-B chunks; load j = 3a + b of
+    // this lane is chunk (b*64 + lane) + 192a, i.e. row 8w + 2a + (b*64+lane)/96, chunk c = (b*64+lane) % 96:
+    // three LDS addresses + an immediate 32-B step per a.
+    uint32_t wr_off[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const uint32_t Lb = (uint32_t)b * 64u + (uint32_t)lane;
+        const uint32_t row = 8u * wave + Lb / 96u, c = Lb % 96u;
+        wr_off[b] = slot_off(row, c >> 1) + (c & 1u) * 8u;
+    }
+    // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
+    const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
+
+    f32x4 st[12];
+    auto issue = [&](uint32_t i) {
+        const f32x4* p =
+            x + ((size_t)first_tile + (size_t)i * tile_stride) * (TILE_ROWS * ROW_F4) + wave * (8 * ROW_F4) + lane;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) st[j] = nt_load(p + j * 64);
+    };
+
+    uint32_t i = blockIdx.x;
+    if (i < n_tiles) issue(i);
+    uint32_t buf = 0;
+    for (; i < n_tiles; i += gridDim.x) {
+        unsigned char* tb = lds + buf * TILE_BYTES;
+        if (!DENSE && threadIdx.x == 0) stage_n[1 + buf] = stage_n[0];  // wave 0 is past its own appends
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            *reinterpret_cast<half4*>(tb + wr_off[j % 3] + (j / 3) * 32) = to_half4_scaled(st[j]);
+        const uint32_t nxt = i + gridDim.x;
+        if (nxt < n_tiles) issue(nxt);
+        // LDS writes visible to the workgroup; the prefetch loads stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!DENSE && stage_n[1 + buf] >= STAGE_FLUSH_AT) {  // same value in every wave: written before the barrier
+            flush();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (threadIdx.x == 0) stage_n[0] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+
+        const uint32_t row_base = (first_tile + i * tile_stride) * TILE_ROWS;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {
+                const half8 a = *reinterpret_cast<const half8*>(tb + sub * SUB_BYTES + rd_off + s * (2 * G_STRIDE) +
+                                                                (s & 3) * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], acc, 0, 0, 0);
+            }
+            // C/D map: this lane holds D[row = (e&3) + 8*(e>>2) + 4*h][query r]
+            const uint32_t row0 = row_base + sub * 32 + 4 * h;
+            if (DENSE) {
+                if (qi < n_q) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t row = row0 + e + 8 * e4;
+                            o[e] = row < n_rows ? acc[e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                        }
+                        *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + (size_t)i * TILE_ROWS + sub * 32 +
+                                                  4 * h + 8 * e4) = o;
+                    }
+                }
+            } else {
+                float mx = acc[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+                if (__any(mx > tau_s)) {
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
+                        mask |= (acc[e] > tau_s && row < n_rows) ? (1u << e) : 0u;
+                    }
+                    if (mask) {
+                        uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
+                        bool dropped = false;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            if (mask & (1u << e)) {
+                                if (pos < STAGE_CAP) {
+                                    stage_q[pos] = (uint32_t)qi;
+                                    stage_s[pos] = acc[e] * (1.0f / SCORE_SCALE);
+                                    stage_r[pos] = row0 + (e & 3) + 8 * (e >> 2);
+                                } else {
+                                    dropped = true;
+                                }
+                                ++pos;
+                            }
+                        }
+                        // staging full (a tile with > 1024 hits): poison the query's counter -> exact pass
+                        if (dropped) atomicAdd(&cnt[qi], (uint32_t)BATCH_CAP + 1u);
+                    }
+                }
+            }
+        }
+        buf ^= 1u;
+    }
+    if (!DENSE) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        flush();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-query top-64 of an unsorted candidate set (block of 1024 threads); result in wave 0, descending
+// ------------------------------------------------------------------------------------------------
+template <bool DENSE>
+__device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, const uint2* __restrict__ cand_q,
+                                            uint32_t count, float& s, uint32_t& p, float (*sh_s)[LIST],
+                                            uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves) {
+    s = NEG_INF;
+    p = NO_POS;
+    const uint32_t n_chunks = (count + 63u) >> 6;
+    for (uint32_t c = wave; c < n_chunks; c += nwaves) {
+        const uint32_t e = c * 64u + lane;
+        float d = POS_INF;  // key = -score: ascending sort = descending score, ties -> lower row
+        uint32_t row = NO_POS;
+        if (e < count) {
+            if (DENSE) {
+                const float sc = dense_q[e];
+                if (sc > NEG_INF) {
+                    d = -sc;
+                    row = e;
+                }
+            } else {
+                const uint2 v = cand_q[e];
+                d = -__builtin_bit_cast(float, v.x);
+                row = v.y;
+            }
+        }
+        sort64_asc(d, row, lane);
+        // merge64 wants the other list reversed: lane i <- other[63 - i]
+        const float os = -__shfl(d, 63 - lane);
+        const uint32_t op = __shfl(row, 63 - lane);
+        merge64(s, p, os, op, lane);
+    }
+    block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+}
+
+// tau[b] = m-th largest score of query b's sample (dense scores or appended candidates); fewer than m
+// samples -> the smallest one; none -> -inf.  Rows scoring <= tau are NOT appended by the next pass.
+template <bool DENSE>
+__global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restrict__ dense,
+                                                         const uint2* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cnt, uint32_t dense_count,
+                                                         uint32_t m, float* __restrict__ tau) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    uint32_t count = DENSE ? dense_count : cnt[b];
+    if (count > (uint32_t)BATCH_CAP) count = BATCH_CAP;
+    float s;
+    uint32_t p;
+    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, count, s, p, sh_s, sh_p, wave,
+                       lane, 16);
+    if (wave != 0) return;
+    const uint32_t have = __popcll(__ballot(p != NO_POS));
+    float t = NEG_INF;
+    if (have > 0) {
+        const uint32_t pick = (m <= have ? m : have) - 1u;
+        t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)pick));
+    }
+    if (lane == 0) tau[b] = t;
+}
+
+// Final: shortlist = top-64 candidates by filter score; exact rescore in the reference order; certificate.
+// Rows outside the shortlist scored <= m: the 64th candidate score if there are >= 64 candidates (every
+// candidate beat tau), else tau itself (DENSE: every row is a candidate, m = 64th score).
+template <bool DENSE>
+__global__ __launch_bounds__(1024) void select_rescore_kernel(
+    const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
+    const float* __restrict__ dense, const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt,
+    const float* __restrict__ tau, uint32_t k, uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
+    uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const uint32_t raw = DENSE ? n_rows : cnt[b];
+    const bool overflow = raw > (uint32_t)BATCH_CAP;
+    const uint32_t count = overflow ? (uint32_t)BATCH_CAP : raw;
+    float s;
+    uint32_t p;
+    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, count, s, p, sh_s, sh_p, wave,
+                       lane, 16);
+    if (wave != 0) return;
+
+    float m = read_lane63(s);  // -inf when fewer than 64 candidates
+    if (!DENSE) {
+        const float t = tau[b];
+        m = (count >= (uint32_t)LIST) ? m : t;
+    }
+    const bool valid = p != NO_POS;
+    float d = POS_INF;
+    if (valid) {
+        const float dot = exact_dot_seq(q + (size_t)b * EM, x + (size_t)p * ROW_F4);
+        d = __fsub_rn(1.0f, dot);  // vector.rs:133
+    }
+    sort64_asc(d, p, lane);
+
+    const uint32_t found = n_rows < k ? n_rows : k;
+    uint32_t flag = FLAG_OK;
+    if (n_rows > (uint32_t)LIST && found > 0) {
+        const uint32_t have = __popcll(__ballot(p != NO_POS));
+        if (have < found || overflow) {
+            flag = FLAG_FALLBACK;
+        } else {
+            // see merge_rescore_kernel: rows outside the shortlist have distance >= fl(1 - up(m + eps))
+            const float t = round_up_f32((double)m + (double)eps);
+            const float d_bound = __fsub_rn(1.0f, t);
+            const float dk =
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
+            if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+        }
+    }
+    if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
+    if ((uint32_t)lane < found && p != NO_POS) {
+        out_labels[(size_t)b * k + lane] = ids[p];
+        out_dist[(size_t)b * k + lane] = d;
+    }
+    if (lane == 0) {
+        out_found[b] = found;
+        out_flags[b] = flag;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: pass planning + launch sequence
+// ------------------------------------------------------------------------------------------------
+BatchPlan plan_batched(uint32_t n_rows) {
+    BatchPlan pl{};
+    const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    pl.n_tiles_total = n_tiles;
+    if (n_rows <= (uint32_t)BATCH_CAP) {
+        pl.dense_only = true;
+        return pl;
+    }
+    // sample 1: 128 strided tiles (8192 rows), dense
+    pl.s1_tiles = BATCH_CAP / TILE_ROWS;
+    pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1 since n_rows > BATCH_CAP
+    const double target = 1536.0;          // expected candidates per query in the full pass
+    const double m_full = target * BATCH_CAP / (double)n_rows;
+    if (m_full >= 8.0) {
+        pl.m1 = (uint32_t)(m_full + 0.999);
+        if (pl.m1 > (uint32_t)LIST) pl.m1 = LIST;
+        pl.s2_tiles = 0;
+        return pl;
+    }
+    // sample 2: n/16 rows, at most 1.5M, appended above tau1
+    uint32_t t2 = n_tiles / 16;
+    if (t2 > 23437u) t2 = 23437u;
+    pl.s2_tiles = t2;
+    pl.s2_stride = n_tiles / t2;
+    const double n2 = (double)t2 * TILE_ROWS;
+    double m1 = 2048.0 * BATCH_CAP / n2;
+    pl.m1 = (uint32_t)(m1 + 0.999);
+    if (pl.m1 < 8) pl.m1 = 8;
+    if (pl.m1 > (uint32_t)LIST) pl.m1 = LIST;
+    double m2 = target * n2 / (double)n_rows;
+    pl.m2 = (uint32_t)(m2 + 0.999);
+    if (pl.m2 < 8) pl.m2 = 8;
+    if (pl.m2 > (uint32_t)LIST) pl.m2 = LIST;
+    return pl;
+}
+
+static bool g_lds_attr_set = false;
+
+template <bool DENSE>
+static void launch_pass(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+                        const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
+    if (n_tiles == 0) return;
+    const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
+    hipLaunchKernelGGL((scan_f16_kernel<DENSE>), dim3(blocks), dim3(512), LDS_BYTES, stream,
+                       reinterpret_cast<const f32x4*>(d_x), n_rows, first, stride, n_tiles,
+                       reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
+                       reinterpret_cast<float*>(ws.cand));
+}
+
+int batched_init() {
+    if (g_lds_attr_set) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f16_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f16_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    g_lds_attr_set = true;
+    return 0;
+}
+
+void launch_batched_dense_scores(const float* d_x, uint32_t n_rows, const float* d_q, int B, const BatchWorkspace& ws,
+                                 int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+    const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
+    launch_pass<true>(d_x, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
+}
+
+void launch_scan_batched(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k,
+                         const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
+                         uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const BatchPlan pl = plan_batched(n_rows);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(d_x);
+    const float* dense = reinterpret_cast<const float*>(ws.cand);
+    const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+    if (pl.dense_only) {
+        if (ev0) (void)hipEventRecord(ev0, stream);
+        launch_pass<true>(d_x, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+        if (ev1) (void)hipEventRecord(ev1, stream);
+        hipLaunchKernelGGL((select_rescore_kernel<true>), dim3(B), dim3(1024), 0, stream, x4, d_ids, n_rows, d_q, dense,
+                           cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback,
+                           FILTER_EPS_F16);
+        return;
+    }
+    launch_pass<true>(d_x, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
+    hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
+                       pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
+    if (pl.s2_tiles) {
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+        launch_pass<false>(d_x, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
+        hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
+                           ws.tau);
+    }
+    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    launch_pass<false>(d_x, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    hipLaunchKernelGGL((select_rescore_kernel<false>), dim3(B), dim3(1024), 0, stream, x4, d_ids, n_rows, d_q, dense,
+                       cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_F16);
+}
+
+}  // namespace dawn

@@ -20,96 +20,9 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf, and
 // the exact paths use separate multiply and add as the reference (Rust) does.
 #include "kernels.hpp"
+#include "wave_topk.hpp"
 
 namespace dawn {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define NEG_INF (-__builtin_inff())
-#define POS_INF (__builtin_inff())
-constexpr uint32_t NO_POS = 0xFFFFFFFFu;
-
-// ------------------------------------------------------------------------------------------------
-// wave-level primitives (64-wide wavefront)
-// ------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
-                                                                 BANK_MASK, BOUND));
-}
-
-// Sum over the 64 lanes; the total is valid in lane 63 (rows 3's lanes).  6 DPP adds, no LDS.
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    v += dpp_mov<0xB1, 0xf, 0xf, true>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E, 0xf, 0xf, true>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141, 0xf, 0xf, true>(v);   // row_half_mirror
-    v += dpp_mov<0x140, 0xf, 0xf, true>(v);   // row_mirror       -> every lane of a 16-row holds the row sum
-    v += dpp_mov<0x142, 0xa, 0xf, false>(v);  // row_bcast15 into rows 1,3
-    v += dpp_mov<0x143, 0xc, 0xf, false>(v);  // row_bcast31 into rows 2,3 -> row 3 holds the total
-    return v;
-}
-
-__device__ __forceinline__ float read_lane63(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// (score desc, row asc) strict order; fillers are (-inf, NO_POS).
-__device__ __forceinline__ bool better(float s, uint32_t p, float s2, uint32_t p2) {
-    return s > s2 || (s == s2 && p < p2);
-}
-
-// Insert a wave-uniform candidate into the wave's descending list (one entry per lane).
-__device__ __forceinline__ void wave_insert(float& ls, uint32_t& lp, float s, uint32_t p, int lane) {
-    const bool ahead = better(ls, lp, s, p);
-    const int pos = __popcll(__ballot(ahead));
-    const float ps = __shfl_up(ls, 1);
-    const uint32_t pp = __shfl_up(lp, 1);
-    if (lane > pos) {
-        ls = ps;
-        lp = pp;
-    } else if (lane == pos) {
-        ls = s;
-        lp = p;
-    }
-}
-
-// Merge another descending list (given REVERSED: lane i holds other[63-i]) into mine; result = top 64 of
-// the union, descending.  Bitonic half-cleaner + 6 compare-exchange stages.
-__device__ __forceinline__ void merge64(float& s, uint32_t& p, float os_rev, uint32_t op_rev, int lane) {
-    if (better(os_rev, op_rev, s, p)) {
-        s = os_rev;
-        p = op_rev;
-    }
-#pragma unroll
-    for (int stride = 32; stride >= 1; stride >>= 1) {
-        const float s2 = __shfl_xor(s, stride);
-        const uint32_t p2 = __shfl_xor(p, stride);
-        const bool lower = (lane & stride) == 0;
-        const bool other_better = better(s2, p2, s, p);
-        if (lower == other_better) {
-            s = s2;
-            p = p2;
-        }
-    }
-}
-
-// Block-level tree merge of per-wave lists through LDS; result in wave 0.  nwaves is a power of two.
-__device__ __forceinline__ void block_merge(float& s, uint32_t& p, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST],
-                                            int wave, int lane, int nwaves) {
-    for (int stride = nwaves >> 1; stride >= 1; stride >>= 1) {
-        if (wave >= stride && wave < 2 * stride) {
-            sh_s[wave][lane] = s;
-            sh_p[wave][lane] = p;
-        }
-        __syncthreads();
-        if (wave < stride) {
-            const float os = sh_s[wave + stride][63 - lane];
-            const uint32_t op = sh_p[wave + stride][63 - lane];
-            merge64(s, p, os, op, lane);
-        }
-        __syncthreads();
-    }
-}
 
 __device__ __forceinline__ float dot4_fma(const f32x4& a, const f32x4& b, float acc) {
     acc = __builtin_fmaf(a.x, b.x, acc);
@@ -119,7 +32,6 @@ __device__ __forceinline__ float dot4_fma(const f32x4& a, const f32x4& b, float 
     return acc;
 }
 
-__device__ __forceinline__ f32x4 nt_load(const f32x4* p) { return __builtin_nontemporal_load(p); }
 
 // ------------------------------------------------------------------------------------------------
 // 1. filter scan
@@ -241,64 +153,11 @@ void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int
 // ------------------------------------------------------------------------------------------------
 // 2. merge + exact rescore + certificate
 // ------------------------------------------------------------------------------------------------
-// Sequential, un-fused f32 dot in the reference's order (vector.rs:128-134): result += a[i]*b[i].
-__device__ __forceinline__ float exact_dot_seq(const float* __restrict__ qv, const f32x4* __restrict__ row) {
-    float acc = 0.0f;
-#pragma unroll 4
-    for (int c = 0; c < ROW_F4; ++c) {
-        const f32x4 xv = row[c];
-        const f32x4 qq = reinterpret_cast<const f32x4*>(qv)[c];
-        acc = __fadd_rn(acc, __fmul_rn(qq.x, xv.x));
-        acc = __fadd_rn(acc, __fmul_rn(qq.y, xv.y));
-        acc = __fadd_rn(acc, __fmul_rn(qq.z, xv.z));
-        acc = __fadd_rn(acc, __fmul_rn(qq.w, xv.w));
-    }
-    return acc;
-}
-
-// (distance asc, row asc)
-__device__ __forceinline__ bool less_dp(float d, uint32_t p, float d2, uint32_t p2) {
-    return d < d2 || (d == d2 && p < p2);
-}
-
-// Full bitonic sort of one (d, p) per lane, ascending.
-__device__ __forceinline__ void sort64_asc(float& d, uint32_t& p, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            const float d2 = __shfl_xor(d, j);
-            const uint32_t p2 = __shfl_xor(p, j);
-            const bool asc = (lane & k2) == 0;
-            const bool lower = (lane & j) == 0;
-            const bool keep_small = (lower == asc);
-            const bool other_less = less_dp(d2, p2, d, p);
-            const bool other_greater = less_dp(d, p, d2, p2);
-            if (keep_small ? other_less : other_greater) {
-                d = d2;
-                p = p2;
-            }
-        }
-    }
-}
-
-// smallest float >= t (t finite, double)
-__device__ __forceinline__ float round_up_f32(double t) {
-    float f = (float)t;
-    if ((double)f < t) {
-        if (f == 0.0f) return 1.0e-45f;
-        int bits = __builtin_bit_cast(int, f);
-        bits += (f > 0.0f) ? 1 : -1;
-        f = __builtin_bit_cast(float, bits);
-    }
-    return f;
-}
-
 __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
     uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
-    uint32_t* __restrict__ out_flags, int force_fallback, float eps, const int* __restrict__ gtau) {
+    uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     const int lane = threadIdx.x & 63;
@@ -318,14 +177,9 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
     if (wave != 0) return;
 
-    // shortlist: 64 best rows by filter score.  m bounds the filter score of every row NOT in it: the worst
-    // score that made it, or (MFMA filter, chip-wide thresholds) the final shared threshold if that is larger.
-    float m = read_lane63(s);
-    if (gtau) {
-        const int gi = gtau[b];
-        const float gt = __builtin_bit_cast(float, gi ^ ((gi >> 31) & 0x7FFFFFFF));
-        m = gt > m ? gt : m;
-    }
+    // shortlist: 64 best rows by filter score.  m (the worst score that made it) bounds the filter score of
+    // every row NOT in it.
+    const float m = read_lane63(s);
     const bool valid = p != NO_POS;
     float d = POS_INF;
     if (valid) {
@@ -360,10 +214,10 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
 void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
-                          const int* d_gtau, hipStream_t stream) {
+                          hipStream_t stream) {
     hipLaunchKernelGGL(merge_rescore_kernel, dim3(B), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_x),
                        d_ids, n_rows, d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags,
-                       force_fallback, eps, d_gtau);
+                       force_fallback, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,16 +457,6 @@ void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_o
 __global__ void iota_u64_kernel(uint64_t* out, uint64_t first, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = first + i;
-}
-
-__global__ void fill_i32_kernel(int* d, int v, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] = v;
-}
-
-void launch_fill_i32(int* d, int value, uint32_t n, hipStream_t stream) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d, value, n);
 }
 
 void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t stream) {

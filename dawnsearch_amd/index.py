@@ -112,6 +112,14 @@ class VectorIndex:
     def set_option(self, name: str, value: int):
         check(lib.dawn_index_set_option(self._h, name.encode(), value))
 
+    def debug_filter_scores(self, queries: np.ndarray) -> np.ndarray:
+        """Test hook: f16 matrix-core filter scores of the queries against rows [0, min(size, 8192))."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, EM_LEN)
+        n = C.c_size_t(0)
+        tmp = np.zeros((q.shape[0], min(self.size(), 8192)), dtype=np.float32)
+        check(lib.dawn_index_debug_filter_scores(self._h, _ptr(q), q.shape[0], _ptr(tmp), C.byref(n)))
+        return tmp[:, :n.value]
+
 
 def topk_merge_device(device: int, G: int, B: int, count: int, d_in_labels: int, d_in_dist: int, d_in_found: int,
                       d_labels: int, d_dist: int, d_found: int, stream: int = 0):

@@ -8,12 +8,12 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 idx = dawn.VectorIndex(0)
 idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, 256)
-for B in (8, 9, 16, 32, 64, 128, 256):
-    for blocks in (256, 512):
+for B in (8, 9, 32, 64, 128, 256):
+    for blocks in (256,):
         idx.set_option("mfma_blocks", blocks)
         idx.search_batch(Q[:B], 10)
         idx.profile_enable(True)
-        t0 = time.time(); it = 5
+        t0 = time.time(); it = 10
         for _ in range(it): idx.search_batch(Q[:B], 10)
         wall = (time.time() - t0) / it
         n, ms = idx.profile_read(); idx.profile_enable(False)
