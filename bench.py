@@ -110,32 +110,29 @@ def main():
         if Bq >= 1:  # planted: query 0 is a noisy copy of global row 4242 (checked after the run)
             q_host[0] = synth.planted_queries(1, [4242 % args.rows], 5)[0]
         d_q = torch.from_numpy(q_host).to(dev)
-        d_lab = torch.zeros((Bq, k), dtype=torch.int64, device=dev)
-        d_dist = torch.zeros((Bq, k), dtype=torch.float32, device=dev)
-        d_found = torch.zeros((Bq,), dtype=torch.int32, device=dev)
-        if world > 1:
-            g_lab = torch.zeros((world * Bq, k), dtype=torch.int64, device=dev)
-            g_dist = torch.zeros((world * Bq, k), dtype=torch.float32, device=dev)
-            g_found = torch.zeros((world * Bq,), dtype=torch.int32, device=dev)
-            o_lab = torch.zeros_like(d_lab)
-            o_dist = torch.zeros_like(d_dist)
-            o_found = torch.zeros_like(d_found)
+        # per-rank result blob: labels | distances | found (dawn_hip.h) — one all-gather per search
+        nbytes = dawn.result_blob_bytes(Bq, k)
+        off_d, off_f = Bq * k * 8, Bq * k * 12
+        blob = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        p = blob.data_ptr()
+        o_lab = torch.zeros((Bq, k), dtype=torch.int64, device=dev)
+        o_dist = torch.zeros((Bq, k), dtype=torch.float32, device=dev)
+        o_found = torch.zeros((Bq,), dtype=torch.int32, device=dev)
+        g_blob = torch.zeros((world * nbytes,), dtype=torch.uint8, device=dev) if world > 1 else None
 
         def step():
-            index.search_device(d_q.data_ptr(), Bq, k, d_lab.data_ptr(), d_dist.data_ptr(), d_found.data_ptr(), stream)
+            index.search_device(d_q.data_ptr(), Bq, k, p, p + off_d, p + off_f, stream)
             if world > 1:
-                dist.all_gather_into_tensor(g_lab, d_lab)
-                dist.all_gather_into_tensor(g_dist, d_dist)
-                dist.all_gather_into_tensor(g_found, d_found)
-                dawn.topk_merge_device(local_rank, world, Bq, k, g_lab.data_ptr(), g_dist.data_ptr(),
-                                       g_found.data_ptr(), o_lab.data_ptr(), o_dist.data_ptr(), o_found.data_ptr(),
-                                       stream)
+                dist.all_gather_into_tensor(g_blob, blob)
+                dawn.topk_merge_packed_device(local_rank, world, Bq, k, g_blob.data_ptr(), o_lab.data_ptr(),
+                                              o_dist.data_ptr(), o_found.data_ptr(), stream)
 
         def result():
             torch.cuda.synchronize()
             if world > 1:
                 return o_lab.cpu().numpy(), o_dist.cpu().numpy()
-            return d_lab.cpu().numpy(), d_dist.cpu().numpy()
+            raw = blob.cpu().numpy()
+            return (raw[:off_d].view(np.int64).reshape(Bq, k), raw[off_d:off_f].view(np.float32).reshape(Bq, k))
 
         return step, result
 
@@ -144,10 +141,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, steps, warmup):
+    def scan_passes(Bq):
+        """Passes over the index rows made by the dominant kernel for a batch of Bq queries."""
+        if Bq >= 9:
+            return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
+        return sum(1 for _ in range(0, Bq, 4)) if Bq > 1 else 1   # streaming path: up to 4 queries per pass
+
+    def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False):
+        """`steps` timed searches of a Bq-query batch.  Returns qps (max over ranks), ms/step and the mean
+        duration of the dominant scan kernel measured with HIP events on its launch stream."""
+        step, result = make_step(index, Bq, seed)
+        index.profile_enable(True)
         for _ in range(warmup):
             step()
         barrier()
+        index.profile_read()  # drop warm-up launches
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -157,47 +165,44 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el
+        n_launch, scan_ms = index.profile_read()
+        index.profile_enable(False)
+        leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3, "steps": steps,
+               "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
+        rows_here = index.size()
+        algo = rows_here * ROW_BYTES * scan_passes(Bq)
+        if leg["scan_kernel_ms"] > 0:
+            leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
+            leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
+            if Bq >= 9:
+                leg["mfma_TFLOPs"] = 2.0 * 256 * rows_here * 384 / (leg["scan_kernel_ms"] * 1e-3) / 1e12
+                leg["mfma_frac_f16_dense_peak"] = leg["mfma_TFLOPs"] / 2500.0
+        if check_planted:
+            labels, _ = result()
+            leg["planted_top1_ok"] = bool(labels[0][0] == 1 + (4242 % args.rows))
+        return leg, algo
 
     # ---- headline leg ------------------------------------------------------------------------
-    step, result = make_step(idx, B)
-    idx.profile_enable(True)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    idx.profile_read()  # drop warm-up launches
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_launch, scan_ms = idx.profile_read()
-    idx.profile_enable(False)
-    labels, dists = result()
-    planted_ok = bool(labels[0][0] == 1 + (4242 % args.rows))
-    qps = args.steps * B / elapsed
-    scan_avg_ms = scan_ms / max(n_launch, 1)
-    passes = -(-B // 4) if B > 1 else 1  # filter passes per call (4 queries per pass)
-    algo_bytes = rows_local * ROW_BYTES * passes
-    achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+    head, algo_bytes = run_leg(idx, B, args.steps, args.warmup, check_planted=True)
+    qps = head["queries_per_s"]
+    elapsed_ms = head["ms_per_step"]
+    scan_avg_ms = head["scan_kernel_ms"]
+    achieved = head.get("scan_GBps", 0.0)
+    kernel = "scan_f16_kernel<append>" if B >= 9 else "scan_filter_kernel"
 
     out = {
         "metric": "queries/sec, exact cosine top-k over a 384-d f32 index resident in HBM",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
-                   "sharding": f"row-sharded x{world}" + (", RCCL all-gather of per-shard top-k + merge" if world > 1 else "")},
-        "roofline": {"bound": "hbm", "kernel": "scan_filter_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
-                     "launches_timed": n_launch},
-        "checks": {"planted_top1_ok": planted_ok, "fallbacks": idx.stats()["fallbacks"]},
+                     "launches_timed": head["launches_timed"]},
+        "checks": {"planted_top1_ok": head["planted_top1_ok"], "fallbacks": idx.stats()["fallbacks"]},
         "fill_seconds": fill_s,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -213,12 +218,10 @@ def main():
     # ---- extra legs (rank-collective where needed) --------------------------------------------
     if not args.no_extras:
         extra = {}
-        # batch-256 on the same index
-        b256_steps = max(2, min(args.steps, 3 if rows_local > 20_000_000 else 20))
-        s256, r256 = make_step(idx, 256, seed=3)
-        el = timed(s256, b256_steps, 1)
-        extra["batch256"] = {"queries_per_s": b256_steps * 256 / el, "ms_per_batch": el / b256_steps * 1e3,
-                             "steps": b256_steps}
+        # batch-256 on the same index: one pass of the matrix-core kernel serves all 256 queries
+        b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
+        leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)
+        extra["batch256"] = leg
         if world == 1:
             # host-API latency (host buffers in/out: includes H2D of the query and D2H of k results)
             q = synth.unit_rows(2, 1, 1)[0]
@@ -230,36 +233,29 @@ def main():
             lat = np.array(lat[5:])
             extra["host_api_batch1"] = {"p50_ms": float(np.percentile(lat, 50) * 1e3),
                                         "p95_ms": float(np.percentile(lat, 95) * 1e3)}
-            # configs[1]: 1M x 384, batch 1 (scan + top-k only)
-            del s256, r256
+            # configs[1] / configs[2] scan leg: 1M x 384, batch 1 and batch 256
             idx1 = dawn.VectorIndex(local_rank)
             idx1.fill_synthetic(1, 0, 1_000_000, 1)
-            s1, r1 = make_step(idx1, 1)
-            idx1.profile_enable(True)
-            for _ in range(20):
-                s1()
-            barrier()
-            idx1.profile_read()
-            n1 = 200
-            t0 = time.perf_counter()
-            for _ in range(n1):
-                s1()
-            barrier()
-            el1 = time.perf_counter() - t0
-            nl, ms = idx1.profile_read()
-            a1 = 1_000_000 * ROW_BYTES / (ms / max(nl, 1) * 1e-3) / 1e9
+            leg1, _ = run_leg(idx1, 1, 200, 20)
             lat = []
             for i in range(60):
                 t0 = time.perf_counter()
                 idx1.search(q, k)
                 lat.append(time.perf_counter() - t0)
             lat = np.array(lat[10:])
-            extra["rows_1M_batch1"] = {"queries_per_s": n1 / el1, "scan_kernel_us": ms / max(nl, 1) * 1e3,
-                                       "scan_GBps": a1, "roofline_frac": a1 / HBM_PEAK_GBS,
-                                       "host_api_p50_ms": float(np.percentile(lat, 50) * 1e3)}
-            s256b, _ = make_step(idx1, 256, seed=3)
-            el = timed(s256b, 10, 2)
-            extra["rows_1M_batch256"] = {"queries_per_s": 10 * 256 / el, "ms_per_batch": el / 10 * 1e3}
+            leg1["host_api_p50_ms"] = float(np.percentile(lat, 50) * 1e3)
+            extra["rows_1M_batch1"] = leg1
+            leg2, _ = run_leg(idx1, 256, 50, 5, seed=3)
+            Q256 = synth.unit_rows(3, 0, 256)
+            lat = []
+            for i in range(25):
+                t0 = time.perf_counter()
+                idx1.search_batch(Q256, k)
+                lat.append(time.perf_counter() - t0)
+            leg2["host_api_p50_ms"] = float(np.percentile(np.array(lat[5:]), 50) * 1e3)
+            extra["rows_1M_batch256"] = leg2
+            extra["fallbacks_1M"] = idx1.stats()["fallbacks"]
+        out["checks"]["fallbacks"] = idx.stats()["fallbacks"]
         out["extra"] = extra
         if world == 1 and rank == 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, k, args.rows)

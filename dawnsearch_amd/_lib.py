@@ -68,6 +68,8 @@ _SIGS = {
     "dawn_index_load_page_entries": (_i32, [_vp, C.c_char_p, _u64]),
     "dawn_index_search_device": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "dawn_topk_merge_device": (_i32, [_i32, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dawn_result_blob_bytes": (_sz, [_sz, _sz]),
+    "dawn_topk_merge_packed_device": (_i32, [_i32, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     "dawn_topk_merge_host": (_i32, [_sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dawn_index_fill_synthetic": (_i32, [_vp, _u64, _u64, _sz, _u64]),
     "dawn_index_get_rows": (_i32, [_vp, _sz, _sz, _vp, _vp]),

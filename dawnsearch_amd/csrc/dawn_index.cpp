@@ -338,8 +338,26 @@ int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const u
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
     if (B == 0) return DAWN_OK;
-    dawn::launch_shard_merge(G, B, count, d_in_labels, d_in_distances, d_in_found, d_labels, d_distances, d_found,
-                             (hipStream_t)stream);
+    dawn::launch_shard_merge(G, B, count, d_in_labels, d_in_distances, d_in_found, B * count, B * count, B, d_labels,
+                             d_distances, d_found, (hipStream_t)stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    return DAWN_OK;
+}
+
+size_t dawn_result_blob_bytes(size_t B, size_t count) { return (B * count * 12 + B * 4 + 15) / 16 * 16; }
+
+int dawn_topk_merge_packed_device(int device, size_t G, size_t B, size_t count, const void* d_blobs,
+                                  uint64_t* d_labels, float* d_distances, uint32_t* d_found, void* stream) {
+    if (!d_blobs || !d_labels || !d_distances || !d_found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (G == 0 || count == 0 || G * count > 512) return fail(DAWN_ERR_UNSUPPORTED, "G*count must be 1..512");
+    DAWN_TRY(dawn::require_device(device));
+    DAWN_HIP_TRY(hipSetDevice(device));
+    if (B == 0) return DAWN_OK;
+    const size_t stride = dawn_result_blob_bytes(B, count);
+    const char* base = (const char*)d_blobs;
+    dawn::launch_shard_merge(G, B, count, (const uint64_t*)base, (const float*)(base + B * count * 8),
+                             (const uint32_t*)(base + B * count * 12), stride / 8, stride / 4, stride / 4, d_labels,
+                             d_distances, d_found, (hipStream_t)stream);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }
@@ -537,6 +555,11 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_blocks") {
         if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
         idx->mfma_blocks = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "mfma_waves") {
+        if (value != 4 && value != 8) return fail(DAWN_ERR_INVALID_ARG, "mfma_waves must be 4 or 8");
+        dawn::g_batched_waves = (int)value;
         return DAWN_OK;
     }
     if (n == "scan_threads") {

@@ -62,6 +62,7 @@ BatchPlan plan_batched(uint32_t n_rows);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const float* d_x, uint32_t n_rows, const float* d_q, int B, const BatchWorkspace& ws,
                                  int grid, hipStream_t stream);
+extern int g_batched_waves;  // 8 (default) or 4 waves per scan workgroup
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
 void launch_scan_batched(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k,
                          const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
@@ -75,8 +76,8 @@ void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uin
 
 // Stable G-way merge of per-shard results (multi-GPU).
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
-                        const uint32_t* in_found, uint64_t* out_labels, float* out_dist, uint32_t* out_found,
-                        hipStream_t stream);
+                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, uint64_t* out_labels,
+                        float* out_dist, uint32_t* out_found, hipStream_t stream);
 
 // is_normalized (vector.rs:185-192) over n rows; *d_bad_count += number of failing rows.
 void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count, hipStream_t stream);

@@ -68,12 +68,21 @@ __device__ __forceinline__ uint32_t slot_off(uint32_t row, uint32_t g) {
 
 // Tiles visited by a pass: first_tile + i*tile_stride, i < n_tiles.  DENSE: score of sample row (i*64 + r) of
 // query b goes to dense[b][i*64 + r] (-inf past the end of the index); n_tiles*64 <= BATCH_CAP.
-template <bool DENSE>
-__global__ __launch_bounds__(512) void scan_f16_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
-                                                      uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
-                                                      const half8* __restrict__ qh, int n_q,
-                                                      const float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                      uint2* __restrict__ cand, float* __restrict__ dense) {
+// NW waves per workgroup (one workgroup per CU); a wave owns QG = 8/NW groups of 32 queries and converts
+// 64/NW rows of every tile; PF tiles are in flight per wave (register-staged: 96/NW 16-B loads per lane and tile).
+//   NW = 4: one wave per SIMD, 512 registers: 2 x 24 loads in flight per lane = 192 KiB per CU
+//   NW = 8: two waves per SIMD, 256 registers: 12 loads in flight per lane     =  96 KiB per CU
+template <bool DENSE, int NW>
+__global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+                                                          uint32_t first_tile, uint32_t tile_stride,
+                                                          uint32_t n_tiles, const half8* __restrict__ qh, int n_q,
+                                                          const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                          uint2* __restrict__ cand, float* __restrict__ dense) {
+    constexpr int QG = 8 / NW;          // 32-query groups per wave
+    constexpr int LPL = 96 / NW;        // loads per lane per tile
+    constexpr int RPW = TILE_ROWS / NW; // tile rows converted by one wave
+    constexpr int PF = NW == 4 ? 2 : 1; // tiles in flight
+    constexpr int NT = NW * 64;
     // 2 x TILE_BYTES | stage_q[STAGE_CAP] | stage_s[STAGE_CAP] | stage_r[STAGE_CAP] | count, latch[2]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint32_t* stage_q = reinterpret_cast<uint32_t*>(lds + 2 * TILE_BYTES);
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(512) void scan_f16_kernel(const f32x4* __restrict__
     auto flush = [&]() {
         uint32_t n = stage_n[0];
         if (n > STAGE_CAP) n = STAGE_CAP;
-        for (uint32_t e = threadIdx.x; e < n; e += 512) {
+        for (uint32_t e = threadIdx.x; e < n; e += NT) {
             const uint32_t q_ = stage_q[e];
             const uint32_t slot = atomicAdd(&cnt[q_], 1u);
             if (slot < (uint32_t)BATCH_CAP)
@@ -97,47 +106,51 @@ __global__ __launch_bounds__(512) void scan_f16_kernel(const f32x4* __restrict__
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t r = lane & 31, h = lane >> 5;
-    const int qi = wave * 32 + (int)r;  // this lane's query
+    const int q0 = wave * (32 * QG) + (int)r;  // this lane's queries: q0 + 32*g
+    const bool wave_has_queries = wave * (32 * QG) < n_q;  // wave-uniform
 
     // B operand: B[k = 16s + 8h + j][col = query r], j = 0..7  ->  qh[query][2s + h]
-    half8 qf[24];
+    half8 qf[QG][24];
+    float tau_s[QG];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) qf[s] = qh[(size_t)qi * 48 + 2 * s + h];
-    float tau_s = __builtin_inff();
-    if (!DENSE && qi < n_q) tau_s = tau[qi] * SCORE_SCALE;
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) qf[g][s] = qh[(size_t)(q0 + 32 * g) * 48 + 2 * s + h];
+        tau_s[g] = __builtin_inff();
+        if (!DENSE && q0 + 32 * g < n_q) tau_s[g] = tau[q0 + 32 * g] * SCORE_SCALE;
+    }
 
-    // producer map: wave w converts rows 8w..8w+7 of the tile = 768 consecutive 16-B chunks; load j = 3a + b of
-    // this lane is chunk (b*64 + lane) + 192a, i.e. row 8w + 2a + (b*64+lane)/96, chunk c = (b*64+lane) % 96:
+    // producer map: wave w converts rows RPW*w.. of the tile = RPW*96 consecutive 16-B chunks; load j = 3a + b of
+    // this lane is chunk (b*64 + lane) + 192a, i.e. row RPW*w + 2a + (b*64+lane)/96, chunk c = (b*64+lane) % 96:
     // three LDS addresses + an immediate 32-B step per a.
     uint32_t wr_off[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const uint32_t Lb = (uint32_t)b * 64u + (uint32_t)lane;
-        const uint32_t row = 8u * wave + Lb / 96u, c = Lb % 96u;
+        const uint32_t row = (uint32_t)RPW * wave + Lb / 96u, c = Lb % 96u;
         wr_off[b] = slot_off(row, c >> 1) + (c & 1u) * 8u;
     }
     // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
     const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
 
-    f32x4 st[12];
-    auto issue = [&](uint32_t i) {
-        const f32x4* p =
-            x + ((size_t)first_tile + (size_t)i * tile_stride) * (TILE_ROWS * ROW_F4) + wave * (8 * ROW_F4) + lane;
+    f32x4 st[PF][LPL];
+    auto issue = [&](f32x4(&dst)[LPL], uint32_t i) {
+        const f32x4* p = x + ((size_t)first_tile + (size_t)i * tile_stride) * (TILE_ROWS * ROW_F4) +
+                         wave * (RPW * ROW_F4) + lane;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) st[j] = nt_load(p + j * 64);
+        for (int j = 0; j < LPL; ++j) dst[j] = nt_load(p + j * 64);
     };
 
-    uint32_t i = blockIdx.x;
-    if (i < n_tiles) issue(i);
-    uint32_t buf = 0;
-    for (; i < n_tiles; i += gridDim.x) {
+    // One tile: convert the staged rows into LDS buffer `buf`, refill the staging registers with tile i + PF*grid,
+    // barrier, contract, threshold test.
+    auto process = [&](f32x4(&src)[LPL], uint32_t i, uint32_t buf) {
         unsigned char* tb = lds + buf * TILE_BYTES;
         if (!DENSE && threadIdx.x == 0) stage_n[1 + buf] = stage_n[0];  // wave 0 is past its own appends
 #pragma unroll
-        for (int j = 0; j < 12; ++j)
-            *reinterpret_cast<half4*>(tb + wr_off[j % 3] + (j / 3) * 32) = to_half4_scaled(st[j]);
-        const uint32_t nxt = i + gridDim.x;
-        if (nxt < n_tiles) issue(nxt);
+        for (int j = 0; j < LPL; ++j)
+            *reinterpret_cast<half4*>(tb + wr_off[j % 3] + (j / 3) * 32) = to_half4_scaled(src[j]);
+        const uint32_t nxt = i + PF * gridDim.x;
+        if (nxt < n_tiles) issue(src, nxt);
         // LDS writes visible to the workgroup; the prefetch loads stay in flight across the barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (!DENSE && stage_n[1 + buf] >= STAGE_FLUSH_AT) {  // same value in every wave: written before the barrier
@@ -147,68 +160,91 @@ __global__ __launch_bounds__(512) void scan_f16_kernel(const f32x4* __restrict__
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 
+        if (!wave_has_queries) return;  // every query of this wave is padding: it only converts rows
         const uint32_t row_base = (first_tile + i * tile_stride) * TILE_ROWS;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            f32x16 acc;
+            f32x16 acc[QG];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
 #pragma unroll
             for (int s = 0; s < 24; ++s) {
                 const half8 a = *reinterpret_cast<const half8*>(tb + sub * SUB_BYTES + rd_off + s * (2 * G_STRIDE) +
                                                                 (s & 3) * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[g][s], acc[g], 0, 0, 0);
             }
             // C/D map: this lane holds D[row = (e&3) + 8*(e>>2) + 4*h][query r]
             const uint32_t row0 = row_base + sub * 32 + 4 * h;
-            if (DENSE) {
-                if (qi < n_q) {
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        f32x4 o;
+            for (int g = 0; g < QG; ++g) {
+                const int qi = q0 + 32 * g;
+                if (DENSE) {
+                    if (qi < n_q) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint32_t row = row0 + e + 8 * e4;
-                            o[e] = row < n_rows ? acc[e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t row = row0 + e + 8 * e4;
+                                o[e] = row < n_rows ? acc[g][e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                            }
+                            *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + (size_t)i * TILE_ROWS +
+                                                      sub * 32 + 4 * h + 8 * e4) = o;
                         }
-                        *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + (size_t)i * TILE_ROWS + sub * 32 +
-                                                  4 * h + 8 * e4) = o;
                     }
-                }
-            } else {
-                float mx = acc[0];
+                } else {
+                    float mx = acc[g][0];
 #pragma unroll
-                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
-                if (__any(mx > tau_s)) {
-                    uint32_t mask = 0;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
-                        mask |= (acc[e] > tau_s && row < n_rows) ? (1u << e) : 0u;
-                    }
-                    if (mask) {
-                        uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
-                        bool dropped = false;
+                    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[g][e]);
+                    if (__any(mx > tau_s[g])) {
+                        uint32_t mask = 0;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
-                            if (mask & (1u << e)) {
-                                if (pos < STAGE_CAP) {
-                                    stage_q[pos] = (uint32_t)qi;
-                                    stage_s[pos] = acc[e] * (1.0f / SCORE_SCALE);
-                                    stage_r[pos] = row0 + (e & 3) + 8 * (e >> 2);
-                                } else {
-                                    dropped = true;
-                                }
-                                ++pos;
-                            }
+                            const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
+                            mask |= (acc[g][e] > tau_s[g] && row < n_rows) ? (1u << e) : 0u;
                         }
-                        // staging full (a tile with > 1024 hits): poison the query's counter -> exact pass
-                        if (dropped) atomicAdd(&cnt[qi], (uint32_t)BATCH_CAP + 1u);
+                        if (mask) {
+                            uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
+                            bool dropped = false;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                if (mask & (1u << e)) {
+                                    if (pos < STAGE_CAP) {
+                                        stage_q[pos] = (uint32_t)qi;
+                                        stage_s[pos] = acc[g][e] * (1.0f / SCORE_SCALE);
+                                        stage_r[pos] = row0 + (e & 3) + 8 * (e >> 2);
+                                    } else {
+                                        dropped = true;
+                                    }
+                                    ++pos;
+                                }
+                            }
+                            // staging full (a tile with > 1024 hits): poison the query's counter -> exact pass
+                            if (dropped) atomicAdd(&cnt[qi], (uint32_t)BATCH_CAP + 1u);
+                        }
                     }
                 }
             }
         }
-        buf ^= 1u;
+    };
+
+    uint32_t i = blockIdx.x;
+#pragma unroll
+    for (int f = 0; f < PF; ++f)
+        if (i + f * gridDim.x < n_tiles) issue(st[f], i + f * gridDim.x);
+    uint32_t buf = 0;
+    while (i < n_tiles) {
+#pragma unroll
+        for (int f = 0; f < PF; ++f) {
+            if (i < n_tiles) {
+                process(st[f], i, buf);
+                buf ^= 1u;
+                i += gridDim.x;
+            }
+        }
     }
     if (!DENSE) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -383,25 +419,36 @@ BatchPlan plan_batched(uint32_t n_rows) {
 
 static bool g_lds_attr_set = false;
 
-template <bool DENSE>
-static void launch_pass(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
-                        const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
-    if (n_tiles == 0) return;
+int g_batched_waves = 8;  // workgroup shape of the scan kernel (4 or 8 waves); tuning knob
+
+template <bool DENSE, int NW>
+static void launch_pass_nw(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+                           const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-    hipLaunchKernelGGL((scan_f16_kernel<DENSE>), dim3(blocks), dim3(512), LDS_BYTES, stream,
+    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream,
                        reinterpret_cast<const f32x4*>(d_x), n_rows, first, stride, n_tiles,
                        reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
                        reinterpret_cast<float*>(ws.cand));
 }
 
+template <bool DENSE>
+static void launch_pass(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+                        const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
+    if (n_tiles == 0) return;
+    if (g_batched_waves == 8) launch_pass_nw<DENSE, 8>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else launch_pass_nw<DENSE, 4>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+}
+
 int batched_init() {
     if (g_lds_attr_set) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f16_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f16_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 4>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+    }
     g_lds_attr_set = true;
     return 0;
 }

@@ -317,11 +317,13 @@ void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uin
 // ------------------------------------------------------------------------------------------------
 // multi-GPU: stable G-way merge of per-shard (distance-ascending) results
 // ------------------------------------------------------------------------------------------------
+// Shard g's lists start at in_labels + g*sl, in_dist + g*sd, in_found + g*sf (element strides): separate
+// [G][B][k] arrays (sl = sd = B*k, sf = B) or one packed blob per shard as all-gathered by the ranks.
 __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B, uint32_t k,
                                                          const uint64_t* __restrict__ in_labels,
                                                          const float* __restrict__ in_dist,
-                                                         const uint32_t* __restrict__ in_found,
-                                                         uint64_t* __restrict__ out_labels,
+                                                         const uint32_t* __restrict__ in_found, size_t sl, size_t sd,
+                                                         size_t sf, uint64_t* __restrict__ out_labels,
                                                          float* __restrict__ out_dist,
                                                          uint32_t* __restrict__ out_found) {
     __shared__ float sh_d[512];
@@ -333,10 +335,10 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
     uint64_t label = 0;
     bool valid = false;
     if (t < total) {
-        valid = i < in_found[(size_t)g * B + b];
+        valid = i < in_found[g * sf + b];
         if (valid) {
-            d = in_dist[((size_t)g * B + b) * k + i];
-            label = in_labels[((size_t)g * B + b) * k + i];
+            d = in_dist[g * sd + (size_t)b * k + i];
+            label = in_labels[g * sl + (size_t)b * k + i];
         }
     }
     sh_d[t] = d;
@@ -355,16 +357,16 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
     }
     if (t == 0) {
         uint32_t sum = 0;
-        for (uint32_t gg = 0; gg < G; ++gg) sum += in_found[(size_t)gg * B + b];
+        for (uint32_t gg = 0; gg < G; ++gg) sum += in_found[gg * sf + b];
         out_found[b] = sum < k ? sum : k;
     }
 }
 
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
-                        const uint32_t* in_found, uint64_t* out_labels, float* out_dist, uint32_t* out_found,
-                        hipStream_t stream) {
+                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, uint64_t* out_labels,
+                        float* out_dist, uint32_t* out_found, hipStream_t stream) {
     hipLaunchKernelGGL(shard_merge_kernel, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
-                       (uint32_t)k, in_labels, in_dist, in_found, out_labels, out_dist, out_found);
+                       (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, out_labels, out_dist, out_found);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -127,6 +127,15 @@ def topk_merge_device(device: int, G: int, B: int, count: int, d_in_labels: int,
                                      d_found, stream))
 
 
+def result_blob_bytes(B: int, count: int) -> int:
+    return lib.dawn_result_blob_bytes(B, count)
+
+
+def topk_merge_packed_device(device: int, G: int, B: int, count: int, d_blobs: int, d_labels: int, d_dist: int,
+                             d_found: int, stream: int = 0):
+    check(lib.dawn_topk_merge_packed_device(device, G, B, count, d_blobs, d_labels, d_dist, d_found, stream))
+
+
 # ---- src/search/vector.rs ---------------------------------------------------------------------
 
 def is_normalized(v: np.ndarray) -> bool:

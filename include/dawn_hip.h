@@ -98,6 +98,14 @@ int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const u
                            const float *d_in_distances, const uint32_t *d_in_found, uint64_t *d_labels,
                            float *d_distances, uint32_t *d_found, void *stream);
 
+/* One-collective form.  Each shard writes its results into ONE blob of dawn_result_blob_bytes(B, count) bytes:
+ *   labels u64 [B][count] at +0 | distances f32 [B][count] at +B*count*8 | found u32 [B] at +B*count*12
+ * (dawn_index_search_device accepts pointers into such a blob), the ranks all-gather the blobs (one
+ * ncclAllGather over xGMI), and d_blobs = the G gathered blobs back to back. */
+size_t dawn_result_blob_bytes(size_t B, size_t count);
+int dawn_topk_merge_packed_device(int device, size_t G, size_t B, size_t count, const void *d_blobs,
+                                  uint64_t *d_labels, float *d_distances, uint32_t *d_found, void *stream);
+
 /* Host form of the same stable merge (host pointers; used where the lists already sit in host memory,
  * e.g. the reference's own local+remote merge point, and by the CPU/gloo tests of the sharded path). */
 int dawn_topk_merge_host(size_t G, size_t B, size_t count, const uint64_t *in_labels, const float *in_distances,

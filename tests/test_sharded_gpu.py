@@ -63,3 +63,40 @@ def test_sharded_search_world1(dawn):
     torch.cuda.synchronize()
     l2, d2, f2 = idx.search_batch(Q, 10)
     assert np.array_equal(lab.cpu().numpy().view(np.uint64), l2) and np.array_equal(d.cpu().numpy(), d2)
+
+
+@pytest.mark.parametrize("G,B,k", [(8, 6, 10), (4, 40, 20)])
+def test_packed_blob_merge_equals_single_index(dawn, G, B, k):
+    """The one-collective exchange: every shard's scan writes into its slot of the gathered blob array; the
+    packed merge must equal the single-index answer (B = 40 goes through the matrix-core path)."""
+    import torch
+    n = 60_000
+    dev = torch.device("cuda", 0)
+    full = dawn.VectorIndex(0)
+    full.fill_synthetic(1, 0, n, 1)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B - 1] = synth.planted_queries(1, [n - 1], 3)[0]
+    dq = torch.from_numpy(Q).to(dev)
+    nbytes = dawn.result_blob_bytes(B, k)
+    assert nbytes % 16 == 0 and nbytes >= B * k * 12 + B * 4
+    g_blob = torch.zeros((G * nbytes,), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for g in range(G):
+        first, m = dawn.shard_range(n, G, g)
+        s = dawn.VectorIndex(0)
+        s.fill_synthetic(1, first, m, 1 + first)
+        shards.append(s)
+        p = g_blob.data_ptr() + g * nbytes
+        s.search_device(dq.data_ptr(), B, k, p, p + B * k * 8, p + B * k * 12, st)
+    o_lab = torch.zeros((B, k), dtype=torch.int64, device=dev)
+    o_dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    o_found = torch.zeros((B,), dtype=torch.int32, device=dev)
+    dawn.topk_merge_packed_device(0, G, B, k, g_blob.data_ptr(), o_lab.data_ptr(), o_dist.data_ptr(),
+                                  o_found.data_ptr(), st)
+    torch.cuda.synchronize()
+    lab1, dist1, found1 = full.search_batch(Q, k)
+    assert np.array_equal(o_found.cpu().numpy(), found1.astype(np.int32))
+    assert np.array_equal(o_lab.cpu().numpy().view(np.uint64), lab1)
+    assert np.array_equal(o_dist.cpu().numpy().view(np.uint32), dist1.view(np.uint32))
+    assert lab1[B - 1][0] == n

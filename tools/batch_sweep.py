@@ -1,16 +1,17 @@
-"""Batched-scan timing on the GPU box (dev tool): python tools/batch_sweep.py [rows]"""
+"""Batched-scan timing on the GPU box (dev tool): python tools/batch_sweep.py [rows] [B,B,...]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dawnsearch_amd as dawn
 from dawnsearch_amd import synth
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+Bs = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 64, 256]
 idx = dawn.VectorIndex(0)
 idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, 256)
-for B in (8, 9, 32, 64, 128, 256):
-    for blocks in (256,):
-        idx.set_option("mfma_blocks", blocks)
+for B in Bs:
+    for waves in (4, 8):
+        idx.set_option("mfma_waves", waves)
         idx.search_batch(Q[:B], 10)
         idx.profile_enable(True)
         t0 = time.time(); it = 10
@@ -18,6 +19,6 @@ for B in (8, 9, 32, 64, 128, 256):
         wall = (time.time() - t0) / it
         n, ms = idx.profile_read(); idx.profile_enable(False)
         k_ms = ms / max(n, 1)
-        flops = 2.0 * B * rows * 384
-        print(f"rows={rows} B={B:3d} blocks={blocks} filter {k_ms*1e3:9.1f} us  {flops/k_ms/1e9:7.1f} TFLOP/s  {rows*1536/k_ms/1e6:7.1f} GB/s-equiv  wall {wall*1e3:8.3f} ms  qps {B/wall:9.0f}", flush=True)
+        flops = 2.0 * 256 * rows * 384
+        print(f"rows={rows} B={B:3d} waves={waves} scan {k_ms*1e3:9.1f} us  {flops/k_ms/1e9:7.1f} TFLOP/s(256q)  {rows*1536/k_ms/1e6:7.1f} GB/s  wall {wall*1e3:8.3f} ms  qps {B/wall:9.0f}", flush=True)
 print(idx.stats())
