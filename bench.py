@@ -182,6 +182,47 @@ def main():
             leg["planted_top1_ok"] = bool(labels[0][0] == 1 + (4242 % args.rows))
         return leg, algo
 
+    def e2e_leg(index, Bq, steps=30):
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            st, cj = dawn.write_synthetic_model(d, seed=3)
+            ep = dawn.EmbeddingProvider(st, cj, local_rank)
+        seqs = synth.token_sequences(5, Bq, 4, 32)
+        lens = np.array([len(x) for x in seqs])
+        offs = np.zeros(Bq + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(lens)
+        T, max_len = int(offs[-1]), int(lens.max())
+        d_ids = torch.from_numpy(np.concatenate(seqs).astype(np.int32)).to(dev)
+        d_off = torch.from_numpy(offs).to(dev)
+        d_emb = torch.zeros((Bq, 384), dtype=torch.float32, device=dev)
+        nbytes = dawn.result_blob_bytes(Bq, k)
+        blob = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        p = blob.data_ptr()
+
+        def embed():
+            ep.forward_device(d_ids.data_ptr(), d_off.data_ptr(), Bq, T, max_len, d_emb.data_ptr(), stream)
+
+        def both():
+            embed()
+            index.search_device(d_emb.data_ptr(), Bq, k, p, p + Bq * k * 8, p + Bq * k * 12, stream)
+
+        res = {"tokens": T, "max_len": max_len}
+        for name, fn in (("embed", embed), ("embed_plus_scan", both)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            res[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+        fl = float(np.sum(lens * (21.23e6 + 9216.0 * lens)))  # per-token GEMM + attention flops
+        res["embed_TFLOPs"] = fl / (res["embed_ms"] * 1e-3) / 1e12
+        res["embed_frac_f32_mfma_peak"] = res["embed_TFLOPs"] / 157.3
+        res["queries_per_s"] = Bq / (res["embed_plus_scan_ms"] * 1e-3)
+        ep.close()
+        return res
+
     # ---- headline leg ------------------------------------------------------------------------
     head, algo_bytes = run_leg(idx, B, args.steps, args.warmup, check_planted=True)
     qps = head["queries_per_s"]
@@ -255,6 +296,10 @@ def main():
             leg2["host_api_p50_ms"] = float(np.percentile(np.array(lat[5:]), 50) * 1e3)
             extra["rows_1M_batch256"] = leg2
             extra["fallbacks_1M"] = idx1.stats()["fallbacks"]
+            # configs[2] end to end: 256 token sequences -> MiniLM-L6-v2 HIP forward -> cosine scan over 1M rows,
+            # everything device-resident on one stream (synthetic seeded weights: no checkpoint on disk)
+            extra["e2e_1M_batch256"] = e2e_leg(idx1, 256)
+            extra["embed_batch1"] = e2e_leg(idx1, 1, steps=100)
         out["checks"]["fallbacks"] = idx.stats()["fallbacks"]
         out["extra"] = extra
         if world == 1 and rank == 0:

@@ -94,7 +94,11 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
 
 // ------------------------------------------------------------------------------------------------
 // Y[M,N] = X[M,K] · W[N,K]ᵀ + bias (+ activation).  64x64 block tile, 4 waves of 32x32 (one
-// v_mfma_f32_32x32x2_f32 accumulator each), K-step 32, register-prefetched LDS staging.
+// v_mfma_f32_32x32x2_f32 accumulator each), K-step 32, double-buffered LDS with one barrier per K-step.
+// Tiles are staged with 16-B global loads and ds_write_b128 into [row][36] images (144-B rows: the
+// ds_read_b128 of 16 rows x one 16-B column covers every bank once).  Inside a K-step the 32 k-values are
+// consumed in the order (j, 16+j), j = 0..15: lane half kh reads its 16 values k = 16kh..16kh+15 as four
+// ds_read_b128, identically for both operands (a sum over k in a fixed, permuted order — still exact f32 FMAs).
 // N % 64 == 0 and K % 32 == 0 for every MiniLM shape (384, 1152, 1536).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -106,16 +110,21 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+constexpr int GT = 64;    // block tile (rows of X, rows of W)
+constexpr int GK = 32;    // K-step
+constexpr int GLD = 36;   // LDS row stride in floats
+
 template <int ACT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ Y,
                                                      int M, int N, int K) {
-    __shared__ float As[64][33];
-    __shared__ float Bs[64][33];
+    __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: rows lr, lr+32 ; cols lc..lc+3
+    // staging: thread -> rows lr, lr+32 ; 16-B column lc of the 32-wide K-step
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
 
     f32x16 acc;
 #pragma unroll
@@ -131,43 +140,57 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             rb[j] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k0 + lc);
         }
     };
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    auto lstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = lr + 32 * j;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                As[r][lc + c] = ra[j][c];
-                Bs[r][lc + c] = rb[j][c];
-            }
+            *reinterpret_cast<f32x4*>(&As[buf][r * GLD + lc]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Bs[buf][r * GLD + lc]) = rb[j];
         }
-        __syncthreads();
-        if (k0 + 32 < K) gload(k0 + 32);
-        const int ar = wm + (lane & 31), br = wn + (lane & 31), kh = lane >> 5;
+    };
+    const int kh = lane >> 5;
+    const int a_off = (wm + (lane & 31)) * GLD + 16 * kh;
+    const int b_off = (wn + (lane & 31)) * GLD + 16 * kh;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        const bool more = k0 + GK < K;
+        if (more) gload(k0 + GK);
+        f32x4 av[4], bv[4];
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float a = As[ar][kk + kh];
-            const float b = Bs[br][kk + kh];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+            av[c] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + 4 * c]);
+            bv[c] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + 4 * c]);
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);  // the other buffer was last read before the previous barrier
         __syncthreads();
+        buf ^= 1;
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int n = n0 + wn + (lane & 31);
-    const float bv = bias[n];
+    const float bvv = bias[n];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         const int m = m0 + wm + row;
-        if (m < M) Y[(size_t)m * N + n] = act_apply(acc[reg] + bv, ACT);
+        if (m < M) Y[(size_t)m * N + n] = act_apply(acc[reg] + bvv, ACT);
     }
 }
 
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
                     hipStream_t s) {
     if (M <= 0) return;
-    dim3 grid(N / 64, (M + 63) / 64), block(256);
+    dim3 grid(N / GT, (M + GT - 1) / GT), block(256);
     if (act == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, s, A, W, bias, Y, M, N, K);
     else if (act == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, s, A, W, bias, Y, M, N, K);
     else hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, block, 0, s, A, W, bias, Y, M, N, K);
