@@ -34,7 +34,10 @@ struct dawn_index {
     size_t cap_phys = 0;      // rows actually allocated (geometric growth)
 
     // search workspaces
-    dawn::ScanGeom geom{512, 1024};
+    // batch-1..8 streaming scan: one 4-wave block per CU, 3 row pairs (9 KiB) in flight per wave.  Measured on
+    // MI355X (tools/scan_sweep.py, 40M rows): 36 KiB in flight per CU reads 7.17 TB/s; the full-occupancy
+    // geometry (32 waves, 192 KiB per CU) only 6.55 TB/s.
+    dawn::ScanGeom geom{256, 256, 3};
     size_t ws_B = 0;
     float* d_cand_s = nullptr;
     uint32_t* d_cand_p = nullptr;
@@ -188,7 +191,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     idx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-        idx->geom.blocks = prop.multiProcessorCount * 2;  // 2 x 16 waves per CU = full occupancy
+        idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
     if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -557,13 +560,19 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         idx->mfma_blocks = (int)value;
         return DAWN_OK;
     }
+    if (n == "scan_unroll") {
+        if (value < 1 || value > 8 || value == 7) return fail(DAWN_ERR_INVALID_ARG, "scan_unroll must be 1..6 or 8");
+        idx->geom.unroll = (int)value;
+        return DAWN_OK;
+    }
     if (n == "mfma_waves") {
         if (value != 4 && value != 8) return fail(DAWN_ERR_INVALID_ARG, "mfma_waves must be 4 or 8");
         dawn::g_batched_waves = (int)value;
         return DAWN_OK;
     }
     if (n == "scan_threads") {
-        if (value != 256 && value != 512 && value != 1024) return fail(DAWN_ERR_INVALID_ARG, "scan_threads must be 256/512/1024");
+        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return fail(DAWN_ERR_INVALID_ARG, "scan_threads must be 64/128/256/512/1024");
         idx->geom.threads = (int)value;
         return DAWN_OK;
     }

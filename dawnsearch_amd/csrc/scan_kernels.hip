@@ -118,12 +118,23 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
     }
 }
 
+template <int QB, int U>
+static void launch_filter_qbu(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
+                              const ScanGeom& g, hipStream_t stream) {
+    hipLaunchKernelGGL((scan_filter_kernel<QB, U>), dim3(g.blocks), dim3(g.threads), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, cand_s, cand_p, (uint32_t)g.blocks);
+}
+
 template <int QB>
 static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
                              const ScanGeom& g, hipStream_t stream) {
-    constexpr int U = 2;
-    hipLaunchKernelGGL((scan_filter_kernel<QB, U>), dim3(g.blocks), dim3(g.threads), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, cand_s, cand_p, (uint32_t)g.blocks);
+    if (QB == 1 && g.unroll == 1) launch_filter_qbu<1, 1>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else if (QB == 1 && g.unroll == 3) launch_filter_qbu<1, 3>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else if (QB == 1 && g.unroll == 4) launch_filter_qbu<1, 4>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else if (QB == 1 && g.unroll == 5) launch_filter_qbu<1, 5>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else if (QB == 1 && g.unroll == 6) launch_filter_qbu<1, 6>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else if (QB == 1 && g.unroll == 8) launch_filter_qbu<1, 8>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+    else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
 }
 
 void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int B, float* cand_s, uint32_t* cand_p,

@@ -1,4 +1,4 @@
-"""Sweep scan-kernel launch geometry on the GPU box and print achieved HBM GB/s (dev tool).
+"""Sweep batch-1 scan-kernel launch geometry on the GPU box and print achieved HBM GB/s (dev tool).
 usage: python tools/scan_sweep.py [rows] [iters]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,25 +6,27 @@ import numpy as np
 import dawnsearch_amd as dawn
 from dawnsearch_amd import synth
 
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 idx = dawn.VectorIndex(0)
 t = time.time(); idx.fill_synthetic(1, 0, rows, 1); print(f"fill {rows} rows: {time.time()-t:.2f}s", flush=True)
 Q = synth.unit_rows(2, 0, 8)
 bytes_per = rows * 1536
-for B in (1, 2, 4, 8):
-    for threads in (256, 512, 1024):
-        for blocks in (256, 512, 1024, 2048, 4096):
-            idx.set_option("scan_threads", threads); idx.set_option("scan_blocks", blocks)
-            idx.search_batch(Q[:B], 10)
+res = []
+for unroll in (2, 3, 4, 5, 6, 8):
+    for threads in (64, 128, 256):
+        for blocks in (256, 512, 768, 1024):
+            if blocks * threads > 256 * 512 or blocks * threads < 256 * 128:
+                continue
+            idx.set_option("scan_unroll", unroll); idx.set_option("scan_threads", threads); idx.set_option("scan_blocks", blocks)
+            idx.search_batch(Q[:1], 10)
             idx.profile_enable(True)
-            t0 = time.time()
             for _ in range(iters):
-                idx.search_batch(Q[:B], 10)
-            wall = (time.time() - t0) / iters
+                idx.search_batch(Q[:1], 10)
             n, ms = idx.profile_read()
             idx.profile_enable(False)
             k_ms = ms / max(n, 1)
-            print(f"B={B} threads={threads:4d} blocks={blocks:4d}  scan {k_ms*1e3:9.1f} us  {bytes_per/k_ms/1e6:8.1f} GB/s"
-                  f"  wall/call {wall*1e6:9.1f} us", flush=True)
-print(idx.stats())
+            res.append((bytes_per / k_ms / 1e6, unroll, threads, blocks))
+            print(f"U={unroll} threads={threads:4d} blocks={blocks:4d}  scan {k_ms*1e3:9.1f} us  {bytes_per/k_ms/1e6:8.1f} GB/s", flush=True)
+res.sort(reverse=True)
+print("best:", res[:8])
