@@ -561,7 +561,7 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         return DAWN_OK;
     }
     if (n == "scan_unroll") {
-        if (value < 1 || value > 8 || value == 7) return fail(DAWN_ERR_INVALID_ARG, "scan_unroll must be 1..6 or 8");
+        if (value < 1 || value > 4) return fail(DAWN_ERR_INVALID_ARG, "scan_unroll must be 1..4");
         idx->geom.unroll = (int)value;
         return DAWN_OK;
     }

@@ -32,7 +32,7 @@ constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass mus
 struct ScanGeom {
     int blocks;           // scan grid (== number of candidate lists per query)
     int threads;          // 1024 / 512 / 256
-    int unroll = 2;       // row pairs per wave iteration (batch-1 kernel: 1..4)
+    int unroll = 2;       // row pairs per wave iteration (batch-1 kernel)
 };
 
 // Filter pass: approximate scores for all rows, per-block top-64 lists.

@@ -131,9 +131,6 @@ static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q
     if (QB == 1 && g.unroll == 1) launch_filter_qbu<1, 1>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
     else if (QB == 1 && g.unroll == 3) launch_filter_qbu<1, 3>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
     else if (QB == 1 && g.unroll == 4) launch_filter_qbu<1, 4>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else if (QB == 1 && g.unroll == 5) launch_filter_qbu<1, 5>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else if (QB == 1 && g.unroll == 6) launch_filter_qbu<1, 6>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else if (QB == 1 && g.unroll == 8) launch_filter_qbu<1, 8>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
     else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
 }
 

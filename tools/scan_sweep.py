@@ -13,7 +13,7 @@ t = time.time(); idx.fill_synthetic(1, 0, rows, 1); print(f"fill {rows} rows: {t
 Q = synth.unit_rows(2, 0, 8)
 bytes_per = rows * 1536
 res = []
-for unroll in (2, 3, 4, 5, 6, 8):
+for unroll in (1, 2, 3, 4):
     for threads in (64, 128, 256):
         for blocks in (256, 512, 768, 1024):
             if blocks * threads > 256 * 512 or blocks * threads < 256 * 128:
