@@ -17,6 +17,7 @@ ERR_INVALID_ARG, ERR_NOT_NORMALIZED, ERR_HIP, ERR_IO, ERR_NO_DEVICE, ERR_UNSUPPO
 EM_LEN = 384
 MAX_K = 64
 DTYPE_F32 = 0
+DTYPE_BF16 = 1
 
 
 class DawnError(RuntimeError):

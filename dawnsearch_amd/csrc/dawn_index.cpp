@@ -27,7 +27,11 @@ struct dawn_index {
     size_t dims = DAWN_EM_LEN;
     hipStream_t stream = nullptr;
 
-    float* d_x = nullptr;       // [(cap_phys + ROW_PAD)][384]
+    int dtype = DAWN_DTYPE_F32;  // row storage: f32 (1536 B/row) or bf16 (768 B/row)
+    char* d_x = nullptr;         // [(cap_phys + ROW_PAD)][384] of dtype
+    float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
+    size_t stage_rows = 0;
+    size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }
     uint64_t* d_ids = nullptr;  // [cap_phys]
     size_t size = 0;
     size_t cap_reported = 0;  // what reserve() promised (usearch semantics)
@@ -74,24 +78,23 @@ size_t padded_rows(size_t rows) { return ((rows + dawn::ROW_PAD - 1) / dawn::ROW
 int grow_phys(dawn_index* idx, size_t rows) {
     if (rows <= idx->cap_phys) return DAWN_OK;
     if (rows >= 0xFFFFFF00ull) return fail(DAWN_ERR_UNSUPPORTED, "index limited to 2^32-256 rows per device");
-    float* nx = nullptr;
+    char* nx = nullptr;
     uint64_t* nid = nullptr;
     const size_t prow = padded_rows(rows);
-    DAWN_HIP_TRY(hipMalloc((void**)&nx, prow * dawn::EM * sizeof(float)));
+    const size_t rb = idx->row_bytes();
+    DAWN_HIP_TRY(hipMalloc((void**)&nx, prow * rb));
     hipError_t e = hipMalloc((void**)&nid, std::max<size_t>(rows, 1) * sizeof(uint64_t));
     if (e != hipSuccess) {
         (void)hipFree(nx);
         return fail(DAWN_ERR_OOM, "hipMalloc(ids): %s", hipGetErrorString(e));
     }
     if (idx->size) {
-        DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, idx->size * dawn::EM * sizeof(float), hipMemcpyDeviceToDevice,
-                                    idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, idx->size * rb, hipMemcpyDeviceToDevice, idx->stream));
         DAWN_HIP_TRY(hipMemcpyAsync(nid, idx->d_ids, idx->size * sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                     idx->stream));
     }
     // zero everything past the live rows: the scan may read (never use) up to ROW_PAD rows past size
-    DAWN_HIP_TRY(hipMemsetAsync(nx + idx->size * dawn::EM, 0, (prow - idx->size) * dawn::EM * sizeof(float),
-                                idx->stream));
+    DAWN_HIP_TRY(hipMemsetAsync(nx + idx->size * rb, 0, (prow - idx->size) * rb, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     if (idx->d_x) (void)hipFree(idx->d_x);
     if (idx->d_ids) (void)hipFree(idx->d_ids);
@@ -157,18 +160,19 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
         // matrix-core path, BATCH_QT queries per pass over the index
         for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
             const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
-            dawn::launch_scan_batched(idx->d_x, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
+            dawn::launch_scan_batched(idx->d_x, idx->dtype, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
                                       idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
                                       idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                       b0 == 0 ? e1 : nullptr);
         }
     } else {
-        dawn::launch_scan_filter(idx->d_x, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
-        dawn::launch_merge_rescore(idx->d_x, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
+        dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0,
+                                 e1);
+        dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
                                    idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                                    idx->force_fallback, dawn::FILTER_EPS_F32, stream);
     }
-    dawn::launch_scan_exact(idx->d_x, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
+    dawn::launch_scan_exact(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
                             stream);
     dawn::launch_merge_exact(idx->d_ids, n, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
                              (uint32_t)k, d_labels, d_dist, d_found, stream);
@@ -184,11 +188,17 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     if (!out) return fail(DAWN_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (dims != DAWN_EM_LEN) return fail(DAWN_ERR_UNSUPPORTED, "dims must be %d (EM_LEN)", DAWN_EM_LEN);
-    if (dtype != DAWN_DTYPE_F32) return fail(DAWN_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
+    if (dtype != DAWN_DTYPE_F32 && dtype != DAWN_DTYPE_BF16)
+        return fail(DAWN_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
     auto* idx = new dawn_index();
     idx->device = device;
+    idx->dtype = dtype;
+    if (dtype == DAWN_DTYPE_BF16) {  // twice the rows per byte: the reduction needs two waves per SIMD to keep up
+        idx->geom.threads = 512;
+        idx->geom.unroll = 1;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
@@ -221,7 +231,7 @@ void dawn_index_destroy(dawn_index* idx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    void* ptrs[] = {idx->d_x, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
+    void* ptrs[] = {idx->d_x, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
                     idx->bws.cnt, idx->bws.cand, idx->d_q, idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -241,23 +251,49 @@ int dawn_index_reserve(dawn_index* idx, size_t capacity) {
 size_t dawn_index_size(const dawn_index* idx) { return idx ? idx->size : 0; }
 size_t dawn_index_capacity(const dawn_index* idx) { return idx ? idx->cap_reported : 0; }
 
+// bf16 index: f32 rows pass through a device staging buffer (validated there, then rounded into the index)
+static int ensure_stage(dawn_index* idx, size_t rows) {
+    if (rows <= idx->stage_rows) return DAWN_OK;
+    if (idx->d_stage) (void)hipFree(idx->d_stage);
+    idx->d_stage = nullptr;
+    idx->stage_rows = 0;
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stage, rows * dawn::EM * sizeof(float)));
+    idx->stage_rows = rows;
+    return DAWN_OK;
+}
+constexpr size_t kStageChunk = 1u << 18;  // 256 Ki rows = 384 MiB of f32 staging at most
+
 int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const float* v) {
     if (!idx || (!ids && n) || (!v && n)) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (n == 0) return DAWN_OK;
     DAWN_TRY(set_device(idx));
     DAWN_TRY(ensure_room(idx, n));
-    float* dst = idx->d_x + idx->size * dawn::EM;
+    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
+    const size_t rb = idx->row_bytes();
     // rows land past `size` (invisible to searches) and become live only after validation
-    DAWN_HIP_TRY(hipMemcpyAsync(dst, v, n * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), idx->stream));
+    if (!bf16) {
+        float* dst = reinterpret_cast<float*>(idx->d_x + idx->size * rb);
+        DAWN_HIP_TRY(hipMemcpyAsync(dst, v, n * rb, hipMemcpyHostToDevice, idx->stream));
+        dawn::launch_validate_rows(dst, (uint32_t)n, idx->d_bad, idx->stream);
+    } else {
+        DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk)));
+        for (size_t o = 0; o < n; o += kStageChunk) {
+            const size_t m = std::min(kStageChunk, n - o);
+            DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, v + o * dawn::EM, m * dawn::EM * sizeof(float),
+                                        hipMemcpyHostToDevice, idx->stream));
+            dawn::launch_validate_rows(idx->d_stage, (uint32_t)m, idx->d_bad, idx->stream);  // gate on the f32 input
+            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x + (idx->size + o) * rb, m, idx->stream);
+            if (o + kStageChunk < n) DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));  // staging buffer reuse
+        }
+    }
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, ids, n * sizeof(uint64_t), hipMemcpyHostToDevice,
                                 idx->stream));
-    DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), idx->stream));
-    dawn::launch_validate_rows(dst, (uint32_t)n, idx->d_bad, idx->stream);
     uint32_t bad = 0;
     DAWN_HIP_TRY(hipMemcpyAsync(&bad, idx->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     if (bad) {
-        (void)hipMemsetAsync(dst, 0, n * dawn::EM * sizeof(float), idx->stream);
+        (void)hipMemsetAsync(idx->d_x + idx->size * rb, 0, n * rb, idx->stream);
         (void)hipStreamSynchronize(idx->stream);
         return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized (%u of %zu rows)", bad, n);
     }
@@ -274,8 +310,14 @@ int dawn_index_add(dawn_index* idx, uint64_t id, const float* v) {
     std::memcpy(hp, v, dawn::EM * sizeof(float));
     uint64_t* hid = (uint64_t*)(hp + dawn::EM);
     *hid = id;
-    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_x + idx->size * dawn::EM, hp, dawn::EM * sizeof(float), hipMemcpyHostToDevice,
-                                idx->stream));
+    const size_t rb = idx->row_bytes();
+    if (idx->dtype == DAWN_DTYPE_BF16) {
+        DAWN_TRY(ensure_stage(idx, 1));
+        DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, hp, dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+        dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x + idx->size * rb, 1, idx->stream);
+    } else {
+        DAWN_HIP_TRY(hipMemcpyAsync(idx->d_x + idx->size * rb, hp, rb, hipMemcpyHostToDevice, idx->stream));
+    }
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, hid, sizeof(uint64_t), hipMemcpyHostToDevice, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     idx->size += 1;
@@ -370,12 +412,21 @@ int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row
     if (n == 0) return DAWN_OK;
     DAWN_TRY(set_device(idx));
     DAWN_TRY(ensure_room(idx, n));
-    const size_t chunk = 1u << 22;  // 4M rows per generator launch (16 MiB of row lengths)
+    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
+    const size_t rb = idx->row_bytes();
+    const size_t chunk = bf16 ? kStageChunk : (size_t)1u << 22;  // rows per generator launch
+    if (bf16) DAWN_TRY(ensure_stage(idx, std::min(n, chunk)));
     float* d_len = nullptr;
     DAWN_HIP_TRY(hipMalloc((void**)&d_len, std::min(n, chunk) * sizeof(float)));
     for (size_t o = 0; o < n; o += chunk) {
         const size_t m = std::min(chunk, n - o);
-        dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, idx->d_x + (idx->size + o) * dawn::EM, d_len, idx->stream);
+        char* dst = idx->d_x + (idx->size + o) * rb;
+        if (bf16) {  // f32 unit rows of the spec, then rounded: the bf16 index holds round_bf16(spec row)
+            dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, idx->d_stage, d_len, idx->stream);
+            dawn::launch_rows_f32_to_bf16(idx->d_stage, dst, m, idx->stream);
+        } else {
+            dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->stream);
+        }
         dawn::launch_iota_u64(idx->d_ids + idx->size + o, first_id + o, (uint32_t)m, idx->stream);
     }
     hipError_t e = hipStreamSynchronize(idx->stream);
@@ -385,23 +436,37 @@ int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row
     return DAWN_OK;
 }
 
+// Rows come back as f32 whatever the storage type (bf16 rows widened exactly).
 int dawn_index_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (first + n > idx->size) return fail(DAWN_ERR_INVALID_ARG, "rows [%zu, %zu) out of range (size %zu)", first, first + n, idx->size);
     if (n == 0) return DAWN_OK;
     DAWN_TRY(set_device(idx));
-    if (out_rows) DAWN_HIP_TRY(hipMemcpy(out_rows, idx->d_x + first * dawn::EM, n * dawn::EM * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t rb = idx->row_bytes();
+    if (out_rows && idx->dtype == DAWN_DTYPE_BF16) {
+        DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk)));
+        for (size_t o = 0; o < n; o += kStageChunk) {
+            const size_t m = std::min(kStageChunk, n - o);
+            dawn::launch_rows_bf16_to_f32(idx->d_x + (first + o) * rb, idx->d_stage, m, idx->stream);
+            DAWN_HIP_TRY(hipMemcpyAsync(out_rows + o * dawn::EM, idx->d_stage, m * dawn::EM * sizeof(float),
+                                        hipMemcpyDeviceToHost, idx->stream));
+            DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+        }
+    } else if (out_rows) {
+        DAWN_HIP_TRY(hipMemcpy(out_rows, idx->d_x + first * rb, n * rb, hipMemcpyDeviceToHost));
+    }
     if (out_ids) DAWN_HIP_TRY(hipMemcpy(out_ids, idx->d_ids + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return DAWN_OK;
 }
 
-// File layout: "DAWNIDX1" | u32 dims | u32 dtype | u64 n | ids[n] u64 | rows[n][384] f32 (little endian)
+// File layout: "DAWNIDX1" | u32 dims | u32 dtype | u64 n | ids[n] u64 | rows[n][384] f32 (little endian).  Rows are
+// written as f32 for both storage types (a bf16 index widens exactly and re-rounds to the same bits on load).
 int dawn_index_save(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     DAWN_TRY(set_device(idx));
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(DAWN_ERR_IO, "cannot open %s for writing", path);
-    const uint32_t dims = DAWN_EM_LEN, dtype = DAWN_DTYPE_F32;
+    const uint32_t dims = DAWN_EM_LEN, dtype = (uint32_t)idx->dtype;
     const uint64_t n = idx->size;
     bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(&dims, 4, 1, f) == 1 &&
               std::fwrite(&dtype, 4, 1, f) == 1 && std::fwrite(&n, 8, 1, f) == 1;
@@ -414,7 +479,7 @@ int dawn_index_save(dawn_index* idx, const char* path) {
     }
     for (size_t o = 0; ok && o < n; o += chunk) {
         const size_t m = std::min<size_t>(chunk, n - o);
-        if (hipMemcpy(buf.data(), idx->d_x + o * dawn::EM, m * dawn::EM * 4, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        if (dawn_index_get_rows(idx, o, m, reinterpret_cast<float*>(buf.data()), nullptr) != DAWN_OK) ok = false;
         else ok = std::fwrite(buf.data(), dawn::EM * 4, m, f) == m;
     }
     if (std::fclose(f) != 0) ok = false;
@@ -432,7 +497,7 @@ int dawn_index_load(dawn_index* idx, const char* path) {
     uint64_t n = 0;
     if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kMagic, 8) != 0 || std::fread(&dims, 4, 1, f) != 1 ||
         std::fread(&dtype, 4, 1, f) != 1 || std::fread(&n, 8, 1, f) != 1 || dims != DAWN_EM_LEN ||
-        dtype != DAWN_DTYPE_F32) {
+        (dtype != DAWN_DTYPE_F32 && dtype != DAWN_DTYPE_BF16)) {
         std::fclose(f);
         return fail(DAWN_ERR_IO, "%s is not a dawn index file", path);
     }
@@ -528,7 +593,7 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     *n_out = n;
     if (n == 0) return DAWN_OK;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    dawn::launch_batched_dense_scores(idx->d_x, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
+    dawn::launch_batched_dense_scores(idx->d_x, idx->dtype, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
                                       idx->stream);
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),

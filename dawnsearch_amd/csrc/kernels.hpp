@@ -26,6 +26,9 @@ constexpr int BATCH_TILE_ROWS = 64;   // rows per LDS tile of the batched scan
 constexpr int BATCH_QT = 256;         // queries per batched pass (8 waves x 32)
 constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sample size)
 
+constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
+constexpr int ROW_BF16 = 1;  // DAWN_DTYPE_BF16: rows are 384 x bf16 (768 B), scored as their exact f32 widening
+
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
 
@@ -37,11 +40,11 @@ struct ScanGeom {
 
 // Filter pass: approximate scores for all rows, per-block top-64 lists.
 //   cand_s/cand_p: [B][geom.blocks][64]
-void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int B, float* cand_s,
+void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0,
                         hipEvent_t ev1);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
-void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
                           int force_fallback, float eps, hipStream_t stream);
@@ -61,15 +64,16 @@ struct BatchPlan {
 };
 BatchPlan plan_batched(uint32_t n_rows);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
-void launch_batched_dense_scores(const float* d_x, uint32_t n_rows, const float* d_q, int B, const BatchWorkspace& ws,
-                                 int grid, hipStream_t stream);
+void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
+                                 const BatchWorkspace& ws, int grid, hipStream_t stream);
 extern int g_batched_waves;  // 8 (default) or 4 waves per scan workgroup
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
-void launch_scan_batched(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k,
-                         const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
-                         uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_scan_batched(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+                         uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
+                         uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
-void launch_scan_exact(const float* d_x, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
+void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);
 void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags,
                         const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
@@ -86,5 +90,8 @@ void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count
 void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_out, float* d_len,
                        hipStream_t stream);
 void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t stream);
+// Row-type conversion of whole rows: f32 -> bf16 (round to nearest even) and bf16 -> f32 (exact).
+void launch_rows_f32_to_bf16(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream);
+void launch_rows_bf16_to_f32(const void* d_in, float* d_out, size_t n_rows, hipStream_t stream);
 
 }  // namespace dawn

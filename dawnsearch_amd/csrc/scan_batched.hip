@@ -22,6 +22,8 @@
 // converted to f16 and written to LDS in MFMA-fragment order ([k-group g][row] 16-B slots, rows rotated by
 // g&7: conflict-free ds_write_b64 and ds_read_b128); every wave then reads the A fragments back (one
 // ds_read_b128 per MFMA).  D[row][query]: a lane holds 16 rows of ONE query, so the threshold is one VGPR.
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "wave_topk.hpp"
 
@@ -58,6 +60,23 @@ __device__ __forceinline__ half4 to_half4_scaled(const f32x4& v) {
     return r;
 }
 
+// f32 chunk (4 values) -> 8 B at +32 B per step; bf16 chunk (8 values) -> 16 B at +64 B per step
+__device__ __forceinline__ void store_converted(unsigned char* base, int step, const f32x4& v) {
+    *reinterpret_cast<half4*>(base + step * 32) = to_half4_scaled(v);
+}
+__device__ __forceinline__ void store_converted(unsigned char* base, int step, const u32x4& w) {
+    half8 o;
+    o[0] = (_Float16)(bf16_lo(w.x) * ROW_SCALE);  // bf16 -> f32 is exact; the scaled f16 rounding is the only one
+    o[1] = (_Float16)(bf16_hi(w.x) * ROW_SCALE);
+    o[2] = (_Float16)(bf16_lo(w.y) * ROW_SCALE);
+    o[3] = (_Float16)(bf16_hi(w.y) * ROW_SCALE);
+    o[4] = (_Float16)(bf16_lo(w.z) * ROW_SCALE);
+    o[5] = (_Float16)(bf16_hi(w.z) * ROW_SCALE);
+    o[6] = (_Float16)(bf16_lo(w.w) * ROW_SCALE);
+    o[7] = (_Float16)(bf16_hi(w.w) * ROW_SCALE);
+    *reinterpret_cast<half8*>(base + step * 64) = o;
+}
+
 // LDS byte offset (inside one tile buffer) of the 16-B slot holding f16 elements k = 8g..8g+7 of tile row `row`:
 // [sub-tile][g][row + (g & 7)].  The skew by g & 7 spreads one row's consecutive k-groups over all banks
 // (ds_write_b64 of 16 consecutive chunks is conflict-free); a k-group's 32 rows stay contiguous (ds_read_b128
@@ -72,14 +91,15 @@ __device__ __forceinline__ uint32_t slot_off(uint32_t row, uint32_t g) {
 // 64/NW rows of every tile; PF tiles are in flight per wave (register-staged: 96/NW 16-B loads per lane and tile).
 //   NW = 4: one wave per SIMD, 512 registers: 2 x 24 loads in flight per lane = 192 KiB per CU
 //   NW = 8: two waves per SIMD, 256 registers: 12 loads in flight per lane     =  96 KiB per CU
-template <bool DENSE, int NW>
-__global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+template <bool DENSE, int NW, int RT>
+__global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restrict__ xv, uint32_t n_rows,
                                                           uint32_t first_tile, uint32_t tile_stride,
                                                           uint32_t n_tiles, const half8* __restrict__ qh, int n_q,
                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
                                                           uint2* __restrict__ cand, float* __restrict__ dense) {
     constexpr int QG = 8 / NW;          // 32-query groups per wave
-    constexpr int LPL = 96 / NW;        // loads per lane per tile
+    constexpr int CPR = RT == 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16: 8 values each, f32: 4)
+    constexpr int LPL = CPR / NW;       // loads per lane per tile
     constexpr int RPW = TILE_ROWS / NW; // tile rows converted by one wave
     constexpr int PF = NW == 4 ? 2 : 1; // tiles in flight
     constexpr int NT = NW * 64;
@@ -120,35 +140,37 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const f32x4* __restri
         if (!DENSE && q0 + 32 * g < n_q) tau_s[g] = tau[q0 + 32 * g] * SCORE_SCALE;
     }
 
-    // producer map: wave w converts rows RPW*w.. of the tile = RPW*96 consecutive 16-B chunks; load j = 3a + b of
-    // this lane is chunk (b*64 + lane) + 192a, i.e. row RPW*w + 2a + (b*64+lane)/96, chunk c = (b*64+lane) % 96:
-    // three LDS addresses + an immediate 32-B step per a.
+    // producer map: wave w converts rows RPW*w.. of the tile = RPW*CPR consecutive 16-B chunks; load j = 3a + b of
+    // this lane is chunk (b*64 + lane) + 192a.  f32 rows (96 chunks of 4 values): row RPW*w + 2a + (b*64+lane)/96,
+    // chunk c -> k-group c/2, half c&1, 8-B store, +32 B per a.  bf16 rows (48 chunks of 8 values): row
+    // RPW*w + 4a + (b*64+lane)/48, chunk c = k-group c, 16-B store, +64 B per a.  Three LDS addresses either way.
     uint32_t wr_off[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const uint32_t Lb = (uint32_t)b * 64u + (uint32_t)lane;
-        const uint32_t row = (uint32_t)RPW * wave + Lb / 96u, c = Lb % 96u;
-        wr_off[b] = slot_off(row, c >> 1) + (c & 1u) * 8u;
+        const uint32_t row = (uint32_t)RPW * wave + Lb / CPR, c = Lb % CPR;
+        wr_off[b] = RT == 1 ? slot_off(row, c) : slot_off(row, c >> 1) + (c & 1u) * 8u;
     }
     // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
     const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
 
-    f32x4 st[PF][LPL];
-    auto issue = [&](f32x4(&dst)[LPL], uint32_t i) {
-        const f32x4* p = x + ((size_t)first_tile + (size_t)i * tile_stride) * (TILE_ROWS * ROW_F4) +
-                         wave * (RPW * ROW_F4) + lane;
+    typedef typename std::conditional<RT == 1, u32x4, f32x4>::type chunk_t;
+    const chunk_t* x = reinterpret_cast<const chunk_t*>(xv);
+    chunk_t st[PF][LPL];
+    auto issue = [&](chunk_t(&dst)[LPL], uint32_t i) {
+        const chunk_t* p = x + ((size_t)first_tile + (size_t)i * tile_stride) * (TILE_ROWS * CPR) +
+                           wave * (RPW * CPR) + lane;
 #pragma unroll
-        for (int j = 0; j < LPL; ++j) dst[j] = nt_load(p + j * 64);
+        for (int j = 0; j < LPL; ++j) dst[j] = __builtin_nontemporal_load(p + j * 64);
     };
 
     // One tile: convert the staged rows into LDS buffer `buf`, refill the staging registers with tile i + PF*grid,
     // barrier, contract, threshold test.
-    auto process = [&](f32x4(&src)[LPL], uint32_t i, uint32_t buf) {
+    auto process = [&](chunk_t(&src)[LPL], uint32_t i, uint32_t buf) {
         unsigned char* tb = lds + buf * TILE_BYTES;
         if (!DENSE && threadIdx.x == 0) stage_n[1 + buf] = stage_n[0];  // wave 0 is past its own appends
 #pragma unroll
-        for (int j = 0; j < LPL; ++j)
-            *reinterpret_cast<half4*>(tb + wr_off[j % 3] + (j / 3) * 32) = to_half4_scaled(src[j]);
+        for (int j = 0; j < LPL; ++j) store_converted(tb + wr_off[j % 3], j / 3, src[j]);
         const uint32_t nxt = i + PF * gridDim.x;
         if (nxt < n_tiles) issue(src, nxt);
         // LDS writes visible to the workgroup; the prefetch loads stay in flight across the barrier
@@ -319,9 +341,9 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
 // Final: shortlist = top-64 candidates by filter score; exact rescore in the reference order; certificate.
 // Rows outside the shortlist scored <= m: the 64th candidate score if there are >= 64 candidates (every
 // candidate beat tau), else tau itself (DENSE: every row is a candidate, m = 64th score).
-template <bool DENSE>
+template <bool DENSE, int RT>
 __global__ __launch_bounds__(1024) void select_rescore_kernel(
-    const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
+    const void* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ dense, const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt,
     const float* __restrict__ tau, uint32_t k, uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
     uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     const bool valid = p != NO_POS;
     float d = POS_INF;
     if (valid) {
-        const float dot = exact_dot_seq(q + (size_t)b * EM, x + (size_t)p * ROW_F4);
+        const float dot = exact_dot_row<RT>(q + (size_t)b * EM, x, p);
         d = __fsub_rn(1.0f, dot);  // vector.rs:133
     }
     sort64_asc(d, p, lane);
@@ -421,30 +443,38 @@ static bool g_lds_attr_set = false;
 
 int g_batched_waves = 8;  // workgroup shape of the scan kernel (4 or 8 waves); tuning knob
 
-template <bool DENSE, int NW>
-static void launch_pass_nw(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+template <bool DENSE, int NW, int RT>
+static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream,
-                       reinterpret_cast<const f32x4*>(d_x), n_rows, first, stride, n_tiles,
-                       reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
-                       reinterpret_cast<float*>(ws.cand));
+    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, RT>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
+                       first, stride, n_tiles, reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
+                       reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
 }
 
 template <bool DENSE>
-static void launch_pass(const float* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+static void launch_pass(const void* d_x, int dtype, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                         const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     if (n_tiles == 0) return;
-    if (g_batched_waves == 8) launch_pass_nw<DENSE, 8>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-    else launch_pass_nw<DENSE, 4>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    if (dtype == ROW_BF16) {
+        if (g_batched_waves == 8) launch_pass_nw<DENSE, 8, 1>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+        else launch_pass_nw<DENSE, 4, 1>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    } else {
+        if (g_batched_waves == 8) launch_pass_nw<DENSE, 8, 0>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+        else launch_pass_nw<DENSE, 4, 0>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    }
 }
 
 int batched_init() {
     if (g_lds_attr_set) return 0;
-    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 4>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8>)};
+    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 4, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<true, 4, 1>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4, 1>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 1>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 1>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -453,45 +483,60 @@ int batched_init() {
     return 0;
 }
 
-void launch_batched_dense_scores(const float* d_x, uint32_t n_rows, const float* d_q, int B, const BatchWorkspace& ws,
-                                 int grid, hipStream_t stream) {
+void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
+                                 const BatchWorkspace& ws, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
     const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
-    launch_pass<true>(d_x, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
+    launch_pass<true>(d_x, dtype, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
 }
 
-void launch_scan_batched(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k,
-                         const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
-                         uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+template <bool DENSE>
+static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q,
+                                  int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
+                                  uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream) {
+    const float* dense = reinterpret_cast<const float*>(ws.cand);
+    const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
+    // the bf16-rounded rows may exceed the is_normalized band by 2^-8: scale the bound on sum|q_i x_i| accordingly
+    const float eps = dtype == ROW_BF16 ? FILTER_EPS_F16 * 1.004f : FILTER_EPS_F16;
+    if (dtype == ROW_BF16)
+        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q,
+                           dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+    else
+        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 0>), dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q,
+                           dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+}
+
+void launch_scan_batched(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+                         uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
+                         uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1) {
     const BatchPlan pl = plan_batched(n_rows);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(d_x);
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
     if (pl.dense_only) {
         if (ev0) (void)hipEventRecord(ev0, stream);
-        launch_pass<true>(d_x, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+        launch_pass<true>(d_x, dtype, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
         if (ev1) (void)hipEventRecord(ev1, stream);
-        hipLaunchKernelGGL((select_rescore_kernel<true>), dim3(B), dim3(1024), 0, stream, x4, d_ids, n_rows, d_q, dense,
-                           cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback,
-                           FILTER_EPS_F16);
+        launch_select_rescore<true>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+                                    force_fallback, stream);
         return;
     }
-    launch_pass<true>(d_x, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
+    launch_pass<true>(d_x, dtype, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
     hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
                        pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
     if (pl.s2_tiles) {
         (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
-        launch_pass<false>(d_x, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
+        launch_pass<false>(d_x, dtype, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
         hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
                            ws.tau);
     }
     (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
-    launch_pass<false>(d_x, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+    launch_pass<false>(d_x, dtype, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL((select_rescore_kernel<false>), dim3(B), dim3(1024), 0, stream, x4, d_ids, n_rows, d_q, dense,
-                       cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_F16);
+    launch_select_rescore<false>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+                                 force_fallback, stream);
 }
 
 }  // namespace dawn

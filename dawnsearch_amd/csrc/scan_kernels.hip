@@ -118,6 +118,119 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
     }
 }
 
+// bf16 index (DAWN_DTYPE_BF16): a "quad" = 4 consecutive rows = 3072 contiguous bytes = 3 wave-wide 16-B loads
+// (192 chunks of 8 bf16; chunk C = 64*load + lane belongs to row C/48, k = 8*(C%48)..+7):
+//   load 0: lanes 0..47 row 0 | 48..63 row 1 (chunks 0..15)      load 1: lanes 0..31 row 1 (16..47) | 32..63 row 2 (0..31)
+//   load 2: lanes 0..15 row 2 (32..47) | 16..63 row 3
+// Products are exact-f32 (widened row x f32 query), 8-deep FMA chain per lane, then the same DPP tree: the f32
+// filter's error bound applies unchanged.
+__device__ __forceinline__ float dot8_bf16(const u32x4& w, const f32x4& q0, const f32x4& q1) {
+    float acc = bf16_lo(w.x) * q0.x;
+    acc = __builtin_fmaf(bf16_hi(w.x), q0.y, acc);
+    acc = __builtin_fmaf(bf16_lo(w.y), q0.z, acc);
+    acc = __builtin_fmaf(bf16_hi(w.y), q0.w, acc);
+    acc = __builtin_fmaf(bf16_lo(w.z), q1.x, acc);
+    acc = __builtin_fmaf(bf16_hi(w.z), q1.y, acc);
+    acc = __builtin_fmaf(bf16_lo(w.w), q1.z, acc);
+    acc = __builtin_fmaf(bf16_hi(w.w), q1.w, acc);
+    return acc;
+}
+
+template <int QB, int U>
+__global__ __launch_bounds__(1024) void scan_filter_bf16_kernel(const u32x4* __restrict__ x, uint32_t n_rows,
+                                                                const float* __restrict__ q,
+                                                                float* __restrict__ out_s,
+                                                                uint32_t* __restrict__ out_p,
+                                                                uint32_t q_stride_lists) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * nwaves + wave;
+    const uint32_t total_waves = gridDim.x * nwaves;
+    const uint32_t n_quads = (n_rows + 3u) >> 2;
+    const uint32_t n_chunks = (n_quads + U - 1) / U;
+
+    // query fragments for this lane's chunk position in each of the three loads
+    const int c0 = lane < 48 ? lane : lane - 48;
+    const int c1 = lane < 32 ? 16 + lane : lane - 32;
+    const int c2 = lane < 16 ? 32 + lane : lane - 16;
+    f32x4 qf[QB][6];
+    float ls[QB], tau[QB];
+    uint32_t lp[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const f32x4* qq = reinterpret_cast<const f32x4*>(q + b * EM);
+        qf[b][0] = qq[2 * c0];
+        qf[b][1] = qq[2 * c0 + 1];
+        qf[b][2] = qq[2 * c1];
+        qf[b][3] = qq[2 * c1 + 1];
+        qf[b][4] = qq[2 * c2];
+        qf[b][5] = qq[2 * c2 + 1];
+        ls[b] = NEG_INF;
+        lp[b] = NO_POS;
+        tau[b] = NEG_INF;
+    }
+    const bool a48 = lane < 48, a32 = lane < 32, a16 = lane < 16;
+
+    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
+        const u32x4* p = x + (size_t)c * (U * 192) + lane;
+        u32x4 v[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u][0] = __builtin_nontemporal_load(p + u * 192);
+            v[u][1] = __builtin_nontemporal_load(p + u * 192 + 64);
+            v[u][2] = __builtin_nontemporal_load(p + u * 192 + 128);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r0 = (c * U + u) * 4u;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const float d0 = dot8_bf16(v[u][0], qf[b][0], qf[b][1]);
+                const float d1 = dot8_bf16(v[u][1], qf[b][2], qf[b][3]);
+                const float d2 = dot8_bf16(v[u][2], qf[b][4], qf[b][5]);
+                float sc[4];
+                sc[0] = read_lane63(wave_sum_lane63(a48 ? d0 : 0.f));
+                sc[1] = read_lane63(wave_sum_lane63((a48 ? 0.f : d0) + (a32 ? d1 : 0.f)));
+                sc[2] = read_lane63(wave_sum_lane63((a32 ? 0.f : d1) + (a16 ? d2 : 0.f)));
+                sc[3] = read_lane63(wave_sum_lane63(a16 ? 0.f : d2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r = r0 + j;
+                    const float sj = (r < n_rows && sc[j] == sc[j]) ? sc[j] : NEG_INF;
+                    if (sj > tau[b]) {
+                        wave_insert(ls[b], lp[b], sj, r, lane);
+                        tau[b] = read_lane63(ls[b]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+        if (wave == 0) {
+            const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
+            out_s[o] = ls[b];
+            out_p[o] = lp[b];
+        }
+    }
+}
+
+template <int QB>
+static void launch_filter_bf16_qb(const void* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
+                                  const ScanGeom& g, hipStream_t stream) {
+    const u32x4* x4 = reinterpret_cast<const u32x4*>(d_x);
+    if (g.unroll <= 1)
+        hipLaunchKernelGGL((scan_filter_bf16_kernel<QB, 1>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, d_q,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+    else
+        hipLaunchKernelGGL((scan_filter_bf16_kernel<QB, 2>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, d_q,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+}
+
 template <int QB, int U>
 static void launch_filter_qbu(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
                               const ScanGeom& g, hipStream_t stream) {
@@ -134,8 +247,9 @@ static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q
     else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
 }
 
-void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int B, float* cand_s, uint32_t* cand_p,
-                        const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+void launch_scan_filter(const void* d_xv, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
+                        uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const float* d_x = reinterpret_cast<const float*>(d_xv);
     if (ev0) (void)hipEventRecord(ev0, stream);
     int b = 0;
     const size_t per_q = (size_t)g.blocks * LIST;
@@ -145,13 +259,16 @@ void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int
         float* cs = cand_s + (size_t)b * per_q;
         uint32_t* cp = cand_p + (size_t)b * per_q;
         if (rem >= 4) {
-            launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
+            if (dtype == ROW_BF16) launch_filter_bf16_qb<4>(d_xv, n_rows, q, cs, cp, g, stream);
+            else launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
             b += 4;
         } else if (rem >= 2) {
-            launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
+            if (dtype == ROW_BF16) launch_filter_bf16_qb<2>(d_xv, n_rows, q, cs, cp, g, stream);
+            else launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
             b += 2;
         } else {
-            launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
+            if (dtype == ROW_BF16) launch_filter_bf16_qb<1>(d_xv, n_rows, q, cs, cp, g, stream);
+            else launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
             b += 1;
         }
     }
@@ -161,8 +278,9 @@ void launch_scan_filter(const float* d_x, uint32_t n_rows, const float* d_q, int
 // ------------------------------------------------------------------------------------------------
 // 2. merge + exact rescore + certificate
 // ------------------------------------------------------------------------------------------------
+template <int RT>
 __global__ __launch_bounds__(1024) void merge_rescore_kernel(
-    const f32x4* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
+    const void* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
     uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
     uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
@@ -191,7 +309,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const bool valid = p != NO_POS;
     float d = POS_INF;
     if (valid) {
-        const float dot = exact_dot_seq(q + (size_t)b * EM, x + (size_t)p * ROW_F4);
+        const float dot = exact_dot_row<RT>(q + (size_t)b * EM, x, p);
         d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
     }
     sort64_asc(d, p, lane);
@@ -219,19 +337,23 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     }
 }
 
-void launch_merge_rescore(const float* d_x, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
                           hipStream_t stream) {
-    hipLaunchKernelGGL(merge_rescore_kernel, dim3(B), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_x),
-                       d_ids, n_rows, d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags,
-                       force_fallback, eps);
+    if (dtype == ROW_BF16)
+        hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q, cand_s,
+                           cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+    else
+        hipLaunchKernelGGL(merge_rescore_kernel<0>, dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q, cand_s,
+                           cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
 // 3. exact fallback: lane-per-row, reference summation order, key = -distance
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_exact_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
+template <int RT>
+__global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, uint32_t n_rows,
                                                         const float* __restrict__ q,
                                                         const uint32_t* __restrict__ flags,
                                                         float* __restrict__ out_s, uint32_t* __restrict__ out_p,
@@ -254,7 +376,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const f32x4* __restrict
         const uint32_t r = g * 64u + lane;
         float key = NEG_INF;
         if (r < n_rows) {
-            const float dot = exact_dot_seq(qv, x + (size_t)r * ROW_F4);
+            const float dot = exact_dot_row<RT>(qv, x, r);
             const float d = __fsub_rn(1.0f, dot);
             key = (d == d) ? -d : NEG_INF;
         }
@@ -309,10 +431,14 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
     if (lane == 0) out_found[b] = found;
 }
 
-void launch_scan_exact(const float* d_x, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
+void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream) {
-    hipLaunchKernelGGL(scan_exact_kernel, dim3(n_lists, B), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, d_flags, cand_s, cand_p, (uint32_t)n_lists);
+    if (dtype == ROW_BF16)
+        hipLaunchKernelGGL(scan_exact_kernel<1>, dim3(n_lists, B), dim3(256), 0, stream, d_x, n_rows, d_q, d_flags,
+                           cand_s, cand_p, (uint32_t)n_lists);
+    else
+        hipLaunchKernelGGL(scan_exact_kernel<0>, dim3(n_lists, B), dim3(256), 0, stream, d_x, n_rows, d_q, d_flags,
+                           cand_s, cand_p, (uint32_t)n_lists);
 }
 
 void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags, const float* cand_s,
@@ -443,6 +569,45 @@ __global__ void synth_write_kernel(uint64_t key, uint64_t first_row, uint32_t n,
         v.w = synth_uniform(key, base + 3) / l;
         out[i] = v;
     }
+}
+
+// f32 rows -> bf16 rows (round to nearest even), 8 values per thread; and back (exact widening)
+__global__ void rows_f32_to_bf16_kernel(const f32x4* __restrict__ in, u32x4* __restrict__ out, size_t n_chunks8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = in[2 * i], b = in[2 * i + 1];
+        u32x4 w;
+        w.x = f32_to_bf16_rne(a.x) | (f32_to_bf16_rne(a.y) << 16);
+        w.y = f32_to_bf16_rne(a.z) | (f32_to_bf16_rne(a.w) << 16);
+        w.z = f32_to_bf16_rne(b.x) | (f32_to_bf16_rne(b.y) << 16);
+        w.w = f32_to_bf16_rne(b.z) | (f32_to_bf16_rne(b.w) << 16);
+        out[i] = w;
+    }
+}
+
+__global__ void rows_bf16_to_f32_kernel(const u32x4* __restrict__ in, f32x4* __restrict__ out, size_t n_chunks8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 w = in[i];
+        out[2 * i] = f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+        out[2 * i + 1] = f32x4{bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w)};
+    }
+}
+
+void launch_rows_f32_to_bf16(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream) {
+    if (n_rows == 0) return;
+    const size_t n = n_rows * ROW_C8;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<u32x4*>(d_out), n);
+}
+
+void launch_rows_bf16_to_f32(const void* d_in, float* d_out, size_t n_rows, hipStream_t stream) {
+    if (n_rows == 0) return;
+    const size_t n = n_rows * ROW_C8;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rows_bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const u32x4*>(d_in), reinterpret_cast<f32x4*>(d_out), n);
 }
 
 static uint64_t host_splitmix64(uint64_t z) {

@@ -111,6 +111,46 @@ __device__ __forceinline__ float exact_dot_seq(const float* __restrict__ qv, con
     return acc;
 }
 
+// ---- bf16 rows (DAWN_DTYPE_BF16): 384 x bf16 = 768 B = 48 16-B chunks of 8 values; element k of a chunk word w:
+// even k in the low half, odd k in the high half (little endian).  Widening to f32 is exact.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ROW_C8 = 48;  // 16-B chunks per bf16 row
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+
+// f32 -> bf16 bits, round to nearest even (inputs are finite: every row passed is_normalized)
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ float exact_dot_seq_bf16(const float* __restrict__ qv, const u32x4* __restrict__ row) {
+    float acc = 0.0f;
+#pragma unroll 2
+    for (int c = 0; c < ROW_C8; ++c) {
+        const u32x4 w = row[c];
+        const f32x4 q0 = reinterpret_cast<const f32x4*>(qv)[2 * c];
+        const f32x4 q1 = reinterpret_cast<const f32x4*>(qv)[2 * c + 1];
+        acc = __fadd_rn(acc, __fmul_rn(q0.x, bf16_lo(w.x)));
+        acc = __fadd_rn(acc, __fmul_rn(q0.y, bf16_hi(w.x)));
+        acc = __fadd_rn(acc, __fmul_rn(q0.z, bf16_lo(w.y)));
+        acc = __fadd_rn(acc, __fmul_rn(q0.w, bf16_hi(w.y)));
+        acc = __fadd_rn(acc, __fmul_rn(q1.x, bf16_lo(w.z)));
+        acc = __fadd_rn(acc, __fmul_rn(q1.y, bf16_hi(w.z)));
+        acc = __fadd_rn(acc, __fmul_rn(q1.z, bf16_lo(w.w)));
+        acc = __fadd_rn(acc, __fmul_rn(q1.w, bf16_hi(w.w)));
+    }
+    return acc;
+}
+
+// Reference-order exact dot of query qv with row `p` of an index of row type RT (0 = f32, 1 = bf16).
+template <int RT>
+__device__ __forceinline__ float exact_dot_row(const float* __restrict__ qv, const void* __restrict__ x, size_t p) {
+    if (RT == 1) return exact_dot_seq_bf16(qv, reinterpret_cast<const u32x4*>(x) + p * ROW_C8);
+    return exact_dot_seq(qv, reinterpret_cast<const f32x4*>(x) + p * ROW_F4);
+}
+
 // (distance asc, row asc)
 __device__ __forceinline__ bool less_dp(float d, uint32_t p, float d2, uint32_t p2) {
     return d < d2 || (d == d2 && p < p2);

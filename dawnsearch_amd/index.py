@@ -17,11 +17,13 @@ def _ptr(a: np.ndarray) -> C.c_void_p:
 class VectorIndex:
     """usearch::ffi::Index replacement (search_provider.rs:102-284) living in HBM on one MI355X."""
 
-    def __init__(self, device: int = 0, dims: int = EM_LEN):
+    def __init__(self, device: int = 0, dims: int = EM_LEN, dtype: str = "f32"):
         h = C.c_void_p()
-        check(lib.dawn_index_create(dims, _lib.DTYPE_F32, device, C.byref(h)))
+        code = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[dtype]
+        check(lib.dawn_index_create(dims, code, device, C.byref(h)))
         self._h = h
         self.device = device
+        self.dtype = dtype
 
     def close(self):
         if getattr(self, "_h", None):

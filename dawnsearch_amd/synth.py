@@ -60,6 +60,13 @@ def unit_rows(seed: int, first_row: int, n: int) -> np.ndarray:
     return normalize_rows(uniform(seed, idx))
 
 
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """f32 -> nearest-even bf16 -> f32 (what a DAWN_DTYPE_BF16 index stores and scores)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    return r.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
 def scaled(seed: int, n: int, scale: float, offset: float) -> np.ndarray:
     u = uniform(seed, np.arange(n, dtype=np.uint64))
     m = (np.float32(scale) * u).astype(np.float32)

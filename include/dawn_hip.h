@@ -39,7 +39,10 @@ extern "C" {
 #define DAWN_EM_LEN 384 /* src/search/vector.rs:26 */
 #define DAWN_MAX_K 64   /* largest `count` of one search call (reference uses 20: search_provider.rs:214) */
 
-#define DAWN_DTYPE_F32 0 /* ScalarKind::F32, search_provider.rs:38 */
+#define DAWN_DTYPE_F32 0  /* ScalarKind::F32, search_provider.rs:38 */
+#define DAWN_DTYPE_BF16 1 /* rows stored as bf16 (768 B): twice the rows per GB of HBM (1B x 384 on 8 GPUs).  Vectors
+                           * are given and gated as f32, rounded to nearest-even on add; distances are
+                           * 1 - sum(q_i * bf16(x_i)) in the same sequential f32 arithmetic, exact for the stored rows */
 
 const char *dawn_last_error(void);
 int dawn_version(void);
@@ -51,7 +54,7 @@ int dawn_device_count(int *count);
 typedef struct dawn_index dawn_index;
 
 /* new_index(&INDEX_OPTIONS) — search_provider.rs:35-42,102.  dims must be 384, metric is IP
- * (distance = 1 - sum(q_i*x_i)), dtype DAWN_DTYPE_F32.  `device` = HIP device ordinal. */
+ * (distance = 1 - sum(q_i*x_i)), dtype DAWN_DTYPE_F32 or DAWN_DTYPE_BF16.  `device` = HIP device ordinal. */
 int dawn_index_create(size_t dims, int dtype, int device, dawn_index **out);
 void dawn_index_destroy(dawn_index *idx); /* drop of UniquePtr<Index> */
 

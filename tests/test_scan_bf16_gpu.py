@@ -1,0 +1,112 @@
+"""GPU parity tests for the bf16 index (configs[4] of BASELINE.json: bf16 rows, f32 accumulation).
+
+Oracle per SURVEY §8(d): the CPU scan (oracle/dawn_oracle.c) over the bf16-ROUNDED rows — the index stores
+round-to-nearest-even bf16 of the f32 vectors it is given and scores their exact f32 widening in the reference's
+sequential f32 order, so distances must be bit-identical and label order identical, as for the f32 index."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+
+def _mk(dawn, n):
+    idx = dawn.VectorIndex(0, dtype="bf16")
+    idx.fill_synthetic(1, 0, n, 1)
+    return idx
+
+
+def _same(lab, dist, olab, odist):
+    assert np.array_equal(lab, olab), (lab, olab)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), (dist, odist)
+
+
+def test_bf16_rows_are_rounded_spec_rows(dawn, oracle):
+    n = 3000
+    idx = _mk(dawn, n)
+    rows, ids = idx.get_rows(0, n)
+    want = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(ids, np.arange(1, n + 1, dtype=np.uint64))
+    # the same rows through add_batch (host f32 in, rounded on the device)
+    idx2 = dawn.VectorIndex(0, dtype="bf16")
+    idx2.add_batch(ids, oracle.unit_rows(1, 0, n))
+    idx2.add(n + 1, oracle.unit_rows(1, n, 1)[0])
+    rows2, _ = idx2.get_rows(0, n + 1)
+    assert np.array_equal(rows2[:n].view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(rows2[n].view(np.uint32), synth.round_bf16(oracle.unit_rows(1, n, 1)[0]).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 255, 1000, 4097, 100_003])
+@pytest.mark.parametrize("k", [1, 10, 20])
+def test_bf16_scan_matches_oracle_sizes(dawn, oracle, n, k):
+    idx = _mk(dawn, n)
+    x = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    for q in synth.unit_rows(2, 0, 3):
+        lab, dist = idx.search(q, k)
+        olab, odist = oracle.scan_topk(x, ids, q, k)
+        assert len(lab) == min(k, n)
+        _same(lab, dist, olab, odist)
+    assert idx.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("n,B,k", [(100_003, 2, 10), (100_003, 7, 20), (50_000, 9, 10), (100_003, 33, 20), (31, 16, 10),
+                                   (4097, 256, 20), (8193, 200, 10), (20_001, 256, 10)])
+def test_bf16_batches_match_oracle(dawn, oracle, n, B, k):
+    idx = _mk(dawn, n)
+    x = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B // 2] = synth.planted_queries(1, [n // 3], 2)[0]
+    labels, dist, found = idx.search_batch(Q, k)
+    for b in range(B):
+        olab, odist = oracle.scan_topk(x, ids, Q[b], k, threads=8)
+        assert found[b] == min(k, n)
+        _same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
+    assert labels[B // 2][0] == n // 3 + 1
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_bf16_1m_batch1_and_256(dawn, oracle):
+    n = 1_000_000
+    idx = _mk(dawn, n)
+    x = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 256)
+    labels, dist, found = idx.search_batch(Q, 10)
+    for b in range(0, 256, 16):
+        _same(labels[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10, threads=8))
+    for b in (0, 100, 255):  # the streaming (batch-1) path agrees with the matrix-core path
+        lab, d = idx.search(Q[b], 10)
+        _same(lab, d, labels[b], dist[b])
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_bf16_forced_exact_pass_and_gate_and_save_load(dawn, oracle):
+    n = 20_000
+    idx = _mk(dawn, n)
+    x = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 3)
+    want = [oracle.scan_topk(x, ids, q, 20) for q in Q]
+    idx.set_option("force_fallback", 1)
+    labels, dist, found = idx.search_batch(Q, 20)
+    for b in range(3):
+        _same(labels[b], dist[b], *want[b])
+    idx.set_option("force_fallback", 0)
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.add_batch(np.array([7, 8], dtype=np.uint64), np.stack([Q[0], Q[1] * 1.5]))
+    assert idx.size() == n
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "index.dawn")
+        idx.save(path)
+        idx2 = dawn.VectorIndex(0, dtype="bf16")
+        idx2.load(path)
+        assert idx2.size() == n
+        lab, dd = idx2.search(Q[1], 20)
+        _same(lab, dd, *want[1])
