@@ -170,7 +170,7 @@ def main():
         leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3, "steps": steps,
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
-        algo = rows_here * ROW_BYTES * scan_passes(Bq)
+        algo = rows_here * (ROW_BYTES // 2 if getattr(index, "dtype", "f32") == "bf16" else ROW_BYTES) * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
@@ -301,6 +301,18 @@ def main():
             extra["e2e_1M_batch256"] = e2e_leg(idx1, 256)
             extra["embed_batch1"] = e2e_leg(idx1, 1, steps=100)
         out["checks"]["fallbacks"] = idx.stats()["fallbacks"]
+        if world == 1:
+            # configs[4] sizing point on one GPU: the same 100 M rows stored as bf16 (76.8 GB), f32 accumulation;
+            # parity of this path: tests/test_scan_bf16_gpu.py (oracle over the bf16-rounded rows)
+            idx1.close()
+            idx.close()
+            idxh = dawn.VectorIndex(local_rank, dtype="bf16")
+            idxh.fill_synthetic(1, 0, args.rows, 1)
+            legh, _ = run_leg(idxh, 1, max(5, args.steps // 2), 3, check_planted=True)
+            extra["bf16_index_batch1"] = legh
+            legh2, _ = run_leg(idxh, 256, 5, 1, seed=3)
+            extra["bf16_index_batch256"] = legh2
+            idxh.close()
         out["extra"] = extra
         if world == 1 and rank == 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, k, args.rows)

@@ -195,9 +195,11 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     auto* idx = new dawn_index();
     idx->device = device;
     idx->dtype = dtype;
-    if (dtype == DAWN_DTYPE_BF16) {  // twice the rows per byte: the reduction needs two waves per SIMD to keep up
-        idx->geom.threads = 512;
-        idx->geom.unroll = 1;
+    if (dtype == DAWN_DTYPE_BF16) {
+        // twice the rows per byte: the per-row reduction needs 4 waves per SIMD to keep up with the stream
+        // (tools/scan_sweep_bf16.py, 80M rows: 16 waves x 6 KiB per CU 6.93 TB/s; 8 waves 6.7; 4 waves 4.2)
+        idx->geom.threads = 1024;
+        idx->geom.unroll = 2;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
