@@ -187,9 +187,83 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny form for few rows (the reference's call shape: ONE text per call, embedding_service.rs:161-163).
+// The 64x64 kernel above is latency-bound there (N/64 blocks walking K in 12..48 dependent steps).  Here a block
+// owns a 16-row x 16-column tile of Y, its NWV waves split K (K/NWV = 48 or 96 values each), every wave loads
+// its operand fragments straight from global memory up front (no LDS staging, one latency), runs 12..24
+// v_mfma_f32_16x16x4_f32, and the partial tiles are summed through LDS in wave order.
+// Lane (r = l&15, kq = l>>4) loads A[m0+r][kb + 4kq .. +3] and W[n0+r][same] as one 16-B load per
+// 16-wide k-step; MFMA j consumes element j of every lane (k = kb + 4kq + j).
+// ------------------------------------------------------------------------------------------------
+int g_skinny_max_m = 640;  // rows up to which launch_gemm_nt takes the skinny form (measured crossover with the 64x64 tile kernel: ~768 tokens)
+
+template <int ACT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __restrict__ A,
+                                                                const float* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ Y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float part[];  // [NWV][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    const int kw = K / NWV;
+    const int k_begin = wave * kw;
+    constexpr int MAXS = 6;
+    const int steps = kw / 16;
+    f32x4 av[MAXS], bv[MAXS];
+    const float* arow = A + (size_t)(m0 + r) * K + k_begin + 4 * kq;
+    const float* wrow = W + (size_t)(n0 + r) * K + k_begin + 4 * kq;
+    const bool a_ok = m0 + r < M;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s < steps) {
+            av[s] = a_ok ? *reinterpret_cast<const f32x4*>(arow + 16 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[s] = *reinterpret_cast<const f32x4*>(wrow + 16 * s);
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s < steps) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].x, bv[s].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].y, bv[s].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].z, bv[s].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].w, bv[s].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[(wave * 4 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // 256 tile elements (reg e, lane l): row = 4*(l>>4) + e, col = l&15
+    if (tid < 256) {
+        const int e = tid >> 6, l = tid & 63;
+        float sum = part[e * 64 + l];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) sum += part[(w * 4 + e) * 64 + l];
+        const int row = m0 + 4 * (l >> 4) + e;
+        const int n = n0 + (l & 15);
+        if (row < M) Y[(size_t)row * N + n] = act_apply(sum + bias[n], ACT);
+    }
+}
+
+template <int NWV>
+static void launch_skinny16(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                            hipStream_t s) {
+    dim3 grid(N / 16, (M + 15) / 16), block(NWV * 64);
+    const size_t lds = (size_t)NWV * 4 * 64 * sizeof(float);
+    if (act == 1) hipLaunchKernelGGL((gemm_skinny16_kernel<1, NWV>), grid, block, lds, s, A, W, bias, Y, M, N, K);
+    else if (act == 2) hipLaunchKernelGGL((gemm_skinny16_kernel<2, NWV>), grid, block, lds, s, A, W, bias, Y, M, N, K);
+    else hipLaunchKernelGGL((gemm_skinny16_kernel<0, NWV>), grid, block, lds, s, A, W, bias, Y, M, N, K);
+}
+
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
                     hipStream_t s) {
     if (M <= 0) return;
+    if (M <= g_skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
+        if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
+        if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
+    }
     dim3 grid(N / GT, (M + GT - 1) / GT), block(256);
     if (act == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, s, A, W, bias, Y, M, N, K);
     else if (act == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, s, A, W, bias, Y, M, N, K);

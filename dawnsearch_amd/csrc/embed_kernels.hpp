@@ -15,4 +15,5 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s);
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s);
 int attention_set_max_lds();
+extern int g_skinny_max_m;
 }  // namespace dawn

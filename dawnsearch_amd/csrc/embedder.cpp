@@ -468,6 +468,16 @@ void dawn_embedder_destroy(dawn_embedder* e) {
     delete e;
 }
 
+int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) {
+    if (!e || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (std::string(name) == "skinny_max_rows") {  // token count up to which the GEMMs take the split-K skinny form
+        if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "skinny_max_rows out of range");
+        dawn::g_skinny_max_m = (int)value;
+        return DAWN_OK;
+    }
+    return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
+}
+
 int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, const int32_t* d_seq_offsets, int B,
                                  int total_tokens, int max_len, float* d_out, void* stream) {
     if (!e || !d_token_ids || !d_seq_offsets || !d_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");

@@ -72,6 +72,9 @@ class EmbeddingProvider:
         check(lib.dawn_embedder_hidden_states(self._h, _ptr(flat), _ptr(offs), len(seqs), _ptr(out)))
         return [out[offs[i]:offs[i + 1]] for i in range(len(seqs))]
 
+    def set_option(self, name: str, value: int):
+        check(lib.dawn_embedder_set_option(self._h, name.encode(), value))
+
     def forward_device(self, d_token_ids: int, d_seq_offsets: int, B: int, total_tokens: int, max_len: int,
                        d_out: int, stream: int = 0):
         check(lib.dawn_embedder_forward_device(self._h, d_token_ids, d_seq_offsets, B, total_tokens, max_len, d_out,

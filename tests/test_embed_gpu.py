@@ -48,7 +48,9 @@ def test_batch_equals_batch1_and_oracle(provider, oracle):
     batch = provider.calculate_embedding(seqs)
     for i, s in enumerate(seqs):
         single = provider.calculate_embedding([s])[0]
-        assert np.array_equal(single, batch[i])  # bitwise: same kernels, same per-sequence arithmetic
+        # same per-sequence arithmetic up to the GEMM's k-summation order (a lone short text takes the
+        # split-K skinny GEMM, a packed batch the 64x64 tile kernel): rounding-level agreement
+        assert np.abs(single - batch[i]).max() < 5e-7
         ref = sb.embed(s)
         assert np.abs(batch[i] - ref).max() < TOL_EMB
     hs = provider.hidden_states(seqs[:3])
