@@ -10,4 +10,5 @@ from .index import (VectorIndex, BestResults, is_normalized, normalize, to24, fr
 from .search_provider import (SearchProvider, SearchResult, FoundPage, ExtractedPage, SearchStats,  # noqa: F401
                               search_remote_merge)
 from .embedding_provider import EmbeddingProvider, write_synthetic_model  # noqa: F401,E402
+from .tokenizer import Tokenizer  # noqa: F401,E402
 from .sharded import ShardedSearch, shard_range, merge_host  # noqa: F401,E402

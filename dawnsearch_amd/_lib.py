@@ -96,6 +96,12 @@ _SIGS = {
     "dawn_embedder_forward_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "dawn_embedder_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "dawn_embedder_hidden_states": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "dawn_tokenizer_create": (_i32, [C.c_char_p, _pp]),
+    "dawn_tokenizer_destroy": (None, [_vp]),
+    "dawn_tokenizer_set_max_length": (_i32, [_vp, _sz]),
+    "dawn_tokenizer_vocab_size": (_sz, [_vp]),
+    "dawn_tokenizer_encode": (_i32, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_sz)]),
+    "dawn_tokenizer_encode_batch": (_i32, [_vp, C.POINTER(C.c_char_p), _sz, _vp, _sz, _vp]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

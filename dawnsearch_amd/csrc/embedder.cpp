@@ -16,166 +16,14 @@
 
 #include "common.hpp"
 #include "embed_kernels.hpp"
+#include "mini_json.hpp"
 
 using dawn::fail;
+using dawn::JParser;
+using dawn::JVal;
+using dawn::read_file;
 
 namespace {
-
-// ---- minimal JSON (objects / arrays / strings / numbers / literals) — enough for safetensors headers
-// and HF config.json ----------------------------------------------------------------------------
-struct JVal {
-    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
-    double num = 0;
-    bool b = false;
-    std::string str;
-    std::vector<JVal> arr;
-    std::vector<std::pair<std::string, JVal>> obj;
-    const JVal* get(const std::string& k) const {
-        for (auto& kv : obj)
-            if (kv.first == k) return &kv.second;
-        return nullptr;
-    }
-};
-
-struct JParser {
-    const char* p;
-    const char* end;
-    bool ok = true;
-    void ws() {
-        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
-    }
-    bool lit(const char* s) {
-        size_t n = std::strlen(s);
-        if ((size_t)(end - p) >= n && std::memcmp(p, s, n) == 0) {
-            p += n;
-            return true;
-        }
-        return false;
-    }
-    std::string parse_string() {
-        std::string out;
-        if (p >= end || *p != '"') {
-            ok = false;
-            return out;
-        }
-        ++p;
-        while (p < end && *p != '"') {
-            if (*p == '\\' && p + 1 < end) {
-                ++p;
-                switch (*p) {
-                    case 'n': out += '\n'; break;
-                    case 't': out += '\t'; break;
-                    case 'r': out += '\r'; break;
-                    case 'b': out += '\b'; break;
-                    case 'f': out += '\f'; break;
-                    case 'u':  // keep BMP escapes as '?': names we care about are ASCII
-                        out += '?';
-                        p += std::min<ptrdiff_t>(4, end - p - 1);
-                        break;
-                    default: out += *p;
-                }
-                ++p;
-            } else {
-                out += *p++;
-            }
-        }
-        if (p >= end) ok = false;
-        else ++p;
-        return out;
-    }
-    JVal parse() {
-        JVal v;
-        ws();
-        if (p >= end) {
-            ok = false;
-            return v;
-        }
-        if (*p == '{') {
-            v.kind = JVal::Obj;
-            ++p;
-            ws();
-            if (p < end && *p == '}') {
-                ++p;
-                return v;
-            }
-            while (ok) {
-                ws();
-                std::string k = parse_string();
-                ws();
-                if (p >= end || *p != ':') {
-                    ok = false;
-                    break;
-                }
-                ++p;
-                v.obj.emplace_back(k, parse());
-                ws();
-                if (p < end && *p == ',') {
-                    ++p;
-                    continue;
-                }
-                if (p < end && *p == '}') {
-                    ++p;
-                    break;
-                }
-                ok = false;
-            }
-        } else if (*p == '[') {
-            v.kind = JVal::Arr;
-            ++p;
-            ws();
-            if (p < end && *p == ']') {
-                ++p;
-                return v;
-            }
-            while (ok) {
-                v.arr.push_back(parse());
-                ws();
-                if (p < end && *p == ',') {
-                    ++p;
-                    continue;
-                }
-                if (p < end && *p == ']') {
-                    ++p;
-                    break;
-                }
-                ok = false;
-            }
-        } else if (*p == '"') {
-            v.kind = JVal::Str;
-            v.str = parse_string();
-        } else if (lit("true")) {
-            v.kind = JVal::Bool;
-            v.b = true;
-        } else if (lit("false")) {
-            v.kind = JVal::Bool;
-        } else if (lit("null")) {
-            v.kind = JVal::Null;
-        } else {
-            char* e = nullptr;
-            v.kind = JVal::Num;
-            v.num = std::strtod(p, &e);
-            if (e == p || e > end) ok = false;
-            else p = e;
-        }
-        return v;
-    }
-};
-
-bool read_file(const char* path, std::vector<char>& out) {
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    if (n < 0) {
-        std::fclose(f);
-        return false;
-    }
-    out.resize((size_t)n);
-    bool ok = n == 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-    std::fclose(f);
-    return ok;
-}
 
 struct Config {  // model.rs:115-133 ; defaults = Config::_all_mini_lm_l6_v2 (:160-180)
     int vocab_size = 30522, hidden_size = 384, num_hidden_layers = 6, num_attention_heads = 12;

@@ -179,6 +179,27 @@ int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);
 int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,
                                 int B, float *out);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Host tokenizer — the `tokenizers` crate calls of EmbeddingProvider (embedding_service.rs:88,     */
+/* 101-113): Tokenizer::from_file + encode_batch(inputs, add_special_tokens = true).  Pure host   */
+/* code (no device needed).  BERT WordPiece pipeline as configured by all-MiniLM-L6-v2's           */
+/* tokenizer.json: BertNormalizer (clean, CJK spacing, strip accents, lowercase), BertPreTokenizer,*/
+/* WordPiece("##", [UNK], 100 chars/word), [CLS] $A [SEP], truncation to max_length (128).         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct dawn_tokenizer dawn_tokenizer;
+/* path: a HF tokenizer.json (model.vocab, normalizer.lowercase, truncation.max_length, added_tokens are
+ * honoured) or a vocab.txt (one token per line; lowercase, max_length 128). */
+int dawn_tokenizer_create(const char *path, dawn_tokenizer **out);
+void dawn_tokenizer_destroy(dawn_tokenizer *t);
+int dawn_tokenizer_set_max_length(dawn_tokenizer *t, size_t max_length); /* 0 = no truncation */
+size_t dawn_tokenizer_vocab_size(const dawn_tokenizer *t);
+/* One text -> ids incl. [CLS]/[SEP].  *n = ids needed; DAWN_ERR_INVALID_ARG if cap is too small. */
+int dawn_tokenizer_encode(const dawn_tokenizer *t, const char *text_utf8, uint32_t *out_ids, size_t cap, size_t *n);
+/* B texts -> packed ids + seq_offsets[B+1]: exactly the inputs of dawn_embedder_forward (no padding: every
+ * text keeps its own length, which is what the reference's one-text-per-call path computes). */
+int dawn_tokenizer_encode_batch(const dawn_tokenizer *t, const char *const *texts, size_t B, uint32_t *out_ids,
+                                size_t cap, int32_t *seq_offsets);
+
 #ifdef __cplusplus
 }
 #endif

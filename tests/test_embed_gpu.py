@@ -117,3 +117,28 @@ def test_embed_then_rank_end_to_end(provider, dawn, oracle):
     gaps = np.diff(cd)
     if gaps.min() > 1e-4:
         assert np.array_equal(gl, cl)
+
+
+def test_text_in_vectors_out_with_the_host_tokenizer(provider, dawn, oracle, tmp_path):
+    """calculate_embedding(&[&str]) end to end (embedding_service.rs:97-139): C++ WordPiece tokenizer -> packed ids ->
+    HIP forward.  The vocabulary is synthetic (ids must stay < 30522); the vectors must equal the oracle's embedding
+    of the same ids."""
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"tok{i}" for i in range(95)]
+    words += ["dawn", "search", "##es", "the", "web", "distributed", "engine", ",", ".", "a", "##n", "open"]
+    # place [CLS]/[SEP] at the BERT ids the synthetic sequences use elsewhere (101 / 102)
+    words[2], words[101] = words[101], "[CLS]"
+    words[3], words[102] = words[102], "[SEP]"
+    vt = tmp_path / "vocab.txt"
+    vt.write_text("\n".join(words) + "\n", encoding="utf-8")
+    tk = dawn.Tokenizer(str(vt))
+    assert tk("Dawn searches the web.") == [101, words.index("dawn"), words.index("search"), words.index("##es"),
+                                            words.index("the"), words.index("web"), words.index("."), 102]
+    provider.tokenizer = tk
+    try:
+        texts = ["Dawn searches the web.", "An open, distributed search engine", "unknownword the web"]
+        emb = provider.calculate_embedding(texts)
+    finally:
+        provider.tokenizer = None
+    sb = oracle.SynthBert(3)
+    for t, e in zip(texts, emb):
+        assert np.abs(e - sb.embed(np.array(tk(t), dtype=np.uint32))).max() < TOL_EMB
