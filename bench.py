@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip batch-256 / 1M / latency / cpu legs")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the all-gather + packed merge even at world size 1 (exercises the N>1 code path)")
     return ap.parse_args()
 
 
@@ -87,8 +89,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -118,18 +122,19 @@ def main():
         o_lab = torch.zeros((Bq, k), dtype=torch.int64, device=dev)
         o_dist = torch.zeros((Bq, k), dtype=torch.float32, device=dev)
         o_found = torch.zeros((Bq,), dtype=torch.int32, device=dev)
-        g_blob = torch.zeros((world * nbytes,), dtype=torch.uint8, device=dev) if world > 1 else None
+        collective = world > 1 or args.force_collective
+        g_blob = torch.zeros((world * nbytes,), dtype=torch.uint8, device=dev) if collective else None
 
         def step():
             index.search_device(d_q.data_ptr(), Bq, k, p, p + off_d, p + off_f, stream)
-            if world > 1:
+            if collective:
                 dist.all_gather_into_tensor(g_blob, blob)
                 dawn.topk_merge_packed_device(local_rank, world, Bq, k, g_blob.data_ptr(), o_lab.data_ptr(),
                                               o_dist.data_ptr(), o_found.data_ptr(), stream)
 
         def result():
             torch.cuda.synchronize()
-            if world > 1:
+            if collective:
                 return o_lab.cpu().numpy(), o_dist.cpu().numpy()
             raw = blob.cpu().numpy()
             return (raw[:off_d].view(np.int64).reshape(Bq, k), raw[off_d:off_f].view(np.float32).reshape(Bq, k))
@@ -317,10 +322,17 @@ def main():
         if world == 1 and rank == 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, k, args.rows)
 
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    # RCCL writes a version banner to C stdout; get every rank's C buffers out before rank 0 prints the ONE JSON
+    # line, so that the line is the last thing on stdout.
+    import ctypes
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if rank == 0:
+        time.sleep(0.5 if world > 1 else 0.0)  # let the other ranks' flushed banners reach the shared pipe first
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
