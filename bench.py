@@ -175,7 +175,10 @@ def main():
         leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3, "steps": steps,
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
-        algo = rows_here * (ROW_BYTES // 2 if getattr(index, "dtype", "f32") == "bf16" else ROW_BYTES) * scan_passes(Bq)
+        # bytes the dominant kernel has to read per row: 1536 (f32 rows); 768 for a bf16 index and for the
+        # matrix-core filter (B >= 9) of an f32 index, which streams the scaled-f16 shadow copy of the rows
+        row_bytes = ROW_BYTES // 2 if (getattr(index, "dtype", "f32") == "bf16" or Bq >= 9) else ROW_BYTES
+        algo = rows_here * row_bytes * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS

@@ -29,6 +29,15 @@ struct dawn_index {
 
     int dtype = DAWN_DTYPE_F32;  // row storage: f32 (1536 B/row) or bf16 (768 B/row)
     char* d_x = nullptr;         // [(cap_phys + ROW_PAD)][384] of dtype
+    // f32 index only: scaled-f16 shadow copy of the rows ([cap][384] f16(2^8 x), 768 B/row) read by the matrix-core
+    // FILTER instead of the f32 rows: half the bytes and no conversion work in the scan.  Built lazily at the first
+    // batched search, extended on add; results stay exact (the rescore reads the f32 rows).  Costs +50 % HBM; if
+    // the allocation fails the filter converts f32 rows on the fly as before.
+    char* d_shadow = nullptr;
+    size_t shadow_cap = 0;       // rows allocated
+    size_t shadow_rows = 0;      // rows converted so far (prefix)
+    int use_shadow = 1;          // option "f16_shadow"
+    bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
     float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
     size_t stage_rows = 0;
     size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }
@@ -139,6 +148,38 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     return DAWN_OK;
 }
 
+// Bring the f16 shadow up to date with the f32 rows (no-op when disabled / not an f32 index / out of memory).
+// Returns the filter's row source.
+const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
+    *frt = idx->dtype;
+    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_shadow || idx->shadow_failed) return idx->d_x;
+    if (idx->shadow_cap < idx->cap_phys) {
+        char* ns = nullptr;
+        const size_t prow = padded_rows(idx->cap_phys);
+        if (hipMalloc((void**)&ns, prow * dawn::EM * 2) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->shadow_failed = true;
+            return idx->d_x;
+        }
+        (void)hipMemsetAsync(ns, 0, prow * dawn::EM * 2, stream);
+        if (idx->d_shadow) {  // keep what is converted already (the old buffer is idle: searches are serialised)
+            (void)hipMemcpyAsync(ns, idx->d_shadow, idx->shadow_rows * dawn::EM * 2, hipMemcpyDeviceToDevice, stream);
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(idx->d_shadow);
+        }
+        idx->d_shadow = ns;
+        idx->shadow_cap = idx->cap_phys;
+    }
+    if (idx->shadow_rows < idx->size) {
+        dawn::launch_rows_f32_to_f16s(reinterpret_cast<const float*>(idx->d_x) + idx->shadow_rows * dawn::EM,
+                                      idx->d_shadow + idx->shadow_rows * dawn::EM * 2, idx->size - idx->shadow_rows,
+                                      stream);
+        idx->shadow_rows = idx->size;
+    }
+    *frt = dawn::ROW_F16S;
+    return idx->d_shadow;
+}
+
 // The whole search as a fixed launch sequence on `stream` (no host decisions in between).
 int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
                      uint32_t* d_found, hipStream_t stream) {
@@ -158,9 +199,11 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
     const uint32_t n = (uint32_t)idx->size;
     if ((int)B >= idx->mfma_min_batch) {
         // matrix-core path, BATCH_QT queries per pass over the index
+        int frt = idx->dtype;
+        const void* frows = filter_rows(idx, &frt, stream);
         for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
             const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
-            dawn::launch_scan_batched(idx->d_x, idx->dtype, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
+            dawn::launch_scan_batched(idx->d_x, idx->dtype, frows, frt, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
                                       idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
                                       idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                       b0 == 0 ? e1 : nullptr);
@@ -233,7 +276,7 @@ void dawn_index_destroy(dawn_index* idx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    void* ptrs[] = {idx->d_x, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
                     idx->bws.cnt, idx->bws.cand, idx->d_q, idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -509,6 +552,7 @@ int dawn_index_load(dawn_index* idx, const char* path) {
         return fail(DAWN_ERR_IO, "%s: truncated id table", path);
     }
     idx->size = 0;  // load replaces the contents (usearch load semantics)
+    idx->shadow_rows = 0;
     const size_t chunk = 1u << 16;
     std::vector<float> buf(chunk * dawn::EM);
     for (size_t o = 0; o < n; o += chunk) {
@@ -595,12 +639,24 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     *n_out = n;
     if (n == 0) return DAWN_OK;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    dawn::launch_batched_dense_scores(idx->d_x, idx->dtype, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
+    int frt = idx->dtype;
+    const void* frows = filter_rows(idx, &frt, idx->stream);
+    dawn::launch_batched_dense_scores(frows, frt, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
                                       idx->stream);
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),
                                   n * sizeof(float), B, hipMemcpyDeviceToHost, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return DAWN_OK;
+}
+
+// Diagnostic: per-wave phase cycle sums of the last batched full pass run with mfma_sched = 2: out [blocks][8][8].
+int dawn_index_debug_read_diag(dawn_index* idx, unsigned long long* out, size_t blocks) {
+    if (!idx || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (!dawn::g_batched_diag || blocks > 4096) return fail(DAWN_ERR_INVALID_ARG, "no diagnostic buffer");
+    DAWN_TRY(set_device(idx));
+    DAWN_HIP_TRY(hipDeviceSynchronize());
+    DAWN_HIP_TRY(hipMemcpy(out, dawn::g_batched_diag, blocks * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DAWN_OK;
 }
 
@@ -632,9 +688,17 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         idx->geom.unroll = (int)value;
         return DAWN_OK;
     }
-    if (n == "mfma_waves") {
-        if (value != 4 && value != 8) return fail(DAWN_ERR_INVALID_ARG, "mfma_waves must be 4 or 8");
-        dawn::g_batched_waves = (int)value;
+    if (n == "f16_shadow") {
+        idx->use_shadow = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "mfma_sched") {
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0..2");
+        if (value == 2 && !dawn::g_batched_diag) {
+            DAWN_HIP_TRY(hipMalloc((void**)&dawn::g_batched_diag, 4096 * 8 * 8 * sizeof(unsigned long long)));
+            DAWN_HIP_TRY(hipMemset(dawn::g_batched_diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));
+        }
+        dawn::g_batched_sched = (int)value;
         return DAWN_OK;
     }
     if (n == "scan_threads") {

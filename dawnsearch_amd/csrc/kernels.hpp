@@ -28,6 +28,7 @@ constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sa
 
 constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
 constexpr int ROW_BF16 = 1;  // DAWN_DTYPE_BF16: rows are 384 x bf16 (768 B), scored as their exact f32 widening
+constexpr int ROW_F16S = 2;  // filter-only shadow of an f32 index: rows as f16(2^8 * x) (768 B), see dawn_index.cpp
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
@@ -66,12 +67,14 @@ BatchPlan plan_batched(uint32_t n_rows);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);
-extern int g_batched_waves;  // 8 (default) or 4 waves per scan workgroup
+extern int g_batched_sched;  // 1 = default (LDS-DMA kernel over the f16 shadow), 0 = lockstep kernel everywhere, 2 = + stamps
+extern unsigned long long* g_batched_diag;
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
-void launch_scan_batched(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
-                         uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
-                         uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0,
-                         hipEvent_t ev1);
+void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int frt, const uint64_t* d_ids, uint32_t n_rows,
+                         const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
+                         float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
+                         hipEvent_t ev0, hipEvent_t ev1);
+void launch_rows_f32_to_f16s(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
 void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);

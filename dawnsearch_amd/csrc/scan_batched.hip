@@ -77,6 +77,11 @@ __device__ __forceinline__ void store_converted(unsigned char* base, int step, c
     *reinterpret_cast<half8*>(base + step * 64) = o;
 }
 
+// f16 shadow chunk (8 values, already scaled and rounded): a plain copy
+__device__ __forceinline__ void store_converted(unsigned char* base, int step, const half8& v) {
+    *reinterpret_cast<half8*>(base + step * 64) = v;
+}
+
 // LDS byte offset (inside one tile buffer) of the 16-B slot holding f16 elements k = 8g..8g+7 of tile row `row`:
 // [sub-tile][g][row + (g & 7)].  The skew by g & 7 spreads one row's consecutive k-groups over all banks
 // (ds_write_b64 of 16 consecutive chunks is conflict-free); a k-group's 32 rows stay contiguous (ds_read_b128
@@ -91,14 +96,29 @@ __device__ __forceinline__ uint32_t slot_off(uint32_t row, uint32_t g) {
 // 64/NW rows of every tile; PF tiles are in flight per wave (register-staged: 96/NW 16-B loads per lane and tile).
 //   NW = 4: one wave per SIMD, 512 registers: 2 x 24 loads in flight per lane = 192 KiB per CU
 //   NW = 8: two waves per SIMD, 256 registers: 12 loads in flight per lane     =  96 KiB per CU
-template <bool DENSE, int NW, int RT>
+template <bool DENSE, int NW, int RT, int SCHED>
 __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restrict__ xv, uint32_t n_rows,
                                                           uint32_t first_tile, uint32_t tile_stride,
                                                           uint32_t n_tiles, const half8* __restrict__ qh, int n_q,
                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                          uint2* __restrict__ cand, float* __restrict__ dense) {
+                                                          uint2* __restrict__ cand, float* __restrict__ dense,
+                                                          unsigned long long* __restrict__ diag) {
+    // SCHED == 2: diagnostic build of the lockstep schedule — s_memtime stamps around the phases of every tile,
+    // per-wave sums written to diag[block][wave][8] (shares only: the stamps' waits forbid overlaps the real kernel has)
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int k) {
+        if (SCHED == 2) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 0) seg[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
     constexpr int QG = 8 / NW;          // 32-query groups per wave
-    constexpr int CPR = RT == 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16: 8 values each, f32: 4)
+    constexpr int CPR = RT >= 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16 / f16 shadow: 8 values each, f32: 4)
     constexpr int LPL = CPR / NW;       // loads per lane per tile
     constexpr int RPW = TILE_ROWS / NW; // tile rows converted by one wave
     constexpr int PF = NW == 4 ? 2 : 1; // tiles in flight
@@ -149,12 +169,12 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
     for (int b = 0; b < 3; ++b) {
         const uint32_t Lb = (uint32_t)b * 64u + (uint32_t)lane;
         const uint32_t row = (uint32_t)RPW * wave + Lb / CPR, c = Lb % CPR;
-        wr_off[b] = RT == 1 ? slot_off(row, c) : slot_off(row, c >> 1) + (c & 1u) * 8u;
+        wr_off[b] = RT >= 1 ? slot_off(row, c) : slot_off(row, c >> 1) + (c & 1u) * 8u;
     }
     // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
     const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
 
-    typedef typename std::conditional<RT == 1, u32x4, f32x4>::type chunk_t;
+    typedef typename std::conditional<RT == 0, f32x4, typename std::conditional<RT == 1, u32x4, half8>::type>::type chunk_t;
     const chunk_t* x = reinterpret_cast<const chunk_t*>(xv);
     chunk_t st[PF][LPL];
     auto issue = [&](chunk_t(&dst)[LPL], uint32_t i) {
@@ -164,24 +184,29 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
         for (int j = 0; j < LPL; ++j) dst[j] = __builtin_nontemporal_load(p + j * 64);
     };
 
-    // One tile: convert the staged rows into LDS buffer `buf`, refill the staging registers with tile i + PF*grid,
-    // barrier, contract, threshold test.
-    auto process = [&](chunk_t(&src)[LPL], uint32_t i, uint32_t buf) {
+    // convert: the staged rows -> f16 fragments in LDS buffer `buf`; then refill the staging registers with tile `nxt`
+    auto convert = [&](chunk_t(&src)[LPL], uint32_t buf, uint32_t nxt) {
         unsigned char* tb = lds + buf * TILE_BYTES;
-        if (!DENSE && threadIdx.x == 0) stage_n[1 + buf] = stage_n[0];  // wave 0 is past its own appends
 #pragma unroll
         for (int j = 0; j < LPL; ++j) store_converted(tb + wr_off[j % 3], j / 3, src[j]);
-        const uint32_t nxt = i + PF * gridDim.x;
         if (nxt < n_tiles) issue(src, nxt);
-        // LDS writes visible to the workgroup; the prefetch loads stay in flight across the barrier
+    };
+    // barrier: LDS writes visible to the workgroup (the prefetch loads stay in flight across it); when the
+    // candidate stage is half full (snapshot taken by thread 0 before the barrier: the same value in every wave)
+    // all waves flush it — nobody appends between this barrier and the end of the flush
+    auto barrier_and_flush = [&](uint32_t par) {
+        if (!DENSE && threadIdx.x == 0) stage_n[1 + par] = stage_n[0];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (!DENSE && stage_n[1 + buf] >= STAGE_FLUSH_AT) {  // same value in every wave: written before the barrier
+        if (!DENSE && stage_n[1 + par] >= STAGE_FLUSH_AT) {
             flush();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (threadIdx.x == 0) stage_n[0] = 0;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-
+    };
+    // contract: the 64 rows of tile i (LDS buffer `buf`) against this wave's queries, threshold test / dense store
+    auto contract = [&](uint32_t i, uint32_t buf) {
+        const unsigned char* tb = lds + buf * TILE_BYTES;
         if (!wave_has_queries) return;  // every query of this wave is padding: it only converts rows
         const uint32_t row_base = (first_tile + i * tile_stride) * TILE_ROWS;
 #pragma unroll
@@ -191,13 +216,25 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
             for (int g = 0; g < QG; ++g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+            // A fragments through a register ring PD k-steps deep: an LDS read has ~100+ cycles of latency with eight
+            // waves reading, an MFMA issues every 32 — reads issued one or two MFMAs ahead leave the matrix pipe waiting
+            constexpr int PD = 8;
+            const unsigned char* ab = tb + sub * SUB_BYTES + rd_off;
+            half8 a[PD];
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+                a[d] = *reinterpret_cast<const half8*>(ab + d * (2 * G_STRIDE) + (d & 3) * 32);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 24; ++s) {
-                const half8 a = *reinterpret_cast<const half8*>(tb + sub * SUB_BYTES + rd_off + s * (2 * G_STRIDE) +
-                                                                (s & 3) * 32);
 #pragma unroll
-                for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[g][s], acc[g], 0, 0, 0);
+                for (int g = 0; g < QG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[g][s], acc[g], 0, 0, 0);
+                if (s + PD < 24)
+                    a[s % PD] = *reinterpret_cast<const half8*>(ab + (s + PD) * (2 * G_STRIDE) + ((s + PD) & 3) * 32);
+                __builtin_amdgcn_sched_barrier(0);  // keep the read here, PD steps ahead of its use (hipcc sinks it otherwise)
             }
+            stamp(2 + 2 * sub);  // contraction of sub-tile `sub`
             // C/D map: this lane holds D[row = (e&3) + 8*(e>>2) + 4*h][query r]
             const uint32_t row0 = row_base + sub * 32 + 4 * h;
 #pragma unroll
@@ -230,44 +267,300 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
                         }
                         if (mask) {
                             uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
-                            bool dropped = false;
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
                                 if (mask & (1u << e)) {
+                                    const float sc = acc[g][e] * (1.0f / SCORE_SCALE);
+                                    const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
                                     if (pos < STAGE_CAP) {
                                         stage_q[pos] = (uint32_t)qi;
-                                        stage_s[pos] = acc[g][e] * (1.0f / SCORE_SCALE);
-                                        stage_r[pos] = row0 + (e & 3) + 8 * (e >> 2);
-                                    } else {
-                                        dropped = true;
+                                        stage_s[pos] = sc;
+                                        stage_r[pos] = row;
+                                    } else {  // stage full (a burst: many queries hitting the same rows): append directly
+                                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                        if (slot < (uint32_t)BATCH_CAP)
+                                            cand[(size_t)qi * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, sc), row);
                                     }
                                     ++pos;
                                 }
                             }
-                            // staging full (a tile with > 1024 hits): poison the query's counter -> exact pass
-                            if (dropped) atomicAdd(&cnt[qi], (uint32_t)BATCH_CAP + 1u);
                         }
                     }
+                }
+            }
+            stamp(3 + 2 * sub);  // threshold test / append of sub-tile `sub`
+        }
+    };
+
+    const uint32_t G = gridDim.x;
+    uint32_t i = blockIdx.x;
+    {
+        // lockstep: every wave converts tile i, barrier, every wave contracts tile i
+#pragma unroll
+        for (int f = 0; f < PF; ++f)
+            if (i + f * G < n_tiles) issue(st[f], i + f * G);
+        uint32_t buf = 0;
+        while (i < n_tiles) {
+#pragma unroll
+            for (int f = 0; f < PF; ++f) {
+                if (i < n_tiles) {
+                    stamp(-1);
+                    convert(st[f], buf, i + PF * G);
+                    stamp(0);  // wait for the staged loads, convert, LDS stores, issue the next loads
+                    barrier_and_flush(buf);
+                    stamp(1);  // barrier (arrival skew of the workgroup's waves)
+                    contract(i, buf);
+                    buf ^= 1u;
+                    i += G;
+                }
+            }
+        }
+    }
+    if (!DENSE) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        flush();
+    }
+    if (SCHED == 2 && diag && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) diag[((size_t)blockIdx.x * NW + wave) * 8 + k] = seg[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan_f16_dma_kernel — the matrix-core filter over the scaled-f16 SHADOW rows of an f32 index (ROW_F16S): no
+// conversion, no staging registers, no LDS stores.  Row tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB
+// per wave-instruction, two tiles ahead in a ring of three 48-KiB images), the waves only read fragments and issue
+// MFMAs.
+//   LDS image of a tile: row-major, 64 rows x 48 16-B slots, no padding; slot p of row R holds k-group
+//   g = (p & ~15) | ((p & 15) ^ (R & 15)).  An LDS-DMA writes lane-linear bytes, so the permutation is applied to the
+//   per-lane SOURCE address (still one contiguous 768-B row per 48 lanes: fully coalesced); the A-operand read of
+//   k-group g over 32 rows then hits 16 different 16-B bank slots in every 16-lane group (conflict-free ds_read_b128).
+//   Per tile and wave: 6 DMA instructions, 48 ds_read_b128, 48 MFMAs, two threshold tests, ONE barrier
+//   (s_waitcnt vmcnt(6): the tile for the next iteration has landed, the one after stays in flight).
+// ------------------------------------------------------------------------------------------------
+constexpr int DMA_TILE_BYTES = TILE_ROWS * EM * 2;  // 49152
+constexpr uint32_t DMA_STAGE_CAP = 1024;            // candidates staged per workgroup (12 KiB beside the 144-KiB ring)
+constexpr uint32_t DMA_STAGE_FLUSH_AT = 384;
+
+template <bool DENSE>
+__global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
+                                                          uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                                                          const half8* __restrict__ qh, int n_q,
+                                                          const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                          uint2* __restrict__ cand, float* __restrict__ dense) {
+    constexpr int NT = 512, PD = 8;
+    // three SEPARATE LDS objects: the module-LDS lowering then tags their accesses with alias scopes and hipcc's
+    // waitcnt insertion does not drain the in-flight LDS-DMA (vmcnt(0)) in front of reads of ANOTHER image
+    __shared__ __attribute__((aligned(16))) unsigned char img0[DMA_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char img1[DMA_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char img2[DMA_TILE_BYTES];
+    __shared__ uint32_t stage_q[DMA_STAGE_CAP];
+    __shared__ float stage_s[DMA_STAGE_CAP];
+    __shared__ uint32_t stage_r[DMA_STAGE_CAP];
+    __shared__ uint32_t stage_n[4];
+    if (!DENSE && threadIdx.x < 3) stage_n[threadIdx.x] = 0;
+    auto flush = [&]() {
+        uint32_t n = stage_n[0];
+        if (n > DMA_STAGE_CAP) n = DMA_STAGE_CAP;
+        for (uint32_t e = threadIdx.x; e < n; e += NT) {
+            const uint32_t q_ = stage_q[e];
+            const uint32_t slot = atomicAdd(&cnt[q_], 1u);
+            if (slot < (uint32_t)BATCH_CAP)
+                cand[(size_t)q_ * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, stage_s[e]), stage_r[e]);
+        }
+    };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const int qi = wave * 32 + (int)r;
+    const bool wave_has_queries = wave * 32 < n_q;
+
+    half8 qf[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) qf[s] = qh[(size_t)qi * 48 + 2 * s + h];
+    float tau_s = __builtin_inff();
+    if (!DENSE && qi < n_q) tau_s = tau[qi] * SCORE_SCALE;
+
+    // DMA map: instruction i of this wave fills LDS bytes [(6w+i)*1024, +1024) of the image: slot q = (6w+i)*64 + lane
+    // = row q/48, position q%48; the lane fetches the k-group that belongs there
+    uint32_t src_off[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t q = (uint32_t)(6 * wave + i) * 64u + (uint32_t)lane;
+        const uint32_t R = q / 48u, p = q % 48u;
+        const uint32_t g = (p & ~15u) | ((p & 15u) ^ (R & 15u));
+        src_off[i] = R * 768u + g * 16u;
+    }
+    // fragment map: k-step s = 8a + j reads k-group g = 2s + h of row sub*32 + r: slot (g & ~15) | ((g & 15) ^ (r & 15))
+    uint32_t xo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xo[j] = r * 768u + ((((2u * j + h) & 15u) ^ (r & 15u))) * 16u;
+
+    const uint32_t G = gridDim.x;
+    const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
+    const uint32_t last = n_units - 1;
+    auto unit_row0 = [&](uint32_t t) { return (first_tile + (blockIdx.x + t * G) * tile_stride) * TILE_ROWS; };
+    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * TILE_ROWS; };
+    // The six per-lane source addresses of a tile are kept in registers of their own until the end of the iteration
+    // (fake use below): hipcc otherwise recycles the address temporaries for the A ring / accumulator and then waits
+    // for the whole DMA (vmcnt(0)) before the first MFMA overwrites them.
+    auto dma = [&](uint32_t t, unsigned char* img, const unsigned char* (&gp)[6]) {  // tile t -> LDS image
+        const unsigned char* base = xs + (size_t)unit_row0(t) * (EM * 2);
+        unsigned char* dst = img + wave * 6144;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gp[i] = base + src_off[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[i],
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    auto keep = [&](const unsigned char* (&gp)[6]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(gp[i]));
+    };
+
+    auto tail_slow = [&](const f32x16& acc, uint32_t row0) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
+            mask |= (acc[e] > tau_s && row < n_rows) ? (1u << e) : 0u;
+        }
+        if (mask) {
+            uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (mask & (1u << e)) {
+                    const float sc = acc[e] * (1.0f / SCORE_SCALE);
+                    const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
+                    if (pos < DMA_STAGE_CAP) {
+                        stage_q[pos] = (uint32_t)qi;
+                        stage_s[pos] = sc;
+                        stage_r[pos] = row;
+                    } else {  // stage full (a burst: many queries hitting the same rows): append directly
+                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                        if (slot < (uint32_t)BATCH_CAP)
+                            cand[(size_t)qi * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, sc), row);
+                    }
+                    ++pos;
                 }
             }
         }
     };
 
-    uint32_t i = blockIdx.x;
+    // prologue: tiles 0 and 1 on their way (a workgroup with one tile fetches it twice: no branch around the loads)
+    // The query fragments must be complete BEFORE the loop as far as hipcc can tell (a use it can see): their first
+    // real use is the first MFMA inside the loop, and a wait placed there is re-executed every iteration as vmcnt(0),
+    // i.e. it would also drain the row DMA that is meant to stay in flight.
 #pragma unroll
-    for (int f = 0; f < PF; ++f)
-        if (i + f * gridDim.x < n_tiles) issue(st[f], i + f * gridDim.x);
-    uint32_t buf = 0;
-    while (i < n_tiles) {
+    for (int s = 0; s < 24; ++s) asm volatile("" ::"v"(qf[s]));
+    asm volatile("" ::"v"(tau_s));
+    const unsigned char* gp0[6];
+    const unsigned char* gp1[6];
+    dma(0, img0, gp0);
+    dma(last < 1u ? last : 1u, img1, gp1);
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile 0 landed, everywhere
+    keep(gp0);
+    keep(gp1);
+
+    uint32_t t = 0;
+    // one tile: contract `rd` (tile t), DMA tile t+2 into `wr` (last read in iteration t-1, which every wave left
+    // through the barrier)
+    auto step = [&](uint32_t rd_off, unsigned char* wr) -> bool {
+        if (t >= n_units) return false;
+        const unsigned char* gp[6];
+        dma(t + 2 < n_units ? t + 2 : last, wr, gp);
+        if (wave_has_queries) {
 #pragma unroll
-        for (int f = 0; f < PF; ++f) {
-            if (i < n_tiles) {
-                process(st[f], i, buf);
-                buf ^= 1u;
-                i += gridDim.x;
+            for (int sub = 0; sub < 2; ++sub) {
+                // A fragments by inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains every in-flight
+                // LDS-DMA (s_waitcnt vmcnt(0)) in front of any LDS read it can see, which would serialise the row stream
+                // behind each contraction.  Ring of PD reads; before MFMA s at most PD-1 younger reads are outstanding.
+                const uint32_t sbase = rd_off + (uint32_t)sub * (32u * 768u);
+                uint32_t ad[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ad[j] = sbase + xo[j];
+                half8 a[PD];
+#pragma unroll
+                for (int d = 0; d < PD; ++d)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[d]) : "v"(ad[d & 7]), "n"((d >> 3) * 256));
+                f32x16 acc;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 24; ++s) {
+                    // reads s .. min(s+PD,24)-1 are outstanding; the oldest must have landed
+                    // (no "memory" clobber: hipcc treats such an asm as an LDS access and drains the DMA in front of it)
+                    if (s + PD <= 24) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));
+                    else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0], z, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[s], acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + PD < 24)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(a[s % PD])
+                                     : "v"(ad[(s + PD) & 7]), "n"(((s + PD) >> 3) * 256));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint32_t row0 = unit_row0(t) + sub * 32 + 4 * h;
+                if (DENSE) {
+                    if (qi < n_q) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                o[e] = (row0 + e + 8 * e4) < n_rows ? acc[e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                            *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + unit_slot0(t) + sub * 32 + 4 * h +
+                                                      8 * e4) = o;
+                        }
+                    }
+                } else {
+                    float mx = acc[0];
+#pragma unroll
+                    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+                    if (__any(mx > tau_s)) tail_slow(acc, row0);
+                }
             }
         }
+        keep(gp);
+        // publish: tile t+1 has landed (this wave's share), tile t+2 may stay in flight; candidate stage check
+        // (the stage fill is read by asm as well: a visible LDS read would make hipcc drain the DMA of tile t+2)
+        uint32_t fill = 0;
+        if (!DENSE) {
+            const uint32_t sn = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage_n;
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(fill)
+                         : "v"(sn)
+                         : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (!DENSE && __builtin_amdgcn_readfirstlane(fill) >= DMA_STAGE_FLUSH_AT) {
+            flush();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (threadIdx.x == 0) stage_n[0] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        ++t;
+        return true;
+    };
+    const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img0;
+    const uint32_t o1 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img1;
+    const uint32_t o2 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img2;
+    for (;;) {
+        if (!step(o0, img2)) break;
+        if (!step(o1, img0)) break;
+        if (!step(o2, img1)) break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
     if (!DENSE) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         flush();
@@ -441,50 +734,94 @@ BatchPlan plan_batched(uint32_t n_rows) {
 
 static bool g_lds_attr_set = false;
 
-int g_batched_waves = 8;  // workgroup shape of the scan kernel (4 or 8 waves); tuning knob
 
-template <bool DENSE, int NW, int RT>
+unsigned long long* g_batched_diag = nullptr;  // device buffer [grid][8 waves][8] for the SCHED == 2 diagnostic build
+// 1 (default): f16 shadow rows go through the LDS-DMA kernel, other row sources through the lockstep kernel;
+// 0: lockstep kernel for every row source; 2: lockstep kernel with diagnostic stamps
+int g_batched_sched = 1;
+
+template <bool DENSE, int NW, int RT, int SCHED>
 static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, RT>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
+    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, RT, SCHED>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
                        first, stride, n_tiles, reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
-                       reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+                       reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), g_batched_diag);
 }
 
+template <bool DENSE, int RT>
+static void launch_pass_rt(const void* d_rows, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+                           const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
+    const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
+    if (RT == 2 && g_batched_sched != 0 && g_batched_sched != 2) {  // f16 shadow rows: LDS-DMA kernel
+        hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE>), dim3(blocks), dim3(512), 0, stream,
+                           reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
+                           reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
+                           reinterpret_cast<float*>(ws.cand));
+        return;
+    }
+    if (g_batched_sched == 2 && !DENSE)  // lockstep kernel with diagnostic stamps (full append pass only)
+        launch_pass_nw<false, 8, RT, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else
+        launch_pass_nw<DENSE, 8, RT, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+}
+
+// rows: the filter's row source; rt: its row type (ROW_F32, ROW_BF16 or ROW_F16S = the scaled f16 shadow copy)
 template <bool DENSE>
-static void launch_pass(const void* d_x, int dtype, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                         const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     if (n_tiles == 0) return;
-    if (dtype == ROW_BF16) {
-        if (g_batched_waves == 8) launch_pass_nw<DENSE, 8, 1>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-        else launch_pass_nw<DENSE, 4, 1>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-    } else {
-        if (g_batched_waves == 8) launch_pass_nw<DENSE, 8, 0>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-        else launch_pass_nw<DENSE, 4, 0>(d_x, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    if (rt == ROW_F16S) launch_pass_rt<DENSE, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else if (rt == ROW_BF16) launch_pass_rt<DENSE, 1>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else launch_pass_rt<DENSE, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+}
+
+template <int RT>
+static hipError_t set_lds_attr_rt() {
+    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 8, RT, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, RT, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, RT, 2>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
     }
+    return hipSuccess;
 }
 
 int batched_init() {
     if (g_lds_attr_set) return 0;
-    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 4, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<true, 4, 1>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 4, 1>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 1>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 1>)};
-    for (const void* f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-    }
+    hipError_t e = set_lds_attr_rt<0>();
+    if (e == hipSuccess) e = set_lds_attr_rt<1>();
+    if (e == hipSuccess) e = set_lds_attr_rt<2>();
+    if (e != hipSuccess) return (int)e;
     g_lds_attr_set = true;
     return 0;
 }
 
-void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
+// f32 rows -> scaled f16 rows (the filter's shadow copy): value * 2^8, round to nearest even
+__global__ void rows_f32_to_f16s_kernel(const f32x4* __restrict__ in, half8* __restrict__ out, size_t n_chunks8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
+        const half4 lo = to_half4_scaled(in[2 * i]), hi = to_half4_scaled(in[2 * i + 1]);
+        half8 o;
+        o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
+        o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+        out[i] = o;
+    }
+}
+
+void launch_rows_f32_to_f16s(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream) {
+    if (n_rows == 0) return;
+    const size_t n = n_rows * ROW_C8;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rows_f32_to_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<half8*>(d_out), n);
+}
+
+void launch_batched_dense_scores(const void* d_frows, int frt, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream) {
+    const void* d_x = d_frows;
+    const int dtype = frt;
     hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
     const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
     launch_pass<true>(d_x, dtype, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
@@ -506,34 +843,36 @@ static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_
                            dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
 }
 
-void launch_scan_batched(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
-                         uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
-                         uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream, hipEvent_t ev0,
-                         hipEvent_t ev1) {
+// d_x/dtype: the index rows (exact rescore); d_frows/frt: the filter's row source (the same rows, or the scaled f16
+// shadow copy ROW_F16S of an f32 index)
+void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int frt, const uint64_t* d_ids, uint32_t n_rows,
+                         const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
+                         float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
+                         hipEvent_t ev0, hipEvent_t ev1) {
     const BatchPlan pl = plan_batched(n_rows);
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
     if (pl.dense_only) {
         if (ev0) (void)hipEventRecord(ev0, stream);
-        launch_pass<true>(d_x, dtype, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+        launch_pass<true>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
         if (ev1) (void)hipEventRecord(ev1, stream);
         launch_select_rescore<true>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
                                     force_fallback, stream);
         return;
     }
-    launch_pass<true>(d_x, dtype, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
+    launch_pass<true>(d_frows, frt, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
     hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
                        pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
     if (pl.s2_tiles) {
         (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
-        launch_pass<false>(d_x, dtype, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
+        launch_pass<false>(d_frows, frt, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
         hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
                            ws.tau);
     }
     (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
-    launch_pass<false>(d_x, dtype, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+    launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
     if (ev1) (void)hipEventRecord(ev1, stream);
     launch_select_rescore<false>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
                                  force_fallback, stream);

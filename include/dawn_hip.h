@@ -130,6 +130,9 @@ int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
  * rows [0, n), n = min(size, 8192): out [B][n].  Lets a test check the bound the certificate relies on. */
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
+/* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
+ * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
+int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
 /* Tuning knobs (tests sweep them; defaults are the tuned values): name in
  * {"scan_blocks","scan_threads","mfma_blocks","mfma_min_batch","force_fallback"}. */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);

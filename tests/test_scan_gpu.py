@@ -343,3 +343,45 @@ def test_batched_clustered_index_overflow_falls_back(dawn, oracle):
         _assert_same(labels[b], dist[b], *oracle.scan_topk(rows, ids, Q[b], 10, threads=8))
     assert labels[4][0] == 2 * 64 * (123 // 64) + 123 % 64 + 1  # where base[123] landed
     assert idx.stats()["fallbacks"] >= 1
+
+
+def test_batched_correlated_queries_burst(dawn, oracle):
+    """256 near-identical queries (a realistic batch: one topic) hit the SAME rows, so a qualifying row appends 256
+    candidates at once.  The workgroup's candidate stage must absorb or bypass such bursts without dropping
+    anything or sending the batch to the exact pass."""
+    n, B, k = 200_000, 256, 10
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    base = synth.unit_rows(2, 0, 1)[0]
+    rng = np.random.default_rng(3)
+    Q = np.stack([dawn.normalize(base + (0.01 / np.sqrt(384)) * rng.standard_normal(384).astype(np.float32))
+                  for _ in range(B)])
+    labels, dist, found = idx.search_batch(Q, k)
+    for b in range(0, B, 17):
+        _assert_same(labels[b], dist[b], *oracle.scan_topk(x, ids, Q[b], k, threads=8))
+    assert idx.stats()["fallbacks"] == 0
+    idx.set_option("mfma_sched", 0)  # the lockstep kernel (on-the-fly conversion path) as well
+    idx.set_option("f16_shadow", 0)
+    l2, d2, f2 = idx.search_batch(Q, k)
+    assert np.array_equal(labels, l2) and np.array_equal(dist.view(np.uint32), d2.view(np.uint32))
+    assert idx.stats()["fallbacks"] == 0
+    idx.set_option("mfma_sched", 1)
+
+
+def test_batched_shadow_tracks_adds_and_growth(dawn, oracle):
+    """The f16 shadow copy is built at the first batched search and must follow later adds / reallocation."""
+    rows = oracle.unit_rows(1, 0, 30_000)
+    ids = np.arange(1, 30_001, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids[:9_000], rows[:9_000])
+    Q = synth.unit_rows(2, 0, 40)
+    Q[7] = rows[29_999]
+    l, d, f = idx.search_batch(Q, 10)                      # builds the shadow for 9000 rows
+    for b in (0, 7, 39):
+        _assert_same(l[b], d[b], *oracle.scan_topk(rows[:9_000], ids[:9_000], Q[b], 10))
+    idx.add_batch(ids[9_000:], rows[9_000:])               # grows the index: shadow must be extended + reallocated
+    l, d, f = idx.search_batch(Q, 10)
+    for b in (0, 7, 39):
+        _assert_same(l[b], d[b], *oracle.scan_topk(rows, ids, Q[b], 10, threads=4))
+    assert l[7][0] == 30_000 and idx.stats()["fallbacks"] == 0
