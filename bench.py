@@ -152,7 +152,7 @@ def main():
             return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
         return sum(1 for _ in range(0, Bq, 4)) if Bq > 1 else 1   # streaming path: up to 4 queries per pass
 
-    def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False):
+    def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False, f32_stream=False):
         """`steps` timed searches of a Bq-query batch.  Returns qps (max over ranks), ms/step and the mean
         duration of the dominant scan kernel measured with HIP events on its launch stream."""
         step, result = make_step(index, Bq, seed)
@@ -175,9 +175,10 @@ def main():
         leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3, "steps": steps,
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
-        # bytes the dominant kernel has to read per row: 1536 (f32 rows); 768 for a bf16 index and for the
-        # matrix-core filter (B >= 9) of an f32 index, which streams the scaled-f16 shadow copy of the rows
-        row_bytes = ROW_BYTES // 2 if (getattr(index, "dtype", "f32") == "bf16" or Bq >= 9) else ROW_BYTES
+        # bytes the dominant kernel has to read per row: 768 for a bf16 index and for an f32 index, whose FILTER
+        # streams the scaled-f16 shadow copy of the rows (the exact rescore touches 64 f32 rows per query);
+        # 1536 when the f32 rows themselves are streamed (shadow switched off: f32_stream)
+        row_bytes = ROW_BYTES if f32_stream else ROW_BYTES // 2
         algo = rows_here * row_bytes * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
@@ -237,14 +238,16 @@ def main():
     elapsed_ms = head["ms_per_step"]
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
-    kernel = "scan_f16_kernel<append>" if B >= 9 else "scan_filter_kernel"
+    kernel = "scan_f16_dma_kernel<append> (f16 shadow rows, LDS-DMA)" if B >= 9 else "scan_filter_f16s_kernel (f16 shadow rows)"
 
     out = {
         "metric": "queries/sec, exact cosine top-k over a 384-d f32 index resident in HBM",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k",
+        "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k "
+                               "(f16 filter over a shadow copy of every row + exact f32 rescore: results bit-identical "
+                               "to the f32 scan)",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
                    "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -267,6 +270,12 @@ def main():
     # ---- extra legs (rank-collective where needed) --------------------------------------------
     if not args.no_extras:
         extra = {}
+        # the same batch-1 search streaming the f32 rows themselves (1536 B/row; shadow filter off): the f32-stream
+        # roofline of DESIGN.md §4.1
+        idx.set_option("f16_shadow_b1", 0)
+        legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, f32_stream=True)
+        idx.set_option("f16_shadow_b1", 1)
+        extra["batch1_streaming_f32_rows"] = legf
         # batch-256 on the same index: one pass of the matrix-core kernel serves all 256 queries
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
         leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)

@@ -37,6 +37,10 @@ struct dawn_index {
     size_t shadow_cap = 0;       // rows allocated
     size_t shadow_rows = 0;      // rows converted so far (prefix)
     int use_shadow = 1;          // option "f16_shadow"
+    int shadow_small_batches = 1;  // option "f16_shadow_b1": batches of 1..8 queries also filter on the shadow
+    // geometry of that 16-bit-row stream: one 8-wave block per CU, 2 quads (6 KiB) in flight per wave
+    // (tools/scan_sweep_shadow.py, 80M rows: 6.99 TB/s; 4 waves per CU are VALU-bound at 6.6, 16 waves 6.57)
+    dawn::ScanGeom geom_h{256, 512, 2};
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
     float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
     size_t stage_rows = 0;
@@ -125,7 +129,9 @@ int ensure_room(dawn_index* idx, size_t extra) {
 }
 
 int ensure_workspace(dawn_index* idx, size_t B) {
-    if (B >= (size_t)idx->mfma_min_batch && !idx->bws.cand) {
+    // the batched workspace also serves the f16-shadow streaming filter of small batches (scaled query images)
+    const bool shadow_possible = idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed;
+    if ((B >= (size_t)idx->mfma_min_batch || shadow_possible) && !idx->bws.cand) {
         if (int e = dawn::batched_init()) return fail(DAWN_ERR_HIP, "hipFuncSetAttribute(LDS): %s", hipGetErrorString((hipError_t)e));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * dawn::EM * sizeof(_Float16)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.tau, dawn::BATCH_QT * sizeof(float)));
@@ -140,7 +146,7 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
     idx->ws_B = 0;
-    const size_t n = B * (size_t)idx->geom.blocks * dawn::LIST;
+    const size_t n = B * (size_t)std::max(idx->geom.blocks, idx->geom_h.blocks) * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
@@ -209,11 +215,23 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
                                       b0 == 0 ? e1 : nullptr);
         }
     } else {
-        dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0,
-                                 e1);
-        dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                   idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                                   idx->force_fallback, dawn::FILTER_EPS_F32, stream);
+        int frt = idx->dtype;
+        const void* frows = filter_rows(idx, &frt, stream);
+        if (frt == dawn::ROW_F16S && idx->shadow_small_batches) {
+            // 1..8 queries: stream the f16 shadow (768 B/row) instead of the f32 rows (1536 B/row)
+            dawn::launch_prep_queries(d_q, (int)B, idx->bws, stream);
+            dawn::launch_scan_filter_f16s(frows, n, idx->bws.qh, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom_h, stream,
+                                          e0, e1);
+            dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
+                                       idx->geom_h.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                                       idx->force_fallback, dawn::FILTER_EPS_F16, stream);
+        } else {
+            dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream,
+                                     e0, e1);
+            dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
+                                       idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                                       idx->force_fallback, dawn::FILTER_EPS_F32, stream);
+        }
     }
     dawn::launch_scan_exact(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
                             stream);
@@ -247,6 +265,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
+    if (prop.multiProcessorCount > 0) idx->geom_h.blocks = prop.multiProcessorCount;
     if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -690,6 +709,16 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     }
     if (n == "f16_shadow") {
         idx->use_shadow = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "f16_shadow_b1") {
+        idx->shadow_small_batches = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "shadow_scan_blocks" || n == "shadow_scan_threads" || n == "shadow_scan_unroll") {
+        if (n == "shadow_scan_blocks") idx->geom_h.blocks = (int)value, idx->ws_B = 0;
+        else if (n == "shadow_scan_threads") idx->geom_h.threads = (int)value;
+        else idx->geom_h.unroll = (int)value;
         return DAWN_OK;
     }
     if (n == "mfma_sched") {

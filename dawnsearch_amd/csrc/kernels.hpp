@@ -33,6 +33,12 @@ constexpr int ROW_F16S = 2;  // filter-only shadow of an f32 index: rows as f16(
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
 
+struct BatchWorkspace {
+    _Float16* qh;    // [BATCH_QT][384] scaled f16 queries
+    float* tau;      // [BATCH_QT]
+    uint32_t* cnt;   // [BATCH_QT]
+    void* cand;      // [BATCH_QT][BATCH_CAP] uint2 (score bits, row); first half doubles as dense f32 scores
+};
 struct ScanGeom {
     int blocks;           // scan grid (== number of candidate lists per query)
     int threads;          // 1024 / 512 / 256
@@ -44,6 +50,11 @@ struct ScanGeom {
 void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0,
                         hipEvent_t ev1);
+// The same for B = 1..8 over the scaled-f16 shadow rows of an f32 index (half the bytes; filter error FILTER_EPS_F16);
+// d_qh = scaled f16 query images [B][384] (launch_prep_queries).
+void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const void* d_qh, int B, float* cand_s,
+                             uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
@@ -51,12 +62,6 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
                           int force_fallback, float eps, hipStream_t stream);
 // Batched search on the matrix cores (9 <= B <= BATCH_QT): f16 MFMA filter with sampled thresholds,
 // candidate append, exact rescore + certificate (scan_batched.hip).  ev0/ev1 bracket the full pass.
-struct BatchWorkspace {
-    _Float16* qh;    // [BATCH_QT][384] scaled f16 queries
-    float* tau;      // [BATCH_QT]
-    uint32_t* cnt;   // [BATCH_QT]
-    void* cand;      // [BATCH_QT][BATCH_CAP] uint2 (score bits, row); first half doubles as dense f32 scores
-};
 struct BatchPlan {
     bool dense_only;          // n_rows <= BATCH_CAP: one dense pass, no thresholds
     uint32_t n_tiles_total;

@@ -818,6 +818,10 @@ void launch_rows_f32_to_f16s(const float* d_in, void* d_out, size_t n_rows, hipS
                        reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<half8*>(d_out), n);
 }
 
+void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+}
+
 void launch_batched_dense_scores(const void* d_frows, int frt, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream) {
     const void* d_x = d_frows;

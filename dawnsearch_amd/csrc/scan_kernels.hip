@@ -219,6 +219,150 @@ __global__ __launch_bounds__(1024) void scan_filter_bf16_kernel(const u32x4* __r
     }
 }
 
+// f16 SHADOW rows of an f32 index (ROW_F16S: f16(2^8 x), 768 B per row; dawn_index.cpp): the same quad-row stream as
+// the bf16 kernel, scored with v_dot2_f32_f16 (two exact f16 products + f32 accumulate per instruction) against the
+// query rounded the same way — the f16 FILTER of the matrix-core path (error bound FILTER_EPS_F16) for 1..8
+// queries.  Half the bytes of the f32 rows; exactness comes from the rescore tail on the f32 rows.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+
+// (the chunk words are copied to scalars first: __builtin_bit_cast applied directly to an ext-vector element `w.x`
+// of a reference made hipcc 7.2 use element 0 for all four words)
+__device__ __forceinline__ float dot8_f16(const u32x4& w, const u32x4& q) {
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    float acc = __builtin_amdgcn_fdot2(as_half2(w0), as_half2(q0), 0.f, false);
+    acc = __builtin_amdgcn_fdot2(as_half2(w1), as_half2(q1), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_half2(w2), as_half2(q2), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_half2(w3), as_half2(q3), acc, false);
+    return acc;
+}
+
+// qh: scaled f16 queries [.][384] (prep_queries_kernel of scan_batched.hip)
+template <int QB, int U>
+__global__ __launch_bounds__(1024) void scan_filter_f16s_kernel(const u32x4* __restrict__ x, uint32_t n_rows,
+                                                                const u32x4* __restrict__ qh,
+                                                                float* __restrict__ out_s,
+                                                                uint32_t* __restrict__ out_p,
+                                                                uint32_t q_stride_lists) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * nwaves + wave;
+    const uint32_t total_waves = gridDim.x * nwaves;
+    const uint32_t n_quads = (n_rows + 3u) >> 2;
+    const uint32_t n_chunks = (n_quads + U - 1) / U;
+    const int c0 = lane < 48 ? lane : lane - 48;
+    const int c1 = lane < 32 ? 16 + lane : lane - 32;
+    const int c2 = lane < 16 ? 32 + lane : lane - 16;
+    u32x4 qf[QB][3];
+    float ls[QB], tau[QB];
+    uint32_t lp[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        qf[b][0] = qh[b * ROW_C8 + c0];
+        qf[b][1] = qh[b * ROW_C8 + c1];
+        qf[b][2] = qh[b * ROW_C8 + c2];
+        ls[b] = NEG_INF;
+        lp[b] = NO_POS;
+        tau[b] = NEG_INF;
+    }
+    const bool a48 = lane < 48, a32 = lane < 32, a16 = lane < 16;
+    const float unscale = 1.0f / 65536.0f;
+
+    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
+        const u32x4* p = x + (size_t)c * (U * 192) + lane;
+        u32x4 v[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u][0] = __builtin_nontemporal_load(p + u * 192);
+            v[u][1] = __builtin_nontemporal_load(p + u * 192 + 64);
+            v[u][2] = __builtin_nontemporal_load(p + u * 192 + 128);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r0 = (c * U + u) * 4u;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const float d0 = dot8_f16(v[u][0], qf[b][0]);
+                const float d1 = dot8_f16(v[u][1], qf[b][1]);
+                const float d2 = dot8_f16(v[u][2], qf[b][2]);
+                float sc[4];
+                sc[0] = read_lane63(wave_sum_lane63(a48 ? d0 : 0.f));
+                sc[1] = read_lane63(wave_sum_lane63((a48 ? 0.f : d0) + (a32 ? d1 : 0.f)));
+                sc[2] = read_lane63(wave_sum_lane63((a32 ? 0.f : d1) + (a16 ? d2 : 0.f)));
+                sc[3] = read_lane63(wave_sum_lane63(a16 ? 0.f : d2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r = r0 + j;
+                    const float sj = (r < n_rows && sc[j] == sc[j]) ? sc[j] * unscale : NEG_INF;
+                    if (sj > tau[b]) {
+                        wave_insert(ls[b], lp[b], sj, r, lane);
+                        tau[b] = read_lane63(ls[b]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+        if (wave == 0) {
+            const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
+            out_s[o] = ls[b];
+            out_p[o] = lp[b];
+        }
+    }
+}
+
+template <int QB>
+static void launch_filter_f16s_qb(const void* d_shadow, uint32_t n_rows, const void* d_qh, float* cand_s, uint32_t* cand_p,
+                                  const ScanGeom& g, hipStream_t stream) {
+    const u32x4* x4 = reinterpret_cast<const u32x4*>(d_shadow);
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(d_qh);
+    if (g.unroll <= 1)
+        hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, 1>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+    else if (g.unroll == 3 && QB == 1)
+        hipLaunchKernelGGL((scan_filter_f16s_kernel<1, 3>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+    else if (g.unroll >= 4 && QB == 1)
+        hipLaunchKernelGGL((scan_filter_f16s_kernel<1, 4>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+    else
+        hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, 2>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
+                           cand_s, cand_p, (uint32_t)g.blocks);
+}
+
+// Streaming filter over the f16 shadow rows for B = 1..8 queries; d_qh = their scaled f16 images [B][384].
+void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const void* d_qh, int B, float* cand_s,
+                             uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    int b = 0;
+    const size_t per_q = (size_t)g.blocks * LIST;
+    const unsigned char* qh = reinterpret_cast<const unsigned char*>(d_qh);
+    while (b < B) {
+        const int rem = B - b;
+        const void* q = qh + (size_t)b * EM * 2;
+        float* cs = cand_s + (size_t)b * per_q;
+        uint32_t* cp = cand_p + (size_t)b * per_q;
+        if (rem >= 4) {
+            launch_filter_f16s_qb<4>(d_shadow, n_rows, q, cs, cp, g, stream);
+            b += 4;
+        } else if (rem >= 2) {
+            launch_filter_f16s_qb<2>(d_shadow, n_rows, q, cs, cp, g, stream);
+            b += 2;
+        } else {
+            launch_filter_f16s_qb<1>(d_shadow, n_rows, q, cs, cp, g, stream);
+            b += 1;
+        }
+    }
+    if (ev1) (void)hipEventRecord(ev1, stream);
+}
+
 template <int QB>
 static void launch_filter_bf16_qb(const void* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
                                   const ScanGeom& g, hipStream_t stream) {

@@ -1,0 +1,27 @@
+"""Sweep the batch-1 geometry of the f16-shadow streaming filter (dev tool): python tools/scan_sweep_shadow.py [rows]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dawnsearch_amd as dawn
+from dawnsearch_amd import synth
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 80_000_000
+idx = dawn.VectorIndex(0)
+idx.fill_synthetic(1, 0, rows, 1)
+Q = synth.unit_rows(2, 0, 8)
+res = []
+for unroll in (2, 3, 4):
+    for threads in (128, 256, 512):
+        for blocks in (256, 512):
+            if blocks * threads > 256 * 512 or blocks * threads < 256 * 128:
+                continue
+            idx.set_option("shadow_scan_unroll", unroll); idx.set_option("shadow_scan_threads", threads); idx.set_option("shadow_scan_blocks", blocks)
+            idx.search_batch(Q[:1], 10)
+            idx.profile_enable(True)
+            for _ in range(6):
+                idx.search_batch(Q[:1], 10)
+            n, ms = idx.profile_read()
+            idx.profile_enable(False)
+            k_ms = ms / max(n, 1)
+            res.append((rows * 768 / k_ms / 1e6, unroll, threads, blocks))
+            print(f"U={unroll} threads={threads:4d} blocks={blocks:4d}  scan {k_ms*1e3:9.1f} us  {rows*768/k_ms/1e6:8.1f} GB/s (768 B/row)", flush=True)
+res.sort(reverse=True)
+print("best:", res[:5], idx.stats())
