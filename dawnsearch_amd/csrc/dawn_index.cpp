@@ -19,6 +19,8 @@ using dawn::fail;
 namespace {
 constexpr size_t kMaxBatch = 256;        // queries per internal pass of the host API
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
+constexpr size_t kZeroCopyBatch = 8;      // host API: up to this many queries get their results by zero-copy stores
+constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
 constexpr char kMagic[8] = {'D', 'A', 'W', 'N', 'I', 'D', 'X', '1'};
 }  // namespace
 
@@ -29,7 +31,8 @@ struct dawn_index {
 
     int dtype = DAWN_DTYPE_F32;  // row storage: f32 (1536 B/row) or bf16 (768 B/row)
     char* d_x = nullptr;         // [(cap_phys + ROW_PAD)][384] of dtype
-    // f32 index only: scaled-f16 shadow copy of the rows ([cap][384] f16(2^8 x), 768 B/row) read by the matrix-core
+    // f32 index only: scaled-f16 shadow copy of the rows (f16(2^8 x), 768 B/row, tiles in MFMA-fragment order: ROW_F16S
+    // in kernels.hpp) read by the matrix-core
     // FILTER instead of the f32 rows: half the bytes and no conversion work in the scan.  Built lazily at the first
     // batched search, extended on add; results stay exact (the rescore reads the f32 rows).  Costs +50 % HBM; if
     // the allocation fails the filter converts f32 rows on the fly as before.
@@ -38,9 +41,17 @@ struct dawn_index {
     size_t shadow_rows = 0;      // rows converted so far (prefix)
     int use_shadow = 1;          // option "f16_shadow"
     int shadow_small_batches = 1;  // option "f16_shadow_b1": batches of 1..8 queries also filter on the shadow
-    // geometry of that 16-bit-row stream: one 8-wave block per CU, 2 quads (6 KiB) in flight per wave
-    // (tools/scan_sweep_shadow.py, 80M rows: 6.99 TB/s; 4 waves per CU are VALU-bound at 6.6, 16 waves 6.57)
-    dawn::ScanGeom geom_h{256, 512, 2};
+    // geometry of the shadow stream (MFMA from registers): one 2-wave block per CU, `unroll` picks the load schedule
+    // (launch_filter_f16s_qb: 3 = ring of 12 fragments = 12 KiB in flight per wave).  tools/scan_sweep_shadow.py,
+    // 80M rows: 7.02-7.07 TB/s; every schedule with 2-4 waves per CU lands within 1 % of it
+    dawn::ScanGeom geom_h{256, 128, 3};
+    // ... and below kShadowSmallRows rows (a few dozen sub-tiles per wave: start-up, tail and load balance count)
+    // two 4-wave blocks per CU: 1M rows 154 -> 128 us.  Setting any shadow_scan_* option pins geom_h for every size.
+    dawn::ScanGeom geom_h_small{512, 256, 3};
+    bool geom_h_pinned = false;
+    const dawn::ScanGeom& shadow_geom() const {
+        return (!geom_h_pinned && size < kShadowSmallRows) ? geom_h_small : geom_h;
+    }
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
     float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
     size_t stage_rows = 0;
@@ -146,7 +157,7 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
     idx->ws_B = 0;
-    const size_t n = B * (size_t)std::max(idx->geom.blocks, idx->geom_h.blocks) * dawn::LIST;
+    const size_t n = B * (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks}) * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
@@ -169,7 +180,8 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
         }
         (void)hipMemsetAsync(ns, 0, prow * dawn::EM * 2, stream);
         if (idx->d_shadow) {  // keep what is converted already (the old buffer is idle: searches are serialised)
-            (void)hipMemcpyAsync(ns, idx->d_shadow, idx->shadow_rows * dawn::EM * 2, hipMemcpyDeviceToDevice, stream);
+            (void)hipMemcpyAsync(ns, idx->d_shadow, padded_rows(idx->shadow_rows) * dawn::EM * 2, hipMemcpyDeviceToDevice,
+                                 stream);  // whole tiles
             (void)hipStreamSynchronize(stream);
             (void)hipFree(idx->d_shadow);
         }
@@ -177,8 +189,7 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
         idx->shadow_cap = idx->cap_phys;
     }
     if (idx->shadow_rows < idx->size) {
-        dawn::launch_rows_f32_to_f16s(reinterpret_cast<const float*>(idx->d_x) + idx->shadow_rows * dawn::EM,
-                                      idx->d_shadow + idx->shadow_rows * dawn::EM * 2, idx->size - idx->shadow_rows,
+        dawn::launch_rows_f32_to_f16s(reinterpret_cast<const float*>(idx->d_x), idx->d_shadow, idx->shadow_rows, idx->size,
                                       stream);
         idx->shadow_rows = idx->size;
     }
@@ -206,7 +217,8 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
     if ((int)B >= idx->mfma_min_batch) {
         // matrix-core path, BATCH_QT queries per pass over the index
         int frt = idx->dtype;
-        const void* frows = filter_rows(idx, &frt, stream);
+        const void* frows = idx->d_x;  // mfma_sched 0 / 2: the lockstep kernel converts the index's own rows
+        if (dawn::g_batched_sched != 0 && dawn::g_batched_sched != 2) frows = filter_rows(idx, &frt, stream);
         for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
             const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
             dawn::launch_scan_batched(idx->d_x, idx->dtype, frows, frt, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
@@ -219,11 +231,10 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
         const void* frows = filter_rows(idx, &frt, stream);
         if (frt == dawn::ROW_F16S && idx->shadow_small_batches) {
             // 1..8 queries: stream the f16 shadow (768 B/row) instead of the f32 rows (1536 B/row)
-            dawn::launch_prep_queries(d_q, (int)B, idx->bws, stream);
-            dawn::launch_scan_filter_f16s(frows, n, idx->bws.qh, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom_h, stream,
-                                          e0, e1);
+            const dawn::ScanGeom& gh = idx->shadow_geom();
+            dawn::launch_scan_filter_f16s(frows, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
             dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                       idx->geom_h.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                                       gh.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                                        idx->force_fallback, dawn::FILTER_EPS_F16, stream);
         } else {
             dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream,
@@ -265,7 +276,10 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
-    if (prop.multiProcessorCount > 0) idx->geom_h.blocks = prop.multiProcessorCount;
+    if (prop.multiProcessorCount > 0) {
+        idx->geom_h.blocks = prop.multiProcessorCount;
+        idx->geom_h_small.blocks = 2 * prop.multiProcessorCount;
+    }
     if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -417,10 +431,16 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
         std::memcpy(hq, queries + b0 * dawn::EM, nb * dawn::EM * sizeof(float));
         DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, hq, nb * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
         idx->n_searches += nb;
-        DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, idx->d_labels, idx->d_dist, idx->d_found, idx->stream));
-        DAWN_HIP_TRY(hipMemcpyAsync(hl, idx->d_labels, nb * count * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
-        DAWN_HIP_TRY(hipMemcpyAsync(hd, idx->d_dist, nb * count * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
-        DAWN_HIP_TRY(hipMemcpyAsync(hf, idx->d_found, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+        if (nb <= kZeroCopyBatch) {
+            // few queries: the tail kernels store the results straight into the pinned host block (coherent,
+            // device-visible): no copy commands between the last kernel and the host's wake-up
+            DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, hl, hd, hf, idx->stream));
+        } else {
+            DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, idx->d_labels, idx->d_dist, idx->d_found, idx->stream));
+            DAWN_HIP_TRY(hipMemcpyAsync(hl, idx->d_labels, nb * count * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
+            DAWN_HIP_TRY(hipMemcpyAsync(hd, idx->d_dist, nb * count * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+            DAWN_HIP_TRY(hipMemcpyAsync(hf, idx->d_found, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+        }
         DAWN_HIP_TRY(hipMemcpyAsync(hflag, idx->d_flags, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
         DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
         std::memcpy(labels + b0 * count, hl, nb * count * sizeof(uint64_t));
@@ -669,6 +689,37 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     return DAWN_OK;
 }
 
+// Test hook: the per-workgroup candidate lists of the streaming filter for ONE query (what merge_rescore consumes):
+// out_scores / out_rows [blocks][64] descending, fillers (-inf, 0xFFFFFFFF); *n_blocks = lists written.
+int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* out_scores, uint32_t* out_rows,
+                                  size_t cap_blocks, size_t* n_blocks) {
+    if (!idx || !query || !out_scores || !out_rows || !n_blocks) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_workspace(idx, 1));
+    hipStream_t stream = idx->stream;
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
+    int frt = idx->dtype;
+    const void* frows = filter_rows(idx, &frt, stream);
+    size_t blocks;
+    if (frt == dawn::ROW_F16S && idx->shadow_small_batches) {
+        const dawn::ScanGeom& gh = idx->shadow_geom();
+        blocks = gh.blocks;
+        dawn::launch_scan_filter_f16s(frows, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
+                                      stream, nullptr, nullptr);
+    } else {
+        blocks = idx->geom.blocks;
+        dawn::launch_scan_filter(idx->d_x, idx->dtype, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p,
+                                 idx->geom, stream, nullptr, nullptr);
+    }
+    DAWN_HIP_TRY(hipGetLastError());
+    if (blocks > cap_blocks) return fail(DAWN_ERR_INVALID_ARG, "need room for %zu lists", blocks);
+    *n_blocks = blocks;
+    DAWN_HIP_TRY(hipMemcpyAsync(out_scores, idx->d_cand_s, blocks * dawn::LIST * sizeof(float), hipMemcpyDeviceToHost, stream));
+    DAWN_HIP_TRY(hipMemcpyAsync(out_rows, idx->d_cand_p, blocks * dawn::LIST * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(stream));
+    return DAWN_OK;
+}
+
 // Diagnostic: per-wave phase cycle sums of the last batched full pass run with mfma_sched = 2: out [blocks][8][8].
 int dawn_index_debug_read_diag(dawn_index* idx, unsigned long long* out, size_t blocks) {
     if (!idx || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
@@ -716,13 +767,17 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         return DAWN_OK;
     }
     if (n == "shadow_scan_blocks" || n == "shadow_scan_threads" || n == "shadow_scan_unroll") {
+        idx->geom_h_pinned = true;
         if (n == "shadow_scan_blocks") idx->geom_h.blocks = (int)value, idx->ws_B = 0;
-        else if (n == "shadow_scan_threads") idx->geom_h.threads = (int)value;
-        else idx->geom_h.unroll = (int)value;
+        else if (n == "shadow_scan_threads") {
+            if (value != 64 && value != 128 && value != 256 && value != 512)
+                return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_threads must be 64/128/256/512");
+            idx->geom_h.threads = (int)value;
+        } else idx->geom_h.unroll = (int)value;
         return DAWN_OK;
     }
     if (n == "mfma_sched") {
-        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0..2");
+        if (value < 0 || value > 4 || value == 3) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 2 or 4");
         if (value == 2 && !dawn::g_batched_diag) {
             DAWN_HIP_TRY(hipMalloc((void**)&dawn::g_batched_diag, 4096 * 8 * 8 * sizeof(unsigned long long)));
             DAWN_HIP_TRY(hipMemset(dawn::g_batched_diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));

@@ -28,7 +28,12 @@ constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sa
 
 constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
 constexpr int ROW_BF16 = 1;  // DAWN_DTYPE_BF16: rows are 384 x bf16 (768 B), scored as their exact f32 widening
-constexpr int ROW_F16S = 2;  // filter-only shadow of an f32 index: rows as f16(2^8 * x) (768 B), see dawn_index.cpp
+// ROW_F16S: filter-only shadow of an f32 index: f16(2^8 * x), 768 B per row, stored TILE BY TILE (64 rows = 48 KiB)
+// in the operand order of v_mfma_f32_32x32x16_f16: tile T = rows 64T..64T+63; inside it fragment f = sub*24 + s
+// (sub = 32-row half, s = k-step of 16) is 1 KiB = 64 lanes x 16 B, lane L = h*32 + r holding elements
+// k = 16s + 8h .. +7 of row 64T + 32*sub + r.  A wave-wide 16-B load of a fragment IS the MFMA A operand (streaming
+// filter, scan_kernels.hip) and an LDS-DMA of the tile needs no permutation (matrix-core filter, scan_batched.hip).
+constexpr int ROW_F16S = 2;
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
@@ -50,9 +55,9 @@ struct ScanGeom {
 void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0,
                         hipEvent_t ev1);
-// The same for B = 1..8 over the scaled-f16 shadow rows of an f32 index (half the bytes; filter error FILTER_EPS_F16);
-// d_qh = scaled f16 query images [B][384] (launch_prep_queries).
-void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const void* d_qh, int B, float* cand_s,
+// The same over the scaled-f16 shadow of an f32 index (ROW_F16S: half the bytes, filter error FILTER_EPS_F16), 8 queries
+// per pass; d_q = the f32 queries (converted in the kernel).
+void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                              uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
@@ -79,7 +84,7 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
                          const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
                          hipEvent_t ev0, hipEvent_t ev1);
-void launch_rows_f32_to_f16s(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream);
+void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_row, size_t n_valid, hipStream_t stream);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
 void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);

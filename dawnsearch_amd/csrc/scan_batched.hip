@@ -77,11 +77,6 @@ __device__ __forceinline__ void store_converted(unsigned char* base, int step, c
     *reinterpret_cast<half8*>(base + step * 64) = o;
 }
 
-// f16 shadow chunk (8 values, already scaled and rounded): a plain copy
-__device__ __forceinline__ void store_converted(unsigned char* base, int step, const half8& v) {
-    *reinterpret_cast<half8*>(base + step * 64) = v;
-}
-
 // LDS byte offset (inside one tile buffer) of the 16-B slot holding f16 elements k = 8g..8g+7 of tile row `row`:
 // [sub-tile][g][row + (g & 7)].  The skew by g & 7 spreads one row's consecutive k-groups over all banks
 // (ds_write_b64 of 16 consecutive chunks is conflict-free); a k-group's 32 rows stay contiguous (ds_read_b128
@@ -118,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
         }
     };
     constexpr int QG = 8 / NW;          // 32-query groups per wave
-    constexpr int CPR = RT >= 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16 / f16 shadow: 8 values each, f32: 4)
+    constexpr int CPR = RT >= 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16: 8 values each, f32: 4)
     constexpr int LPL = CPR / NW;       // loads per lane per tile
     constexpr int RPW = TILE_ROWS / NW; // tile rows converted by one wave
     constexpr int PF = NW == 4 ? 2 : 1; // tiles in flight
@@ -174,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
     // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
     const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
 
-    typedef typename std::conditional<RT == 0, f32x4, typename std::conditional<RT == 1, u32x4, half8>::type>::type chunk_t;
+    typedef typename std::conditional<RT == 0, f32x4, u32x4>::type chunk_t;
     const chunk_t* x = reinterpret_cast<const chunk_t*>(xv);
     chunk_t st[PF][LPL];
     auto issue = [&](chunk_t(&dst)[LPL], uint32_t i) {
@@ -331,10 +326,9 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
 // conversion, no staging registers, no LDS stores.  Row tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB
 // per wave-instruction, two tiles ahead in a ring of three 48-KiB images), the waves only read fragments and issue
 // MFMAs.
-//   LDS image of a tile: row-major, 64 rows x 48 16-B slots, no padding; slot p of row R holds k-group
-//   g = (p & ~15) | ((p & 15) ^ (R & 15)).  An LDS-DMA writes lane-linear bytes, so the permutation is applied to the
-//   per-lane SOURCE address (still one contiguous 768-B row per 48 lanes: fully coalesced); the A-operand read of
-//   k-group g over 32 rows then hits 16 different 16-B bank slots in every 16-lane group (conflict-free ds_read_b128).
+//   The shadow is stored tile by tile in MFMA-fragment order (ROW_F16S, kernels.hpp): the LDS image of a tile is a
+//   linear copy of its 48 KiB (an LDS-DMA writes lane-linear bytes; the source is one contiguous 1 KiB per
+//   instruction), and the A-operand read of fragment (sub, s) is 64 consecutive 16-B slots (conflict-free ds_read_b128).
 //   Per tile and wave: 6 DMA instructions, 48 ds_read_b128, 48 MFMAs, two threshold tests, ONE barrier
 //   (s_waitcnt vmcnt(6): the tile for the next iteration has landed, the one after stays in flight).
 // ------------------------------------------------------------------------------------------------
@@ -342,13 +336,17 @@ constexpr int DMA_TILE_BYTES = TILE_ROWS * EM * 2;  // 49152
 constexpr uint32_t DMA_STAGE_CAP = 1024;            // candidates staged per workgroup (12 KiB beside the 144-KiB ring)
 constexpr uint32_t DMA_STAGE_FLUSH_AT = 384;
 
-template <bool DENSE>
-__global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
+// NW waves per workgroup (one workgroup per CU): 8 (two per SIMD, 32 queries each) or 4 (one per SIMD, 64 queries each:
+// every A fragment read from LDS feeds two MFMAs, half the LDS traffic, no sharing of the matrix pipe)
+template <bool DENSE, int NW>
+__global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
                                                           uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                                                           const half8* __restrict__ qh, int n_q,
                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
                                                           uint2* __restrict__ cand, float* __restrict__ dense) {
-    constexpr int NT = 512, PD = 8;
+    constexpr int NT = NW * 64, PD = 8;
+    constexpr int QG = 8 / NW;     // 32-query groups per wave
+    constexpr int DPW = 48 / NW;   // DMA instructions per wave and tile
     // three SEPARATE LDS objects: the module-LDS lowering then tags their accesses with alias scopes and hipcc's
     // waitcnt insertion does not drain the in-flight LDS-DMA (vmcnt(0)) in front of reads of ANOTHER image
     __shared__ __attribute__((aligned(16))) unsigned char img0[DMA_TILE_BYTES];
@@ -373,29 +371,22 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t r = lane & 31, h = lane >> 5;
-    const int qi = wave * 32 + (int)r;
-    const bool wave_has_queries = wave * 32 < n_q;
+    const int q0 = wave * (32 * QG) + (int)r;  // this lane's queries: q0 + 32*g
+    const bool wave_has_queries = wave * (32 * QG) < n_q;
 
-    half8 qf[24];
+    half8 qf[QG][24];
+    float tau_s[QG];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) qf[s] = qh[(size_t)qi * 48 + 2 * s + h];
-    float tau_s = __builtin_inff();
-    if (!DENSE && qi < n_q) tau_s = tau[qi] * SCORE_SCALE;
-
-    // DMA map: instruction i of this wave fills LDS bytes [(6w+i)*1024, +1024) of the image: slot q = (6w+i)*64 + lane
-    // = row q/48, position q%48; the lane fetches the k-group that belongs there
-    uint32_t src_off[6];
+    for (int g = 0; g < QG; ++g) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const uint32_t q = (uint32_t)(6 * wave + i) * 64u + (uint32_t)lane;
-        const uint32_t R = q / 48u, p = q % 48u;
-        const uint32_t g = (p & ~15u) | ((p & 15u) ^ (R & 15u));
-        src_off[i] = R * 768u + g * 16u;
+        for (int s = 0; s < 24; ++s) qf[g][s] = qh[(size_t)(q0 + 32 * g) * 48 + 2 * s + h];
+        tau_s[g] = __builtin_inff();
+        if (!DENSE && q0 + 32 * g < n_q) tau_s[g] = tau[q0 + 32 * g] * SCORE_SCALE;
     }
-    // fragment map: k-step s = 8a + j reads k-group g = 2s + h of row sub*32 + r: slot (g & ~15) | ((g & 15) ^ (r & 15))
-    uint32_t xo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xo[j] = r * 768u + ((((2u * j + h) & 15u) ^ (r & 15u))) * 16u;
+
+    // DMA map: the shadow tile is stored in fragment order already (kernels.hpp, ROW_F16S), so the image is a linear
+    // copy: instruction i of this wave moves bytes [(DPW*w+i)*1024, +1024) of the tile, 16 B per lane
+    const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
 
     const uint32_t G = gridDim.x;
     const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
@@ -405,27 +396,27 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
     // The six per-lane source addresses of a tile are kept in registers of their own until the end of the iteration
     // (fake use below): hipcc otherwise recycles the address temporaries for the A ring / accumulator and then waits
     // for the whole DMA (vmcnt(0)) before the first MFMA overwrites them.
-    auto dma = [&](uint32_t t, unsigned char* img, const unsigned char* (&gp)[6]) {  // tile t -> LDS image
+    auto dma = [&](uint32_t t, unsigned char* img, const unsigned char* (&gp)[DPW]) {  // tile t -> LDS image
         const unsigned char* base = xs + (size_t)unit_row0(t) * (EM * 2);
-        unsigned char* dst = img + wave * 6144;
+        unsigned char* dst = img + wave * (DPW * 1024);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) gp[i] = base + src_off[i];
+        for (int i = 0; i < DPW; ++i) gp[i] = base + src_off0 + i * 1024;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < DPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[i],
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2 /* nt */);
     };
-    auto keep = [&](const unsigned char* (&gp)[6]) {
+    auto keep = [&](const unsigned char* (&gp)[DPW]) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(gp[i]));
+        for (int i = 0; i < DPW; ++i) asm volatile("" ::"v"(gp[i]));
     };
 
-    auto tail_slow = [&](const f32x16& acc, uint32_t row0) {
+    auto tail_slow = [&](const f32x16& acc, uint32_t row0, int qi, float tau_q) {
         uint32_t mask = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
-            mask |= (acc[e] > tau_s && row < n_rows) ? (1u << e) : 0u;
+            mask |= (acc[e] > tau_q && row < n_rows) ? (1u << e) : 0u;
         }
         if (mask) {
             uint32_t pos = atomicAdd(&stage_n[0], (uint32_t)__popc(mask));  // LDS atomic
@@ -454,13 +445,16 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
     // real use is the first MFMA inside the loop, and a wait placed there is re-executed every iteration as vmcnt(0),
     // i.e. it would also drain the row DMA that is meant to stay in flight.
 #pragma unroll
-    for (int s = 0; s < 24; ++s) asm volatile("" ::"v"(qf[s]));
-    asm volatile("" ::"v"(tau_s));
-    const unsigned char* gp0[6];
-    const unsigned char* gp1[6];
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) asm volatile("" ::"v"(qf[g][s]));
+        asm volatile("" ::"v"(tau_s[g]));
+    }
+    const unsigned char* gp0[DPW];
+    const unsigned char* gp1[DPW];
     dma(0, img0, gp0);
     dma(last < 1u ? last : 1u, img1, gp1);
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile 0 landed, everywhere
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");  // tile 0 landed
     keep(gp0);
     keep(gp1);
 
@@ -469,7 +463,7 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
     // through the barrier)
     auto step = [&](uint32_t rd_off, unsigned char* wr) -> bool {
         if (t >= n_units) return false;
-        const unsigned char* gp[6];
+        const unsigned char* gp[DPW];
         dma(t + 2 < n_units ? t + 2 : last, wr, gp);
         if (wave_has_queries) {
 #pragma unroll
@@ -477,15 +471,13 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
                 // A fragments by inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains every in-flight
                 // LDS-DMA (s_waitcnt vmcnt(0)) in front of any LDS read it can see, which would serialise the row stream
                 // behind each contraction.  Ring of PD reads; before MFMA s at most PD-1 younger reads are outstanding.
-                const uint32_t sbase = rd_off + (uint32_t)sub * (32u * 768u);
-                uint32_t ad[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ad[j] = sbase + xo[j];
+                // fragment (sub, s) = bytes [(sub*24+s)*1024, +1024) of the image, lane-linear: conflict-free reads
+                const uint32_t ad = rd_off + (uint32_t)lane * 16u;
                 half8 a[PD];
 #pragma unroll
                 for (int d = 0; d < PD; ++d)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[d]) : "v"(ad[d & 7]), "n"((d >> 3) * 256));
-                f32x16 acc;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[d]) : "v"(ad), "n"((sub * 24 + d) * 1024));
+                f32x16 acc[QG];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 24; ++s) {
@@ -494,39 +486,46 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
                     if (s + PD <= 24) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));
                     else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(0));
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s == 0) {
-                        f32x16 z;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0], z, 0, 0, 0);
-                    } else {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[s], acc, 0, 0, 0);
+                    for (int g = 0; g < QG; ++g) {
+                        if (s == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[g][0], z, 0, 0, 0);
+                        } else {
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[g][s], acc[g], 0, 0, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (s + PD < 24)
                         asm volatile("ds_read_b128 %0, %1 offset:%2"
                                      : "=v"(a[s % PD])
-                                     : "v"(ad[(s + PD) & 7]), "n"(((s + PD) >> 3) * 256));
+                                     : "v"(ad), "n"((sub * 24 + s + PD) * 1024));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const uint32_t row0 = unit_row0(t) + sub * 32 + 4 * h;
-                if (DENSE) {
-                    if (qi < n_q) {
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) {
-                            f32x4 o;
+                for (int g = 0; g < QG; ++g) {
+                    const int qi = q0 + 32 * g;
+                    if (DENSE) {
+                        if (qi < n_q) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                o[e] = (row0 + e + 8 * e4) < n_rows ? acc[e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
-                            *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + unit_slot0(t) + sub * 32 + 4 * h +
-                                                      8 * e4) = o;
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                f32x4 o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    o[e] = (row0 + e + 8 * e4) < n_rows ? acc[g][e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                                *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + unit_slot0(t) + sub * 32 +
+                                                          4 * h + 8 * e4) = o;
+                            }
                         }
-                    }
-                } else {
-                    float mx = acc[0];
+                    } else {
+                        float mx = acc[g][0];
 #pragma unroll
-                    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
-                    if (__any(mx > tau_s)) tail_slow(acc, row0);
+                        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[g][e]);
+                        if (__any(mx > tau_s[g])) tail_slow(acc[g], row0, qi, tau_s[g]);
+                    }
                 }
             }
         }
@@ -536,12 +535,12 @@ __global__ __launch_bounds__(512) void scan_f16_dma_kernel(const unsigned char* 
         uint32_t fill = 0;
         if (!DENSE) {
             const uint32_t sn = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage_n;
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+            asm volatile("s_waitcnt vmcnt(%2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                          : "=v"(fill)
-                         : "v"(sn)
+                         : "v"(sn), "n"(DPW)
                          : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
         }
         if (!DENSE && __builtin_amdgcn_readfirstlane(fill) >= DMA_STAGE_FLUSH_AT) {
             flush();
@@ -642,6 +641,8 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
+    __shared__ uint32_t sh_rows[LIST];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rescore_stage[];  // RescoreStage<RT>::BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     uint32_t p;
     block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, count, s, p, sh_s, sh_p, wave,
                        lane, 16);
+    const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
     if (wave != 0) return;
 
     float m = read_lane63(s);  // -inf when fewer than 64 candidates
@@ -661,10 +663,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     }
     const bool valid = p != NO_POS;
     float d = POS_INF;
-    if (valid) {
-        const float dot = exact_dot_row<RT>(q + (size_t)b * EM, x, p);
-        d = __fsub_rn(1.0f, dot);  // vector.rs:133
-    }
+    if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133
     sort64_asc(d, p, lane);
 
     const uint32_t found = n_rows < k ? n_rows : k;
@@ -752,14 +751,6 @@ static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uin
 template <bool DENSE, int RT>
 static void launch_pass_rt(const void* d_rows, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
-    const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-    if (RT == 2 && g_batched_sched != 0 && g_batched_sched != 2) {  // f16 shadow rows: LDS-DMA kernel
-        hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE>), dim3(blocks), dim3(512), 0, stream,
-                           reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
-                           reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
-                           reinterpret_cast<float*>(ws.cand));
-        return;
-    }
     if (g_batched_sched == 2 && !DENSE)  // lockstep kernel with diagnostic stamps (full append pass only)
         launch_pass_nw<false, 8, RT, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else
@@ -771,8 +762,19 @@ template <bool DENSE>
 static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                         const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     if (n_tiles == 0) return;
-    if (rt == ROW_F16S) launch_pass_rt<DENSE, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-    else if (rt == ROW_BF16) launch_pass_rt<DENSE, 1>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    if (rt == ROW_F16S) {  // f16 shadow tiles: LDS-DMA kernel
+        const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
+        if (g_batched_sched == 4)
+            hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 4>), dim3(blocks), dim3(256), 0, stream,
+                               reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
+                               reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
+                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+        else
+            hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8>), dim3(blocks), dim3(512), 0, stream,
+                               reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
+                               reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
+                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+    } else if (rt == ROW_BF16) launch_pass_rt<DENSE, 1>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else launch_pass_rt<DENSE, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
@@ -792,30 +794,47 @@ int batched_init() {
     if (g_lds_attr_set) return 0;
     hipError_t e = set_lds_attr_rt<0>();
     if (e == hipSuccess) e = set_lds_attr_rt<1>();
-    if (e == hipSuccess) e = set_lds_attr_rt<2>();
+    const void* tails[] = {reinterpret_cast<const void*>(select_rescore_kernel<true, 0>),
+                           reinterpret_cast<const void*>(select_rescore_kernel<false, 0>),
+                           reinterpret_cast<const void*>(select_rescore_kernel<true, 1>),
+                           reinterpret_cast<const void*>(select_rescore_kernel<false, 1>)};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(tails[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                i < 2 ? RescoreStage<0>::BYTES : RescoreStage<1>::BYTES);
     if (e != hipSuccess) return (int)e;
     g_lds_attr_set = true;
     return 0;
 }
 
-// f32 rows -> scaled f16 rows (the filter's shadow copy): value * 2^8, round to nearest even
-__global__ void rows_f32_to_f16s_kernel(const f32x4* __restrict__ in, half8* __restrict__ out, size_t n_chunks8) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
-        const half4 lo = to_half4_scaled(in[2 * i]), hi = to_half4_scaled(in[2 * i + 1]);
-        half8 o;
-        o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
-        o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
-        out[i] = o;
+// f32 rows -> the filter's shadow copy (ROW_F16S, kernels.hpp): value * 2^8 rounded to nearest even, stored tile by
+// tile (64 rows, 48 KiB) in MFMA-fragment order.  One workgroup per tile: coalesced f32 reads, fragment-order
+// image assembled in LDS, linear coalesced write.  Rows >= n_valid of the last tile are written as zeros.
+__global__ __launch_bounds__(256) void rows_f32_to_f16s_kernel(const f32x4* __restrict__ x, half8* __restrict__ shadow,
+                                                              uint32_t first_tile, uint32_t n_valid) {
+    __shared__ __attribute__((aligned(16))) half4 img[TILE_ROWS * ROW_F4];  // 48 KiB, half4 units
+    const uint32_t tile = first_tile + blockIdx.x;
+    const f32x4* src = x + (size_t)tile * (TILE_ROWS * ROW_F4);
+    for (uint32_t c = threadIdx.x; c < TILE_ROWS * ROW_F4; c += 256) {
+        const uint32_t row = c / ROW_F4, c4 = c % ROW_F4;  // f32x4 chunk c4 of tile row `row`: k = 4*c4..4*c4+3
+        half4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (tile * TILE_ROWS + row < n_valid) v = to_half4_scaled(src[c]);
+        const uint32_t g = c4 >> 1;  // k-group (8 values) -> fragment (sub, s = g/2), lane (h = g&1, r)
+        const uint32_t slot = ((row >> 5) * 24u + (g >> 1)) * 64u + (g & 1u) * 32u + (row & 31u);
+        img[slot * 2u + (c4 & 1u)] = v;
     }
+    __syncthreads();
+    const half8* im8 = reinterpret_cast<const half8*>(img);
+    half8* dst = shadow + (size_t)tile * (TILE_ROWS * ROW_C8);
+    for (uint32_t c = threadIdx.x; c < TILE_ROWS * ROW_C8; c += 256) dst[c] = im8[c];
 }
 
-void launch_rows_f32_to_f16s(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream) {
-    if (n_rows == 0) return;
-    const size_t n = n_rows * ROW_C8;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(rows_f32_to_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<half8*>(d_out), n);
+// Converts the tiles that hold rows [first_row, n_valid) of the f32 rows d_rows (row 0 = index row 0; the capacity
+// is padded to whole tiles) into d_shadow; rows below first_row in the first tile are converted again (same values).
+void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_row, size_t n_valid, hipStream_t stream) {
+    if (n_valid <= first_row) return;
+    const uint32_t t0 = (uint32_t)(first_row / TILE_ROWS), t1 = (uint32_t)((n_valid + TILE_ROWS - 1) / TILE_ROWS);
+    hipLaunchKernelGGL(rows_f32_to_f16s_kernel, dim3(t1 - t0), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(d_rows),
+                       reinterpret_cast<half8*>(d_shadow), t0, (uint32_t)n_valid);
 }
 
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream) {
@@ -840,11 +859,13 @@ static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_
     // the bf16-rounded rows may exceed the is_normalized band by 2^-8: scale the bound on sum|q_i x_i| accordingly
     const float eps = dtype == ROW_BF16 ? FILTER_EPS_F16 * 1.004f : FILTER_EPS_F16;
     if (dtype == ROW_BF16)
-        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q,
-                           dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x,
+                           d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
+                           force_fallback, eps);
     else
-        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 0>), dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q,
-                           dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+        hipLaunchKernelGGL((select_rescore_kernel<DENSE, 0>), dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x,
+                           d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
+                           force_fallback, eps);
 }
 
 // d_x/dtype: the index rows (exact rescore); d_frows/frt: the filter's row source (the same rows, or the scaled f16

@@ -219,33 +219,27 @@ __global__ __launch_bounds__(1024) void scan_filter_bf16_kernel(const u32x4* __r
     }
 }
 
-// f16 SHADOW rows of an f32 index (ROW_F16S: f16(2^8 x), 768 B per row; dawn_index.cpp): the same quad-row stream as
-// the bf16 kernel, scored with v_dot2_f32_f16 (two exact f16 products + f32 accumulate per instruction) against the
-// query rounded the same way — the f16 FILTER of the matrix-core path (error bound FILTER_EPS_F16) for 1..8
-// queries.  Half the bytes of the f32 rows; exactness comes from the rescore tail on the f32 rows.
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// f16 SHADOW of an f32 index (ROW_F16S, kernels.hpp: f16(2^8 x), 768 B per row, tiles in MFMA-fragment order) — the
+// streaming filter for 1..8 queries.  A wave-wide 16-B load of a 1-KiB fragment IS the A operand of
+// v_mfma_f32_32x32x16_f16 (32 rows x 16 k), so the rows go HBM -> VGPR -> matrix core with no LDS, no cross-lane
+// reduction and almost no VALU work: the queries sit in the B operand's first columns (96 VGPRs for the whole kernel,
+// zero columns beyond B), and after 24 k-steps lane (h, c) holds the scores of query c against 16 rows of the
+// 32-row sub-tile.  One compare against the lane's threshold (the 64th best score of query c in this wave so far)
+// decides whether the slow path runs: ballot, read the hit, insert it into the wave's sorted 64-entry list.
+// Loads run PD fragments (PD KiB per wave) ahead of the MFMAs in a register ring that continues across sub-tiles.
+// Half the bytes of the f32 rows; exactness comes from the rescore tail on the f32 rows (error bound FILTER_EPS_F16).
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
-
-// (the chunk words are copied to scalars first: __builtin_bit_cast applied directly to an ext-vector element `w.x`
-// of a reference made hipcc 7.2 use element 0 for all four words)
-__device__ __forceinline__ float dot8_f16(const u32x4& w, const u32x4& q) {
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    float acc = __builtin_amdgcn_fdot2(as_half2(w0), as_half2(q0), 0.f, false);
-    acc = __builtin_amdgcn_fdot2(as_half2(w1), as_half2(q1), acc, false);
-    acc = __builtin_amdgcn_fdot2(as_half2(w2), as_half2(q2), acc, false);
-    acc = __builtin_amdgcn_fdot2(as_half2(w3), as_half2(q3), acc, false);
-    return acc;
-}
-
-// qh: scaled f16 queries [.][384] (prep_queries_kernel of scan_batched.hip)
-template <int QB, int U>
-__global__ __launch_bounds__(1024) void scan_filter_f16s_kernel(const u32x4* __restrict__ x, uint32_t n_rows,
-                                                                const u32x4* __restrict__ qh,
+// q: the n_q <= QB queries, f32 [n_q][384]; scaled by 2^8 and rounded to f16 here exactly as prep_queries_kernel
+// (scan_batched.hip) does for the matrix-core path
+template <int QB, int PD, bool BURST>
+__global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __restrict__ x, uint32_t n_rows,
+                                                                const float* __restrict__ q, int n_q,
                                                                 float* __restrict__ out_s,
                                                                 uint32_t* __restrict__ out_p,
                                                                 uint32_t q_stride_lists) {
+    static_assert(24 % PD == 0, "the ring must divide the 24 k-steps of a sub-tile");
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     const int lane = threadIdx.x & 63;
@@ -253,112 +247,170 @@ __global__ __launch_bounds__(1024) void scan_filter_f16s_kernel(const u32x4* __r
     const int nwaves = blockDim.x >> 6;
     const uint32_t gwave = blockIdx.x * nwaves + wave;
     const uint32_t total_waves = gridDim.x * nwaves;
-    const uint32_t n_quads = (n_rows + 3u) >> 2;
-    const uint32_t n_chunks = (n_quads + U - 1) / U;
-    const int c0 = lane < 48 ? lane : lane - 48;
-    const int c1 = lane < 32 ? 16 + lane : lane - 32;
-    const int c2 = lane < 16 ? 32 + lane : lane - 16;
-    u32x4 qf[QB][3];
+    const uint32_t n_sub = (n_rows + 31u) >> 5;  // 32-row sub-tiles = 24 fragments = 24 KiB each
+    const uint32_t c = lane & 31, h = lane >> 5;
+
+    // B operand: column c = query c (zero beyond n_q), lane (h, c) holds k = 16s + 8h .. +7 of k-step s
+    half8_t qf[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)0.0f;
+    }
+    if ((int)c < n_q) {
+        const f32x4* qc = reinterpret_cast<const f32x4*>(q + (size_t)c * EM);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            const f32x4 lo = qc[4 * s + 2 * h], hi = qc[4 * s + 2 * h + 1];
+            qf[s][0] = (_Float16)(lo.x * 256.0f);
+            qf[s][1] = (_Float16)(lo.y * 256.0f);
+            qf[s][2] = (_Float16)(lo.z * 256.0f);
+            qf[s][3] = (_Float16)(lo.w * 256.0f);
+            qf[s][4] = (_Float16)(hi.x * 256.0f);
+            qf[s][5] = (_Float16)(hi.y * 256.0f);
+            qf[s][6] = (_Float16)(hi.z * 256.0f);
+            qf[s][7] = (_Float16)(hi.w * 256.0f);
+        }
+    }
     float ls[QB], tau[QB];
     uint32_t lp[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        qf[b][0] = qh[b * ROW_C8 + c0];
-        qf[b][1] = qh[b * ROW_C8 + c1];
-        qf[b][2] = qh[b * ROW_C8 + c2];
         ls[b] = NEG_INF;
         lp[b] = NO_POS;
         tau[b] = NEG_INF;
     }
-    const bool a48 = lane < 48, a32 = lane < 32, a16 = lane < 16;
     const float unscale = 1.0f / 65536.0f;
+    // the lane's threshold in the units of the accumulator (scores x 2^16); +inf in the padding columns
+    float tau_l = (int)c < n_q ? NEG_INF : __builtin_inff();
 
-    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
-        const u32x4* p = x + (size_t)c * (U * 192) + lane;
-        u32x4 v[U][3];
+    uint32_t t = gwave;
+    if (t < n_sub) {
+        const half8_t* p = x + (size_t)t * (24 * 64) + lane;
+        half8_t a[PD];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v[u][0] = __builtin_nontemporal_load(p + u * 192);
-            v[u][1] = __builtin_nontemporal_load(p + u * 192 + 64);
-            v[u][2] = __builtin_nontemporal_load(p + u * 192 + 128);
-        }
+        for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+        for (;;) {
+            const uint32_t tn = t + total_waves;
+            // the ring runs into the wave's next sub-tile (the last one re-reads its own first fragments: no branch)
+            const half8_t* pn = tn < n_sub ? x + (size_t)tn * (24 * 64) + lane : p;
+            f32x16_t acc;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t r0 = (c * U + u) * 4u;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            if (BURST) {
+                // PD fragments (PD KiB, contiguous) requested back to back, consumed as they arrive, then the next PD
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                const float d0 = dot8_f16(v[u][0], qf[b][0]);
-                const float d1 = dot8_f16(v[u][1], qf[b][1]);
-                const float d2 = dot8_f16(v[u][2], qf[b][2]);
-                float sc[4];
-                sc[0] = read_lane63(wave_sum_lane63(a48 ? d0 : 0.f));
-                sc[1] = read_lane63(wave_sum_lane63((a48 ? 0.f : d0) + (a32 ? d1 : 0.f)));
-                sc[2] = read_lane63(wave_sum_lane63((a32 ? 0.f : d1) + (a16 ? d2 : 0.f)));
-                sc[3] = read_lane63(wave_sum_lane63(a16 ? 0.f : d2));
+                for (int s0 = 0; s0 < 24; s0 += PD) {
+                    if (s0 > 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t r = r0 + j;
-                    const float sj = (r < n_rows && sc[j] == sc[j]) ? sc[j] * unscale : NEG_INF;
-                    if (sj > tau[b]) {
-                        wave_insert(ls[b], lp[b], sj, r, lane);
-                        tau[b] = read_lane63(ls[b]);
+                        for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + (s0 + d) * 64);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int d = 0; d < PD; ++d)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[d], qf[s0 + d], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(pn + d * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 24; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[s], acc, 0, 0, 0);
+                    if (s + PD < 24) a[s % PD] = __builtin_nontemporal_load(p + (s + PD) * 64);
+                    else a[s % PD] = __builtin_nontemporal_load(pn + (s + PD - 24) * 64);
+                    __builtin_amdgcn_sched_barrier(0);  // keep every load PD steps ahead of its use
                 }
             }
+            // this lane: D[row = 32t + (e&3) + 8*(e>>2) + 4h][query c]
+            float mx = acc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+            if (__any(mx > tau_l)) {
+                const uint32_t row_base = t * 32u;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+                    // (copied to a scalar first: __builtin_bit_cast straight on the vector element acc[e] makes
+                    // hipcc 7.2 read element 0 — the same miscompile as in dot8 of the bf16 kernel's sibling)
+                    const float ae = acc[e];
+                    // rows past the end (zero padding) and non-finite garbage never enter a list
+                    unsigned long long m = __ballot(ae > tau_l && row_base + roff + 4u * h < n_rows);
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float sc = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ae), l)) * unscale;
+                        const int qb = l & 31;
+                        const uint32_t row = row_base + roff + 4u * (uint32_t)(l >> 5);
+#pragma unroll
+                        for (int b = 0; b < QB; ++b) {
+                            if (b == qb && sc > tau[b]) {
+                                wave_insert(ls[b], lp[b], sc, row, lane);
+                                tau[b] = read_lane63(ls[b]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+                    if ((int)c == b && b < n_q) tau_l = tau[b] * 65536.0f;
+            }
+            if (tn >= n_sub) break;
+            t = tn;
+            p = pn;
         }
     }
+
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
-        if (wave == 0) {
-            const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
-            out_s[o] = ls[b];
-            out_p[o] = lp[b];
+        if (b < n_q) {  // uniform
+            block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+            if (wave == 0) {
+                const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
+                out_s[o] = ls[b];
+                out_p[o] = lp[b];
+            }
         }
     }
 }
 
 template <int QB>
-static void launch_filter_f16s_qb(const void* d_shadow, uint32_t n_rows, const void* d_qh, float* cand_s, uint32_t* cand_p,
-                                  const ScanGeom& g, hipStream_t stream) {
-    const u32x4* x4 = reinterpret_cast<const u32x4*>(d_shadow);
-    const u32x4* q4 = reinterpret_cast<const u32x4*>(d_qh);
-    if (g.unroll <= 1)
-        hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, 1>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
-                           cand_s, cand_p, (uint32_t)g.blocks);
-    else if (g.unroll == 3 && QB == 1)
-        hipLaunchKernelGGL((scan_filter_f16s_kernel<1, 3>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
-                           cand_s, cand_p, (uint32_t)g.blocks);
-    else if (g.unroll >= 4 && QB == 1)
-        hipLaunchKernelGGL((scan_filter_f16s_kernel<1, 4>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
-                           cand_s, cand_p, (uint32_t)g.blocks);
-    else
-        hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, 2>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, q4,
-                           cand_s, cand_p, (uint32_t)g.blocks);
+static void launch_filter_f16s_qb(const void* d_shadow, uint32_t n_rows, const float* q8, int n_q, float* cand_s,
+                                  uint32_t* cand_p, const ScanGeom& g, hipStream_t stream) {
+    const half8_t* x8 = reinterpret_cast<const half8_t*>(d_shadow);
+    // geom.unroll picks the load schedule: 1..4 -> ring of 6 / 8 / 12 / 24 fragments running ahead of the MFMAs;
+    // 11..14 -> bursts of 6 / 8 / 12 / 24 fragments (KiB per wave) requested back to back
+#define DAWN_F16S_LAUNCH(PD_, BURST_)                                                                              \
+    hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, PD_, BURST_>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, \
+                       n_rows, q8, n_q, cand_s, cand_p, (uint32_t)g.blocks)
+    switch (g.unroll) {
+        case 1: DAWN_F16S_LAUNCH(6, false); break;
+        case 2: DAWN_F16S_LAUNCH(8, false); break;
+        case 4: DAWN_F16S_LAUNCH(24, false); break;
+        case 11: DAWN_F16S_LAUNCH(6, true); break;
+        case 12: DAWN_F16S_LAUNCH(8, true); break;
+        case 13: DAWN_F16S_LAUNCH(12, true); break;
+        case 14: DAWN_F16S_LAUNCH(24, true); break;
+        default: DAWN_F16S_LAUNCH(12, false); break;
+    }
+#undef DAWN_F16S_LAUNCH
 }
 
-// Streaming filter over the f16 shadow rows for B = 1..8 queries; d_qh = their scaled f16 images [B][384].
-void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const void* d_qh, int B, float* cand_s,
+// Streaming filter over the f16 shadow, 8 queries per pass; d_q = the f32 queries [B][384].
+void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                              uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, stream);
-    int b = 0;
     const size_t per_q = (size_t)g.blocks * LIST;
-    const unsigned char* qh = reinterpret_cast<const unsigned char*>(d_qh);
-    while (b < B) {
-        const int rem = B - b;
-        const void* q = qh + (size_t)b * EM * 2;
+    for (int b = 0; b < B; b += 8) {  // 8 queries per pass over the index
+        const int nb = B - b < 8 ? B - b : 8;
+        const float* q = d_q + (size_t)b * EM;
         float* cs = cand_s + (size_t)b * per_q;
         uint32_t* cp = cand_p + (size_t)b * per_q;
-        if (rem >= 4) {
-            launch_filter_f16s_qb<4>(d_shadow, n_rows, q, cs, cp, g, stream);
-            b += 4;
-        } else if (rem >= 2) {
-            launch_filter_f16s_qb<2>(d_shadow, n_rows, q, cs, cp, g, stream);
-            b += 2;
-        } else {
-            launch_filter_f16s_qb<1>(d_shadow, n_rows, q, cs, cp, g, stream);
-            b += 1;
-        }
+        if (nb <= 1) launch_filter_f16s_qb<1>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+        else if (nb <= 4) launch_filter_f16s_qb<4>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+        else launch_filter_f16s_qb<8>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
 }
@@ -430,6 +482,8 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
+    __shared__ uint32_t sh_rows[LIST];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rescore_stage[];  // RescoreStage<RT>::BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -439,23 +493,28 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     uint32_t p = NO_POS;
     const float* cs = cand_s + (size_t)b * n_lists * LIST;
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
-    for (int l = wave; l < n_lists; l += nwaves) {
-        const float os = cs[(size_t)l * LIST + 63 - lane];
-        const uint32_t op = cp[(size_t)l * LIST + 63 - lane];
-        merge64(s, p, os, op, lane);
+    for (int l0 = wave; l0 < n_lists; l0 += 4 * nwaves) {  // four lists in flight per wave
+        float os[4];
+        uint32_t op[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + j * nwaves;
+            os[j] = l < n_lists ? cs[(size_t)l * LIST + 63 - lane] : NEG_INF;
+            op[j] = l < n_lists ? cp[(size_t)l * LIST + 63 - lane] : NO_POS;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) merge64(s, p, os[j], op[j], lane);
     }
     block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+    // shortlist (wave 0): 64 best rows by filter score; every wave helps to fetch them for the exact rescore
+    const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
     if (wave != 0) return;
 
-    // shortlist: 64 best rows by filter score.  m (the worst score that made it) bounds the filter score of
-    // every row NOT in it.
+    // m (the worst score that made it) bounds the filter score of every row NOT in the shortlist.
     const float m = read_lane63(s);
     const bool valid = p != NO_POS;
     float d = POS_INF;
-    if (valid) {
-        const float dot = exact_dot_row<RT>(q + (size_t)b * EM, x, p);
-        d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
-    }
+    if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
     sort64_asc(d, p, lane);
 
     const uint32_t found = n_rows < k ? n_rows : k;
@@ -485,12 +544,20 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
                           hipStream_t stream) {
+    static bool attr_set = false;  // the f32 stage (97 KiB) is above the default dynamic-LDS limit
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<0>::BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<1>::BYTES);
+        attr_set = true;
+    }
     if (dtype == ROW_BF16)
-        hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q, cand_s,
-                           cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+        hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x, d_ids, n_rows,
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
     else
-        hipLaunchKernelGGL(merge_rescore_kernel<0>, dim3(B), dim3(1024), 0, stream, d_x, d_ids, n_rows, d_q, cand_s,
-                           cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+        hipLaunchKernelGGL(merge_rescore_kernel<0>, dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x, d_ids, n_rows,
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,49 +565,52 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
 // ------------------------------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, uint32_t n_rows,
-                                                        const float* __restrict__ q,
+                                                        const float* __restrict__ q, int n_q,
                                                         const uint32_t* __restrict__ flags,
                                                         float* __restrict__ out_s, uint32_t* __restrict__ out_p,
                                                         uint32_t n_lists) {
     __shared__ float sh_s[4][LIST];
     __shared__ uint32_t sh_p[4][LIST];
-    const int b = blockIdx.y;
-    if (flags[b] != FLAG_FALLBACK) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const uint32_t gwave = blockIdx.x * nwaves + wave;
     const uint32_t total_waves = gridDim.x * nwaves;
-    const float* qv = q + (size_t)b * EM;
+    // grid.y <= 16 query slots: the common launch (no flag set) costs a few thousand workgroups less than one per query
+    for (int b = blockIdx.y; b < n_q; b += gridDim.y) {
+        if (flags[b] != FLAG_FALLBACK) continue;  // block-uniform
+        const float* qv = q + (size_t)b * EM;
 
-    float ls = NEG_INF, tau = NEG_INF;
-    uint32_t lp = NO_POS;
-    const uint32_t n_groups = (n_rows + 63u) >> 6;
-    for (uint32_t g = gwave; g < n_groups; g += total_waves) {
-        const uint32_t r = g * 64u + lane;
-        float key = NEG_INF;
-        if (r < n_rows) {
-            const float dot = exact_dot_row<RT>(qv, x, r);
-            const float d = __fsub_rn(1.0f, dot);
-            key = (d == d) ? -d : NEG_INF;
-        }
-        // rows of this group arrive in ascending row order; insert the lanes that beat the threshold
-        unsigned long long hits = __ballot(key > tau);
-        while (hits) {
-            const int src = __builtin_ctzll(hits);
-            hits &= hits - 1;
-            const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
-            if (ks > tau) {
-                wave_insert(ls, lp, ks, g * 64u + (uint32_t)src, lane);
-                tau = read_lane63(ls);
+        float ls = NEG_INF, tau = NEG_INF;
+        uint32_t lp = NO_POS;
+        const uint32_t n_groups = (n_rows + 63u) >> 6;
+        for (uint32_t g = gwave; g < n_groups; g += total_waves) {
+            const uint32_t r = g * 64u + lane;
+            float key = NEG_INF;
+            if (r < n_rows) {
+                const float dot = exact_dot_row<RT>(qv, x, r);
+                const float d = __fsub_rn(1.0f, dot);
+                key = (d == d) ? -d : NEG_INF;
+            }
+            // rows of this group arrive in ascending row order; insert the lanes that beat the threshold
+            unsigned long long hits = __ballot(key > tau);
+            while (hits) {
+                const int src = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
+                if (ks > tau) {
+                    wave_insert(ls, lp, ks, g * 64u + (uint32_t)src, lane);
+                    tau = read_lane63(ls);
+                }
             }
         }
-    }
-    block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
-    if (wave == 0) {
-        const size_t o = ((size_t)b * n_lists + blockIdx.x) * LIST + lane;
-        out_s[o] = ls;
-        out_p[o] = lp;
+        block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
+        if (wave == 0) {
+            const size_t o = ((size_t)b * n_lists + blockIdx.x) * LIST + lane;
+            out_s[o] = ls;
+            out_p[o] = lp;
+        }
+        __syncthreads();  // sh_s / sh_p are reused by the next query
     }
 }
 
@@ -577,12 +647,13 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
 
 void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
                        float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream) {
+    const dim3 grid(n_lists, B < 16 ? B : 16);
     if (dtype == ROW_BF16)
-        hipLaunchKernelGGL(scan_exact_kernel<1>, dim3(n_lists, B), dim3(256), 0, stream, d_x, n_rows, d_q, d_flags,
-                           cand_s, cand_p, (uint32_t)n_lists);
+        hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, n_rows, d_q, B, d_flags, cand_s, cand_p,
+                           (uint32_t)n_lists);
     else
-        hipLaunchKernelGGL(scan_exact_kernel<0>, dim3(n_lists, B), dim3(256), 0, stream, d_x, n_rows, d_q, d_flags,
-                           cand_s, cand_p, (uint32_t)n_lists);
+        hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, n_rows, d_q, B, d_flags, cand_s, cand_p,
+                           (uint32_t)n_lists);
 }
 
 void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags, const float* cand_s,

@@ -38,6 +38,38 @@ __device__ __forceinline__ float read_lane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Lane i <- lane i ^ STRIDE without the LDS crossbar (ds_bpermute costs ~100+ cycles of latency per dependent
+// step; the bitonic networks below are chains of them): quad_perm / row_shl+row_shr / row_ror DPP inside a 16-lane
+// row, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+    const int iv = (int)v;
+    if (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    if (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    if (STRIDE == 4) {
+        const int up = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xf, 0xf, false);  // row_shl:4: lane i <- i + 4
+        const int dn = __builtin_amdgcn_update_dpp(iv, iv, 0x114, 0xf, 0xf, false);  // row_shr:4: lane i <- i - 4
+        return (uint32_t)((lane & 4) ? dn : up);
+    }
+    if (STRIDE == 8) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false);  // row_ror:8
+    if (STRIDE == 16) {
+        // rows (r0 r1 r2 r3) x2 -> [0] = (r0 r0 r2 r2), [1] = (r1 r1 r3 r3)
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    // halves (lo hi) x2 -> [0] = (lo lo), [1] = (hi hi)
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+template <int STRIDE>
+__device__ __forceinline__ float lane_xor_f32(float v, int lane) {
+    return __builtin_bit_cast(float, lane_xor_u32<STRIDE>(__builtin_bit_cast(uint32_t, v), lane));
+}
+// lane i <- lane i - 1 (lane 0 keeps its own value): DPP wave_shr:1
+__device__ __forceinline__ uint32_t lane_up1_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 // (score desc, row asc) strict order; fillers are (-inf, NO_POS).
 __device__ __forceinline__ bool better(float s, uint32_t p, float s2, uint32_t p2) {
     return s > s2 || (s == s2 && p < p2);
@@ -47,14 +79,26 @@ __device__ __forceinline__ bool better(float s, uint32_t p, float s2, uint32_t p
 __device__ __forceinline__ void wave_insert(float& ls, uint32_t& lp, float s, uint32_t p, int lane) {
     const bool ahead = better(ls, lp, s, p);
     const int pos = __popcll(__ballot(ahead));
-    const float ps = __shfl_up(ls, 1);
-    const uint32_t pp = __shfl_up(lp, 1);
+    const float ps = __builtin_bit_cast(float, lane_up1_u32(__builtin_bit_cast(uint32_t, ls)));
+    const uint32_t pp = lane_up1_u32(lp);
     if (lane > pos) {
         ls = ps;
         lp = pp;
     } else if (lane == pos) {
         ls = s;
         lp = p;
+    }
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void merge64_stage(float& s, uint32_t& p, int lane) {
+    const float s2 = lane_xor_f32<STRIDE>(s, lane);
+    const uint32_t p2 = lane_xor_u32<STRIDE>(p, lane);
+    const bool lower = (lane & STRIDE) == 0;
+    const bool other_better = better(s2, p2, s, p);
+    if (lower == other_better) {
+        s = s2;
+        p = p2;
     }
 }
 
@@ -65,17 +109,12 @@ __device__ __forceinline__ void merge64(float& s, uint32_t& p, float os_rev, uin
         s = os_rev;
         p = op_rev;
     }
-#pragma unroll
-    for (int stride = 32; stride >= 1; stride >>= 1) {
-        const float s2 = __shfl_xor(s, stride);
-        const uint32_t p2 = __shfl_xor(p, stride);
-        const bool lower = (lane & stride) == 0;
-        const bool other_better = better(s2, p2, s, p);
-        if (lower == other_better) {
-            s = s2;
-            p = p2;
-        }
-    }
+    merge64_stage<32>(s, p, lane);
+    merge64_stage<16>(s, p, lane);
+    merge64_stage<8>(s, p, lane);
+    merge64_stage<4>(s, p, lane);
+    merge64_stage<2>(s, p, lane);
+    merge64_stage<1>(s, p, lane);
 }
 
 // Block-level tree merge of per-wave lists through LDS; result in wave 0.  nwaves is a power of two.
@@ -151,30 +190,83 @@ __device__ __forceinline__ float exact_dot_row(const float* __restrict__ qv, con
     return exact_dot_seq(qv, reinterpret_cast<const f32x4*>(x) + p * ROW_F4);
 }
 
+// Exact dots of ONE query with the 64 shortlisted rows held by wave 0 (row index p per lane, NO_POS = none), for a
+// whole workgroup: every wave copies its share of the rows into LDS with independent coalesced 16-B loads (all in
+// flight together — a lane walking its own row through HBM pays the memory latency 24 times over), then wave 0 runs
+// the reference-order sums out of LDS.  stage: RescoreStage<RT>::BYTES of LDS (row stride + 16 B: lanes of a
+// 16-lane group read different banks); sh_rows: 64 words; blockDim.x >= 384.  Returns the dot in wave 0 (0 for
+// NO_POS lanes).
+template <int RT>
+struct RescoreStage {
+    static constexpr int CH = RT == 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per row
+    static constexpr int STRIDE = CH * 16 + 16;
+    static constexpr int ROWS_BYTES = LIST * STRIDE;
+    static constexpr int BYTES = ROWS_BYTES + EM * 4;  // + the query
+};
+
+template <int RT>
+__device__ __forceinline__ float block_exact_dots(const float* __restrict__ qv, const void* __restrict__ x, uint32_t p,
+                                                  unsigned char* stage, uint32_t* sh_rows, int wave, int lane) {
+    typedef RescoreStage<RT> S;
+    float* sh_q = reinterpret_cast<float*>(stage + S::ROWS_BYTES);  // the query too: 96 dependent global reads otherwise
+    if (wave == 0) sh_rows[lane] = p;
+    if (threadIdx.x < EM) sh_q[threadIdx.x] = qv[threadIdx.x];
+    __syncthreads();
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x);
+    for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
+        const int r = i / S::CH, c = i % S::CH;
+        const uint32_t row = sh_rows[r];
+        if (row != NO_POS)
+            *reinterpret_cast<u32x4*>(stage + r * S::STRIDE + c * 16) = xr[(size_t)row * S::CH + c];
+    }
+    __syncthreads();
+    float dot = 0.0f;
+    if (wave == 0 && p != NO_POS) {
+        if (RT == 1) dot = exact_dot_seq_bf16(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
+        else dot = exact_dot_seq(sh_q, reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
+    }
+    return dot;
+}
+
 // (distance asc, row asc)
 __device__ __forceinline__ bool less_dp(float d, uint32_t p, float d2, uint32_t p2) {
     return d < d2 || (d == d2 && p < p2);
 }
 
+template <int K2, int J>
+__device__ __forceinline__ void sort64_stage(float& d, uint32_t& p, int lane) {
+    const float d2 = lane_xor_f32<J>(d, lane);
+    const uint32_t p2 = lane_xor_u32<J>(p, lane);
+    const bool asc = (lane & K2) == 0;
+    const bool lower = (lane & J) == 0;
+    const bool keep_small = (lower == asc);
+    const bool other_less = less_dp(d2, p2, d, p);
+    const bool other_greater = less_dp(d, p, d2, p2);
+    if (keep_small ? other_less : other_greater) {
+        d = d2;
+        p = p2;
+    }
+}
+template <int K2, int J>
+struct Sort64Run {
+    static __device__ __forceinline__ void run(float& d, uint32_t& p, int lane) {
+        sort64_stage<K2, J>(d, p, lane);
+        Sort64Run<K2, J / 2>::run(d, p, lane);
+    }
+};
+template <int K2>
+struct Sort64Run<K2, 0> {
+    static __device__ __forceinline__ void run(float&, uint32_t&, int) {}
+};
+
 // Full bitonic sort of one (d, p) per lane, ascending.
 __device__ __forceinline__ void sort64_asc(float& d, uint32_t& p, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            const float d2 = __shfl_xor(d, j);
-            const uint32_t p2 = __shfl_xor(p, j);
-            const bool asc = (lane & k2) == 0;
-            const bool lower = (lane & j) == 0;
-            const bool keep_small = (lower == asc);
-            const bool other_less = less_dp(d2, p2, d, p);
-            const bool other_greater = less_dp(d, p, d2, p2);
-            if (keep_small ? other_less : other_greater) {
-                d = d2;
-                p = p2;
-            }
-        }
-    }
+    Sort64Run<2, 1>::run(d, p, lane);
+    Sort64Run<4, 2>::run(d, p, lane);
+    Sort64Run<8, 4>::run(d, p, lane);
+    Sort64Run<16, 8>::run(d, p, lane);
+    Sort64Run<32, 16>::run(d, p, lane);
+    Sort64Run<64, 32>::run(d, p, lane);
 }
 
 // smallest float >= t (t finite, double)

@@ -123,6 +123,15 @@ class VectorIndex:
         return tmp[:, :n.value]
 
 
+    def debug_stream_lists(self, query: np.ndarray, cap_blocks: int = 4096):
+        """Test hook: per-workgroup candidate lists of the batch-1 streaming filter -> (scores [blocks,64], rows)."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(EM_LEN)
+        sc = np.zeros((cap_blocks, 64), dtype=np.float32)
+        rows = np.zeros((cap_blocks, 64), dtype=np.uint32)
+        n = C.c_size_t(0)
+        check(lib.dawn_index_debug_stream_lists(self._h, _ptr(q), _ptr(sc), _ptr(rows), cap_blocks, C.byref(n)))
+        return sc[:n.value], rows[:n.value]
+
 def topk_merge_device(device: int, G: int, B: int, count: int, d_in_labels: int, d_in_dist: int, d_in_found: int,
                       d_labels: int, d_dist: int, d_found: int, stream: int = 0):
     check(lib.dawn_topk_merge_device(device, G, B, count, d_in_labels, d_in_dist, d_in_found, d_labels, d_dist,

@@ -306,6 +306,32 @@ def test_batched_filter_error_within_bound(dawn):
     assert np.abs(f.astype(np.float64) - exact).mean() < 5e-5
 
 
+@pytest.mark.parametrize("n", [127, 5000, 300_001])
+def test_stream_filter_lists_hold_the_top64(dawn, n):
+    """The batch-1 streaming filter (MFMA straight from the fragment-ordered f16 shadow) hands merge_rescore one
+    descending 64-entry list per workgroup: every listed score is within FILTER_EPS_F16 of the exact dot of ITS row,
+    no row is listed twice, and the union of the lists holds every row whose exact score clears the 64th best by
+    more than twice that bound (what the certificate relies on)."""
+    idx = _mk_index(dawn, n)
+    x = synth.unit_rows(1, 0, n)
+    for q in list(synth.unit_rows(2, 0, 2)) + [synth.planted_queries(1, [n // 2], 4)[0]]:
+        sc, rows = idx.debug_stream_lists(q)
+        valid = rows != 0xFFFFFFFF
+        assert np.all(np.isneginf(sc[~valid]))
+        got = rows[valid].astype(np.int64)
+        assert got.max() < n and len(np.unique(got)) == len(got)
+        exact = x.astype(np.float64) @ q.astype(np.float64)
+        assert np.abs(sc[valid].astype(np.float64) - exact[got]).max() < 1.25e-3 / 2
+        for b in range(len(sc)):  # descending inside a list, fillers last
+            nv = int(valid[b].sum())
+            assert np.all(valid[b][:nv]) and np.all(np.diff(sc[b][:nv]) <= 0)
+        order = np.argsort(-exact, kind="stable")
+        need = order[: min(64, n)]
+        if n > 64:
+            need = need[exact[need] > exact[order[63]] + 2 * 1.25e-3]
+        assert set(need.tolist()) <= set(got.tolist())
+
+
 def test_batched_duplicates_fall_back_and_stay_exact(dawn, oracle):
     base = synth.unit_rows(1, 0, 3000)
     rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])

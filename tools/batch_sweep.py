@@ -12,7 +12,7 @@ idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, 256)
 rb = 768 if dtype == "bf16" else 1536
 for B in Bs:
-    for waves, sched in ((8, 0), (8, 1)):
+    for waves, sched in ((8, 0), (8, 1), (4, 4)):
         idx.set_option("mfma_sched", sched)
         idx.search_batch(Q[:B], 10)
         idx.profile_enable(True)

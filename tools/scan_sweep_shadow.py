@@ -8,15 +8,15 @@ idx = dawn.VectorIndex(0)
 idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, 8)
 res = []
-for unroll in (2, 3, 4):
+for unroll in ([int(u) for u in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 2, 3, 12)):
     for threads in (128, 256, 512):
-        for blocks in (256, 512):
-            if blocks * threads > 256 * 512 or blocks * threads < 256 * 128:
+        for blocks in (256, 512, 1024):
+            if blocks * threads > 256 * 512 or blocks * threads < 256 * 128 or blocks > 512:
                 continue
             idx.set_option("shadow_scan_unroll", unroll); idx.set_option("shadow_scan_threads", threads); idx.set_option("shadow_scan_blocks", blocks)
             idx.search_batch(Q[:1], 10)
             idx.profile_enable(True)
-            for _ in range(6):
+            for _ in range(6 if rows > 10_000_000 else 50):
                 idx.search_batch(Q[:1], 10)
             n, ms = idx.profile_read()
             idx.profile_enable(False)
