@@ -46,8 +46,8 @@ struct dawn_index {
     // 80M rows: 7.02-7.07 TB/s; every schedule with 2-4 waves per CU lands within 1 % of it
     dawn::ScanGeom geom_h{256, 128, 3};
     // ... and below kShadowSmallRows rows (a few dozen sub-tiles per wave: start-up, tail and load balance count)
-    // two 4-wave blocks per CU: 1M rows 154 -> 128 us.  Setting any shadow_scan_* option pins geom_h for every size.
-    dawn::ScanGeom geom_h_small{512, 256, 3};
+    // one 8-wave block per CU: 1M rows 154 -> 130 us.  Setting any shadow_scan_* option pins geom_h for every size.
+    dawn::ScanGeom geom_h_small{256, 512, 3};
     bool geom_h_pinned = false;
     const dawn::ScanGeom& shadow_geom() const {
         return (!geom_h_pinned && size < kShadowSmallRows) ? geom_h_small : geom_h;
@@ -278,7 +278,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
     if (prop.multiProcessorCount > 0) {
         idx->geom_h.blocks = prop.multiProcessorCount;
-        idx->geom_h_small.blocks = 2 * prop.multiProcessorCount;
+        idx->geom_h_small.blocks = prop.multiProcessorCount;
     }
     if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);

@@ -493,17 +493,19 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     uint32_t p = NO_POS;
     const float* cs = cand_s + (size_t)b * n_lists * LIST;
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
-    for (int l0 = wave; l0 < n_lists; l0 += 4 * nwaves) {  // four lists in flight per wave
-        float os[4];
-        uint32_t op[4];
+    constexpr int INF = 16;  // lists in flight per wave: the usual 256 lists are ONE round of loads
+    for (int l0 = wave; l0 < n_lists; l0 += INF * nwaves) {
+        float os[INF];
+        uint32_t op[INF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < INF; ++j) {
             const int l = l0 + j * nwaves;
             os[j] = l < n_lists ? cs[(size_t)l * LIST + 63 - lane] : NEG_INF;
             op[j] = l < n_lists ? cp[(size_t)l * LIST + 63 - lane] : NO_POS;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) merge64(s, p, os[j], op[j], lane);
+        for (int j = 0; j < INF; ++j)
+            if (l0 + j * nwaves < n_lists) merge64(s, p, os[j], op[j], lane);  // wave-uniform
     }
     block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
     // shortlist (wave 0): 64 best rows by filter score; every wave helps to fetch them for the exact rescore
