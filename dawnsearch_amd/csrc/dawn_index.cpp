@@ -720,6 +720,27 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     return DAWN_OK;
 }
 
+// Timing hook: mean duration (ms) of the matrix-core full pass alone over `iters` launches for B queries, with the
+// thresholds of the last batched search (run one first) and the current mfma_sched variant; results are discarded.
+int dawn_index_debug_time_full_pass(dawn_index* idx, size_t B, int iters, double* mean_ms) {
+    if (!idx || !mean_ms || iters < 1) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
+    if (B == 0 || B > (size_t)dawn::BATCH_QT || !idx->bws.cand) return fail(DAWN_ERR_INVALID_ARG, "run a batched search first");
+    DAWN_TRY(set_device(idx));
+    int frt = idx->dtype;
+    const void* frows = filter_rows(idx, &frt, idx->stream);
+    hipEvent_t e0, e1;
+    DAWN_HIP_TRY(hipEventCreate(&e0));
+    DAWN_HIP_TRY(hipEventCreate(&e1));
+    dawn::launch_batched_full_pass(frows, frt, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters, idx->stream, e0, e1);
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    float ms = 0.f;
+    DAWN_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_ms = ms / iters;
+    return DAWN_OK;
+}
+
 // Diagnostic: per-wave phase cycle sums of the last batched full pass run with mfma_sched = 2: out [blocks][8][8].
 int dawn_index_debug_read_diag(dawn_index* idx, unsigned long long* out, size_t blocks) {
     if (!idx || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
@@ -777,7 +798,8 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
         return DAWN_OK;
     }
     if (n == "mfma_sched") {
-        if (value < 0 || value > 4 || value == 3) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 2 or 4");
+        if (value < 0 || value == 3 || (value > 5 && value < 41) || value > 55)
+            return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 2, 4 or 5 (41..55: timing experiments)");
         if (value == 2 && !dawn::g_batched_diag) {
             DAWN_HIP_TRY(hipMalloc((void**)&dawn::g_batched_diag, 4096 * 8 * 8 * sizeof(unsigned long long)));
             DAWN_HIP_TRY(hipMemset(dawn::g_batched_diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));

@@ -77,7 +77,11 @@ BatchPlan plan_batched(uint32_t n_rows);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);
-extern int g_batched_sched;  // 1 = default (LDS-DMA kernel over the f16 shadow), 0 = lockstep kernel everywhere, 2 = + stamps
+void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
+                              int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+extern int g_batched_sched;  // 4 = default (f16 shadow: pipelined 4-wave LDS-DMA kernel for long passes, 8-wave kernel for
+                             // short ones), 5 = pipelined kernel always, 1 = 8-wave kernel always, 0 = lockstep kernel on
+                             // the index rows, 2 = + stamps, 41..55 = timing experiments
 extern unsigned long long* g_batched_diag;
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
 void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int frt, const uint64_t* d_ids, uint32_t n_rows,

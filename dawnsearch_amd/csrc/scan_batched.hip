@@ -567,6 +567,343 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
 }
 
 // ------------------------------------------------------------------------------------------------
+// scan_f16_pipe_kernel — the same filter with ONE wave per SIMD (256 threads), 64 queries per wave: every A fragment
+// read from LDS feeds two MFMAs, so the LDS pipe (128 B/clk per CU, exactly the rate at which eight 32-query waves
+// consume fragments) runs at half load and the matrix pipe is shared with nobody.  With one wave per SIMD nothing hides
+// a bubble, so the tile loop is one software pipeline:
+//   * the ring of PD fragment reads never drains: the last PD k-steps of a sub-tile already fetch the first fragments
+//     of the next one (across the tile boundary: from the next LDS image);
+//   * two accumulator sets: the threshold test of a sub-tile runs after the first MFMAs of the next one are issued;
+//   * two barriers per tile, neither waits for LDS reads: P1 (k-step 2: every wave has left the previous tile, its
+//     image may be overwritten -> issue the DMA of tile t+2) and P2 (k-step 39: s_waitcnt vmcnt -> this wave's share
+//     of tile t+1 has landed; after the barrier all of it has, and k-step 40 starts reading it).  A DMA has 1.7 tile
+//     times to land;
+//   * candidates are staged per WAVE (private LDS region and counter, flushed by the wave itself): no LDS atomics,
+//     no fill snapshot, no flush barriers.
+// Query groups are dealt round-robin (wave w: groups w and w+4), so up to 128 queries use one group per wave.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t PIPE_WCAP = 256;  // staged candidates per wave (4 x 3 KiB beside the 144-KiB ring)
+
+// DBG (timing experiments only, results are wrong): 1 = no DMA, 2 = no barriers, 4 = no threshold tests, 8 = no LDS reads
+template <bool DENSE, int DBG = 0>
+__global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
+                                                           uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                                                           const half8* __restrict__ qh, int n_q,
+                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                           uint2* __restrict__ cand, float* __restrict__ dense) {
+    constexpr int NW = 4, PD = 8, DPW = 48 / NW;
+    // ring of three tile images; which one is read / filled rotates at run time (the fast path has no LDS access
+    // hipcc can see — the fragment reads are inline asm — so it has no reason to drain the DMA)
+    __shared__ __attribute__((aligned(16))) unsigned char img[3 * DMA_TILE_BYTES];
+    // candidate stage: [query | score bits | row] planes of NW * PIPE_WCAP words; written by inline asm (a store hipcc
+    // can see makes it wait for every DMA in flight first: vmcnt(0), ~2 us, on ~8 % of the sub-tiles)
+    constexpr uint32_t PLANE = NW * PIPE_WCAP * 4;
+    __shared__ uint32_t stage[3 * NW * PIPE_WCAP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const int qg0 = wave * 32 + (int)r, qg1 = (wave + NW) * 32 + (int)r;  // this lane's query in group 0 / 1
+    const bool live0 = wave * 32 < n_q, live1 = (wave + NW) * 32 < n_q;    // wave-uniform
+
+    half8 qf[2][24];
+    float tau_s[2];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+        qf[0][s] = qh[(size_t)qg0 * 48 + 2 * s + h];
+        qf[1][s] = qh[(size_t)qg1 * 48 + 2 * s + h];
+    }
+    tau_s[0] = tau_s[1] = __builtin_inff();
+    if (!DENSE && qg0 < n_q) tau_s[0] = tau[qg0] * SCORE_SCALE;
+    if (!DENSE && qg1 < n_q) tau_s[1] = tau[qg1] * SCORE_SCALE;
+
+    const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t G = gridDim.x;
+    const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
+    const uint32_t last = n_units - 1;
+    auto unit_row0 = [&](uint32_t t) { return (first_tile + (blockIdx.x + t * G) * tile_stride) * TILE_ROWS; };
+    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * TILE_ROWS; };
+    // 12 DMA instructions per wave and tile = 3 address registers x 4 immediate offsets (the instruction offset moves
+    // the global and the LDS address alike)
+    constexpr int NGP = DPW / 4;
+    auto dma = [&](uint32_t t, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_row0(t) * (EM * 2) + src_off0;
+        unsigned char* dst = img + image * DMA_TILE_BYTES + wave * (DPW * 1024);
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)gp[j];
+            __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 4096);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 2 /* nt */);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 2);
+        }
+    };
+    // the same, one instruction at a time (spread over the k-steps of a tile so that the matrix pipe never waits for a
+    // block of address arithmetic and 12 back-to-back issues)
+    auto dma_setup = [&](uint32_t t, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_row0(t) * (EM * 2) + src_off0;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+    };
+    auto dma_one = [&](auto i_c, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_c)::value, J = I / 4, O = (I % 4) * 1024;
+        unsigned char* dst = img + image * DMA_TILE_BYTES + wave * (DPW * 1024) + J * 4096;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[J],
+                                         (__attribute__((address_space(3))) void*)dst, 16, O, 2 /* nt */);
+    };
+    auto keep = [&](const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) asm volatile("" ::"v"(gp[j]));
+    };
+
+    // ---- candidate staging, private to the wave ----
+    uint32_t wpos = 0;  // wave-uniform fill of this wave's region
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores below
+        // the region is 4 entries per lane: all four slot reservations in flight together (each is a round trip to the
+        // memory-side atomic unit, ~2 us when 1024 waves hammer the 256 counters of a small index)
+        uint32_t q_[PIPE_WCAP / 64], slot[PIPE_WCAP / 64];
+#pragma unroll
+        for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            q_[j] = e < wpos ? stage[wave * PIPE_WCAP + e] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            slot[j] = 0xFFFFFFFFu;
+            if (e < wpos) slot[j] = (DBG & 16) ? e : atomicAdd(&cnt[q_[j]], 1u);
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            if (slot[j] < (uint32_t)BATCH_CAP)
+                cand[(size_t)q_[j] * BATCH_CAP + slot[j]] =
+                    make_uint2(stage[NW * PIPE_WCAP + wave * PIPE_WCAP + e], stage[2 * NW * PIPE_WCAP + wave * PIPE_WCAP + e]);
+        }
+        wpos = 0;
+    };
+    const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
+    // Slow path of the threshold test (some lane of the wave holds a score above its query's threshold): one ballot
+    // per accumulator element — most find nothing and cost two compares — and a scalar walk over the hits: read the
+    // score from its lane, append (query, score, row) to the wave's stage.  row0: first row of the sub-tile;
+    // q_first: query of lane 0 in this group; tau_lane: the lane's threshold (x 2^16).
+    auto tail_slow = [&](const f32x16& acc, uint32_t row0, uint32_t q_first, float tau_lane) __attribute__((always_inline)) {
+        const uint32_t lim = n_rows > row0 + 4 * h ? n_rows - row0 - 4 * h : 0u;  // rows of this lane's column that exist
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float ae = acc[e];  // (a scalar copy first: see the bit_cast note in scan_kernels.hip)
+            const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+            unsigned long long m = __ballot(ae > tau_lane && roff < lim);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ae), l)) *
+                                 (1.0f / SCORE_SCALE);
+                const uint32_t qi = q_first + (uint32_t)(l & 31);
+                const uint32_t row = row0 + roff + 4u * (uint32_t)(l >> 5);
+                if (wpos >= PIPE_WCAP) flush_wave();
+                if (lane == 0) {
+                    const uint32_t pa = stage_base + (wave * PIPE_WCAP + wpos) * 4u;
+                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                                 :
+                                 : "v"(pa), "v"(qi), "v"(__builtin_bit_cast(uint32_t, sc)), "v"(row), "n"(PLANE), "n"(2 * PLANE));
+                }
+                ++wpos;
+            }
+        }
+    };
+    // two accumulator sets (even / odd sub-tiles) x two query groups; mx: running maxima of the set under test
+    f32x16 acc[2][2];
+    float mx[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[1][0][e] = acc[1][1][e] = 0.f;  // (read by the max slices of the first tile)
+    // threshold test / dense store of one finished 32-row sub-tile (accumulator set `set`, NL live query groups)
+    auto tail = [&](auto set_c, auto nl_c, uint32_t row_base, uint32_t slot_base) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
+        const uint32_t row0 = row_base + 4 * h;
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            const int qi = g == 0 ? qg0 : qg1;
+            if (DENSE) {
+                if (qi < n_q) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = (row0 + e + 8 * e4) < n_rows ? acc[SET][g][e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                        *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + slot_base + 4 * h + 8 * e4) = o;
+                    }
+                }
+            } else {
+                float mx = acc[SET][g][0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[SET][g][e]);
+                if (__any(mx > tau_s[g])) tail_slow(acc[SET][g], row_base, (uint32_t)((wave + NW * g) * 32), tau_s[g]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) asm volatile("" ::"v"(qf[g][s]));
+        asm volatile("" ::"v"(tau_s[g]));
+    }
+    const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
+
+    // prologue: tiles 0 and 1 on their way, tile 0 landed everywhere, ring primed with its first PD fragments
+    const unsigned char* gp0[NGP];
+    const unsigned char* gp1[NGP];
+    dma(0, 0, gp0);
+    dma(last < 1u ? last : 1u, 1, gp1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
+    keep(gp0);
+    keep(gp1);
+    half8 a[PD];
+    {
+        const uint32_t ad = o0 + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[d]) : "v"(ad), "n"(d * 1024));
+    }
+
+    uint32_t t = 0;
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    // one tile: image `rd` holds tile t (its first PD fragments are already in the ring), `nx` tile t+1, `wr` gets t+2;
+    // NL = live query groups of this wave (0: the wave only moves rows)
+    auto step = [&](auto nl_c, uint32_t rd, uint32_t nx, uint32_t wr) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        const uint32_t ad = o0 + rd * DMA_TILE_BYTES + (uint32_t)lane * 16u;
+        const uint32_t adn = o0 + nx * DMA_TILE_BYTES + (uint32_t)lane * 16u;
+        const unsigned char* gp[NGP];
+#pragma unroll
+        for (int f = 0; f < 48; ++f) {
+            const int sub = f / 24, s = f % 24;
+            if (NL > 0) {
+                if (!(DBG & 8)) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));  // fragment f has landed (younger reads may be out)
+                __builtin_amdgcn_sched_barrier(0);
+                // MFMAs by inline asm so that the operands stay where they are: accumulators in VGPRs (the test reads
+                // them with plain VALU ops), group 0's query fragments in VGPRs, group 1's in AGPRs read directly as
+                // SrcB.  (Left to hipcc, group 1 lives in AGPRs and is COPIED out before every MFMA — and a
+                // v_accvgpr_read waits for the MFMA in flight: measured 127 clk per k-step instead of 64.)
+                if (s == 0) {
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[sub][0]) : "v"(a[f % PD]), "v"(qf[0][0]));
+                    if (NL > 1)
+                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
+                                     : "=&v"(acc[sub][1])
+                                     : "v"(a[f % PD]), "a"(qf[1][0]));
+                } else {
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[sub][0]) : "v"(a[f % PD]), "v"(qf[0][s]));
+                    if (NL > 1)
+                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+                                     : "+v"(acc[sub][1])
+                                     : "v"(a[f % PD]), "a"(qf[1][s]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // The threshold test of the sub-tile finished 24 k-steps ago (the other accumulator set), two or three
+                // VALU instructions per k-step so that they issue in the shadow of this step's MFMAs — a wave issues
+                // in order, a block of 40 VALU instructions is 150 clk without an MFMA in the queue.  Starts 2 k-steps
+                // after that set's last MFMA (results complete; hipcc pads no hazards for asm MFMAs: s_nop).
+                if (!DENSE && !(DBG & 4)) {
+                    constexpr int FIRST = 2;
+                    if (s == FIRST) asm volatile("s_nop 7");
+                    if (s >= FIRST && s < FIRST + 8) {
+                        const int j = s - FIRST;
+#pragma unroll
+                        for (int g = 0; g < NL; ++g) {
+                            mx[g] = j == 0 ? fmaxf(acc[1 - sub][g][0], acc[1 - sub][g][1])
+                                           : fmaxf(fmaxf(mx[g], acc[1 - sub][g][2 * j]), acc[1 - sub][g][2 * j + 1]);
+                            asm volatile("" : "+v"(mx[g]));  // computed HERE (hipcc otherwise sinks the slices to the test)
+                        }
+                    }
+                    if (s == FIRST + 8 && (sub == 1 || t > 0)) {
+                        bool hit = mx[0] > tau_s[0];
+                        if (NL > 1) hit = hit || mx[1] > tau_s[1];
+                        if (__any(hit)) {
+                            const uint32_t rb = sub == 1 ? unit_row0(t) : unit_row0(t - 1) + 32;
+#pragma unroll
+                            for (int g = 0; g < NL; ++g)
+                                if (__any(mx[g] > tau_s[g]))
+                                    tail_slow(acc[1 - sub][g], rb, (uint32_t)((wave + NW * g) * 32), tau_s[g]);
+                        }
+                    }
+                }
+                if (DENSE && s == 2 && (sub == 1 || t > 0)) {
+                    asm volatile("s_nop 7");
+                    if (sub == 1) tail(C0(), nl_c, unit_row0(t), unit_slot0(t));
+                    else tail(C1(), nl_c, unit_row0(t - 1) + 32, unit_slot0(t - 1) + 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f == 12) {  // P1: every wave has left tile t-1, its image may be overwritten
+                if (!(DBG & 2)) asm volatile("s_barrier");
+                __builtin_amdgcn_sched_barrier(0);
+                dma_setup(t + 2 < n_units ? t + 2 : last, gp);
+            }
+            if (!(DBG & 1)) {  // DMA of tile t+2: one instruction per k-step
+                if (f == 13) dma_one(std::integral_constant<int, 0>(), wr, gp);
+                if (f == 14) dma_one(std::integral_constant<int, 1>(), wr, gp);
+                if (f == 15) dma_one(std::integral_constant<int, 2>(), wr, gp);
+                if (f == 16) dma_one(std::integral_constant<int, 3>(), wr, gp);
+                if (f == 17) dma_one(std::integral_constant<int, 4>(), wr, gp);
+                if (f == 18) dma_one(std::integral_constant<int, 5>(), wr, gp);
+                if (f == 19) dma_one(std::integral_constant<int, 6>(), wr, gp);
+                if (f == 20) dma_one(std::integral_constant<int, 7>(), wr, gp);
+                if (f == 21) dma_one(std::integral_constant<int, 8>(), wr, gp);
+                if (f == 22) dma_one(std::integral_constant<int, 9>(), wr, gp);
+                if (f == 23) dma_one(std::integral_constant<int, 10>(), wr, gp);
+                if (f == 24) dma_one(std::integral_constant<int, 11>(), wr, gp);
+            }
+            if (f == 39) {  // P2: tile t+1 has landed (this wave's share; after the barrier all of it)
+                __builtin_amdgcn_sched_barrier(0);
+                if (DBG & 2) {
+                    if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW));
+                } else if (DENSE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier");  // (dense stores share vmcnt)
+                else if (DBG & 1) asm volatile("s_barrier");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPW));
+            }
+            if (NL > 0 && !(DBG & 8)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (f + PD < 48)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[f % PD]) : "v"(ad), "n"((f + PD) * 1024));
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                 : "=v"(a[f % PD])
+                                 : "v"(adn), "n"((f + PD < 48 ? 0 : f + PD - 48) * 1024));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        keep(gp);
+        ++t;
+    };
+    auto run = [&](auto nl_c) __attribute__((always_inline)) {
+        uint32_t rd = 0, nx = 1, wr = 2;  // image indices: read, next, fill
+        while (t < n_units) {
+            step(nl_c, rd, nx, wr);
+            const uint32_t o = rd;
+            rd = nx;
+            nx = wr;
+            wr = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15");  // the ring's look-ahead reads; the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(nl_c)::value > 0 && !(DBG & 4)) tail(C1(), nl_c, unit_row0(last) + 32, unit_slot0(last) + 32);
+    };
+    if (live1) run(C2());
+    else if (live0) run(C1());
+    else run(C0());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
+    if (!DENSE) flush_wave();
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-query top-64 of an unsorted candidate set (block of 1024 threads); result in wave 0, descending
 // ------------------------------------------------------------------------------------------------
 template <bool DENSE>
@@ -737,7 +1074,7 @@ static bool g_lds_attr_set = false;
 unsigned long long* g_batched_diag = nullptr;  // device buffer [grid][8 waves][8] for the SCHED == 2 diagnostic build
 // 1 (default): f16 shadow rows go through the LDS-DMA kernel, other row sources through the lockstep kernel;
 // 0: lockstep kernel for every row source; 2: lockstep kernel with diagnostic stamps
-int g_batched_sched = 1;
+int g_batched_sched = 4;
 
 template <bool DENSE, int NW, int RT, int SCHED>
 static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
@@ -764,16 +1101,32 @@ static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t fi
     if (n_tiles == 0) return;
     if (rt == ROW_F16S) {  // f16 shadow tiles: LDS-DMA kernel
         const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-        if (g_batched_sched == 4)
-            hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 4>), dim3(blocks), dim3(256), 0, stream,
-                               reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
-                               reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
-                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
-        else
+#define DAWN_PIPE_LAUNCH(DBG_)                                                                                          \
+    hipLaunchKernelGGL((scan_f16_pipe_kernel<DENSE, DBG_>), dim3(blocks), dim3(256), 0, stream,                         \
+                       reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,                  \
+                       reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),   \
+                       reinterpret_cast<float*>(ws.cand))
+        // mfma_sched 4 (default): the pipelined kernel for long append passes; short ones (below ~1000 tiles per CU =
+        // 16M rows) are dominated by candidate handling, where two waves per SIMD hide each other's slow paths, and go
+        // to the 8-wave kernel like the sample passes (measured full pass, 256 queries: 40M rows 7.43 vs 7.82 ms,
+        // 4M rows 0.91 vs 0.87 ms, 1M rows 0.42 vs 0.35 ms).  5: pipelined kernel for every pass (tests).  1: 8-wave only.
+        const int v = g_batched_sched;
+        const bool pipe = v >= 5 || (v == 4 && !DENSE && n_tiles >= (1u << 18));
+        if (!pipe)
             hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8>), dim3(blocks), dim3(512), 0, stream,
                                reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
                                reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
                                reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+        else if (!DENSE && v == 41) DAWN_PIPE_LAUNCH(1);   // 41..55: timing experiments, parts switched off
+        else if (!DENSE && v == 42) DAWN_PIPE_LAUNCH(2);
+        else if (!DENSE && v == 43) DAWN_PIPE_LAUNCH(3);
+        else if (!DENSE && v == 44) DAWN_PIPE_LAUNCH(4);
+        else if (!DENSE && v == 47) DAWN_PIPE_LAUNCH(7);
+        else if (!DENSE && v == 48) DAWN_PIPE_LAUNCH(8);
+        else if (!DENSE && v == 55) DAWN_PIPE_LAUNCH(15);
+        else if (!DENSE && v == 54) DAWN_PIPE_LAUNCH(16);
+        else DAWN_PIPE_LAUNCH(0);
+#undef DAWN_PIPE_LAUNCH
     } else if (rt == ROW_BF16) launch_pass_rt<DENSE, 1>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else launch_pass_rt<DENSE, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
@@ -839,6 +1192,18 @@ void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_r
 
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+}
+
+// Timing hook: the full append pass alone (thresholds ws.tau as left by the last search), `iters` times.
+void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
+                              int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const BatchPlan pl = plan_batched(n_rows);
+    (void)hipEventRecord(ev0, stream);
+    for (int i = 0; i < iters; ++i) {
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+        launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
+    }
+    (void)hipEventRecord(ev1, stream);
 }
 
 void launch_batched_dense_scores(const void* d_frows, int frt, uint32_t n_rows, const float* d_q, int B,

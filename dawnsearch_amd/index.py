@@ -123,6 +123,12 @@ class VectorIndex:
         return tmp[:, :n.value]
 
 
+    def debug_time_full_pass(self, B: int, iters: int = 5) -> float:
+        """Timing hook: mean ms of the matrix-core full pass alone (after a batched search set the thresholds)."""
+        ms = C.c_double(0.0)
+        check(lib.dawn_index_debug_time_full_pass(self._h, B, iters, C.byref(ms)))
+        return ms.value
+
     def debug_stream_lists(self, query: np.ndarray, cap_blocks: int = 4096):
         """Test hook: per-workgroup candidate lists of the batch-1 streaming filter -> (scores [blocks,64], rows)."""
         q = np.ascontiguousarray(query, dtype=np.float32).reshape(EM_LEN)

@@ -133,6 +133,8 @@ int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
+/* Timing hook: mean ms of the matrix-core full pass alone (thresholds of the last batched search; results discarded). */
+int dawn_index_debug_time_full_pass(dawn_index *idx, size_t B, int iters, double *mean_ms);
 /* Test hook: per-workgroup candidate lists of the batch-1 streaming filter (scores descending, rows; [blocks][64]). */
 int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *out_scores, uint32_t *out_rows,
                                   size_t cap_blocks, size_t *n_blocks);

@@ -392,7 +392,39 @@ def test_batched_correlated_queries_burst(dawn, oracle):
     l2, d2, f2 = idx.search_batch(Q, k)
     assert np.array_equal(labels, l2) and np.array_equal(dist.view(np.uint32), d2.view(np.uint32))
     assert idx.stats()["fallbacks"] == 0
+    idx.set_option("f16_shadow", 1)
+    idx.set_option("mfma_sched", 5)  # ... and the pipelined kernel (per-wave stage: a burst must flush and go on)
+    try:
+        l3, d3, f3 = idx.search_batch(Q, k)
+        assert np.array_equal(labels, l3) and np.array_equal(dist.view(np.uint32), d3.view(np.uint32))
+        assert idx.stats()["fallbacks"] == 0
+    finally:
+        idx.set_option("mfma_sched", 4)  # process-wide setting: back to the default
+
+
+@pytest.mark.parametrize("n,B,k", [(64, 16, 10), (4097, 256, 10), (8193, 9, 20), (20_001, 200, 10), (100_003, 33, 10),
+                                   (1_000_000, 256, 10), (3_000_000, 130, 20)])
+def test_batched_pipelined_kernel_matches(dawn, oracle, n, B, k):
+    """The software-pipelined 4-wave kernel (default for long passes only) forced onto every pass (mfma_sched 5):
+    same results as the 8-wave kernel for every query, and as the oracle for a sample; sizes cover one tile, odd
+    tile counts, 1 / 2 live query groups per wave, idle waves, both sampling plans."""
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B - 1] = x[n - 1]
     idx.set_option("mfma_sched", 1)
+    try:
+        l1, d1, f1 = idx.search_batch(Q, k)
+        idx.set_option("mfma_sched", 5)
+        l5, d5, f5 = idx.search_batch(Q, k)
+    finally:
+        idx.set_option("mfma_sched", 4)
+    assert np.array_equal(f1, f5) and np.array_equal(l1, l5) and np.array_equal(d1.view(np.uint32), d5.view(np.uint32))
+    for b in list(range(0, B, max(1, B // 6))) + [B - 1]:
+        _assert_same(l5[b][:f5[b]], d5[b][:f5[b]], *oracle.scan_topk(x, ids, Q[b], k, threads=8))
+    assert l5[B - 1][0] == n
+    assert idx.stats()["fallbacks"] == 0
 
 
 def test_batched_shadow_tracks_adds_and_growth(dawn, oracle):

@@ -12,11 +12,11 @@ idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, 256)
 rb = 768 if dtype == "bf16" else 1536
 for B in Bs:
-    for waves, sched in ((8, 0), (8, 1), (4, 4)):
+    for waves, sched in ([(4, int(x)) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else ((8, 0), (8, 1), (4, 4))):
         idx.set_option("mfma_sched", sched)
         idx.search_batch(Q[:B], 10)
         idx.profile_enable(True)
-        t0 = time.time(); it = 10
+        t0 = time.time(); it = 10 if sched < 40 else 2
         for _ in range(it): idx.search_batch(Q[:B], 10)
         wall = (time.time() - t0) / it
         n, ms = idx.profile_read(); idx.profile_enable(False)

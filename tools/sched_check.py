@@ -10,7 +10,7 @@ for dtype in ("f32", "bf16"):
         Q = synth.unit_rows(2, 0, B)
         idx.set_option("mfma_sched", 0)
         l0, d0, f0 = idx.search_batch(Q, 10)
-        for sched in (1, 4):
+        for sched in (1, 5):
             idx.set_option("mfma_sched", sched)
             l1, d1, f1 = idx.search_batch(Q, 10)
             ok = np.array_equal(l0, l1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(f0, f1)
