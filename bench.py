@@ -238,7 +238,11 @@ def main():
     elapsed_ms = head["ms_per_step"]
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
-    kernel = "scan_f16_dma_kernel<append> (f16 shadow rows, LDS-DMA)" if B >= 9 else "scan_filter_f16s_kernel (f16 shadow rows)"
+    if B >= 9:
+        kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 24)
+                  else "scan_f16_dma_kernel<append> (f16 shadow tiles by LDS-DMA, 8 waves x 32 queries)")
+    else:
+        kernel = "scan_filter_f16s_kernel (f16 shadow fragments, global load -> MFMA)"
 
     out = {
         "metric": "queries/sec, exact cosine top-k over a 384-d f32 index resident in HBM",
