@@ -1,0 +1,144 @@
+"""BASELINE.json's full single-GPU size — 100 M x 384 f32 rows resident in HBM — checked through properties that do not
+need the CPU oracle to scan 153.6 GB: independent GPU paths must agree bit for bit (f16-shadow MFMA stream, f32-row
+stream, matrix-core batched pass, forced exact pass: four different kernels over the same rows), planted rows must
+come back first with the distance the oracle computes for that ONE row, results are ascending, in range, idempotent,
+and equal to the merge of two half-index searches (the sharded identity).  Skipped when the card cannot hold the index.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+N = 100_000_000
+K = 10
+
+
+@pytest.fixture(scope="module")
+def big(dawn):
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 245e9:
+        pytest.skip("needs ~235 GB of free HBM (100 M f32 rows + f16 shadow)")
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, N, 1)
+    yield idx
+    idx.close()
+
+
+def _queries():
+    planted_rows = np.array([0, 1, 63, 64, 12_345_678, 49_999_999, 50_000_000, N - 65, N - 2, N - 1])
+    Q = np.concatenate([synth.unit_rows(2, 0, 6), synth.planted_queries(1, planted_rows, 7)])
+    return Q, planted_rows
+
+
+def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
+    idx = big
+    Q, planted = _queries()
+    assert idx.size() == N
+    # (1) batch-1 stream over the f16 shadow (default)
+    res1 = [idx.search(q, K) for q in Q]
+    for lab, dist in res1:
+        assert len(lab) == K and np.all(np.diff(dist) >= 0) and lab.min() >= 1 and lab.max() <= N
+    # planted rows first; their distance is the oracle's for that one row
+    for i, r in enumerate(planted):
+        lab, dist = res1[6 + i]
+        assert lab[0] == r + 1
+        row = synth.unit_rows(1, int(r), 1)
+        olab, odist = oracle.scan_topk(row, np.array([r + 1], dtype=np.uint64), Q[6 + i], 1)
+        assert dist[0].view(np.uint32) == odist[0].view(np.uint32)
+    # idempotent
+    lab, dist = idx.search(Q[0], K)
+    assert np.array_equal(lab, res1[0][0]) and np.array_equal(dist.view(np.uint32), res1[0][1].view(np.uint32))
+    # (2) all 16 at once: the matrix-core path (pipelined kernel at this size)
+    labels, dist, found = idx.search_batch(Q, K)
+    for b in range(len(Q)):
+        assert found[b] == K
+        assert np.array_equal(labels[b], res1[b][0]) and np.array_equal(dist[b].view(np.uint32), res1[b][1].view(np.uint32))
+    # (3) 8 queries in one streaming pass
+    l8, d8, f8 = idx.search_batch(Q[:8], K)
+    assert np.array_equal(l8, labels[:8]) and np.array_equal(d8.view(np.uint32), dist[:8].view(np.uint32))
+    # (4) the f32 rows streamed directly (no shadow involved)
+    idx.set_option("f16_shadow_b1", 0)
+    try:
+        for b in (0, 5, 6, 15):
+            lab, dd = idx.search(Q[b], K)
+            assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    finally:
+        idx.set_option("f16_shadow_b1", 1)
+    # (5) the exact pass (reference summation order over every row) forced for two queries
+    before = idx.stats()["fallbacks"]
+    idx.set_option("force_fallback", 1)
+    try:
+        for b in (1, 11):
+            lab, dd = idx.search(Q[b], K)
+            assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    finally:
+        idx.set_option("force_fallback", 0)
+    assert idx.stats()["fallbacks"] == before + 2
+
+
+def test_100m_k_edge_and_sharded_identity(dawn, big):
+    """k = 1 and k = 64 (no certificate margin: exact pass) agree on the common prefix with k = 10; the top-k of the
+    whole index equals the stable merge of the top-k of its two halves (what the multi-GPU path computes)."""
+    idx = big
+    Q, _ = _queries()
+    q = Q[3]
+    l10, d10 = idx.search(q, 10)
+    l1, d1 = idx.search(q, 1)
+    l64, d64 = idx.search(q, 64)
+    assert l1[0] == l10[0] and d1[0].view(np.uint32) == d10[0].view(np.uint32)
+    assert np.array_equal(l64[:10], l10) and np.array_equal(d64[:10].view(np.uint32), d10.view(np.uint32))
+    assert np.all(np.diff(d64) >= 0) and len(np.unique(l64)) == 64
+    # two half-size indexes holding the same rows (ids follow the rows); the full index is released first: the card
+    # cannot hold both (this is the last test of the module)
+    idx.close()
+    half = N // 2
+    parts = []
+    for g in range(2):
+        h = dawn.VectorIndex(0)
+        try:
+            h.fill_synthetic(1, g * half, half, 1 + g * half)
+        except Exception:
+            h.close()
+            pytest.skip("not enough HBM left for the half-index copies")
+        parts.append(h.search(q, 10))
+        h.close()
+    lab = np.concatenate([p[0] for p in parts])
+    dd = np.concatenate([p[1] for p in parts])
+    order = np.lexsort((np.arange(20), dd))[:10]  # stable: ties -> lower shard / earlier rows
+    assert np.array_equal(lab[order], l10) and np.array_equal(dd[order].view(np.uint32), d10.view(np.uint32))
+
+
+def test_125m_bf16_shard_paths_agree(dawn, oracle):
+    """configs[4]: 1 B x 384 bf16 rows over 8 GPUs = 125 M rows (96 GB) per GPU.  One such shard at full size: the
+    bf16 stream, the matrix-core pass and the forced exact pass agree bit for bit; planted rows come back first with the
+    oracle's distance for the bf16-ROUNDED row (the oracle of a bf16 index scans the rounded rows)."""
+    import torch
+    n = 125_000_000
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 110e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    idx = dawn.VectorIndex(0, dtype="bf16")
+    idx.fill_synthetic(1, 0, n, 1)
+    planted = np.array([0, 77, 62_500_000, n - 1])
+    Q = np.concatenate([synth.unit_rows(2, 0, 8), synth.planted_queries(1, planted, 9)])
+    labels, dist, found = idx.search_batch(Q, K)  # matrix-core pass (12 queries)
+    for b in range(len(Q)):
+        assert found[b] == K and np.all(np.diff(dist[b]) >= 0) and labels[b].max() <= n
+    for b in (0, 7, 8, 11):  # batch-1 stream
+        lab, dd = idx.search(Q[b], K)
+        assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    for i, r in enumerate(planted):
+        assert labels[8 + i][0] == r + 1
+        row = synth.round_bf16(synth.unit_rows(1, int(r), 1))
+        olab, odist = oracle.scan_topk(row, np.array([r + 1], dtype=np.uint64), Q[8 + i], 1)
+        assert dist[8 + i][0].view(np.uint32) == odist[0].view(np.uint32)
+    idx.set_option("force_fallback", 1)
+    try:
+        lab, dd = idx.search(Q[2], K)
+    finally:
+        idx.set_option("force_fallback", 0)
+    assert np.array_equal(lab, labels[2]) and np.array_equal(dd.view(np.uint32), dist[2].view(np.uint32))
+    idx.close()
