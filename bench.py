@@ -239,7 +239,7 @@ def main():
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
     if B >= 9:
-        kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 24)
+        kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 23)
                   else "scan_f16_dma_kernel<append> (f16 shadow tiles by LDS-DMA, 8 waves x 32 queries)")
     else:
         kernel = "scan_filter_f16s_kernel (f16 shadow fragments, global load -> MFMA)"

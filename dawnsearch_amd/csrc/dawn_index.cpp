@@ -146,7 +146,7 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         if (int e = dawn::batched_init()) return fail(DAWN_ERR_HIP, "hipFuncSetAttribute(LDS): %s", hipGetErrorString((hipError_t)e));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * dawn::EM * sizeof(_Float16)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.tau, dawn::BATCH_QT * sizeof(float)));
-        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMalloc(&idx->bws.cand, (size_t)dawn::BATCH_QT * dawn::BATCH_CAP * 8));
     }
     if (B <= idx->ws_B) return DAWN_OK;

@@ -25,6 +25,7 @@ constexpr float FILTER_EPS_F16 = 1.25e-3f;
 constexpr int BATCH_TILE_ROWS = 64;   // rows per LDS tile of the batched scan
 constexpr int BATCH_QT = 256;         // queries per batched pass (8 waves x 32)
 constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sample size)
+constexpr int BATCH_CAND_SEGS = 16;   // segments (and counters) per query candidate buffer, scan_batched.hip
 
 constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
 constexpr int ROW_BF16 = 1;  // DAWN_DTYPE_BF16: rows are 384 x bf16 (768 B), scored as their exact f32 widening
@@ -41,8 +42,9 @@ constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass mus
 struct BatchWorkspace {
     _Float16* qh;    // [BATCH_QT][384] scaled f16 queries
     float* tau;      // [BATCH_QT]
-    uint32_t* cnt;   // [BATCH_QT]
-    void* cand;      // [BATCH_QT][BATCH_CAP] uint2 (score bits, row); first half doubles as dense f32 scores
+    uint32_t* cnt;   // [BATCH_QT][BATCH_CAND_SEGS] candidates appended per segment
+    void* cand;      // [BATCH_QT][BATCH_CAND_SEGS][BATCH_CAP / BATCH_CAND_SEGS] uint2 (score bits, row); first half doubles
+                     // as the dense f32 score matrix [BATCH_QT][BATCH_CAP]
 };
 struct ScanGeom {
     int blocks;           // scan grid (== number of candidate lists per query)

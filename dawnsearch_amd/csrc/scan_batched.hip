@@ -43,6 +43,17 @@ constexpr uint32_t STAGE_CAP = 2048;             // LDS-staged candidates per wo
 constexpr uint32_t STAGE_FLUSH_AT = 1024;        // flush to the global per-query buffers beyond this fill
 constexpr int LDS_BYTES = 2 * TILE_BYTES + (int)STAGE_CAP * 12 + 16;
 
+// A query's candidate buffer is cut into CAND_SEGS segments with a counter each; a workgroup (or wave) appends to the
+// segment picked by its index.  One counter per query would take ~1500 same-address atomics per pass; on a short pass
+// (1 M rows: 150 us) they arrive faster than the memory-side atomic unit retires them (measured +130 us).
+constexpr uint32_t SEG_CAP = (uint32_t)BATCH_CAP / (uint32_t)BATCH_CAND_SEGS;  // 512
+
+__device__ __forceinline__ void append_candidate(uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t q,
+                                                 uint32_t seg, uint32_t score_bits, uint32_t row) {
+    const uint32_t slot = atomicAdd(&cnt[q * BATCH_CAND_SEGS + seg], 1u);
+    if (slot < SEG_CAP) cand[(size_t)q * BATCH_CAP + seg * SEG_CAP + slot] = make_uint2(score_bits, row);
+}
+
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int n_q,
                                                           _Float16* __restrict__ qh) {
     const int i = blockIdx.x * 256 + threadIdx.x;  // over BATCH_QT * EM
@@ -131,10 +142,8 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
         uint32_t n = stage_n[0];
         if (n > STAGE_CAP) n = STAGE_CAP;
         for (uint32_t e = threadIdx.x; e < n; e += NT) {
-            const uint32_t q_ = stage_q[e];
-            const uint32_t slot = atomicAdd(&cnt[q_], 1u);
-            if (slot < (uint32_t)BATCH_CAP)
-                cand[(size_t)q_ * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, stage_s[e]), stage_r[e]);
+            append_candidate(cnt, cand, stage_q[e], blockIdx.x % BATCH_CAND_SEGS, __builtin_bit_cast(uint32_t, stage_s[e]),
+                             stage_r[e]);
         }
     };
     const int tid = threadIdx.x;
@@ -272,9 +281,8 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
                                         stage_s[pos] = sc;
                                         stage_r[pos] = row;
                                     } else {  // stage full (a burst: many queries hitting the same rows): append directly
-                                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                                        if (slot < (uint32_t)BATCH_CAP)
-                                            cand[(size_t)qi * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, sc), row);
+                                        append_candidate(cnt, cand, (uint32_t)qi, blockIdx.x % BATCH_CAND_SEGS,
+                                                         __builtin_bit_cast(uint32_t, sc), row);
                                     }
                                     ++pos;
                                 }
@@ -361,10 +369,8 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
         uint32_t n = stage_n[0];
         if (n > DMA_STAGE_CAP) n = DMA_STAGE_CAP;
         for (uint32_t e = threadIdx.x; e < n; e += NT) {
-            const uint32_t q_ = stage_q[e];
-            const uint32_t slot = atomicAdd(&cnt[q_], 1u);
-            if (slot < (uint32_t)BATCH_CAP)
-                cand[(size_t)q_ * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, stage_s[e]), stage_r[e]);
+            append_candidate(cnt, cand, stage_q[e], blockIdx.x % BATCH_CAND_SEGS, __builtin_bit_cast(uint32_t, stage_s[e]),
+                             stage_r[e]);
         }
     };
     const int tid = threadIdx.x;
@@ -430,9 +436,8 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
                         stage_s[pos] = sc;
                         stage_r[pos] = row;
                     } else {  // stage full (a burst: many queries hitting the same rows): append directly
-                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                        if (slot < (uint32_t)BATCH_CAP)
-                            cand[(size_t)qi * BATCH_CAP + slot] = make_uint2(__builtin_bit_cast(uint32_t, sc), row);
+                        append_candidate(cnt, cand, (uint32_t)qi, blockIdx.x % BATCH_CAND_SEGS,
+                                         __builtin_bit_cast(uint32_t, sc), row);
                     }
                     ++pos;
                 }
@@ -666,6 +671,7 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
         // the region is 4 entries per lane: all four slot reservations in flight together (each is a round trip to the
         // memory-side atomic unit, ~2 us when 1024 waves hammer the 256 counters of a small index)
         uint32_t q_[PIPE_WCAP / 64], slot[PIPE_WCAP / 64];
+        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;  // (a query belongs to ONE wave of every workgroup)
 #pragma unroll
         for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
             const uint32_t e = lane + 64u * j;
@@ -675,13 +681,13 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
         for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
             const uint32_t e = lane + 64u * j;
             slot[j] = 0xFFFFFFFFu;
-            if (e < wpos) slot[j] = (DBG & 16) ? e : atomicAdd(&cnt[q_[j]], 1u);
+            if (e < wpos) slot[j] = (DBG & 16) ? e : atomicAdd(&cnt[q_[j] * BATCH_CAND_SEGS + seg], 1u);
         }
 #pragma unroll
         for (int j = 0; j < (int)(PIPE_WCAP / 64); ++j) {
             const uint32_t e = lane + 64u * j;
-            if (slot[j] < (uint32_t)BATCH_CAP)
-                cand[(size_t)q_[j] * BATCH_CAP + slot[j]] =
+            if (slot[j] < SEG_CAP)
+                cand[(size_t)q_[j] * BATCH_CAP + seg * SEG_CAP + slot[j]] =
                     make_uint2(stage[NW * PIPE_WCAP + wave * PIPE_WCAP + e], stage[2 * NW * PIPE_WCAP + wave * PIPE_WCAP + e]);
         }
         wpos = 0;
@@ -906,14 +912,21 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
 // ------------------------------------------------------------------------------------------------
 // per-query top-64 of an unsorted candidate set (block of 1024 threads); result in wave 0, descending
 // ------------------------------------------------------------------------------------------------
+// DENSE: `count` scores dense_q[0..count); else: wave w takes segment w of the query's candidate buffer (seg_cnt_q[w]
+// entries, clamped to SEG_CAP) — the kernels run 16 waves = BATCH_CAND_SEGS.
 template <bool DENSE>
 __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, const uint2* __restrict__ cand_q,
-                                            uint32_t count, float& s, uint32_t& p, float (*sh_s)[LIST],
-                                            uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves) {
+                                            const uint32_t* __restrict__ seg_cnt_q, uint32_t count, float& s, uint32_t& p,
+                                            float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves) {
     s = NEG_INF;
     p = NO_POS;
+    if (!DENSE) {
+        count = seg_cnt_q[wave];
+        if (count > SEG_CAP) count = SEG_CAP;
+        cand_q += (size_t)wave * SEG_CAP;
+    }
     const uint32_t n_chunks = (count + 63u) >> 6;
-    for (uint32_t c = wave; c < n_chunks; c += nwaves) {
+    for (uint32_t c = DENSE ? wave : 0; c < n_chunks; c += DENSE ? nwaves : 1) {
         const uint32_t e = c * 64u + lane;
         float d = POS_INF;  // key = -score: ascending sort = descending score, ties -> lower row
         uint32_t row = NO_POS;
@@ -951,12 +964,12 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
-    uint32_t count = DENSE ? dense_count : cnt[b];
+    uint32_t count = DENSE ? dense_count : 0u;
     if (count > (uint32_t)BATCH_CAP) count = BATCH_CAP;
     float s;
     uint32_t p;
-    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, count, s, p, sh_s, sh_p, wave,
-                       lane, 16);
+    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
+                       s, p, sh_s, sh_p, wave, lane, 16);
     if (wave != 0) return;
     const uint32_t have = __popcll(__ballot(p != NO_POS));
     float t = NEG_INF;
@@ -983,13 +996,22 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
-    const uint32_t raw = DENSE ? n_rows : cnt[b];
-    const bool overflow = raw > (uint32_t)BATCH_CAP;
-    const uint32_t count = overflow ? (uint32_t)BATCH_CAP : raw;
+    // candidates of this query: DENSE every row; else the segments' counts (a segment past its capacity dropped
+    // candidates: the query goes to the exact pass)
+    uint32_t count = n_rows;
+    bool overflow = false;
+    if (!DENSE) {
+        count = 0;
+        for (int sg = 0; sg < BATCH_CAND_SEGS; ++sg) {
+            const uint32_t c = cnt[(size_t)b * BATCH_CAND_SEGS + sg];
+            overflow = overflow || c > SEG_CAP;
+            count += c > SEG_CAP ? SEG_CAP : c;
+        }
+    }
     float s;
     uint32_t p;
-    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, count, s, p, sh_s, sh_p, wave,
-                       lane, 16);
+    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
+                       s, p, sh_s, sh_p, wave, lane, 16);
     const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
     if (wave != 0) return;
 
@@ -1106,12 +1128,12 @@ static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t fi
                        reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,                  \
                        reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),   \
                        reinterpret_cast<float*>(ws.cand))
-        // mfma_sched 4 (default): the pipelined kernel for long append passes; short ones (below ~1000 tiles per CU =
-        // 16M rows) are dominated by candidate handling, where two waves per SIMD hide each other's slow paths, and go
+        // mfma_sched 4 (default): the pipelined kernel for long append passes; short ones (below ~500 tiles per CU =
+        // 8M rows) are dominated by candidate handling, where two waves per SIMD hide each other's slow paths, and go
         // to the 8-wave kernel like the sample passes (measured full pass, 256 queries: 40M rows 7.43 vs 7.82 ms,
-        // 4M rows 0.91 vs 0.87 ms, 1M rows 0.42 vs 0.35 ms).  5: pipelined kernel for every pass (tests).  1: 8-wave only.
+        // 12.5M 2.47 vs 2.53, 4M 0.91 vs 0.87, 1M 0.34 vs 0.28 ms).  5: pipelined kernel for every pass (tests).  1: 8-wave.
         const int v = g_batched_sched;
-        const bool pipe = v >= 5 || (v == 4 && !DENSE && n_tiles >= (1u << 18));
+        const bool pipe = v >= 5 || (v == 4 && !DENSE && n_tiles >= (1u << 17));
         if (!pipe)
             hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8>), dim3(blocks), dim3(512), 0, stream,
                                reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
@@ -1200,7 +1222,7 @@ void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int
     const BatchPlan pl = plan_batched(n_rows);
     (void)hipEventRecord(ev0, stream);
     for (int i = 0; i < iters; ++i) {
-        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
         launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
     }
     (void)hipEventRecord(ev1, stream);
@@ -1255,12 +1277,12 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
     hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
                        pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
     if (pl.s2_tiles) {
-        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
         launch_pass<false>(d_frows, frt, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
         hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
                            ws.tau);
     }
-    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
     if (ev1) (void)hipEventRecord(ev1, stream);
