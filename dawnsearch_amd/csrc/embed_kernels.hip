@@ -13,6 +13,7 @@
 //   add_ln_kernel         LayerNorm(dense_out + residual)                       (model.rs:374-379, 458-463)
 //   pool_norm_kernel      mean over the sequence's tokens, then x/√Σx²          (embedding_service.rs:126-136)
 #include "embed_kernels.hpp"
+#include "wave_topk.hpp"
 
 namespace dawn {
 
@@ -23,9 +24,26 @@ constexpr int H = 384;   // hidden_size
 constexpr int DH = 32;   // attention_head_size
 constexpr int NH = 12;   // num_attention_heads
 
+// xor-butterfly all-reduce (the summation order of the classic __shfl_xor loop) on DPP / permlane-swap lane
+// exchanges (wave_topk.hpp): a ds_bpermute per step costs ~100 clk of dependent latency, 12 of them per LayerNorm row
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63;
+    v += lane_xor_f32<32>(v, lane);
+    v += lane_xor_f32<16>(v, lane);
+    v += lane_xor_f32<8>(v, lane);
+    v += lane_xor_f32<4>(v, lane);
+    v += lane_xor_f32<2>(v, lane);
+    v += lane_xor_f32<1>(v, lane);
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+    const int lane = threadIdx.x & 63;
+    v = fmaxf(v, lane_xor_f32<32>(v, lane));
+    v = fmaxf(v, lane_xor_f32<16>(v, lane));
+    v = fmaxf(v, lane_xor_f32<8>(v, lane));
+    v = fmaxf(v, lane_xor_f32<4>(v, lane));
+    v = fmaxf(v, lane_xor_f32<2>(v, lane));
+    v = fmaxf(v, lane_xor_f32<1>(v, lane));
     return v;
 }
 
@@ -271,11 +289,75 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention: one block per (head, sequence); K and V of the head staged in LDS (S*256 B <= 128 KiB at
-// S = 512); one thread per query row, two passes over the keys (max, then exp/sum/PV) = the
-// max-subtract softmax of candle_nn::ops::softmax.  No mask inside a sequence; nothing outside it exists.
+// attention, sequences of up to 64 tokens (queries): one block (4 waves) per (head, sequence), everything in LDS,
+// three phases that each spread over all 256 threads — a 27-token text has 729 scores and 864 outputs, a thread per
+// query row kept 27 lanes busy for 15 us:
+//   1. scores  S[i][j] = (q_i . k_j) / sqrt(32): one thread per (i, j), the 32-long FMA chain in d order
+//   2. softmax per row (wave per row, lanes over the keys): max, exp(s - max), sum — the max-subtract softmax of
+//      candle_nn::ops::softmax
+//   3. out[i][d] = (sum_j P[i][j] V[j][d]) / sum_i: one thread per (i, d)
+// No mask inside a sequence; nothing outside it exists.  K rows are stored with stride 33 (phase 1 reads one key row
+// per lane), scores with stride 65.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void attention_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+constexpr int ATT_LD = DH + 1;
+
+// ATT_SMAX = 32 or 64: longest sequence of the call (the LDS footprint, 17 / 42 KB, sets how many of the B x 12
+// blocks a CU holds at once)
+template <int ATT_SMAX>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+                                                       const int* __restrict__ seq_offsets,
+                                                       float* __restrict__ ctx /*[T][384]*/) {
+    __shared__ __attribute__((aligned(16))) float Qs[ATT_SMAX * DH];
+    __shared__ float Ks[ATT_SMAX * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_SMAX * DH];
+    __shared__ float Sc[ATT_SMAX * (ATT_SMAX + 1)];
+    __shared__ float Sum[ATT_SMAX];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < S * (DH / 4); i += 256) {
+        const int j = i >> 3, c = (i & 7) * 4;
+        const float* row = qkv + (size_t)(start + j) * (3 * H) + h * DH + c;
+        const f32x4 qq = *reinterpret_cast<const f32x4*>(row);
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(row + H);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(row + 2 * H);
+        *reinterpret_cast<f32x4*>(Qs + j * DH + c) = qq;
+        *reinterpret_cast<f32x4*>(Vs + j * DH + c) = vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ks[j * ATT_LD + c + e] = kk[e];
+    }
+    __syncthreads();
+    const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx - i * S;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) sc = __builtin_fmaf(Qs[i * DH + d], Ks[j * ATT_LD + d], sc);
+        Sc[i * (ATT_SMAX + 1) + j] = sc * inv_scale;
+    }
+    __syncthreads();
+    for (int i = wave; i < S; i += 4) {
+        const float sc = lane < S ? Sc[i * (ATT_SMAX + 1) + lane] : -__builtin_inff();
+        const float mx = wave_allreduce_max(sc);
+        const float p = lane < S ? expf(sc - mx) : 0.f;
+        if (lane < S) Sc[i * (ATT_SMAX + 1) + lane] = p;
+        const float sum = wave_allreduce_sum(p);
+        if (lane == 0) Sum[i] = sum;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * DH; idx += 256) {
+        const int i = idx >> 5, d = idx & 31;
+        float acc = 0.f;
+        for (int j = 0; j < S; ++j) acc = __builtin_fmaf(Sc[i * (ATT_SMAX + 1) + j], Vs[j * DH + d], acc);
+        ctx[(size_t)(start + i) * H + h * DH + d] = acc / Sum[i];
+    }
+}
+
+// Long sequences (max_len > 64: pages): one THREAD per query row, two passes over the keys (max, then exp/sum/PV);
+// K and V unpadded in LDS (every thread reads the same key row: broadcasts).  At S = 128 this keeps two full waves
+// busy per block; up to 64 tokens the three-phase kernel above is used.
+__global__ __launch_bounds__(128) void attention_rows_kernel(const float* __restrict__ qkv /*[T][1152]*/,
                                                        const int* __restrict__ seq_offsets,
                                                        float* __restrict__ ctx /*[T][384]*/) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -365,8 +447,13 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
 
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s) {
     if (B <= 0) return;
-    const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
-    hipLaunchKernelGGL(attention_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
+    if (max_len > 64) {
+        const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
+        hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
+        return;
+    }
+    if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
+    else hipLaunchKernelGGL(attention_kernel<64>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
 }
 
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s) {
@@ -388,7 +475,7 @@ void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s) 
 
 int attention_set_max_lds() {
     // S = 512 needs 128 KiB of dynamic LDS: raise the kernel's limit once
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 512 * DH * 2 * (int)sizeof(float));
 }
 
