@@ -354,6 +354,117 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attention, sequences of 65..128 tokens (pages; the indexer embeds one page per call): one block (4 waves) per (head,
+// sequence), both contractions on v_mfma_f32_32x32x2_f32 (exact f32 FMAs).  Wave w owns query rows 32w..32w+31:
+//   scores: 4 key tiles x 16 MFMAs (A = Q rows, B = K rows, both read from LDS with row stride 33: conflict-free);
+//   softmax in the accumulator layout (a lane holds one key column of 16 rows per tile: row max / row sum are a
+//   5-step xor butterfly over the 32 lanes of its half-wave);
+//   P is written to the wave's LDS strip and read back as the A operand of P.V (64 MFMAs, B = V rows).
+// 1 block per CU (117 KB of LDS); a thread per query row took 51 us per layer for one 128-token page.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATM_S = 128;            // keys / query rows covered
+constexpr int ATM_LD = DH + 1;        // Q, K, V row stride
+constexpr int ATM_PLD = ATM_S + 1;    // P row stride
+constexpr int ATM_LDS_FLOATS = 3 * ATM_S * ATM_LD + 4 * 32 * ATM_PLD;
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+                                                            const int* __restrict__ seq_offsets,
+                                                            float* __restrict__ ctx /*[T][384]*/) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;
+    float* Ks = sm + ATM_S * ATM_LD;
+    float* Vs = sm + 2 * ATM_S * ATM_LD;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* Ps = sm + 3 * ATM_S * ATM_LD + wave * (32 * ATM_PLD);
+    for (int i = tid; i < ATM_S * (DH / 4); i += 256) {
+        const int j = i >> 3, c = (i & 7) * 4;
+        f32x4 qq = {0.f, 0.f, 0.f, 0.f}, kk = qq, vv = qq;  // rows past the sequence: zeros (masked below)
+        if (j < S) {
+            const float* row = qkv + (size_t)(start + j) * (3 * H) + h * DH + c;
+            qq = *reinterpret_cast<const f32x4*>(row);
+            kk = *reinterpret_cast<const f32x4*>(row + H);
+            vv = *reinterpret_cast<const f32x4*>(row + 2 * H);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Qs[j * ATM_LD + c + e] = qq[e];
+            Ks[j * ATM_LD + c + e] = kk[e];
+            Vs[j * ATM_LD + c + e] = vv[e];
+        }
+    }
+    __syncthreads();
+    if (wave * 32 >= S) return;  // none of this wave's query rows exists (no barrier below)
+    const int r = lane & 31, kh = lane >> 5;
+    // ---- scores: acc[jt][e] = S[row 32w + 8(e>>2) + (e&3) + 4kh][key 32jt + r]
+    float qa[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qa[kk] = Qs[(wave * 32 + r) * ATM_LD + 2 * kk + kh];
+    f32x16 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], Ks[(jt * 32 + r) * ATM_LD + 2 * kk + kh], acc[jt], 0, 0, 0);
+    }
+    const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
+    float mx[16], sum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx[e] = -__builtin_inff();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const bool key_ok = jt * 32 + r < S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc[jt][e] = key_ok ? acc[jt][e] * inv_scale : -__builtin_inff();
+            mx[e] = fmaxf(mx[e], acc[jt][e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {  // over the 32 lanes of this half-wave (the row's keys)
+        mx[e] = fmaxf(mx[e], lane_xor_f32<16>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<8>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<4>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<2>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<1>(mx[e], lane));
+        sum[e] = 0.f;
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
+            sum[e] += p;
+            Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_PLD + jt * 32 + r] = p;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        sum[e] += lane_xor_f32<16>(sum[e], lane);
+        sum[e] += lane_xor_f32<8>(sum[e], lane);
+        sum[e] += lane_xor_f32<4>(sum[e], lane);
+        sum[e] += lane_xor_f32<2>(sum[e], lane);
+        sum[e] += lane_xor_f32<1>(sum[e], lane);
+    }
+    // ---- out = P.V: A = P[row r][key 2kk + kh] (this wave's strip), B = V[key 2kk + kh][dim r]
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    const int n_kk = (S + 1) >> 1;  // keys beyond S have P = 0 and V = 0: skip them
+    for (int kk = 0; kk < n_kk; ++kk)
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_PLD + 2 * kk + kh], Vs[(2 * kk + kh) * ATM_LD + r], o, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + 8 * (e >> 2) + (e & 3) + 4 * kh;
+        if (row < S) ctx[(size_t)(start + row) * H + h * DH + r] = o[e] / sum[e];
+    }
+}
+
 // Long sequences (max_len > 64: pages): one THREAD per query row, two passes over the keys (max, then exp/sum/PV);
 // K and V unpadded in LDS (every thread reads the same key row: broadcasts).  At S = 128 this keeps two full waves
 // busy per block; up to 64 tokens the three-phase kernel above is used.
@@ -447,6 +558,11 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
 
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s) {
     if (B <= 0) return;
+    if (max_len > 64 && max_len <= ATM_S) {
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3(NH, B), dim3(256), ATM_LDS_FLOATS * sizeof(float), s, qkv, seq_offsets,
+                           ctx);
+        return;
+    }
     if (max_len > 64) {
         const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
         hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
@@ -475,6 +591,10 @@ void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s) 
 
 int attention_set_max_lds() {
     // S = 512 needs 128 KiB of dynamic LDS: raise the kernel's limit once
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              ATM_LDS_FLOATS * (int)sizeof(float));
+    if (e1 != hipSuccess) return (int)e1;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 512 * DH * 2 * (int)sizeof(float));
 }

@@ -58,6 +58,21 @@ def test_batch_equals_batch1_and_oracle(provider, oracle):
         assert np.abs(h - sb.forward(s)).max() < TOL_HID
 
 
+def test_page_lengths_use_the_mfma_attention(provider, oracle):
+    """65..128 tokens (pages) take the matrix-core attention kernel; a batch takes the kernel of its longest member, so
+    the short texts here run through it as well and must agree with their own batch-1 result (three-phase kernel) and
+    with the oracle."""
+    sb = oracle.SynthBert(3)
+    seqs = [synth.token_sequences(40 + n, 1, n, n)[0] for n in (65, 96, 127, 128, 7, 33, 64)]
+    batch = provider.calculate_embedding(seqs)
+    for i, s in enumerate(seqs):
+        single = provider.calculate_embedding([s])[0]
+        assert np.abs(single - batch[i]).max() < 5e-7
+        assert np.abs(batch[i] - sb.embed(s)).max() < TOL_EMB
+    hs = provider.hidden_states([seqs[2]])[0]
+    assert np.abs(hs - sb.forward(seqs[2])).max() < TOL_HID
+
+
 def test_long_sequences_and_limits(provider, oracle, dawn):
     sb = oracle.SynthBert(3)
     s512 = synth.token_sequences(5, 1, 512, 512)[0]
