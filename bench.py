@@ -191,12 +191,12 @@ def main():
             leg["planted_top1_ok"] = bool(labels[0][0] == 1 + (4242 % args.rows))
         return leg, algo
 
-    def e2e_leg(index, Bq, steps=30):
+    def e2e_leg(index, Bq, steps=30, len_lo=4, len_hi=32):
         import tempfile
         with tempfile.TemporaryDirectory() as d:
             st, cj = dawn.write_synthetic_model(d, seed=3)
             ep = dawn.EmbeddingProvider(st, cj, local_rank)
-        seqs = synth.token_sequences(5, Bq, 4, 32)
+        seqs = synth.token_sequences(5, Bq, len_lo, len_hi)
         lens = np.array([len(x) for x in seqs])
         offs = np.zeros(Bq + 1, dtype=np.int32)
         offs[1:] = np.cumsum(lens)
@@ -321,6 +321,9 @@ def main():
             # everything device-resident on one stream (synthetic seeded weights: no checkpoint on disk)
             extra["e2e_1M_batch256"] = e2e_leg(idx1, 256)
             extra["embed_batch1"] = e2e_leg(idx1, 1, steps=100)
+            # page-like inputs (S = 128): the indexer's one page per call, and bulk embedding
+            extra["embed_page_batch1_S128"] = e2e_leg(idx1, 1, steps=50, len_lo=128, len_hi=128)
+            extra["embed_pages_batch256_S128"] = e2e_leg(idx1, 256, steps=5, len_lo=128, len_hi=128)
         out["checks"]["fallbacks"] = idx.stats()["fallbacks"]
         if world == 1:
             # configs[4] sizing point on one GPU: the same 100 M rows stored as bf16 (76.8 GB), f32 accumulation;
