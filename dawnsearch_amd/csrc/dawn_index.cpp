@@ -112,13 +112,15 @@ int grow_phys(dawn_index* idx, size_t rows) {
         (void)hipFree(nx);
         return fail(DAWN_ERR_OOM, "hipMalloc(ids): %s", hipGetErrorString(e));
     }
+    // (a bf16 index is stored in 64-row tiles: copy and clear whole tiles)
+    const size_t live = idx->dtype == DAWN_DTYPE_BF16 ? (idx->size + dawn::ROW_PAD - 1) / dawn::ROW_PAD * dawn::ROW_PAD : idx->size;
     if (idx->size) {
-        DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, idx->size * rb, hipMemcpyDeviceToDevice, idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, live * rb, hipMemcpyDeviceToDevice, idx->stream));
         DAWN_HIP_TRY(hipMemcpyAsync(nid, idx->d_ids, idx->size * sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                     idx->stream));
     }
     // zero everything past the live rows: the scan may read (never use) up to ROW_PAD rows past size
-    DAWN_HIP_TRY(hipMemsetAsync(nx + idx->size * rb, 0, (prow - idx->size) * rb, idx->stream));
+    DAWN_HIP_TRY(hipMemsetAsync(nx + live * rb, 0, (prow - live) * rb, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     if (idx->d_x) (void)hipFree(idx->d_x);
     if (idx->d_ids) (void)hipFree(idx->d_ids);
@@ -217,8 +219,9 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
     if ((int)B >= idx->mfma_min_batch) {
         // matrix-core path, BATCH_QT queries per pass over the index
         int frt = idx->dtype;
-        const void* frows = idx->d_x;  // mfma_sched 0 / 2: the lockstep kernel converts the index's own rows
-        if (dawn::g_batched_sched != 0 && dawn::g_batched_sched != 2) frows = filter_rows(idx, &frt, stream);
+        const void* frows = idx->d_x;  // f32 index with mfma_sched 0 / 2: the lockstep kernel converts the f32 rows
+        if (idx->dtype == DAWN_DTYPE_BF16 || (dawn::g_batched_sched != 0 && dawn::g_batched_sched != 2))
+            frows = filter_rows(idx, &frt, stream);  // (a bf16 index is its own fragment-ordered filter source)
         for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
             const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
             dawn::launch_scan_batched(idx->d_x, idx->dtype, frows, frt, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
@@ -229,13 +232,14 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
     } else {
         int frt = idx->dtype;
         const void* frows = filter_rows(idx, &frt, stream);
-        if (frt == dawn::ROW_F16S && idx->shadow_small_batches) {
-            // 1..8 queries: stream the f16 shadow (768 B/row) instead of the f32 rows (1536 B/row)
+        if (frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
+            // 1..8 queries: stream the 16-bit fragments (768 B/row: the f16 shadow instead of the f32 rows, or the
+            // bf16 index itself) through the matrix cores
             const dawn::ScanGeom& gh = idx->shadow_geom();
-            dawn::launch_scan_filter_f16s(frows, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
+            dawn::launch_scan_filter_f16s(frows, frt, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
             dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                       gh.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                                       idx->force_fallback, dawn::FILTER_EPS_F16, stream);
+                                       gh.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback,
+                                       frt == dawn::ROW_BF16 ? dawn::FILTER_EPS_BF16_STREAM : dawn::FILTER_EPS_F16, stream);
         } else {
             dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream,
                                      e0, e1);
@@ -267,12 +271,6 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     auto* idx = new dawn_index();
     idx->device = device;
     idx->dtype = dtype;
-    if (dtype == DAWN_DTYPE_BF16) {
-        // twice the rows per byte: the per-row reduction needs 4 waves per SIMD to keep up with the stream
-        // (tools/scan_sweep_bf16.py, 80M rows: 16 waves x 6 KiB per CU 6.93 TB/s; 8 waves 6.7; 4 waves 4.2)
-        idx->geom.threads = 1024;
-        idx->geom.unroll = 2;
-    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
@@ -361,7 +359,7 @@ int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const f
             DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, v + o * dawn::EM, m * dawn::EM * sizeof(float),
                                         hipMemcpyHostToDevice, idx->stream));
             dawn::launch_validate_rows(idx->d_stage, (uint32_t)m, idx->d_bad, idx->stream);  // gate on the f32 input
-            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x + (idx->size + o) * rb, m, idx->stream);
+            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size + o, m, idx->stream);
             if (o + kStageChunk < n) DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));  // staging buffer reuse
         }
     }
@@ -371,7 +369,8 @@ int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const f
     DAWN_HIP_TRY(hipMemcpyAsync(&bad, idx->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     if (bad) {
-        (void)hipMemsetAsync(idx->d_x + idx->size * rb, 0, n * rb, idx->stream);
+        // (a bf16 index keeps the rejected rows' fragments: rows >= size are masked by position in every kernel)
+        if (!bf16) (void)hipMemsetAsync(idx->d_x + idx->size * rb, 0, n * rb, idx->stream);
         (void)hipStreamSynchronize(idx->stream);
         return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized (%u of %zu rows)", bad, n);
     }
@@ -392,7 +391,7 @@ int dawn_index_add(dawn_index* idx, uint64_t id, const float* v) {
     if (idx->dtype == DAWN_DTYPE_BF16) {
         DAWN_TRY(ensure_stage(idx, 1));
         DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, hp, dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-        dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x + idx->size * rb, 1, idx->stream);
+        dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size, 1, idx->stream);
     } else {
         DAWN_HIP_TRY(hipMemcpyAsync(idx->d_x + idx->size * rb, hp, rb, hipMemcpyHostToDevice, idx->stream));
     }
@@ -507,7 +506,7 @@ int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row
         char* dst = idx->d_x + (idx->size + o) * rb;
         if (bf16) {  // f32 unit rows of the spec, then rounded: the bf16 index holds round_bf16(spec row)
             dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, idx->d_stage, d_len, idx->stream);
-            dawn::launch_rows_f32_to_bf16(idx->d_stage, dst, m, idx->stream);
+            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size + o, m, idx->stream);
         } else {
             dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->stream);
         }
@@ -531,7 +530,7 @@ int dawn_index_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows
         DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk)));
         for (size_t o = 0; o < n; o += kStageChunk) {
             const size_t m = std::min(kStageChunk, n - o);
-            dawn::launch_rows_bf16_to_f32(idx->d_x + (first + o) * rb, idx->d_stage, m, idx->stream);
+            dawn::launch_rows_bf16_to_f32(idx->d_x, first + o, idx->d_stage, m, idx->stream);
             DAWN_HIP_TRY(hipMemcpyAsync(out_rows + o * dawn::EM, idx->d_stage, m * dawn::EM * sizeof(float),
                                         hipMemcpyDeviceToHost, idx->stream));
             DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
@@ -701,10 +700,10 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     int frt = idx->dtype;
     const void* frows = filter_rows(idx, &frt, stream);
     size_t blocks;
-    if (frt == dawn::ROW_F16S && idx->shadow_small_batches) {
+    if (frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
         const dawn::ScanGeom& gh = idx->shadow_geom();
         blocks = gh.blocks;
-        dawn::launch_scan_filter_f16s(frows, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
+        dawn::launch_scan_filter_f16s(frows, frt, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
                                       stream, nullptr, nullptr);
     } else {
         blocks = idx->geom.blocks;

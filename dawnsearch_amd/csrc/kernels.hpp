@@ -21,6 +21,14 @@ constexpr float FILTER_EPS_F32 = 2.6e-5f;
 // components below 2^-22 flushed as f16 subnormals (if the hardware does) add < 1e-5; the exact side's own
 // gamma_384 * 1.0201 = 2.4e-5.  Total < 1.08e-3; 1.25e-3 is used.
 constexpr float FILTER_EPS_F16 = 1.25e-3f;
+// bf16 index, bf16 matrix cores.  The rows ARE bf16 (no row-side rounding); products of two bf16 are exact in f32.
+//  * streaming filter: the query enters as hi + lo (hi = bf16(q), lo = bf16(q - hi)): |q - hi - lo| <= 2^-18 |q|, so the
+//    representation error is <= 2^-18 * sum|q_i x_i| <= 4e-6 (sum|q_i x_i| <= 1.0201 * 1.004: is_normalized gate, row
+//    norms moved by at most 2^-8 by their rounding); f32 accumulation of 384 exact products, any order: <= 2.4e-5; the
+//    exact side's own gamma_384: 2.4e-5.  Total < 5.3e-5; 6e-5 is used.
+//  * matrix-core filter (one bf16 image of the query): 2^-9 * 1.0201 * 1.004 = 2.0e-3 + the same 4.8e-5; 2.1e-3 is used.
+constexpr float FILTER_EPS_BF16_STREAM = 6.0e-5f;
+constexpr float FILTER_EPS_BF16_MFMA = 2.1e-3f;
 
 constexpr int BATCH_TILE_ROWS = 64;   // rows per LDS tile of the batched scan
 constexpr int BATCH_QT = 256;         // queries per batched pass (8 waves x 32)
@@ -28,12 +36,15 @@ constexpr int BATCH_CAP = 8192;       // candidate slots per query (and dense sa
 constexpr int BATCH_CAND_SEGS = 16;   // segments (and counters) per query candidate buffer, scan_batched.hip
 
 constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
-constexpr int ROW_BF16 = 1;  // DAWN_DTYPE_BF16: rows are 384 x bf16 (768 B), scored as their exact f32 widening
-// ROW_F16S: filter-only shadow of an f32 index: f16(2^8 * x), 768 B per row, stored TILE BY TILE (64 rows = 48 KiB)
-// in the operand order of v_mfma_f32_32x32x16_f16: tile T = rows 64T..64T+63; inside it fragment f = sub*24 + s
-// (sub = 32-row half, s = k-step of 16) is 1 KiB = 64 lanes x 16 B, lane L = h*32 + r holding elements
-// k = 16s + 8h .. +7 of row 64T + 32*sub + r.  A wave-wide 16-B load of a fragment IS the MFMA A operand (streaming
-// filter, scan_kernels.hip) and an LDS-DMA of the tile needs no permutation (matrix-core filter, scan_batched.hip).
+// 16-bit rows are stored TILE BY TILE (64 rows = 48 KiB) in the operand order of v_mfma_f32_32x32x16_{f16,bf16}:
+// tile T = rows 64T..64T+63; inside it fragment f = sub*24 + s (sub = 32-row half, s = k-step of 16) is 1 KiB =
+// 64 lanes x 16 B, lane L = h*32 + r holding elements k = 16s + 8h .. +7 of row 64T + 32*sub + r.  A wave-wide 16-B load
+// of a fragment IS the MFMA A operand (streaming filter, scan_kernels.hip) and an LDS-DMA of the tile needs no
+// permutation (matrix-core filter, scan_batched.hip).  frag_chunk() in wave_topk.hpp maps (row, 16-B chunk) to its slot.
+//   ROW_BF16: DAWN_DTYPE_BF16, the index itself: bf16 values (rounded to nearest even on add), scored exactly as their
+//             f32 widening by the tail
+//   ROW_F16S: filter-only shadow of an f32 index: f16(2^8 * x)
+constexpr int ROW_BF16 = 1;
 constexpr int ROW_F16S = 2;
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
@@ -57,9 +68,10 @@ struct ScanGeom {
 void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0,
                         hipEvent_t ev1);
-// The same over the scaled-f16 shadow of an f32 index (ROW_F16S: half the bytes, filter error FILTER_EPS_F16), 8 queries
-// per pass; d_q = the f32 queries (converted in the kernel).
-void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const float* d_q, int B, float* cand_s,
+// The same over fragment-ordered 16-bit rows — rt = ROW_F16S: the scaled-f16 shadow of an f32 index (filter error
+// FILTER_EPS_F16), ROW_BF16: a bf16 index (FILTER_EPS_BF16_STREAM) —, 8 queries per pass; d_q = the f32 queries
+// (converted in the kernel).
+void launch_scan_filter_f16s(const void* d_rows, int rt, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                              uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
@@ -109,8 +121,9 @@ void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count
 void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_out, float* d_len,
                        hipStream_t stream);
 void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t stream);
-// Row-type conversion of whole rows: f32 -> bf16 (round to nearest even) and bf16 -> f32 (exact).
-void launch_rows_f32_to_bf16(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream);
-void launch_rows_bf16_to_f32(const void* d_in, float* d_out, size_t n_rows, hipStream_t stream);
+// bf16 index rows <-> f32 rows: d_in[n][384] f32 -> rows first_row.. of the fragment-ordered index d_x (round to nearest
+// even), and back (exact widening).
+void launch_rows_f32_to_bf16(const float* d_in, void* d_x, size_t first_row, size_t n_rows, hipStream_t stream);
+void launch_rows_bf16_to_f32(const void* d_x, size_t first_row, float* d_out, size_t n_rows, hipStream_t stream);
 
 }  // namespace dawn

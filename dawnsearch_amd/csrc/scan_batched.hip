@@ -33,6 +33,15 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// one MFMA on fragments held as half8 registers (bf16 data is reinterpreted)
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma16(const half8& a, const half8& b, const f32x16& c) {
+    if (BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 constexpr int TILE_ROWS = BATCH_TILE_ROWS;       // 64
 constexpr int G_STRIDE = 40 * 16;                // LDS bytes per k-group: 32 row slots + 8 (skew room)
 constexpr int SUB_BYTES = 48 * G_STRIDE;         // one 32-row f16 sub-tile: 30 KiB
@@ -54,12 +63,15 @@ __device__ __forceinline__ void append_candidate(uint32_t* __restrict__ cnt, uin
     if (slot < SEG_CAP) cand[(size_t)q * BATCH_CAP + seg * SEG_CAP + slot] = make_uint2(score_bits, row);
 }
 
+// BF16: a bf16 index — the queries become plain bf16 (round to nearest even, no scaling)
+template <bool BF16>
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int n_q,
-                                                          _Float16* __restrict__ qh) {
+                                                          unsigned short* __restrict__ qh) {
     const int i = blockIdx.x * 256 + threadIdx.x;  // over BATCH_QT * EM
     if (i >= BATCH_QT * EM) return;
     const int b = i / EM;
-    qh[i] = (b < n_q) ? (_Float16)(q[i] * ROW_SCALE) : (_Float16)0.0f;
+    const float v = (b < n_q) ? q[i] : 0.0f;
+    qh[i] = BF16 ? (unsigned short)f32_to_bf16_rne(v) : __builtin_bit_cast(unsigned short, (_Float16)(v * ROW_SCALE));
 }
 
 __device__ __forceinline__ half4 to_half4_scaled(const f32x4& v) {
@@ -346,13 +358,15 @@ constexpr uint32_t DMA_STAGE_FLUSH_AT = 384;
 
 // NW waves per workgroup (one workgroup per CU): 8 (two per SIMD, 32 queries each) or 4 (one per SIMD, 64 queries each:
 // every A fragment read from LDS feeds two MFMAs, half the LDS traffic, no sharing of the matrix pipe)
-template <bool DENSE, int NW>
+// BF16: the tiles are a bf16 INDEX (ROW_BF16), the queries bf16, the contraction v_mfma_f32_32x32x16_bf16, no score scale
+template <bool DENSE, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
                                                           uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                                                           const half8* __restrict__ qh, int n_q,
                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
                                                           uint2* __restrict__ cand, float* __restrict__ dense) {
     constexpr int NT = NW * 64, PD = 8;
+    constexpr float SC = BF16 ? 1.0f : SCORE_SCALE;
     constexpr int QG = 8 / NW;     // 32-query groups per wave
     constexpr int DPW = 48 / NW;   // DMA instructions per wave and tile
     // three SEPARATE LDS objects: the module-LDS lowering then tags their accesses with alias scopes and hipcc's
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
 #pragma unroll
         for (int s = 0; s < 24; ++s) qf[g][s] = qh[(size_t)(q0 + 32 * g) * 48 + 2 * s + h];
         tau_s[g] = __builtin_inff();
-        if (!DENSE && q0 + 32 * g < n_q) tau_s[g] = tau[q0 + 32 * g] * SCORE_SCALE;
+        if (!DENSE && q0 + 32 * g < n_q) tau_s[g] = tau[q0 + 32 * g] * SC;
     }
 
     // DMA map: the shadow tile is stored in fragment order already (kernels.hpp, ROW_F16S), so the image is a linear
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (mask & (1u << e)) {
-                    const float sc = acc[e] * (1.0f / SCORE_SCALE);
+                    const float sc = acc[e] * (1.0f / SC);
                     const uint32_t row = row0 + (e & 3) + 8 * (e >> 2);
                     if (pos < DMA_STAGE_CAP) {
                         stage_q[pos] = (uint32_t)qi;
@@ -497,9 +511,9 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
                             f32x16 z;
 #pragma unroll
                             for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[g][0], z, 0, 0, 0);
+                            acc[g] = mfma16<BF16>(a[0], qf[g][0], z);
                         } else {
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[g][s], acc[g], 0, 0, 0);
+                            acc[g] = mfma16<BF16>(a[s % PD], qf[g][s], acc[g]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
                                 f32x4 o;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    o[e] = (row0 + e + 8 * e4) < n_rows ? acc[g][e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                                    o[e] = (row0 + e + 8 * e4) < n_rows ? acc[g][e4 * 4 + e] * (1.0f / SC) : NEG_INF;
                                 *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + unit_slot0(t) + sub * 32 +
                                                           4 * h + 8 * e4) = o;
                             }
@@ -590,13 +604,14 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_dma_kernel(const unsigned ch
 constexpr uint32_t PIPE_WCAP = 256;  // staged candidates per wave (4 x 3 KiB beside the 144-KiB ring)
 
 // DBG (timing experiments only, results are wrong): 1 = no DMA, 2 = no barriers, 4 = no threshold tests, 8 = no LDS reads
-template <bool DENSE, int DBG = 0>
+template <bool DENSE, int DBG = 0, bool BF16 = false>
 __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char* __restrict__ xs, uint32_t n_rows,
                                                            uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                                                            const half8* __restrict__ qh, int n_q,
                                                            const float* __restrict__ tau, uint32_t* __restrict__ cnt,
                                                            uint2* __restrict__ cand, float* __restrict__ dense) {
     constexpr int NW = 4, PD = 8, DPW = 48 / NW;
+    constexpr float SC = BF16 ? 1.0f : 65536.0f;  // score scale of the f16 path (rows and queries x 2^8)
     // ring of three tile images; which one is read / filled rotates at run time (the fast path has no LDS access
     // hipcc can see — the fragment reads are inline asm — so it has no reason to drain the DMA)
     __shared__ __attribute__((aligned(16))) unsigned char img[3 * DMA_TILE_BYTES];
@@ -619,8 +634,8 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
         qf[1][s] = qh[(size_t)qg1 * 48 + 2 * s + h];
     }
     tau_s[0] = tau_s[1] = __builtin_inff();
-    if (!DENSE && qg0 < n_q) tau_s[0] = tau[qg0] * SCORE_SCALE;
-    if (!DENSE && qg1 < n_q) tau_s[1] = tau[qg1] * SCORE_SCALE;
+    if (!DENSE && qg0 < n_q) tau_s[0] = tau[qg0] * SC;
+    if (!DENSE && qg1 < n_q) tau_s[1] = tau[qg1] * SC;
 
     const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
     const uint32_t G = gridDim.x;
@@ -708,7 +723,7 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
                 const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ae), l)) *
-                                 (1.0f / SCORE_SCALE);
+                                 (1.0f / SC);
                 const uint32_t qi = q_first + (uint32_t)(l & 31);
                 const uint32_t row = row0 + roff + 4u * (uint32_t)(l >> 5);
                 if (wpos >= PIPE_WCAP) flush_wave();
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
                         f32x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            o[e] = (row0 + e + 8 * e4) < n_rows ? acc[SET][g][e4 * 4 + e] * (1.0f / SCORE_SCALE) : NEG_INF;
+                            o[e] = (row0 + e + 8 * e4) < n_rows ? acc[SET][g][e4 * 4 + e] * (1.0f / SC) : NEG_INF;
                         *reinterpret_cast<f32x4*>(dense + (size_t)qi * BATCH_CAP + slot_base + 4 * h + 8 * e4) = o;
                     }
                 }
@@ -799,19 +814,25 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
                 // them with plain VALU ops), group 0's query fragments in VGPRs, group 1's in AGPRs read directly as
                 // SrcB.  (Left to hipcc, group 1 lives in AGPRs and is COPIED out before every MFMA — and a
                 // v_accvgpr_read waits for the MFMA in flight: measured 127 clk per k-step instead of 64.)
+#define DAWN_MFMA_ZERO(T, D, A, B, CB) asm volatile("v_mfma_f32_32x32x16_" T " %0, %1, %2, 0" : "=&v"(D) : "v"(A), CB(B))
+#define DAWN_MFMA_ACC(T, D, A, B, CB) asm volatile("v_mfma_f32_32x32x16_" T " %0, %1, %2, %0" : "+v"(D) : "v"(A), CB(B))
                 if (s == 0) {
-                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[sub][0]) : "v"(a[f % PD]), "v"(qf[0][0]));
-                    if (NL > 1)
-                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
-                                     : "=&v"(acc[sub][1])
-                                     : "v"(a[f % PD]), "a"(qf[1][0]));
+                    if (BF16) DAWN_MFMA_ZERO("bf16", acc[sub][0], a[f % PD], qf[0][0], "v");
+                    else DAWN_MFMA_ZERO("f16", acc[sub][0], a[f % PD], qf[0][0], "v");
+                    if (NL > 1) {
+                        if (BF16) DAWN_MFMA_ZERO("bf16", acc[sub][1], a[f % PD], qf[1][0], "a");
+                        else DAWN_MFMA_ZERO("f16", acc[sub][1], a[f % PD], qf[1][0], "a");
+                    }
                 } else {
-                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[sub][0]) : "v"(a[f % PD]), "v"(qf[0][s]));
-                    if (NL > 1)
-                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
-                                     : "+v"(acc[sub][1])
-                                     : "v"(a[f % PD]), "a"(qf[1][s]));
+                    if (BF16) DAWN_MFMA_ACC("bf16", acc[sub][0], a[f % PD], qf[0][s], "v");
+                    else DAWN_MFMA_ACC("f16", acc[sub][0], a[f % PD], qf[0][s], "v");
+                    if (NL > 1) {
+                        if (BF16) DAWN_MFMA_ACC("bf16", acc[sub][1], a[f % PD], qf[1][s], "a");
+                        else DAWN_MFMA_ACC("f16", acc[sub][1], a[f % PD], qf[1][s], "a");
+                    }
                 }
+#undef DAWN_MFMA_ZERO
+#undef DAWN_MFMA_ACC
                 __builtin_amdgcn_sched_barrier(0);
                 // The threshold test of the sub-tile finished 24 k-steps ago (the other accumulator set), two or three
                 // VALU instructions per k-step so that they issue in the shadow of this step's MFMAs — a wave issues
@@ -1116,40 +1137,48 @@ static void launch_pass_rt(const void* d_rows, uint32_t n_rows, uint32_t first, 
         launch_pass_nw<DENSE, 8, RT, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
-// rows: the filter's row source; rt: its row type (ROW_F32, ROW_BF16 or ROW_F16S = the scaled f16 shadow copy)
+// Fragment-ordered 16-bit tiles (f16 shadow of an f32 index, or a bf16 index): the LDS-DMA kernels.
+template <bool DENSE, bool BF16>
+static void launch_pass_dma(const void* d_rows, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
+                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
+    const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
+#define DAWN_PIPE_LAUNCH(DBG_)                                                                                          \
+    hipLaunchKernelGGL((scan_f16_pipe_kernel<DENSE, DBG_, BF16>), dim3(blocks), dim3(256), 0, stream,                   \
+                       reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,                  \
+                       reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),   \
+                       reinterpret_cast<float*>(ws.cand))
+    // mfma_sched 4 (default; also 0 / 2 on a bf16 index): the pipelined kernel for long append passes; short ones (below
+    // ~500 tiles per CU = 8M rows) are dominated by candidate handling, where two waves per SIMD hide each other's slow
+    // paths, and go to the 8-wave kernel like the sample passes (measured full pass, 256 queries: 40M rows 7.43 vs
+    // 7.82 ms, 12.5M 2.47 vs 2.53, 4M 0.91 vs 0.87, 1M 0.34 vs 0.28 ms).  5: pipelined kernel for every pass (tests).
+    // 1: 8-wave kernel only.
+    const int v = g_batched_sched;
+    const bool pipe = v >= 5 || (v != 1 && !DENSE && n_tiles >= (1u << 17));
+    if (!pipe)
+        hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8, BF16>), dim3(blocks), dim3(512), 0, stream,
+                           reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
+                           reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
+                           reinterpret_cast<float*>(ws.cand));
+    else if (!BF16 && !DENSE && v == 41) DAWN_PIPE_LAUNCH(1);   // 41..55: timing experiments, parts switched off
+    else if (!BF16 && !DENSE && v == 42) DAWN_PIPE_LAUNCH(2);
+    else if (!BF16 && !DENSE && v == 43) DAWN_PIPE_LAUNCH(3);
+    else if (!BF16 && !DENSE && v == 44) DAWN_PIPE_LAUNCH(4);
+    else if (!BF16 && !DENSE && v == 47) DAWN_PIPE_LAUNCH(7);
+    else if (!BF16 && !DENSE && v == 48) DAWN_PIPE_LAUNCH(8);
+    else if (!BF16 && !DENSE && v == 55) DAWN_PIPE_LAUNCH(15);
+    else if (!BF16 && !DENSE && v == 54) DAWN_PIPE_LAUNCH(16);
+    else DAWN_PIPE_LAUNCH(0);
+#undef DAWN_PIPE_LAUNCH
+}
+
+// rows: the filter's row source; rt: its row type (ROW_F32: converted on the fly by the lockstep kernel; ROW_F16S /
+// ROW_BF16: fragment-ordered tiles)
 template <bool DENSE>
 static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                         const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     if (n_tiles == 0) return;
-    if (rt == ROW_F16S) {  // f16 shadow tiles: LDS-DMA kernel
-        const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-#define DAWN_PIPE_LAUNCH(DBG_)                                                                                          \
-    hipLaunchKernelGGL((scan_f16_pipe_kernel<DENSE, DBG_>), dim3(blocks), dim3(256), 0, stream,                         \
-                       reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,                  \
-                       reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),   \
-                       reinterpret_cast<float*>(ws.cand))
-        // mfma_sched 4 (default): the pipelined kernel for long append passes; short ones (below ~500 tiles per CU =
-        // 8M rows) are dominated by candidate handling, where two waves per SIMD hide each other's slow paths, and go
-        // to the 8-wave kernel like the sample passes (measured full pass, 256 queries: 40M rows 7.43 vs 7.82 ms,
-        // 12.5M 2.47 vs 2.53, 4M 0.91 vs 0.87, 1M 0.34 vs 0.28 ms).  5: pipelined kernel for every pass (tests).  1: 8-wave.
-        const int v = g_batched_sched;
-        const bool pipe = v >= 5 || (v == 4 && !DENSE && n_tiles >= (1u << 17));
-        if (!pipe)
-            hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8>), dim3(blocks), dim3(512), 0, stream,
-                               reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
-                               reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
-                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
-        else if (!DENSE && v == 41) DAWN_PIPE_LAUNCH(1);   // 41..55: timing experiments, parts switched off
-        else if (!DENSE && v == 42) DAWN_PIPE_LAUNCH(2);
-        else if (!DENSE && v == 43) DAWN_PIPE_LAUNCH(3);
-        else if (!DENSE && v == 44) DAWN_PIPE_LAUNCH(4);
-        else if (!DENSE && v == 47) DAWN_PIPE_LAUNCH(7);
-        else if (!DENSE && v == 48) DAWN_PIPE_LAUNCH(8);
-        else if (!DENSE && v == 55) DAWN_PIPE_LAUNCH(15);
-        else if (!DENSE && v == 54) DAWN_PIPE_LAUNCH(16);
-        else DAWN_PIPE_LAUNCH(0);
-#undef DAWN_PIPE_LAUNCH
-    } else if (rt == ROW_BF16) launch_pass_rt<DENSE, 1>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    if (rt == ROW_F16S) launch_pass_dma<DENSE, false>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else if (rt == ROW_BF16) launch_pass_dma<DENSE, true>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else launch_pass_rt<DENSE, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
@@ -1168,7 +1197,6 @@ static hipError_t set_lds_attr_rt() {
 int batched_init() {
     if (g_lds_attr_set) return 0;
     hipError_t e = set_lds_attr_rt<0>();
-    if (e == hipSuccess) e = set_lds_attr_rt<1>();
     const void* tails[] = {reinterpret_cast<const void*>(select_rescore_kernel<true, 0>),
                            reinterpret_cast<const void*>(select_rescore_kernel<false, 0>),
                            reinterpret_cast<const void*>(select_rescore_kernel<true, 1>),
@@ -1212,8 +1240,17 @@ void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_r
                        reinterpret_cast<half8*>(d_shadow), t0, (uint32_t)n_valid);
 }
 
+// queries -> the filter's 16-bit operand images: bf16 for a bf16 index (frt = ROW_BF16), scaled f16 otherwise
+static void prep_queries(const float* d_q, int B, const BatchWorkspace& ws, int frt, hipStream_t stream) {
+    unsigned short* qh = reinterpret_cast<unsigned short*>(ws.qh);
+    if (frt == ROW_BF16)
+        hipLaunchKernelGGL(prep_queries_kernel<true>, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, qh);
+    else
+        hipLaunchKernelGGL(prep_queries_kernel<false>, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, qh);
+}
+
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+    prep_queries(d_q, B, ws, ROW_F16S, stream);
 }
 
 // Timing hook: the full append pass alone (thresholds ws.tau as left by the last search), `iters` times.
@@ -1232,7 +1269,7 @@ void launch_batched_dense_scores(const void* d_frows, int frt, uint32_t n_rows, 
                                  const BatchWorkspace& ws, int grid, hipStream_t stream) {
     const void* d_x = d_frows;
     const int dtype = frt;
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+    prep_queries(d_q, B, ws, frt, stream);
     const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
     launch_pass<true>(d_x, dtype, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
 }
@@ -1244,7 +1281,7 @@ static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     // the bf16-rounded rows may exceed the is_normalized band by 2^-8: scale the bound on sum|q_i x_i| accordingly
-    const float eps = dtype == ROW_BF16 ? FILTER_EPS_F16 * 1.004f : FILTER_EPS_F16;
+    const float eps = dtype == ROW_BF16 ? FILTER_EPS_BF16_MFMA : FILTER_EPS_F16;
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x,
                            d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
@@ -1264,7 +1301,7 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
     const BatchPlan pl = plan_batched(n_rows);
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(BATCH_QT * EM / 256), dim3(256), 0, stream, d_q, B, ws.qh);
+    prep_queries(d_q, B, ws, frt, stream);
     if (pl.dense_only) {
         if (ev0) (void)hipEventRecord(ev0, stream);
         launch_pass<true>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);

@@ -118,107 +118,6 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
     }
 }
 
-// bf16 index (DAWN_DTYPE_BF16): a "quad" = 4 consecutive rows = 3072 contiguous bytes = 3 wave-wide 16-B loads
-// (192 chunks of 8 bf16; chunk C = 64*load + lane belongs to row C/48, k = 8*(C%48)..+7):
-//   load 0: lanes 0..47 row 0 | 48..63 row 1 (chunks 0..15)      load 1: lanes 0..31 row 1 (16..47) | 32..63 row 2 (0..31)
-//   load 2: lanes 0..15 row 2 (32..47) | 16..63 row 3
-// Products are exact-f32 (widened row x f32 query), 8-deep FMA chain per lane, then the same DPP tree: the f32
-// filter's error bound applies unchanged.
-__device__ __forceinline__ float dot8_bf16(const u32x4& w, const f32x4& q0, const f32x4& q1) {
-    float acc = bf16_lo(w.x) * q0.x;
-    acc = __builtin_fmaf(bf16_hi(w.x), q0.y, acc);
-    acc = __builtin_fmaf(bf16_lo(w.y), q0.z, acc);
-    acc = __builtin_fmaf(bf16_hi(w.y), q0.w, acc);
-    acc = __builtin_fmaf(bf16_lo(w.z), q1.x, acc);
-    acc = __builtin_fmaf(bf16_hi(w.z), q1.y, acc);
-    acc = __builtin_fmaf(bf16_lo(w.w), q1.z, acc);
-    acc = __builtin_fmaf(bf16_hi(w.w), q1.w, acc);
-    return acc;
-}
-
-template <int QB, int U>
-__global__ __launch_bounds__(1024) void scan_filter_bf16_kernel(const u32x4* __restrict__ x, uint32_t n_rows,
-                                                                const float* __restrict__ q,
-                                                                float* __restrict__ out_s,
-                                                                uint32_t* __restrict__ out_p,
-                                                                uint32_t q_stride_lists) {
-    __shared__ float sh_s[16][LIST];
-    __shared__ uint32_t sh_p[16][LIST];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
-    const uint32_t gwave = blockIdx.x * nwaves + wave;
-    const uint32_t total_waves = gridDim.x * nwaves;
-    const uint32_t n_quads = (n_rows + 3u) >> 2;
-    const uint32_t n_chunks = (n_quads + U - 1) / U;
-
-    // query fragments for this lane's chunk position in each of the three loads
-    const int c0 = lane < 48 ? lane : lane - 48;
-    const int c1 = lane < 32 ? 16 + lane : lane - 32;
-    const int c2 = lane < 16 ? 32 + lane : lane - 16;
-    f32x4 qf[QB][6];
-    float ls[QB], tau[QB];
-    uint32_t lp[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const f32x4* qq = reinterpret_cast<const f32x4*>(q + b * EM);
-        qf[b][0] = qq[2 * c0];
-        qf[b][1] = qq[2 * c0 + 1];
-        qf[b][2] = qq[2 * c1];
-        qf[b][3] = qq[2 * c1 + 1];
-        qf[b][4] = qq[2 * c2];
-        qf[b][5] = qq[2 * c2 + 1];
-        ls[b] = NEG_INF;
-        lp[b] = NO_POS;
-        tau[b] = NEG_INF;
-    }
-    const bool a48 = lane < 48, a32 = lane < 32, a16 = lane < 16;
-
-    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
-        const u32x4* p = x + (size_t)c * (U * 192) + lane;
-        u32x4 v[U][3];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v[u][0] = __builtin_nontemporal_load(p + u * 192);
-            v[u][1] = __builtin_nontemporal_load(p + u * 192 + 64);
-            v[u][2] = __builtin_nontemporal_load(p + u * 192 + 128);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t r0 = (c * U + u) * 4u;
-#pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                const float d0 = dot8_bf16(v[u][0], qf[b][0], qf[b][1]);
-                const float d1 = dot8_bf16(v[u][1], qf[b][2], qf[b][3]);
-                const float d2 = dot8_bf16(v[u][2], qf[b][4], qf[b][5]);
-                float sc[4];
-                sc[0] = read_lane63(wave_sum_lane63(a48 ? d0 : 0.f));
-                sc[1] = read_lane63(wave_sum_lane63((a48 ? 0.f : d0) + (a32 ? d1 : 0.f)));
-                sc[2] = read_lane63(wave_sum_lane63((a32 ? 0.f : d1) + (a16 ? d2 : 0.f)));
-                sc[3] = read_lane63(wave_sum_lane63(a16 ? 0.f : d2));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t r = r0 + j;
-                    const float sj = (r < n_rows && sc[j] == sc[j]) ? sc[j] : NEG_INF;
-                    if (sj > tau[b]) {
-                        wave_insert(ls[b], lp[b], sj, r, lane);
-                        tau[b] = read_lane63(ls[b]);
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
-        if (wave == 0) {
-            const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
-            out_s[o] = ls[b];
-            out_p[o] = lp[b];
-        }
-    }
-}
-
 // f16 SHADOW of an f32 index (ROW_F16S, kernels.hpp: f16(2^8 x), 768 B per row, tiles in MFMA-fragment order) — the
 // streaming filter for 1..8 queries.  A wave-wide 16-B load of a 1-KiB fragment IS the A operand of
 // v_mfma_f32_32x32x16_f16 (32 rows x 16 k), so the rows go HBM -> VGPR -> matrix core with no LDS, no cross-lane
@@ -228,13 +127,36 @@ __global__ __launch_bounds__(1024) void scan_filter_bf16_kernel(const u32x4* __r
 // decides whether the slow path runs: ballot, read the hit, insert it into the wave's sorted 64-entry list.
 // Loads run PD fragments (PD KiB per wave) ahead of the MFMAs in a register ring that continues across sub-tiles.
 // Half the bytes of the f32 rows; exactness comes from the rescore tail on the f32 rows (error bound FILTER_EPS_F16).
+//
+// BF16 = true: the same kernel over a bf16 INDEX (ROW_BF16, rows unscaled) on v_mfma_f32_32x32x16_bf16.  The rows are
+// exact; the query enters twice — column c holds hi = bf16(q), column 8 + c holds lo = bf16(q - hi) — and a lane adds
+// the two accumulators (DPP row_shl:8) before the test: the filter then errs like an f32 one (FILTER_EPS_BF16_STREAM),
+// for 16 extra VALU instructions per 32 rows.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// q: the n_q <= QB queries, f32 [n_q][384]; scaled by 2^8 and rounded to f16 here exactly as prep_queries_kernel
-// (scan_batched.hip) does for the matrix-core path
-template <int QB, int PD, bool BURST>
-__global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __restrict__ x, uint32_t n_rows,
+template <bool BF16>
+__device__ __forceinline__ f32x16_t mfma_16bit(const u32x4& a, const u32x4& b, const f32x16_t& c) {
+    if (BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+
+// f32 -> the 16-bit operand element: f16(2^8 v) for the shadow, bf16 hi / lo part for a bf16 index
+__device__ __forceinline__ uint32_t f16s_bits(float v) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(v * 256.0f));
+}
+__device__ __forceinline__ uint32_t bf16_part(float v, bool lo_part) {
+    const uint32_t hi = f32_to_bf16_rne(v);
+    if (!lo_part) return hi;
+    return f32_to_bf16_rne(v - __builtin_bit_cast(float, hi << 16));  // exact difference, then rounded
+}
+
+// q: the n_q <= QB queries, f32 [n_q][384], converted here (f16 path: exactly as prep_queries_kernel of
+// scan_batched.hip does for the matrix-core path)
+template <int QB, int PD, bool BURST, bool BF16>
+__global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const u32x4* __restrict__ x, uint32_t n_rows,
                                                                 const float* __restrict__ q, int n_q,
                                                                 float* __restrict__ out_s,
                                                                 uint32_t* __restrict__ out_p,
@@ -250,26 +172,29 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
     const uint32_t n_sub = (n_rows + 31u) >> 5;  // 32-row sub-tiles = 24 fragments = 24 KiB each
     const uint32_t c = lane & 31, h = lane >> 5;
 
-    // B operand: column c = query c (zero beyond n_q), lane (h, c) holds k = 16s + 8h .. +7 of k-step s
-    half8_t qf[24];
+    // B operand: column c = query c (zero beyond n_q; BF16: columns 8.. = the lo parts), lane (h, c) holds
+    // k = 16s + 8h .. +7 of k-step s
+    u32x4 qf[24];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)0.0f;
-    }
-    if ((int)c < n_q) {
-        const f32x4* qc = reinterpret_cast<const f32x4*>(q + (size_t)c * EM);
+    for (int s = 0; s < 24; ++s) qf[s] = u32x4{0u, 0u, 0u, 0u};
+    const int qcol = BF16 ? (int)(c & 7u) : (int)c;       // the query this column belongs to
+    const bool lo_part = BF16 && c >= 8;
+    if (qcol < n_q && (BF16 ? c < 16 : true)) {
+        const f32x4* qc = reinterpret_cast<const f32x4*>(q + (size_t)qcol * EM);
 #pragma unroll
         for (int s = 0; s < 24; ++s) {
-            const f32x4 lo = qc[4 * s + 2 * h], hi = qc[4 * s + 2 * h + 1];
-            qf[s][0] = (_Float16)(lo.x * 256.0f);
-            qf[s][1] = (_Float16)(lo.y * 256.0f);
-            qf[s][2] = (_Float16)(lo.z * 256.0f);
-            qf[s][3] = (_Float16)(lo.w * 256.0f);
-            qf[s][4] = (_Float16)(hi.x * 256.0f);
-            qf[s][5] = (_Float16)(hi.y * 256.0f);
-            qf[s][6] = (_Float16)(hi.z * 256.0f);
-            qf[s][7] = (_Float16)(hi.w * 256.0f);
+            const f32x4 v0 = qc[4 * s + 2 * h], v1 = qc[4 * s + 2 * h + 1];
+            if (BF16) {
+                qf[s].x = bf16_part(v0.x, lo_part) | (bf16_part(v0.y, lo_part) << 16);
+                qf[s].y = bf16_part(v0.z, lo_part) | (bf16_part(v0.w, lo_part) << 16);
+                qf[s].z = bf16_part(v1.x, lo_part) | (bf16_part(v1.y, lo_part) << 16);
+                qf[s].w = bf16_part(v1.z, lo_part) | (bf16_part(v1.w, lo_part) << 16);
+            } else {
+                qf[s].x = f16s_bits(v0.x) | (f16s_bits(v0.y) << 16);
+                qf[s].y = f16s_bits(v0.z) | (f16s_bits(v0.w) << 16);
+                qf[s].z = f16s_bits(v1.x) | (f16s_bits(v1.y) << 16);
+                qf[s].w = f16s_bits(v1.z) | (f16s_bits(v1.w) << 16);
+            }
         }
     }
     float ls[QB], tau[QB];
@@ -280,20 +205,20 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
         lp[b] = NO_POS;
         tau[b] = NEG_INF;
     }
-    const float unscale = 1.0f / 65536.0f;
-    // the lane's threshold in the units of the accumulator (scores x 2^16); +inf in the padding columns
+    const float unscale = BF16 ? 1.0f : 1.0f / 65536.0f;
+    // the lane's threshold in the units of the accumulator (f16: scores x 2^16); +inf in the padding columns
     float tau_l = (int)c < n_q ? NEG_INF : __builtin_inff();
 
     uint32_t t = gwave;
     if (t < n_sub) {
-        const half8_t* p = x + (size_t)t * (24 * 64) + lane;
-        half8_t a[PD];
+        const u32x4* p = x + (size_t)t * (24 * 64) + lane;
+        u32x4 a[PD];
 #pragma unroll
         for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
         for (;;) {
             const uint32_t tn = t + total_waves;
             // the ring runs into the wave's next sub-tile (the last one re-reads its own first fragments: no branch)
-            const half8_t* pn = tn < n_sub ? x + (size_t)tn * (24 * 64) + lane : p;
+            const u32x4* pn = tn < n_sub ? x + (size_t)tn * (24 * 64) + lane : p;
             f32x16_t acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -308,7 +233,7 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int d = 0; d < PD; ++d)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[d], qf[s0 + d], acc, 0, 0, 0);
+                        acc = mfma_16bit<BF16>(a[d], qf[s0 + d], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -317,13 +242,21 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
             } else {
 #pragma unroll
                 for (int s = 0; s < 24; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % PD], qf[s], acc, 0, 0, 0);
+                    acc = mfma_16bit<BF16>(a[s % PD], qf[s], acc);
                     if (s + PD < 24) a[s % PD] = __builtin_nontemporal_load(p + (s + PD) * 64);
                     else a[s % PD] = __builtin_nontemporal_load(pn + (s + PD - 24) * 64);
                     __builtin_amdgcn_sched_barrier(0);  // keep every load PD steps ahead of its use
                 }
             }
             // this lane: D[row = 32t + (e&3) + 8*(e>>2) + 4h][query c]
+            if (BF16) {  // hi + lo columns: lane c <- lane c + 8 (same 16-lane row)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float ae = acc[e];
+                    acc[e] = ae + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ae), 0x108,
+                                                                                        0xf, 0xf, true));
+                }
+            }
             float mx = acc[0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
@@ -355,7 +288,7 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
                 }
 #pragma unroll
                 for (int b = 0; b < QB; ++b)
-                    if ((int)c == b && b < n_q) tau_l = tau[b] * 65536.0f;
+                    if ((int)c == b && b < n_q) tau_l = tau[b] * (BF16 ? 1.0f : 65536.0f);
             }
             if (tn >= n_sub) break;
             t = tn;
@@ -376,14 +309,14 @@ __global__ __launch_bounds__(512) void scan_filter_f16s_kernel(const half8_t* __
     }
 }
 
-template <int QB>
+template <int QB, bool BF16>
 static void launch_filter_f16s_qb(const void* d_shadow, uint32_t n_rows, const float* q8, int n_q, float* cand_s,
                                   uint32_t* cand_p, const ScanGeom& g, hipStream_t stream) {
-    const half8_t* x8 = reinterpret_cast<const half8_t*>(d_shadow);
+    const u32x4* x8 = reinterpret_cast<const u32x4*>(d_shadow);
     // geom.unroll picks the load schedule: 1..4 -> ring of 6 / 8 / 12 / 24 fragments running ahead of the MFMAs;
     // 11..14 -> bursts of 6 / 8 / 12 / 24 fragments (KiB per wave) requested back to back
 #define DAWN_F16S_LAUNCH(PD_, BURST_)                                                                              \
-    hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, PD_, BURST_>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, \
+    hipLaunchKernelGGL((scan_filter_f16s_kernel<QB, PD_, BURST_, BF16>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, \
                        n_rows, q8, n_q, cand_s, cand_p, (uint32_t)g.blocks)
     switch (g.unroll) {
         case 1: DAWN_F16S_LAUNCH(6, false); break;
@@ -398,8 +331,9 @@ static void launch_filter_f16s_qb(const void* d_shadow, uint32_t n_rows, const f
 #undef DAWN_F16S_LAUNCH
 }
 
-// Streaming filter over the f16 shadow, 8 queries per pass; d_q = the f32 queries [B][384].
-void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const float* d_q, int B, float* cand_s,
+// Streaming filter over fragment-ordered 16-bit rows (rt = ROW_F16S: the f16 shadow of an f32 index; ROW_BF16: a bf16
+// index), 8 queries per pass; d_q = the f32 queries [B][384].
+void launch_scan_filter_f16s(const void* d_shadow, int rt, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                              uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, stream);
     const size_t per_q = (size_t)g.blocks * LIST;
@@ -408,23 +342,17 @@ void launch_scan_filter_f16s(const void* d_shadow, uint32_t n_rows, const float*
         const float* q = d_q + (size_t)b * EM;
         float* cs = cand_s + (size_t)b * per_q;
         uint32_t* cp = cand_p + (size_t)b * per_q;
-        if (nb <= 1) launch_filter_f16s_qb<1>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
-        else if (nb <= 4) launch_filter_f16s_qb<4>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
-        else launch_filter_f16s_qb<8>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+        if (rt == ROW_BF16) {
+            if (nb <= 1) launch_filter_f16s_qb<1, true>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+            else if (nb <= 4) launch_filter_f16s_qb<4, true>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+            else launch_filter_f16s_qb<8, true>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+        } else {
+            if (nb <= 1) launch_filter_f16s_qb<1, false>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+            else if (nb <= 4) launch_filter_f16s_qb<4, false>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+            else launch_filter_f16s_qb<8, false>(d_shadow, n_rows, q, nb, cs, cp, g, stream);
+        }
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
-}
-
-template <int QB>
-static void launch_filter_bf16_qb(const void* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
-                                  const ScanGeom& g, hipStream_t stream) {
-    const u32x4* x4 = reinterpret_cast<const u32x4*>(d_x);
-    if (g.unroll <= 1)
-        hipLaunchKernelGGL((scan_filter_bf16_kernel<QB, 1>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, d_q,
-                           cand_s, cand_p, (uint32_t)g.blocks);
-    else
-        hipLaunchKernelGGL((scan_filter_bf16_kernel<QB, 2>), dim3(g.blocks), dim3(g.threads), 0, stream, x4, n_rows, d_q,
-                           cand_s, cand_p, (uint32_t)g.blocks);
 }
 
 template <int QB, int U>
@@ -443,8 +371,10 @@ static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q
     else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
 }
 
+// f32 rows streamed directly (no shadow): 1 / 2 / 4 queries per pass
 void launch_scan_filter(const void* d_xv, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    (void)dtype;  // ROW_F32 (a bf16 index streams through launch_scan_filter_f16s)
     const float* d_x = reinterpret_cast<const float*>(d_xv);
     if (ev0) (void)hipEventRecord(ev0, stream);
     int b = 0;
@@ -455,16 +385,13 @@ void launch_scan_filter(const void* d_xv, int dtype, uint32_t n_rows, const floa
         float* cs = cand_s + (size_t)b * per_q;
         uint32_t* cp = cand_p + (size_t)b * per_q;
         if (rem >= 4) {
-            if (dtype == ROW_BF16) launch_filter_bf16_qb<4>(d_xv, n_rows, q, cs, cp, g, stream);
-            else launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
             b += 4;
         } else if (rem >= 2) {
-            if (dtype == ROW_BF16) launch_filter_bf16_qb<2>(d_xv, n_rows, q, cs, cp, g, stream);
-            else launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
             b += 2;
         } else {
-            if (dtype == ROW_BF16) launch_filter_bf16_qb<1>(d_xv, n_rows, q, cs, cp, g, stream);
-            else launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
             b += 1;
         }
     }
@@ -789,42 +716,49 @@ __global__ void synth_write_kernel(uint64_t key, uint64_t first_row, uint32_t n,
 }
 
 // f32 rows -> bf16 rows (round to nearest even), 8 values per thread; and back (exact widening)
-__global__ void rows_f32_to_bf16_kernel(const f32x4* __restrict__ in, u32x4* __restrict__ out, size_t n_chunks8) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 a = in[2 * i], b = in[2 * i + 1];
+// staged f32 rows [n][384] -> rows first_row.. of the fragment-ordered bf16 index (round to nearest even).  One block
+// per 64 staged rows; consecutive threads take consecutive rows of one 16-B chunk column: 512-B contiguous writes.
+__global__ __launch_bounds__(256) void rows_f32_to_bf16_kernel(const f32x4* __restrict__ in, u32x4* __restrict__ x,
+                                                              size_t first_row, size_t n_rows) {
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * ROW_C8; idx += 256) {
+        const size_t r = r0 + (idx & 63);
+        const int c = idx >> 6;
+        if (r >= n_rows) continue;
+        const f32x4 a = in[r * ROW_F4 + 2 * c], b = in[r * ROW_F4 + 2 * c + 1];
         u32x4 w;
         w.x = f32_to_bf16_rne(a.x) | (f32_to_bf16_rne(a.y) << 16);
         w.y = f32_to_bf16_rne(a.z) | (f32_to_bf16_rne(a.w) << 16);
         w.z = f32_to_bf16_rne(b.x) | (f32_to_bf16_rne(b.y) << 16);
         w.w = f32_to_bf16_rne(b.z) | (f32_to_bf16_rne(b.w) << 16);
-        out[i] = w;
+        x[frag_chunk(first_row + r, c)] = w;
     }
 }
 
-__global__ void rows_bf16_to_f32_kernel(const u32x4* __restrict__ in, f32x4* __restrict__ out, size_t n_chunks8) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_chunks8; i += (size_t)gridDim.x * blockDim.x) {
-        const u32x4 w = in[i];
-        out[2 * i] = f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
-        out[2 * i + 1] = f32x4{bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w)};
+// ... and back: rows first_row.. of the index -> f32 rows [n][384] (exact widening)
+__global__ __launch_bounds__(256) void rows_bf16_to_f32_kernel(const u32x4* __restrict__ x, size_t first_row,
+                                                              f32x4* __restrict__ out, size_t n_rows) {
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * ROW_C8; idx += 256) {
+        const size_t r = r0 + (idx & 63);
+        const int c = idx >> 6;
+        if (r >= n_rows) continue;
+        const u32x4 w = x[frag_chunk(first_row + r, c)];
+        out[r * ROW_F4 + 2 * c] = f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+        out[r * ROW_F4 + 2 * c + 1] = f32x4{bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w)};
     }
 }
 
-void launch_rows_f32_to_bf16(const float* d_in, void* d_out, size_t n_rows, hipStream_t stream) {
+void launch_rows_f32_to_bf16(const float* d_in, void* d_x, size_t first_row, size_t n_rows, hipStream_t stream) {
     if (n_rows == 0) return;
-    const size_t n = n_rows * ROW_C8;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<u32x4*>(d_out), n);
+    hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_in), reinterpret_cast<u32x4*>(d_x), first_row, n_rows);
 }
 
-void launch_rows_bf16_to_f32(const void* d_in, float* d_out, size_t n_rows, hipStream_t stream) {
+void launch_rows_bf16_to_f32(const void* d_x, size_t first_row, float* d_out, size_t n_rows, hipStream_t stream) {
     if (n_rows == 0) return;
-    const size_t n = n_rows * ROW_C8;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(rows_bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const u32x4*>(d_in), reinterpret_cast<f32x4*>(d_out), n);
+    hipLaunchKernelGGL(rows_bf16_to_f32_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(256), 0, stream,
+                       reinterpret_cast<const u32x4*>(d_x), first_row, reinterpret_cast<f32x4*>(d_out), n_rows);
 }
 
 static uint64_t host_splitmix64(uint64_t z) {

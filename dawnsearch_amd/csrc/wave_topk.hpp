@@ -164,11 +164,19 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-__device__ __forceinline__ float exact_dot_seq_bf16(const float* __restrict__ qv, const u32x4* __restrict__ row) {
+// Slot (in 16-B units from the start of the array) of chunk c (elements 8c..8c+7) of row `row` in a fragment-ordered
+// 16-bit row array (ROW_BF16 / ROW_F16S, kernels.hpp).  Consecutive rows of a 32-row sub-tile are consecutive slots.
+__device__ __forceinline__ size_t frag_chunk(size_t row, int c) {
+    return (row >> 6) * 3072 + (((row >> 5) & 1) * 24 + (c >> 1)) * 64 + (c & 1) * 32 + (row & 31);
+}
+
+// bf16 row given as 48 16-B chunks, chunk c at row[c * stride] (stride in 16-B units: 1 = a contiguous copy of the row)
+__device__ __forceinline__ float exact_dot_seq_bf16(const float* __restrict__ qv, const u32x4* __restrict__ row,
+                                                    int stride = 1) {
     float acc = 0.0f;
 #pragma unroll 2
     for (int c = 0; c < ROW_C8; ++c) {
-        const u32x4 w = row[c];
+        const u32x4 w = row[(size_t)c * stride];
         const f32x4 q0 = reinterpret_cast<const f32x4*>(qv)[2 * c];
         const f32x4 q1 = reinterpret_cast<const f32x4*>(qv)[2 * c + 1];
         acc = __fadd_rn(acc, __fmul_rn(q0.x, bf16_lo(w.x)));
@@ -186,7 +194,7 @@ __device__ __forceinline__ float exact_dot_seq_bf16(const float* __restrict__ qv
 // Reference-order exact dot of query qv with row `p` of an index of row type RT (0 = f32, 1 = bf16).
 template <int RT>
 __device__ __forceinline__ float exact_dot_row(const float* __restrict__ qv, const void* __restrict__ x, size_t p) {
-    if (RT == 1) return exact_dot_seq_bf16(qv, reinterpret_cast<const u32x4*>(x) + p * ROW_C8);
+    if (RT == 1) return exact_dot_seq_bf16(qv, reinterpret_cast<const u32x4*>(x) + frag_chunk(p, 0), 32);
     return exact_dot_seq(qv, reinterpret_cast<const f32x4*>(x) + p * ROW_F4);
 }
 
@@ -217,7 +225,8 @@ __device__ __forceinline__ float block_exact_dots(const float* __restrict__ qv, 
         const int r = i / S::CH, c = i % S::CH;
         const uint32_t row = sh_rows[r];
         if (row != NO_POS)
-            *reinterpret_cast<u32x4*>(stage + r * S::STRIDE + c * 16) = xr[(size_t)row * S::CH + c];
+            *reinterpret_cast<u32x4*>(stage + r * S::STRIDE + c * 16) =
+                RT == 1 ? xr[frag_chunk(row, c)] : xr[(size_t)row * S::CH + c];
     }
     __syncthreads();
     float dot = 0.0f;
