@@ -110,3 +110,47 @@ def test_bf16_forced_exact_pass_and_gate_and_save_load(dawn, oracle):
         assert idx2.size() == n
         lab, dd = idx2.search(Q[1], 20)
         _same(lab, dd, *want[1])
+
+
+def _hard_rows(dawn):
+    """Random unit rows, near-duplicates of a query and sparse rows with tiny components."""
+    rng = np.random.default_rng(11)
+    base = synth.unit_rows(1, 0, 5000)
+    sparse = np.zeros((600, 384), dtype=np.float32)
+    for i in range(600):
+        sparse[i, rng.integers(0, 384, 3)] = rng.standard_normal(3).astype(np.float32)
+        sparse[i] += (1e-6 * rng.standard_normal(384)).astype(np.float32)
+        sparse[i] = dawn.normalize(sparse[i])
+    return np.concatenate([base, sparse])
+
+
+def test_bf16_filter_errors_within_their_bounds(dawn):
+    """The certificates of a bf16 index assume |filter score - exact dot over the STORED (bf16) rows| <=
+    FILTER_EPS_BF16_STREAM = 7e-5 for the streaming filter (query as hi + lo bf16 columns) and <= FILTER_EPS_BF16_MFMA =
+    4.1e-3 for the matrix-core pass (one bf16 image of the query): measured against float64."""
+    rows = _hard_rows(dawn)
+    idx = dawn.VectorIndex(0, dtype="bf16")
+    idx.add_batch(np.arange(1, len(rows) + 1, dtype=np.uint64), rows)
+    stored = synth.round_bf16(rows).astype(np.float64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 24), synth.planted_queries(1, [5, 77, 4000], 3), rows[5000:5005]])
+    # matrix-core pass: dense scores of every row
+    f = idx.debug_filter_scores(Q)
+    exact = Q.astype(np.float64) @ stored.T
+    assert f.shape == exact.shape
+    err = np.abs(f.astype(np.float64) - exact).max()
+    assert err < 4.1e-3 / 2, err
+    # streaming filter: whatever it lists carries the hi+lo score
+    worst = 0.0
+    for q in Q[:8]:
+        sc, rr = idx.debug_stream_lists(q)
+        valid = rr != 0xFFFFFFFF
+        got = rr[valid].astype(np.int64)
+        assert len(np.unique(got)) == len(got)
+        ex = stored[got] @ q.astype(np.float64)
+        worst = max(worst, np.abs(sc[valid].astype(np.float64) - ex).max())
+        # ... and the lists hold every row that clears the 64th best by twice the bound
+        allx = stored @ q.astype(np.float64)
+        order = np.argsort(-allx, kind="stable")
+        need = order[:64][allx[order[:64]] > allx[order[63]] + 2 * 7e-5]
+        assert set(need.tolist()) <= set(got.tolist())
+    assert worst < 7e-5 / 2, worst
