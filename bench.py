@@ -150,7 +150,7 @@ def main():
         """Passes over the index rows made by the dominant kernel for a batch of Bq queries."""
         if Bq >= 9:
             return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
-        return sum(1 for _ in range(0, Bq, 4)) if Bq > 1 else 1   # streaming path: up to 4 queries per pass
+        return -(-Bq // 8)                # streaming path over 16-bit fragments: 8 queries per pass
 
     def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False, f32_stream=False):
         """`steps` timed searches of a Bq-query batch.  Returns qps (max over ranks), ms/step and the mean

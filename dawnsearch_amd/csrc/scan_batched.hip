@@ -935,12 +935,17 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
 // ------------------------------------------------------------------------------------------------
 // DENSE: `count` scores dense_q[0..count); else: wave w takes segment w of the query's candidate buffer (seg_cnt_q[w]
 // entries, clamped to SEG_CAP) — the kernels run 16 waves = BATCH_CAND_SEGS.
+// keep: only the best `keep` (<= 64) entries of the result are needed (tau_select wants the m-th largest): after its
+// first chunk a wave then inserts just the elements that beat its keep-th best (a handful per chunk) instead of
+// sorting and merging every chunk of 64.
 template <bool DENSE>
 __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, const uint2* __restrict__ cand_q,
                                             const uint32_t* __restrict__ seg_cnt_q, uint32_t count, float& s, uint32_t& p,
-                                            float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves) {
+                                            float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves,
+                                            uint32_t keep = LIST) {
     s = NEG_INF;
     p = NO_POS;
+    bool first = true;
     if (!DENSE) {
         count = seg_cnt_q[wave];
         if (count > SEG_CAP) count = SEG_CAP;
@@ -964,6 +969,19 @@ __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, c
                 row = v.y;
             }
         }
+        if (!first && keep <= 32) {
+            const float bar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)keep - 1));
+            unsigned long long hits = __ballot(-d > bar);  // (fillers: d = +inf -> never)
+            while (hits) {
+                const int l = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                const float sc = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), l));
+                const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)row, l);
+                wave_insert(s, p, sc, rw, lane);
+            }
+            continue;
+        }
+        first = false;
         sort64_asc(d, row, lane);
         // merge64 wants the other list reversed: lane i <- other[63 - i]
         const float os = -__shfl(d, 63 - lane);
@@ -990,7 +1008,7 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
     float s;
     uint32_t p;
     block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
-                       s, p, sh_s, sh_p, wave, lane, 16);
+                       s, p, sh_s, sh_p, wave, lane, 16, m);
     if (wave != 0) return;
     const uint32_t have = __popcll(__ballot(p != NO_POS));
     float t = NEG_INF;
