@@ -148,7 +148,7 @@ def main():
 
     def scan_passes(Bq):
         """Passes over the index rows made by the dominant kernel for a batch of Bq queries."""
-        if Bq >= 9:
+        if Bq >= 4:
             return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
         return -(-Bq // 8)                # streaming path over 16-bit fragments: 8 queries per pass
 
@@ -183,7 +183,7 @@ def main():
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
-            if Bq >= 9:
+            if Bq >= 4:
                 leg["mfma_TFLOPs"] = 2.0 * 256 * rows_here * 384 / (leg["scan_kernel_ms"] * 1e-3) / 1e12
                 leg["mfma_frac_f16_dense_peak"] = leg["mfma_TFLOPs"] / 2500.0
         if check_planted:
@@ -238,7 +238,7 @@ def main():
     elapsed_ms = head["ms_per_step"]
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
-    if B >= 9:
+    if B >= 4:
         kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 23)
                   else "scan_f16_dma_kernel<append> (f16 shadow tiles by LDS-DMA, 8 waves x 32 queries)")
     else:

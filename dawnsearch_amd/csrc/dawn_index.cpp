@@ -72,7 +72,11 @@ struct dawn_index {
     uint32_t* d_flags = nullptr;
     dawn::BatchWorkspace bws{nullptr, nullptr, nullptr, nullptr};  // matrix-core batched path
     int mfma_blocks = 256;   // one 8-wave workgroup per CU
-    int mfma_min_batch = 9;  // B >= this goes to the matrix-core filter
+    // B >= this goes to the matrix-core filter (sampled thresholds, one candidate buffer per query); below it the
+    // streaming filter keeps per-wave top-64 lists, whose warm-up grows with every extra query
+    // (tools/small_batch_paths.py, stream vs matrix-core ms — 1M rows: B=2 0.22 / 0.21, B=4 0.33 / 0.22, B=8 0.74 / 0.23;
+    // 100M rows: B=2 11.00 / 11.15, B=4 11.20 / 11.19, B=8 11.96 / 11.18; B=1 0.176 / 0.199 and 10.93 / 11.15)
+    int mfma_min_batch = 4;
     // host-API staging
     float* d_q = nullptr;
     uint64_t* d_labels = nullptr;

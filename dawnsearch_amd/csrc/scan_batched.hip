@@ -1,4 +1,4 @@
-// scan_batched.hip — batched query x index contraction on the matrix cores (gfx950), B = 9..256 per pass.
+// scan_batched.hip — batched query x index contraction on the matrix cores (gfx950), B = 4..256 per pass.
 //
 // One pass over the f32 index serves up to 256 queries: the row stream stays HBM-bound (1536 B/row read
 // once), the contraction runs on v_mfma_f32_32x32x16_f16 at 1/3 of its peak.  The f16 scores are a FILTER:

@@ -332,6 +332,29 @@ def test_stream_filter_lists_hold_the_top64(dawn, n):
         assert set(need.tolist()) <= set(got.tolist())
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n,B", [(4097, 2), (100_003, 3), (100_003, 5), (300_001, 8), (20_001, 13)])
+def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype):
+    """The streaming filter serves 1..3 queries by default; forced (mfma_min_batch) it takes any batch, 8 queries per
+    pass (QB = 1 / 4 / 8 variants, f16 shadow or bf16 index): same results as the oracle and as the default path."""
+    idx = dawn.VectorIndex(0, dtype=dtype)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    if dtype == "bf16":
+        x = synth.round_bf16(x)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B - 1] = synth.planted_queries(1, [n // 2], 6)[0]
+    l0, d0, f0 = idx.search_batch(Q, 10)
+    idx.set_option("mfma_min_batch", 100000)
+    l1, d1, f1 = idx.search_batch(Q, 10)
+    assert np.array_equal(l0, l1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(f0, f1)
+    for b in range(B):
+        _assert_same(l1[b], d1[b], *oracle.scan_topk(x, ids, Q[b], 10))
+    assert l1[B - 1][0] == n // 2 + 1
+    assert idx.stats()["fallbacks"] == 0
+
+
 def test_batched_duplicates_fall_back_and_stay_exact(dawn, oracle):
     base = synth.unit_rows(1, 0, 3000)
     rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])
