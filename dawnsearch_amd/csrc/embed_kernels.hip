@@ -139,7 +139,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    // XCD-aware tile order.  The grid is 1-D and a multiple of 8: the hardware deals consecutive workgroups to the 8
+    // XCDs round-robin, each with its own L2.  Workgroup b works on tile L = (b % 8) * (grid / 8) + b / 8, so one XCD gets
+    // a contiguous run of tiles — the N/64 tiles that share a 64-row strip of X sit on the SAME XCD back to back and the
+    // strip is fetched into one L2 once (dealt in plain order every strip was pulled into up to 8 L2s, and the MFMA
+    // phase of a K-step is about as long as an L2 miss).
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int tiles_n = N / GT;
+    if (tile >= tiles_n * ((M + GT - 1) / GT)) return;  // padding of the grid
+    const int m0 = (tile / tiles_n) * GT, n0 = (tile % tiles_n) * GT;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     // staging: thread -> rows lr, lr+32 ; 16-B column lc of the 32-wide K-step
     const int lr = tid >> 3, lc = (tid & 7) * 4;
@@ -282,7 +291,8 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
         if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
         if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
     }
-    dim3 grid(N / GT, (M + GT - 1) / GT), block(256);
+    const int n_tiles = (N / GT) * ((M + GT - 1) / GT);
+    dim3 grid((n_tiles + 7) / 8 * 8), block(256);  // 1-D, padded to the 8 XCDs (see the kernel)
     if (act == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, s, A, W, bias, Y, M, N, K);
     else if (act == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, s, A, W, bias, Y, M, N, K);
     else hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, block, 0, s, A, W, bias, Y, M, N, K);
