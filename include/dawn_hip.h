@@ -138,8 +138,17 @@ int dawn_index_debug_time_full_pass(dawn_index *idx, size_t B, int iters, double
 /* Test hook: per-workgroup candidate lists of the batch-1 streaming filter (scores descending, rows; [blocks][64]). */
 int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *out_scores, uint32_t *out_rows,
                                   size_t cap_blocks, size_t *n_blocks);
-/* Tuning knobs (tests sweep them; defaults are the tuned values): name in
- * {"scan_blocks","scan_threads","mfma_blocks","mfma_min_batch","force_fallback"}. */
+/* Tuning knobs (tests and tools sweep them; the defaults are the tuned values):
+ *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 4)
+ *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
+ *   "mfma_sched"       process-wide: 4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave
+ *                      kernel only, 0 / 2 = lockstep converting kernel on the f32 rows (2: with phase stamps),
+ *                      41..55 = timing experiments (parts of the pipelined kernel switched off: wrong results)
+ *   "f16_shadow"       0: an f32 index keeps no f16 shadow (filters read / convert the f32 rows)
+ *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of the shadow
+ *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
+ *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the 16-bit fragment stream
+ *   "force_fallback"   1: every query also takes the exact pass (tests) */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
 
 /* ------------------------------------------------------------------------------------------ */
