@@ -136,9 +136,12 @@ __device__ __forceinline__ void block_merge(float& s, uint32_t& p, float (*sh_s)
 }
 
 // Sequential, un-fused f32 dot in the reference's order (vector.rs:128-134): result += a[i]*b[i].
+// UNROLL: chunks fetched ahead of the dependent add chain (4 for rows in global memory: registers; 16 for rows staged in
+// LDS, where an un-prefetched read costs more than the four adds it feeds)
+template <int UNROLL = 4>
 __device__ __forceinline__ float exact_dot_seq(const float* __restrict__ qv, const f32x4* __restrict__ row) {
     float acc = 0.0f;
-#pragma unroll 4
+#pragma unroll UNROLL
     for (int c = 0; c < ROW_F4; ++c) {
         const f32x4 xv = row[c];
         const f32x4 qq = reinterpret_cast<const f32x4*>(qv)[c];
@@ -171,10 +174,11 @@ __device__ __forceinline__ size_t frag_chunk(size_t row, int c) {
 }
 
 // bf16 row given as 48 16-B chunks, chunk c at row[c * stride] (stride in 16-B units: 1 = a contiguous copy of the row)
+template <int UNROLL = 2>
 __device__ __forceinline__ float exact_dot_seq_bf16(const float* __restrict__ qv, const u32x4* __restrict__ row,
                                                     int stride = 1) {
     float acc = 0.0f;
-#pragma unroll 2
+#pragma unroll UNROLL
     for (int c = 0; c < ROW_C8; ++c) {
         const u32x4 w = row[(size_t)c * stride];
         const f32x4 q0 = reinterpret_cast<const f32x4*>(qv)[2 * c];
@@ -231,8 +235,8 @@ __device__ __forceinline__ float block_exact_dots(const float* __restrict__ qv, 
     __syncthreads();
     float dot = 0.0f;
     if (wave == 0 && p != NO_POS) {
-        if (RT == 1) dot = exact_dot_seq_bf16(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
-        else dot = exact_dot_seq(sh_q, reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
+        if (RT == 1) dot = exact_dot_seq_bf16<8>(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
+        else dot = exact_dot_seq<16>(sh_q, reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
     }
     return dot;
 }
