@@ -1112,8 +1112,10 @@ BatchPlan plan_batched(uint32_t n_rows) {
         pl.s2_tiles = 0;
         return pl;
     }
-    // sample 2: n/16 rows, at most 1.5M, appended above tau1
-    uint32_t t2 = n_tiles / 16;
+    // sample 2: n/64 rows (so that the threshold is the ~24th largest of it: the count of candidates of the full pass then
+    // scatters by ~20 %), at least 16 Ki and at most 1.5M rows, appended above tau1
+    uint32_t t2 = n_tiles / 64;
+    if (t2 < 256u) t2 = 256u;
     if (t2 > 23437u) t2 = 23437u;
     pl.s2_tiles = t2;
     pl.s2_stride = n_tiles / t2;
