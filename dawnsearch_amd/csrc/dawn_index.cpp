@@ -89,7 +89,7 @@ struct dawn_index {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
-    uint64_t n_searches = 0, n_fallbacks = 0;
+    uint64_t n_searches = 0, n_fallbacks = 0, n_second = 0;
     int force_fallback = 0;
 };
 
@@ -450,7 +450,8 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
         std::memcpy(distances + b0 * count, hd, nb * count * sizeof(float));
         for (size_t b = 0; b < nb; ++b) {
             found[b0 + b] = hf[b];
-            if (hflag[b] != dawn::FLAG_OK) idx->n_fallbacks++;
+            if (hflag[b] == dawn::FLAG_FALLBACK) idx->n_fallbacks++;
+            else if (hflag[b] == dawn::FLAG_SECOND) idx->n_second++;
         }
     }
     return DAWN_OK;
@@ -668,6 +669,15 @@ int dawn_index_profile_read(dawn_index* idx, uint64_t* launches, double* total_m
 int dawn_index_stats(dawn_index* idx, uint64_t* searches, uint64_t* fallbacks) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (searches) *searches = idx->n_searches;
+    if (fallbacks) *fallbacks = idx->n_fallbacks;
+    return DAWN_OK;
+}
+
+// ... plus the queries whose first certificate failed and whose 1024-deep second one held (no exact pass needed)
+int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_chances, uint64_t* fallbacks) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    if (searches) *searches = idx->n_searches;
+    if (second_chances) *second_chances = idx->n_second;
     if (fallbacks) *fallbacks = idx->n_fallbacks;
     return DAWN_OK;
 }

@@ -51,6 +51,7 @@ constexpr int ROW_F16S = 2;
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
+constexpr uint32_t FLAG_SECOND = 2;    // first certificate failed, the 1024-deep second one held: result is exact
 
 struct BatchWorkspace {
     _Float16* qh;    // [BATCH_QT][384] scaled f16 queries

@@ -1052,41 +1052,81 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
                        s, p, sh_s, sh_p, wave, lane, 16);
     const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
-    if (wave != 0) return;
-
-    float m = read_lane63(s);  // -inf when fewer than 64 candidates
-    if (!DENSE) {
-        const float t = tau[b];
-        m = (count >= (uint32_t)LIST) ? m : t;
-    }
-    const bool valid = p != NO_POS;
-    float d = POS_INF;
-    if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133
-    sort64_asc(d, p, lane);
-
     const uint32_t found = n_rows < k ? n_rows : k;
-    uint32_t flag = FLAG_OK;
-    if (n_rows > (uint32_t)LIST && found > 0) {
-        const uint32_t have = __popcll(__ballot(p != NO_POS));
-        if (have < found || overflow) {
-            flag = FLAG_FALLBACK;
-        } else {
-            // see merge_rescore_kernel: rows outside the shortlist have distance >= fl(1 - up(m + eps))
-            const float t = round_up_f32((double)m + (double)eps);
-            const float d_bound = __fsub_rn(1.0f, t);
-            const float dk =
-                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
-            if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+    __shared__ uint32_t sh_second;
+    if (wave == 0) {
+        float m = read_lane63(s);  // -inf when fewer than 64 candidates
+        if (!DENSE) {
+            const float t = tau[b];
+            m = (count >= (uint32_t)LIST) ? m : t;
+        }
+        const bool valid = p != NO_POS;
+        float d = POS_INF;
+        if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133
+        sort64_asc(d, p, lane);
+
+        uint32_t flag = FLAG_OK;
+        bool second = false;
+        if (n_rows > (uint32_t)LIST && found > 0) {
+            const uint32_t have = __popcll(__ballot(p != NO_POS));
+            if (have < found || overflow) {
+                flag = FLAG_FALLBACK;
+            } else {
+                // see merge_rescore_kernel: rows outside the shortlist have distance >= fl(1 - up(m + eps))
+                const float t = round_up_f32((double)m + (double)eps);
+                const float d_bound = __fsub_rn(1.0f, t);
+                const float dk =
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
+                if (!(d_bound > dk)) {
+                    flag = FLAG_FALLBACK;
+                    second = !force_fallback;  // the candidates are complete (no overflow): worth a second look
+                }
+            }
+        }
+        if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
+        if ((uint32_t)lane < found && p != NO_POS) {
+            out_labels[(size_t)b * k + lane] = ids[p];
+            out_dist[(size_t)b * k + lane] = d;
+        }
+        if (lane == 0) {
+            out_found[b] = found;
+            out_flags[b] = flag;
+            sh_second = second ? 1u : 0u;
         }
     }
-    if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
-    if ((uint32_t)lane < found && p != NO_POS) {
-        out_labels[(size_t)b * k + lane] = ids[p];
-        out_dist[(size_t)b * k + lane] = d;
-    }
-    if (lane == 0) {
-        out_found[b] = found;
-        out_flags[b] = flag;
+    __syncthreads();
+    if (!sh_second) return;
+
+    // ---- second chance (wave_topk.hpp): every row scoring above tau is a candidate (DENSE: every row is one); the
+    // 1024 best are rescored exactly
+    const float* dense_q = dense + (size_t)b * BATCH_CAP;
+    const uint2* cand_q = cand + (size_t)b * BATCH_CAP;
+    const uint32_t* cnt_q = cnt + (size_t)b * BATCH_CAND_SEGS;
+    auto load = [&](uint32_t e, float& sc, uint32_t& row) {
+        if (DENSE) {
+            if (e >= n_rows) return false;
+            sc = dense_q[e];
+            row = e;
+            return sc > NEG_INF;
+        }
+        const uint32_t sg = e / SEG_CAP, j = e % SEG_CAP;
+        if (j >= cnt_q[sg]) return false;
+        const uint2 v = cand_q[e];
+        sc = __builtin_bit_cast(float, v.x);
+        row = v.y;
+        return true;
+    };
+    float s2;
+    uint32_t p2;
+    const bool ok = second_chance<RT>(load, DENSE ? (n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP) : (uint32_t)BATCH_CAP,
+                                      DENSE ? NEG_INF : tau[b], q + (size_t)b * EM, x, found, eps, rescore_stage, sh_s, sh_p,
+                                      wave, lane, s2, p2);
+    if (wave == 0 && ok) {
+        if ((uint32_t)lane < found) {
+            out_labels[(size_t)b * k + lane] = ids[p2];
+            out_dist[(size_t)b * k + lane] = -s2;
+        }
+        if (lane == 0) out_flags[b] = FLAG_SECOND;
     }
 }
 

@@ -437,35 +437,68 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
     // shortlist (wave 0): 64 best rows by filter score; every wave helps to fetch them for the exact rescore
     const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
-    if (wave != 0) return;
-
-    // m (the worst score that made it) bounds the filter score of every row NOT in the shortlist.
-    const float m = read_lane63(s);
-    const bool valid = p != NO_POS;
-    float d = POS_INF;
-    if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
-    sort64_asc(d, p, lane);
-
     const uint32_t found = n_rows < k ? n_rows : k;
-    uint32_t flag = FLAG_OK;
-    if (n_rows > LIST && found > 0) {
-        // Any row r outside the shortlist has filter score <= m, hence exact dot <= m + eps, hence
-        // distance fl(1 - dot_r) >= fl(1 - up(m + eps)) =: d_bound.  If d_bound > d_k (strictly, so that
-        // not even a tie on the rounded distance is possible) the exact top-k lies inside the shortlist.
-        const float t = round_up_f32((double)m + (double)eps);
-        const float d_bound = __fsub_rn(1.0f, t);
-        const float dk = __builtin_bit_cast(
-            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
-        if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+    __shared__ uint32_t sh_second;
+    if (wave == 0) {
+        // m (the worst score that made it) bounds the filter score of every row NOT in the shortlist.
+        const float m = read_lane63(s);
+        const bool valid = p != NO_POS;
+        float d = POS_INF;
+        if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+        sort64_asc(d, p, lane);
+
+        uint32_t flag = FLAG_OK;
+        if (n_rows > LIST && found > 0) {
+            // Any row r outside the shortlist has filter score <= m, hence exact dot <= m + eps, hence
+            // distance fl(1 - dot_r) >= fl(1 - up(m + eps)) =: d_bound.  If d_bound > d_k (strictly, so that
+            // not even a tie on the rounded distance is possible) the exact top-k lies inside the shortlist.
+            const float t = round_up_f32((double)m + (double)eps);
+            const float d_bound = __fsub_rn(1.0f, t);
+            const float dk = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
+            if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+        }
+        const bool second = flag == FLAG_FALLBACK && !force_fallback;
+        if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
+        if ((uint32_t)lane < found) {
+            out_labels[(size_t)b * k + lane] = ids[p];
+            out_dist[(size_t)b * k + lane] = d;
+        }
+        if (lane == 0) {
+            out_found[b] = found;
+            out_flags[b] = flag;
+            sh_second = second ? 1u : 0u;
+        }
     }
-    if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
-    if ((uint32_t)lane < found) {
-        out_labels[(size_t)b * k + lane] = ids[p];
-        out_dist[(size_t)b * k + lane] = d;
-    }
-    if (lane == 0) {
-        out_found[b] = found;
-        out_flags[b] = flag;
+    __syncthreads();
+    if (!sh_second) return;
+
+    // ---- second chance (wave_topk.hpp): the union of the workgroup lists holds every row whose filter score exceeds
+    // T = the largest 64th entry of any list; its 1024 best are rescored exactly
+    float tmax = NEG_INF;
+    for (int l = threadIdx.x; l < n_lists; l += blockDim.x) tmax = fmaxf(tmax, cs[(size_t)l * LIST + 63]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+    if (lane == 0) sh_s[wave][0] = tmax;
+    __syncthreads();
+    float T = NEG_INF;
+    for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_s[w][0]);
+    __syncthreads();
+    auto load = [&](uint32_t e, float& sc, uint32_t& row) {
+        sc = cs[e];
+        row = cp[e];
+        return row != NO_POS;
+    };
+    float s2;
+    uint32_t p2;
+    const bool ok = second_chance<RT>(load, (uint32_t)n_lists * LIST, T, q + (size_t)b * EM, x, found, eps, rescore_stage, sh_s,
+                                      sh_p, wave, lane, s2, p2);
+    if (wave == 0 && ok) {
+        if ((uint32_t)lane < found) {
+            out_labels[(size_t)b * k + lane] = ids[p2];
+            out_dist[(size_t)b * k + lane] = -s2;
+        }
+        if (lane == 0) out_flags[b] = FLAG_SECOND;
     }
 }
 

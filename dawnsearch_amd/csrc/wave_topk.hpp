@@ -295,4 +295,135 @@ __device__ __forceinline__ float round_up_f32(double t) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Second chance of a failed certificate.  The first certificate bounds everything outside a 64-row shortlist by the
+// 64th filter score; it fails when more than ~54 rows crowd the top of a query within the filter's error band (near-
+// duplicate pages, k = 64).  Before the whole index is rescanned exactly, the candidates the filter pass left behind are
+// used once more: the (up to) 1024 best of them by filter score are ALL rescored exactly, and everything else is
+// bounded by m2 = max(theta, base) — theta: an upper bound on the filter score of every entry not taken, base: the bound
+// the filter pass itself gives for rows that are not entries at all.  Same certificate, 1024 rows deep instead of 64.
+//   load(e, score, row) -> bool: entry e of n_entries (false: empty slot); every row appears at most once.
+// Called by all 1024 threads of the block; scratch: >= 12.5 KB of LDS; the result (score = -distance descending, row)
+// and the verdict are valid in wave 0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key(float s) {  // ascending in s (finite or -inf)
+    const uint32_t u = __builtin_bit_cast(uint32_t, s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+// inclusive prefix sum over the 1024 threads of the block (thread order); lds16: 16 words
+__device__ __forceinline__ uint32_t block_incl_scan_u32(uint32_t v, uint32_t* lds16, int wave, int lane) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+    if (lane == 63) lds16[wave] = (uint32_t)x;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += lds16[w];
+    __syncthreads();
+    return (uint32_t)x + off;
+}
+
+constexpr uint32_t SECOND_CHANCE_K = 1024;
+constexpr int SECOND_CHANCE_LDS = (2048 + 1024 + 32) * 4;
+
+template <int RT, class LoadFn>
+__device__ __forceinline__ bool second_chance(LoadFn load, uint32_t n_entries, float base, const float* __restrict__ qv,
+                                              const void* __restrict__ x, uint32_t found, float eps,
+                                              unsigned char* scratch, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave,
+                                              int lane, float& out_s, uint32_t& out_p) {
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* sel = hist + 2048;
+    uint32_t* misc = sel + 1024;  // [0] crossing bin (or ~0) [1] entries above it [2] selected count; [16..31] scan
+    const uint32_t tid = threadIdx.x;
+    uint32_t prefix = 0;       // bits fixed so far (pass 2: the crossing 11-bit bin of pass 1)
+    uint32_t above_total = 0;  // entries strictly above the crossing bin(s)
+    bool take_all = false;
+    uint32_t edge22 = 0;       // entries with key >> 10 > edge22 are taken
+    for (int pass = 0; pass < 2 && !take_all; ++pass) {
+        for (uint32_t i = tid; i < 2048; i += 1024) hist[i] = 0;
+        if (tid < 3) misc[tid] = 0xFFFFFFFFu * (tid == 0);
+        __syncthreads();
+        for (uint32_t e = tid; e < n_entries; e += 1024) {
+            float sc;
+            uint32_t row;
+            if (!load(e, sc, row)) continue;
+            const uint32_t key = order_key(sc);
+            if (pass == 0) atomicAdd(&hist[key >> 21], 1u);
+            else if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
+        }
+        __syncthreads();
+        // bins in descending order: thread t owns bins 2047 - 2t and 2046 - 2t
+        const uint32_t c0 = hist[2047 - 2 * tid], c1 = hist[2046 - 2 * tid];
+        const uint32_t incl = block_incl_scan_u32(c0 + c1, misc + 16, wave, lane);
+        const uint32_t excl = incl - (c0 + c1);
+        const uint32_t budget = SECOND_CHANCE_K - above_total;  // entries that may still be taken
+        if (excl <= budget && excl + c0 > budget) {
+            misc[0] = 2047 - 2 * tid;
+            misc[1] = excl;
+        } else if (excl + c0 <= budget && incl > budget) {
+            misc[0] = 2046 - 2 * tid;
+            misc[1] = excl + c0;
+        }
+        __syncthreads();
+        const uint32_t bin = misc[0];
+        if (bin == 0xFFFFFFFFu) {  // everything (left) fits
+            if (pass == 0) take_all = true;
+            else edge22 = (prefix << 11);  // whole crossing bin of pass 1 fits after all: cannot happen (kept for safety)
+            if (pass == 1) edge22 = (prefix << 11) - 1;
+        } else {
+            above_total += misc[1];
+            if (pass == 0) prefix = bin;
+            else edge22 = (prefix << 11) | bin;
+        }
+        __syncthreads();
+    }
+    const float theta = take_all ? NEG_INF : key_to_float((edge22 << 10) | 0x3FFu);  // >= score of every entry not taken
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < n_entries; e += 1024) {
+        float sc;
+        uint32_t row;
+        if (!load(e, sc, row)) continue;
+        if (take_all || (order_key(sc) >> 10) > edge22) {
+            const uint32_t pos = atomicAdd(&misc[2], 1u);
+            if (pos < SECOND_CHANCE_K) sel[pos] = row;
+        }
+    }
+    __syncthreads();
+    const uint32_t count = misc[2];
+    if (count > SECOND_CHANCE_K || count < found) return false;  // (the first cannot happen)
+    float d = POS_INF;
+    uint32_t row = NO_POS;
+    if (tid < count) {
+        row = sel[tid];
+        const float dd = __fsub_rn(1.0f, exact_dot_row<RT>(qv, x, row));
+        if (dd == dd) d = dd;
+        else row = NO_POS;
+    }
+    sort64_asc(d, row, lane);
+    out_s = -d;
+    out_p = row;
+    block_merge(out_s, out_p, sh_s, sh_p, wave, lane, 16);
+    bool ok = false;
+    if (wave == 0) {
+        const uint32_t have = __popcll(__ballot(out_p != NO_POS));
+        const float m2 = fmaxf(theta, base);
+        const float t = round_up_f32((double)m2 + (double)eps);
+        const float d_bound = __fsub_rn(1.0f, t);
+        const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_s), (int)found - 1));
+        ok = have >= found && (m2 == NEG_INF || d_bound > dk);
+    }
+    return ok;
+}
+
 }  // namespace dawn

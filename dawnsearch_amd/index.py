@@ -108,8 +108,9 @@ class VectorIndex:
     def stats(self):
         s = C.c_uint64(0)
         f = C.c_uint64(0)
-        check(lib.dawn_index_stats(self._h, C.byref(s), C.byref(f)))
-        return {"searches": s.value, "fallbacks": f.value}
+        c2 = C.c_uint64(0)
+        check(lib.dawn_index_stats_ext(self._h, C.byref(s), C.byref(c2), C.byref(f)))
+        return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value}
 
     def set_option(self, name: str, value: int):
         check(lib.dawn_index_set_option(self._h, name.encode(), value))

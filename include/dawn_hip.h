@@ -127,6 +127,8 @@ int dawn_index_profile_enable(dawn_index *idx, int enable);
 int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_ms);
 /* Counters: searches that needed the exact fallback pass (certificate failed). */
 int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
+/* ... and searches whose 64-row certificate failed but whose 1024-row second certificate held (no exact pass). */
+int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_chances, uint64_t *fallbacks);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
  * rows [0, n), n = min(size, 8192): out [B][n].  Lets a test check the bound the certificate relies on. */
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);

@@ -244,8 +244,10 @@ def test_batched_scan_matches_oracle(dawn, oracle, n, B, k):
         assert found[b] == min(k, n)
         _assert_same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
     assert labels[B // 2][0] == n // 3 + 1 and labels[B - 1][0] == n
-    # k == shortlist length (64) leaves no margin for the certificate: those searches take the exact pass
-    assert idx.stats()["fallbacks"] == (B if (k >= 64 and n > 64) else 0)
+    # k == shortlist length (64) leaves no margin for the 64-row certificate: those searches are decided by the
+    # 1024-row second certificate (every candidate above the threshold rescored exactly), not by the exact pass
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["second_chances"] == (B if (k >= 64 and n > 64) else 0)
 
 
 def test_batched_1m_batch256(dawn, oracle):
@@ -355,7 +357,7 @@ def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype)
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_batched_duplicates_fall_back_and_stay_exact(dawn, oracle):
+def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle):
     base = synth.unit_rows(1, 0, 3000)
     rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])
     ids = np.arange(1, len(rows) + 1, dtype=np.uint64)
@@ -367,7 +369,18 @@ def test_batched_duplicates_fall_back_and_stay_exact(dawn, oracle):
     for b in range(16):
         _assert_same(labels[b], dist[b], *oracle.scan_topk(rows, ids, Q[b], 20))
     assert labels[3][0] == 12 and list(labels[3][1:4]) == [3001, 3002, 3003]
-    assert idx.stats()["fallbacks"] == 1
+    # 301 identical rows at the top: the 64-row certificate cannot hold, the 1024-row one does — no exact pass
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["second_chances"] == 1
+    # 1500 identical rows are more than the second certificate looks at: the exact pass decides, same answer
+    rows3 = np.concatenate([base, np.repeat(base[11:12], 1500, axis=0)])
+    ids3 = np.arange(1, len(rows3) + 1, dtype=np.uint64)
+    idx3 = dawn.VectorIndex(0)
+    idx3.add_batch(ids3, rows3)
+    l3, d3, f3 = idx3.search_batch(Q, 20)
+    for b in (0, 3, 15):
+        _assert_same(l3[b], d3[b], *oracle.scan_topk(rows3, ids3, Q[b], 20))
+    assert idx3.stats()["fallbacks"] == 1
 
 
 def test_batched_clustered_index_overflow_falls_back(dawn, oracle):
