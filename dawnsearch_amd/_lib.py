@@ -64,6 +64,7 @@ _SIGS = {
     "dawn_index_add_batch": (_i32, [_vp, _sz, _vp, _vp]),
     "dawn_index_search": (_i32, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_sz)]),
     "dawn_index_search_batch": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "dawn_index_search_limited": (_i32, [_vp, _vp, _sz, C.c_float, _vp, _vp, _vp]),
     "dawn_index_save": (_i32, [_vp, C.c_char_p]),
     "dawn_index_load": (_i32, [_vp, C.c_char_p]),
     "dawn_index_load_page_entries": (_i32, [_vp, C.c_char_p, _u64]),

@@ -462,6 +462,15 @@ int dawn_index_search(dawn_index* idx, const float* query, size_t count, uint64_
     return dawn_index_search_batch(idx, query, 1, count, labels, distances, found);
 }
 
+int dawn_index_search_limited(dawn_index* idx, const float* query, size_t count, float distance_limit, uint64_t* labels,
+                              float* distances, size_t* found) {
+    DAWN_TRY(dawn_index_search_batch(idx, query, 1, count, labels, distances, found));
+    size_t keep = 0;  // hits are ascending: the reported ones are a prefix
+    while (keep < *found && !(distances[keep] >= distance_limit)) ++keep;
+    *found = keep;
+    return DAWN_OK;
+}
+
 int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const uint64_t* d_in_labels,
                            const float* d_in_distances, const uint32_t* d_in_found, uint64_t* d_labels,
                            float* d_distances, uint32_t* d_found, void* stream) {

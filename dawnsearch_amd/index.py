@@ -62,6 +62,16 @@ class VectorIndex:
         check(lib.dawn_index_search(self._h, _ptr(q), count, _ptr(labels), _ptr(dist), C.byref(found)))
         return labels[:found.value], dist[:found.value]
 
+    def search_limited(self, q: np.ndarray, count: int, distance_limit: float):
+        """The answering side of a remote search (udp_service.rs:196-199): hits with distance < distance_limit only."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        labels = np.zeros(count, dtype=np.uint64)
+        dist = np.zeros(count, dtype=np.float32)
+        found = C.c_size_t(0)
+        check(lib.dawn_index_search_limited(self._h, _ptr(q), count, C.c_float(distance_limit), _ptr(labels), _ptr(dist),
+                                            C.byref(found)))
+        return labels[:found.value], dist[:found.value]
+
     def search_batch(self, Q: np.ndarray, count: int):
         """-> (labels [B,count], distances [B,count], found [B])."""
         Q = np.ascontiguousarray(Q, dtype=np.float32)

@@ -76,6 +76,11 @@ int dawn_index_add_batch(dawn_index *idx, size_t n, const uint64_t *ids, const f
  * is_normalized (:206-208). */
 int dawn_index_search(dawn_index *idx, const float *query, size_t count, uint64_t *labels,
                       float *distances, size_t *found);
+/* The answering side of a remote search (src/net/udp_service.rs:174-215): the same search, then only the hits with
+ * distance < distance_limit are reported ("if page.distance >= d { continue }", :196-199) — *found counts them; the
+ * limit a peer sends is its BestResults::worst_distance(), 0.0 until it holds 20 local results (best_results.rs:40). */
+int dawn_index_search_limited(dawn_index *idx, const float *query, size_t count, float distance_limit,
+                              uint64_t *labels, float *distances, size_t *found);
 /* B queries in one call (the reference has no batching; this is what a batching caller binds).
  * queries [B][384]; labels/distances [B][count]; found [B]. */
 int dawn_index_search_batch(dawn_index *idx, const float *queries, size_t B, size_t count,

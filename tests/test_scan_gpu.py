@@ -204,6 +204,23 @@ def test_page_entry_file_loader(dawn, oracle, tmp_path):
     assert m == 10
 
 
+def test_remote_search_distance_limit(dawn, oracle):
+    """udp_service.rs:196-199: a peer's search reports only the hits with distance < distance_limit (the asker's
+    worst_distance(): 0.0 until it holds 20 results, best_results.rs:40 — which prunes everything but negative
+    distances, exactly as the reference does)."""
+    n = 50_000
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    q = synth.unit_rows(2, 0, 1)[0]
+    olab, odist = oracle.scan_topk(x, ids, q, 20)
+    for limit in (float(odist[7]), float(np.nextafter(odist[7], np.float32(2))), 5.0, 0.0, float(odist[0])):
+        lab, dist = idx.search_limited(q, 20, limit)
+        keep = int(np.sum(odist < np.float32(limit)))
+        assert len(lab) == keep
+        _assert_same(lab, dist, olab[:keep], odist[:keep])
+
+
 def test_search_provider_mirror(dawn, oracle):
     sp = dawn.SearchProvider(0)
     rows = synth.unit_rows(7, 0, 300)
