@@ -46,11 +46,18 @@ def _build_rows(rng, n, kind, q0):
     return rows
 
 
-@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 2500), k=st.integers(1, 64), B=st.sampled_from([1, 2, 3, 4, 7, 9, 33]),
+import os  # noqa: E402
+
+_EXAMPLES = int(os.environ.get("DAWN_HYP_EXAMPLES", "150"))  # soak runs: DAWN_HYP_EXAMPLES=3000
+
+
+@settings(max_examples=_EXAMPLES, deadline=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 2500), st.integers(8000, 30000)), k=st.integers(1, 64),
+       B=st.sampled_from([1, 2, 3, 4, 7, 9, 33, 70]),
        kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal"]), dtype=st.sampled_from(["f32", "bf16"]),
-       force_stream=st.booleans())
-def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream):
+       force_stream=st.booleans(), sched=st.sampled_from([4, 5, 1]))
+def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched):
     rng = np.random.default_rng(seed)
     Q = synth.unit_rows(int(rng.integers(1, 1 << 30)), 0, B)
     rows = _build_rows(rng, n, kind, Q[0])
@@ -63,6 +70,7 @@ def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kin
         stored = synth.round_bf16(rows) if dtype == "bf16" else rows
         if force_stream:
             idx.set_option("mfma_min_batch", 100000)
+        idx.set_option("mfma_sched", sched)  # 5: the pipelined matrix-core kernel for every pass, 1: the 8-wave kernel
         labels, dist, found = idx.search_batch(Q, k)
         for b in range(B):
             olab, odist = oracle.scan_topk(stored, ids, Q[b], k)
@@ -70,4 +78,5 @@ def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kin
             assert np.array_equal(labels[b][:found[b]], olab), (kind, dtype, n, k, B, b)
             assert np.array_equal(dist[b][:found[b]].view(np.uint32), odist.view(np.uint32)), (kind, dtype, n, k, B, b)
     finally:
+        idx.set_option("mfma_sched", 4)  # process-wide
         idx.close()
