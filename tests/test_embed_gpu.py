@@ -157,3 +157,33 @@ def test_text_in_vectors_out_with_the_host_tokenizer(provider, dawn, oracle, tmp
     sb = oracle.SynthBert(3)
     for t, e in zip(texts, emb):
         assert np.abs(e - sb.embed(np.array(tk(t), dtype=np.uint32))).max() < TOL_EMB
+
+
+def test_any_batch_composition_matches_the_oracle(provider, oracle):
+    """Property (hypothesis): for any mix of sequence lengths 1..160 in any order, every text gets the oracle's vector —
+    the batch's longest member picks the attention kernel (three-phase <= 64, matrix-core <= 128, thread-per-row beyond)
+    and its token count picks the GEMM (split-K skinny <= 640 tokens, 64x64 tiles beyond), so the same text travels
+    through different kernels depending on its neighbours and must not notice."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    sb = oracle.SynthBert(3)
+    cache = {}
+
+    def ref(seq):
+        key = seq.tobytes()
+        if key not in cache:
+            cache[key] = sb.embed(seq)
+        return cache[key]
+
+    pool = [synth.token_sequences(900 + n, 1, n, n)[0] for n in (1, 2, 5, 17, 31, 32, 33, 63, 64, 65, 100, 128, 129, 160)]
+
+    @settings(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(picks=st.lists(st.integers(0, len(pool) - 1), min_size=1, max_size=14))
+    def run(picks):
+        seqs = [pool[i] for i in picks]
+        emb = provider.calculate_embedding(seqs)
+        for s, e in zip(seqs, emb):
+            assert np.abs(e - ref(s)).max() < TOL_EMB
+
+    run()
