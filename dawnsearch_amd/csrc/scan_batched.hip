@@ -83,21 +83,9 @@ __device__ __forceinline__ half4 to_half4_scaled(const f32x4& v) {
     return r;
 }
 
-// f32 chunk (4 values) -> 8 B at +32 B per step; bf16 chunk (8 values) -> 16 B at +64 B per step
+// f32 chunk (4 values) -> 8 B at +32 B per step
 __device__ __forceinline__ void store_converted(unsigned char* base, int step, const f32x4& v) {
     *reinterpret_cast<half4*>(base + step * 32) = to_half4_scaled(v);
-}
-__device__ __forceinline__ void store_converted(unsigned char* base, int step, const u32x4& w) {
-    half8 o;
-    o[0] = (_Float16)(bf16_lo(w.x) * ROW_SCALE);  // bf16 -> f32 is exact; the scaled f16 rounding is the only one
-    o[1] = (_Float16)(bf16_hi(w.x) * ROW_SCALE);
-    o[2] = (_Float16)(bf16_lo(w.y) * ROW_SCALE);
-    o[3] = (_Float16)(bf16_hi(w.y) * ROW_SCALE);
-    o[4] = (_Float16)(bf16_lo(w.z) * ROW_SCALE);
-    o[5] = (_Float16)(bf16_hi(w.z) * ROW_SCALE);
-    o[6] = (_Float16)(bf16_lo(w.w) * ROW_SCALE);
-    o[7] = (_Float16)(bf16_hi(w.w) * ROW_SCALE);
-    *reinterpret_cast<half8*>(base + step * 64) = o;
 }
 
 // LDS byte offset (inside one tile buffer) of the 16-B slot holding f16 elements k = 8g..8g+7 of tile row `row`:
@@ -114,7 +102,7 @@ __device__ __forceinline__ uint32_t slot_off(uint32_t row, uint32_t g) {
 // 64/NW rows of every tile; PF tiles are in flight per wave (register-staged: 96/NW 16-B loads per lane and tile).
 //   NW = 4: one wave per SIMD, 512 registers: 2 x 24 loads in flight per lane = 192 KiB per CU
 //   NW = 8: two waves per SIMD, 256 registers: 12 loads in flight per lane     =  96 KiB per CU
-template <bool DENSE, int NW, int RT, int SCHED>
+template <bool DENSE, int NW, int SCHED>
 __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restrict__ xv, uint32_t n_rows,
                                                           uint32_t first_tile, uint32_t tile_stride,
                                                           uint32_t n_tiles, const half8* __restrict__ qh, int n_q,
@@ -136,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
         }
     };
     constexpr int QG = 8 / NW;          // 32-query groups per wave
-    constexpr int CPR = RT >= 1 ? ROW_C8 : ROW_F4;  // 16-B chunks per index row (bf16: 8 values each, f32: 4)
+    constexpr int CPR = ROW_F4;         // 16-B chunks per index row (f32: 4 values each)
     constexpr int LPL = CPR / NW;       // loads per lane per tile
     constexpr int RPW = TILE_ROWS / NW; // tile rows converted by one wave
     constexpr int PF = NW == 4 ? 2 : 1; // tiles in flight
@@ -177,20 +165,19 @@ __global__ __launch_bounds__(NW * 64) void scan_f16_kernel(const void* __restric
     }
 
     // producer map: wave w converts rows RPW*w.. of the tile = RPW*CPR consecutive 16-B chunks; load j = 3a + b of
-    // this lane is chunk (b*64 + lane) + 192a.  f32 rows (96 chunks of 4 values): row RPW*w + 2a + (b*64+lane)/96,
-    // chunk c -> k-group c/2, half c&1, 8-B store, +32 B per a.  bf16 rows (48 chunks of 8 values): row
-    // RPW*w + 4a + (b*64+lane)/48, chunk c = k-group c, 16-B store, +64 B per a.  Three LDS addresses either way.
+    // this lane is chunk (b*64 + lane) + 192a of the f32 rows (96 chunks of 4 values each): row RPW*w + 2a +
+    // (b*64+lane)/96, chunk c -> k-group c/2, half c&1, 8-B store, +32 B per a.  Three LDS addresses.
     uint32_t wr_off[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const uint32_t Lb = (uint32_t)b * 64u + (uint32_t)lane;
         const uint32_t row = (uint32_t)RPW * wave + Lb / CPR, c = Lb % CPR;
-        wr_off[b] = RT >= 1 ? slot_off(row, c) : slot_off(row, c >> 1) + (c & 1u) * 8u;
+        wr_off[b] = slot_off(row, c >> 1) + (c & 1u) * 8u;
     }
     // consumer map: k-step s reads slot g = 2s + h of row r: s*2*G_STRIDE + (s&3)*32 + [h*(G_STRIDE+16) + r*16]
     const uint32_t rd_off = h * (G_STRIDE + 16u) + r * 16u;
 
-    typedef typename std::conditional<RT == 0, f32x4, u32x4>::type chunk_t;
+    typedef f32x4 chunk_t;
     const chunk_t* x = reinterpret_cast<const chunk_t*>(xv);
     chunk_t st[PF][LPL];
     auto issue = [&](chunk_t(&dst)[LPL], uint32_t i) {
@@ -1179,22 +1166,22 @@ unsigned long long* g_batched_diag = nullptr;  // device buffer [grid][8 waves][
 // 0: lockstep kernel for every row source; 2: lockstep kernel with diagnostic stamps
 int g_batched_sched = 4;
 
-template <bool DENSE, int NW, int RT, int SCHED>
+template <bool DENSE, int NW, int SCHED>
 static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
-    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, RT, SCHED>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
+    hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, SCHED>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
                        first, stride, n_tiles, reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
                        reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), g_batched_diag);
 }
 
-template <bool DENSE, int RT>
+template <bool DENSE>
 static void launch_pass_rt(const void* d_rows, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
     if (g_batched_sched == 2 && !DENSE)  // lockstep kernel with diagnostic stamps (full append pass only)
-        launch_pass_nw<false, 8, RT, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+        launch_pass_nw<false, 8, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else
-        launch_pass_nw<DENSE, 8, RT, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+        launch_pass_nw<DENSE, 8, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
 // Fragment-ordered 16-bit tiles (f16 shadow of an f32 index, or a bf16 index): the LDS-DMA kernels.
@@ -1239,14 +1226,13 @@ static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t fi
     if (n_tiles == 0) return;
     if (rt == ROW_F16S) launch_pass_dma<DENSE, false>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
     else if (rt == ROW_BF16) launch_pass_dma<DENSE, true>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-    else launch_pass_rt<DENSE, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+    else launch_pass_rt<DENSE>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
-template <int RT>
 static hipError_t set_lds_attr_rt() {
-    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 8, RT, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, RT, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, RT, 2>)};
+    const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 0>),
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 2>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1256,7 +1242,7 @@ static hipError_t set_lds_attr_rt() {
 
 int batched_init() {
     if (g_lds_attr_set) return 0;
-    hipError_t e = set_lds_attr_rt<0>();
+    hipError_t e = set_lds_attr_rt();
     const void* tails[] = {reinterpret_cast<const void*>(select_rescore_kernel<true, 0>),
                            reinterpret_cast<const void*>(select_rescore_kernel<false, 0>),
                            reinterpret_cast<const void*>(select_rescore_kernel<true, 1>),
