@@ -152,7 +152,7 @@ def main():
             return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
         return -(-Bq // 8)                # streaming path over 16-bit fragments: 8 queries per pass
 
-    def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False, f32_stream=False):
+    def run_leg(index, Bq, steps, warmup, seed=2, check_planted=False, rows_read="default"):
         """`steps` timed searches of a Bq-query batch.  Returns qps (max over ranks), ms/step and the mean
         duration of the dominant scan kernel measured with HIP events on its launch stream."""
         step, result = make_step(index, Bq, seed)
@@ -175,11 +175,15 @@ def main():
         leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3, "steps": steps,
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
-        # bytes the dominant kernel has to read per row: 768 for a bf16 index and for an f32 index, whose FILTER
-        # streams the scaled-f16 shadow copy of the rows (the exact rescore touches 64 f32 rows per query);
-        # 1536 when the f32 rows themselves are streamed (shadow switched off: f32_stream)
-        row_bytes = ROW_BYTES if f32_stream else ROW_BYTES // 2
-        algo = rows_here * row_bytes * scan_passes(Bq)
+        # bytes the dominant kernel has to read per row (the exact rescore touches 64 f32 rows per query on top):
+        #   "i8"  384.25: batches of 1..3 on an f32 index stream its int8 shadow (+ 8 B of scale/bound per 32 rows)
+        #   "f16" 768: the f16 shadow of an f32 index (matrix-core path; batches of 1..3 with i8_shadow = 0), a bf16 index
+        #   "f32" 1536: the f32 rows themselves (both shadows switched off for small batches)
+        if rows_read == "default":
+            rows_read = "i8" if (Bq < 4 and index.dtype == "f32") else "f16"
+        row_bytes = {"i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
+        leg["row_bytes_streamed"] = row_bytes
+        algo = int(rows_here * row_bytes) * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
@@ -242,7 +246,7 @@ def main():
         kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 23)
                   else "scan_f16_dma_kernel<append> (f16 shadow tiles by LDS-DMA, 8 waves x 32 queries)")
     else:
-        kernel = "scan_filter_f16s_kernel (f16 shadow fragments, global load -> MFMA)"
+        kernel = "scan_filter_i8s_kernel (int8 shadow fragments, global load -> integer MFMA; scores are upper bounds)"
 
     out = {
         "metric": "queries/sec, exact cosine top-k over a 384-d f32 index resident in HBM",
@@ -250,8 +254,8 @@ def main():
         "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k "
-                               "(f16 filter over a shadow copy of every row + exact f32 rescore: results bit-identical "
-                               "to the f32 scan)",
+                               "(" + ("f16" if B >= 4 else "int8 upper-bound") + " filter over a shadow copy of every row + "
+                               "exact f32 rescore + certificate: results bit-identical to the f32 scan)",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
                    "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -277,9 +281,14 @@ def main():
         # the same batch-1 search streaming the f32 rows themselves (1536 B/row; shadow filter off): the f32-stream
         # roofline of DESIGN.md §4.1
         idx.set_option("f16_shadow_b1", 0)
-        legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, f32_stream=True)
+        legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="f32")
         idx.set_option("f16_shadow_b1", 1)
         extra["batch1_streaming_f32_rows"] = legf
+        # ... and streaming the f16 shadow (768 B/row; int8 shadow off)
+        idx.set_option("i8_shadow", 0)
+        legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="f16")
+        idx.set_option("i8_shadow", 1)
+        extra["batch1_streaming_f16_shadow"] = legf
         # batch-256 on the same index: one pass of the matrix-core kernel serves all 256 queries
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
         leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)

@@ -52,7 +52,21 @@ struct dawn_index {
     const dawn::ScanGeom& shadow_geom() const {
         return (!geom_h_pinned && size < kShadowSmallRows) ? geom_h_small : geom_h;
     }
+    // int8 shadow stream: 4 waves per CU, whole sub-tiles (12 KiB) in flight per wave (tools/scan_sweep_shadow.py, 80M
+    // rows: 7.01 TB/s against 6.97 with 2 waves; everything with >= 24 KiB in flight per CU lands within 2 %)
+    dawn::ScanGeom geom_i8{256, 256, 3};
+    const dawn::ScanGeom& i8_geom() const {
+        return geom_h_pinned ? geom_h : size < kShadowSmallRows ? geom_h_small : geom_i8;
+    }
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
+    // f32 index only: int8 shadow (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows) read by the streaming filter of
+    // batches below mfma_min_batch — a quarter of the f32 bytes.  Built lazily at the first such search, and only while
+    // the f16 shadow of the matrix-core path still fits beside it.
+    char* d_i8 = nullptr;
+    float* d_i8meta = nullptr;
+    size_t i8_cap = 0, i8_rows = 0;
+    int use_i8 = 1;              // option "i8_shadow"
+    bool i8_failed = false;
     float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
     size_t stage_rows = 0;
     size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }
@@ -163,7 +177,7 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
     idx->ws_B = 0;
-    const size_t n = B * (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks}) * dawn::LIST;
+    const size_t n = B * (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks}) * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
@@ -203,6 +217,44 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
     return idx->d_shadow;
 }
 
+// Bring the int8 shadow up to date; false when it is disabled or does not fit.
+bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
+    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_i8 || !idx->shadow_small_batches || idx->i8_failed) return false;
+    if (idx->i8_cap < idx->cap_phys) {
+        const size_t prow = padded_rows(idx->cap_phys);
+        const size_t bytes = prow * dawn::EM, mbytes = (prow / 32 + 1) * 8;
+        // leave room for the f16 shadow of the matrix-core path (allocated at the first batch of mfma_min_batch queries)
+        (void)hipStreamSynchronize(stream);  // the old buffers are idle: searches are serialised
+        if (idx->d_i8) (void)hipFree(idx->d_i8);
+        if (idx->d_i8meta) (void)hipFree(idx->d_i8meta);
+        idx->d_i8 = nullptr;
+        idx->d_i8meta = nullptr;
+        idx->i8_cap = 0;
+        size_t fr = 0, tot = 0;
+        size_t need = bytes + mbytes + ((size_t)2 << 30);
+        if (idx->use_shadow && !idx->shadow_failed && idx->shadow_cap < idx->cap_phys) need += prow * dawn::EM * 2;
+        char* ns = nullptr;
+        float* nm = nullptr;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need || hipMalloc((void**)&ns, bytes) != hipSuccess ||
+            hipMalloc((void**)&nm, mbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ns) (void)hipFree(ns);
+            idx->i8_failed = true;
+            return false;
+        }
+        idx->d_i8 = ns;
+        idx->d_i8meta = nm;
+        idx->i8_cap = idx->cap_phys;
+        idx->i8_rows = 0;  // (re-quantised from the f32 rows: 0.03 ms per million rows)
+    }
+    if (idx->i8_rows < idx->size) {
+        dawn::launch_rows_f32_to_i8s(reinterpret_cast<const float*>(idx->d_x), idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size,
+                                     stream);
+        idx->i8_rows = idx->size;
+    }
+    return true;
+}
+
 // The whole search as a fixed launch sequence on `stream` (no host decisions in between).
 int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
                      uint32_t* d_found, hipStream_t stream) {
@@ -233,6 +285,13 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
                                       idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                       b0 == 0 ? e1 : nullptr);
         }
+    } else if (i8_rows_ready(idx, stream)) {
+        // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
+        const dawn::ScanGeom& gh = idx->i8_geom();
+        dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
+        dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh.blocks,
+                                   (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback,
+                                   dawn::FILTER_EPS_I8, stream);
     } else {
         int frt = idx->dtype;
         const void* frows = filter_rows(idx, &frt, stream);
@@ -281,6 +340,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     if (prop.multiProcessorCount > 0) {
         idx->geom_h.blocks = prop.multiProcessorCount;
         idx->geom_h_small.blocks = prop.multiProcessorCount;
+        idx->geom_i8.blocks = prop.multiProcessorCount;
     }
     if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -311,7 +371,7 @@ void dawn_index_destroy(dawn_index* idx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
                     idx->bws.cnt, idx->bws.cand, idx->d_q, idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -605,6 +665,7 @@ int dawn_index_load(dawn_index* idx, const char* path) {
     }
     idx->size = 0;  // load replaces the contents (usearch load semantics)
     idx->shadow_rows = 0;
+    idx->i8_rows = 0;
     const size_t chunk = 1u << 16;
     std::vector<float> buf(chunk * dawn::EM);
     for (size_t o = 0; o < n; o += chunk) {
@@ -721,9 +782,14 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     hipStream_t stream = idx->stream;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
     int frt = idx->dtype;
-    const void* frows = filter_rows(idx, &frt, stream);
+    const void* frows = nullptr;
     size_t blocks;
-    if (frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
+    if (i8_rows_ready(idx, stream)) {
+        const dawn::ScanGeom& gh = idx->i8_geom();
+        blocks = gh.blocks;
+        dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
+                                     stream, nullptr, nullptr);
+    } else if ((frows = filter_rows(idx, &frt, stream)), frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
         const dawn::ScanGeom& gh = idx->shadow_geom();
         blocks = gh.blocks;
         dawn::launch_scan_filter_f16s(frows, frt, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
@@ -803,6 +869,11 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     }
     if (n == "f16_shadow") {
         idx->use_shadow = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "i8_shadow") {
+        idx->use_i8 = value != 0;
+        if (value) idx->i8_failed = false;
         return DAWN_OK;
     }
     if (n == "f16_shadow_b1") {

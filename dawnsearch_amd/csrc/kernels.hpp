@@ -48,6 +48,12 @@ constexpr int ROW_F32 = 0;   // DAWN_DTYPE_F32: rows are 384 x f32 (1536 B)
 //   ROW_F16S: filter-only shadow of an f32 index: f16(2^8 * x)
 constexpr int ROW_BF16 = 1;
 constexpr int ROW_F16S = 2;
+// ROW_I8S: int8 filter-only shadow of an f32 index, quantised per 32-row sub-tile (12 fragments of 1 KiB in the operand
+// order of v_mfma_i32_32x32x32_i8 + {scale, error bound} per sub-tile): scan_i8.hip.  Its filter score is an UPPER BOUND
+// of the real dot product; FILTER_EPS_I8 covers the rounding of that bound's evaluation and the reference's own
+// sequential-sum error (gamma_384 * 1.0201 = 2.4e-5).
+constexpr int ROW_I8S = 3;
+constexpr float FILTER_EPS_I8 = 2.6e-5f;
 
 constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
@@ -76,6 +82,11 @@ void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float
 // (converted in the kernel).
 void launch_scan_filter_f16s(const void* d_rows, int rt, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                              uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+// int8 shadow (scan_i8.hip): d_meta = float2 {scale, error bound} per 32-row sub-tile
+void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n_rows, const float* d_q, int B, float* cand_s,
+                            uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_rows_f32_to_i8s(const float* d_rows, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
+                            hipStream_t stream);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,

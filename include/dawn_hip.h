@@ -152,6 +152,7 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *                      kernel only, 0 / 2 = lockstep converting kernel on the f32 rows (2: with phase stamps),
  *                      41..55 = timing experiments (parts of the pipelined kernel switched off: wrong results)
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow (filters read / convert the f32 rows)
+ *   "i8_shadow"        0: batches below mfma_min_batch do not use the int8 shadow (384 B/row, scan_i8.hip) of an f32 index
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of the shadow
  *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
  *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the 16-bit fragment stream

@@ -325,13 +325,18 @@ def test_batched_filter_error_within_bound(dawn):
     assert np.abs(f.astype(np.float64) - exact).mean() < 5e-5
 
 
+@pytest.mark.parametrize("shadow", ["f16", "i8"])
 @pytest.mark.parametrize("n", [127, 5000, 300_001])
-def test_stream_filter_lists_hold_the_top64(dawn, n):
-    """The batch-1 streaming filter (MFMA straight from the fragment-ordered f16 shadow) hands merge_rescore one
-    descending 64-entry list per workgroup: every listed score is within FILTER_EPS_F16 of the exact dot of ITS row,
-    no row is listed twice, and the union of the lists holds every row whose exact score clears the 64th best by
-    more than twice that bound (what the certificate relies on)."""
+def test_stream_filter_lists_hold_the_top64(dawn, n, shadow):
+    """The batch-1 streaming filter (MFMA straight from the fragment-ordered shadow) hands merge_rescore one
+    descending 64-entry list per workgroup, no row listed twice.
+    f16 shadow: every listed score is within FILTER_EPS_F16 of the exact dot of ITS row, and the union of the lists
+    holds every row whose exact score clears the 64th best by more than twice that bound.
+    int8 shadow: every listed score is an UPPER BOUND of its row's exact dot (scan_i8.hip), at most 0.02 above it on
+    this data, and every row whose exact score exceeds T = the largest 64th entry of any list is listed (what the
+    certificates rely on: an unlisted row's bound is <= its workgroup's 64th entry)."""
     idx = _mk_index(dawn, n)
+    idx.set_option("i8_shadow", int(shadow == "i8"))
     x = synth.unit_rows(1, 0, n)
     for q in list(synth.unit_rows(2, 0, 2)) + [synth.planted_queries(1, [n // 2], 4)[0]]:
         sc, rows = idx.debug_stream_lists(q)
@@ -340,23 +345,104 @@ def test_stream_filter_lists_hold_the_top64(dawn, n):
         got = rows[valid].astype(np.int64)
         assert got.max() < n and len(np.unique(got)) == len(got)
         exact = x.astype(np.float64) @ q.astype(np.float64)
-        assert np.abs(sc[valid].astype(np.float64) - exact[got]).max() < 1.25e-3 / 2
+        diff = sc[valid].astype(np.float64) - exact[got]
+        if shadow == "f16":
+            assert np.abs(diff).max() < 1.25e-3 / 2
+        else:
+            assert diff.min() > -1e-6 and diff.max() < 0.02, (diff.min(), diff.max())
         for b in range(len(sc)):  # descending inside a list, fillers last
             nv = int(valid[b].sum())
             assert np.all(valid[b][:nv]) and np.all(np.diff(sc[b][:nv]) <= 0)
         order = np.argsort(-exact, kind="stable")
         need = order[: min(64, n)]
         if n > 64:
-            need = need[exact[need] > exact[order[63]] + 2 * 1.25e-3]
+            if shadow == "f16":
+                need = need[exact[need] > exact[order[63]] + 2 * 1.25e-3]
+            else:
+                T = sc[:, 63].max()
+                need = np.nonzero(exact > T + 1e-6)[0]
         assert set(need.tolist()) <= set(got.tolist())
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def _adversarial_rows(n_base):
+    """Synthetic rows + the rows that stretch a per-sub-tile int8 quantiser: one-hot and two-hot rows (scale 1/127 for
+    their whole sub-tile), sparse rows, near-duplicates of one row, a row and its negation."""
+    rng = np.random.default_rng(11)
+    base = synth.unit_rows(1, 0, n_base)
+    extra = []
+    for j in (0, 5, 383):
+        e = np.zeros(384, np.float32); e[j] = 1.0; extra.append(e)
+        e = np.zeros(384, np.float32); e[j] = -1.0; extra.append(e)
+    e = np.zeros(384, np.float32); e[3] = 0.6; e[200] = 0.8; extra.append(e)
+    for nz in (2, 7, 40):
+        e = np.zeros(384, np.float32)
+        e[rng.choice(384, nz, replace=False)] = rng.standard_normal(nz)
+        extra.append((e / np.linalg.norm(e)).astype(np.float32))
+    for i in range(40):  # near-duplicates of row 9
+        v = base[9] + rng.standard_normal(384).astype(np.float32) * (1e-4 * (i + 1))
+        extra.append((v / np.linalg.norm(v)).astype(np.float32))
+    extra.append(-base[9])
+    extra = np.stack(extra)
+    pos = rng.permutation(n_base + len(extra))  # special rows scattered among the sub-tiles
+    rows = np.concatenate([base, extra])[pos]
+    return np.ascontiguousarray(rows), base, extra
+
+
+@pytest.mark.parametrize("n_base", [3000, 200_000])
+def test_int8_shadow_bounds_and_results_on_adversarial_rows(dawn, oracle, n_base):
+    """int8 shadow on rows that hurt a quantiser (one-hot, sparse, near-duplicate): the listed filter scores stay upper
+    bounds of the exact dots, and the search results equal the oracle's and the f16-shadow path's, batch 1..3."""
+    rows, base, extra = _adversarial_rows(n_base)
+    ids = np.arange(1, len(rows) + 1, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids, rows)
+    onehot = np.zeros(384, np.float32); onehot[5] = 1.0
+    Q = np.stack([synth.unit_rows(2, 0, 1)[0], onehot, extra[7], base[9], synth.planted_queries(1, [9], 5)[0], -base[9]])
+    for q in Q:
+        sc, lr = idx.debug_stream_lists(q)
+        valid = lr != 0xFFFFFFFF
+        got = lr[valid].astype(np.int64)
+        exact = rows[got].astype(np.float64) @ q.astype(np.float64)
+        assert (sc[valid].astype(np.float64) - exact).min() > -1e-6
+    for k in (10, 20):
+        for B in (1, 2, 3):
+            for j in range(0, len(Q), B):
+                qb = Q[j:j + B]
+                idx.set_option("i8_shadow", 1)
+                l1, d1, f1 = idx.search_batch(qb, k)
+                idx.set_option("i8_shadow", 0)
+                l0, d0, f0 = idx.search_batch(qb, k)
+                assert np.array_equal(l0, l1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+                for b in range(len(qb)):
+                    _assert_same(l1[b], d1[b], *oracle.scan_topk(rows, ids, qb[b], k))
+
+
+def test_int8_shadow_tracks_adds_and_growth(dawn, oracle):
+    """Rows added in ragged batches (the last sub-tile is re-quantised with its new rows, growth re-quantises all):
+    every search in between equals the oracle."""
+    x = synth.unit_rows(1, 0, 5000)
+    ids = np.arange(1, 5001, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    q = synth.planted_queries(1, [3], 5)[0]
+    done = 0
+    for step in (1, 30, 1, 33, 64, 1000, 7, 2864, 1000):
+        idx.add_batch(ids[done:done + step], x[done:done + step])
+        done += step
+        for qq in (q, synth.unit_rows(2, done, 1)[0]):
+            lab, dist = idx.search(qq, 10)
+            _assert_same(lab, dist, *oracle.scan_topk(x[:done], ids[:done], qq, 10))
+    assert done == 5000 and idx.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32-f16shadow", "bf16"])
 @pytest.mark.parametrize("n,B", [(4097, 2), (100_003, 3), (100_003, 5), (300_001, 8), (20_001, 13)])
 def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype):
     """The streaming filter serves 1..3 queries by default; forced (mfma_min_batch) it takes any batch, 8 queries per
-    pass (QB = 1 / 4 / 8 variants, f16 shadow or bf16 index): same results as the oracle and as the default path."""
-    idx = dawn.VectorIndex(0, dtype=dtype)
+    pass (QB = 1 / 4 / 8 variants; int8 shadow, f16 shadow or bf16 index): same results as the oracle and as the
+    default path."""
+    idx = dawn.VectorIndex(0, dtype=dtype.split("-")[0])
+    if dtype == "f32-f16shadow":
+        idx.set_option("i8_shadow", 0)
     idx.fill_synthetic(1, 0, n, 1)
     x = oracle.unit_rows(1, 0, n)
     if dtype == "bf16":
