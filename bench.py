@@ -176,11 +176,11 @@ def main():
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
         # bytes the dominant kernel has to read per row (the exact rescore touches 64 f32 rows per query on top):
-        #   "i8"  384.25: batches of 1..3 on an f32 index stream its int8 shadow (+ 8 B of scale/bound per 32 rows)
-        #   "f16" 768: the f16 shadow of an f32 index (matrix-core path; batches of 1..3 with i8_shadow = 0), a bf16 index
+        #   "i8"  384.25: the int8 shadow of an f32 index (+ 8 B of scale/bound per 32 rows), every batch size
+        #   "f16" 768: the f16 shadow of an f32 index (i8_shadow = 0), a bf16 index
         #   "f32" 1536: the f32 rows themselves (both shadows switched off for small batches)
         if rows_read == "default":
-            rows_read = "i8" if (Bq < 4 and index.dtype == "f32") else "f16"
+            rows_read = "i8" if index.dtype == "f32" else "f16"
         row_bytes = {"i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
         leg["row_bytes_streamed"] = row_bytes
         algo = int(rows_here * row_bytes) * scan_passes(Bq)
@@ -188,8 +188,13 @@ def main():
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
             if Bq >= 4:
+                # 256 query columns are multiplied whatever Bq is; dense peaks: 2.5 PFLOP/s f16/bf16, int8 twice that
+                # (MI355X_MICROARCH.md: the i8 MFMA has the cycles of the bf16 form at 2x the K)
                 leg["mfma_TFLOPs"] = 2.0 * 256 * rows_here * 384 / (leg["scan_kernel_ms"] * 1e-3) / 1e12
-                leg["mfma_frac_f16_dense_peak"] = leg["mfma_TFLOPs"] / 2500.0
+                if rows_read == "i8":
+                    leg["mfma_frac_i8_dense_peak"] = leg["mfma_TFLOPs"] / 5000.0
+                else:
+                    leg["mfma_frac_f16_dense_peak"] = leg["mfma_TFLOPs"] / 2500.0
         if check_planted:
             labels, _ = result()
             leg["planted_top1_ok"] = bool(labels[0][0] == 1 + (4242 % args.rows))
@@ -243,8 +248,7 @@ def main():
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
     if B >= 4:
-        kernel = ("scan_f16_pipe_kernel<append> (f16 shadow tiles by LDS-DMA, 4 waves x 64 queries)" if rows_local >= (1 << 23)
-                  else "scan_f16_dma_kernel<append> (f16 shadow tiles by LDS-DMA, 8 waves x 32 queries)")
+        kernel = "scan_i8_pipe_kernel<append> (int8 shadow tiles by LDS-DMA, 4 waves x 64 queries, v_mfma_i32_32x32x32_i8)"
     else:
         kernel = "scan_filter_i8s_kernel (int8 shadow fragments, global load -> integer MFMA; scores are upper bounds)"
 
@@ -254,7 +258,7 @@ def main():
         "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k "
-                               "(" + ("f16" if B >= 4 else "int8 upper-bound") + " filter over a shadow copy of every row + "
+                               "(int8 upper-bound filter over a shadow copy of every row + "
                                "exact f32 rescore + certificate: results bit-identical to the f32 scan)",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
                    "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else "")},
@@ -293,6 +297,11 @@ def main():
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
         leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)
         extra["batch256"] = leg
+        # ... and on the f16 shadow (scan_f16_pipe_kernel; int8 shadow off)
+        idx.set_option("i8_shadow", 0)
+        leg, _ = run_leg(idx, 256, max(3, b256_steps // 2), 1, seed=3, rows_read="f16")
+        idx.set_option("i8_shadow", 1)
+        extra["batch256_f16_shadow"] = leg
         if world == 1:
             # host-API latency (host buffers in/out: includes H2D of the query and D2H of k results)
             q = synth.unit_rows(2, 1, 1)[0]

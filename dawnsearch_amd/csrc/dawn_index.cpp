@@ -5,6 +5,7 @@
 // exact brute-force index: rows [N][384] f32 + ids [N] u64 live in one HBM allocation each, appended in
 // insertion order; search = scan_kernels.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,7 @@ struct dawn_index {
     float* d_i8meta = nullptr;
     size_t i8_cap = 0, i8_rows = 0;
     int use_i8 = 1;              // option "i8_shadow"
+    int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
     bool i8_failed = false;
     float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
     size_t stage_rows = 0;
@@ -219,9 +221,9 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
 
 // Bring the int8 shadow up to date; false when it is disabled or does not fit.
 bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
-    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_i8 || !idx->shadow_small_batches || idx->i8_failed) return false;
+    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_i8 || idx->i8_failed) return false;
     if (idx->i8_cap < idx->cap_phys) {
-        const size_t prow = padded_rows(idx->cap_phys);
+        const size_t prow = padded_rows(idx->cap_phys) + 128;  // (the batched kernel moves 128-row tiles)
         const size_t bytes = prow * dawn::EM, mbytes = (prow / 32 + 1) * 8;
         // leave room for the f16 shadow of the matrix-core path (allocated at the first batch of mfma_min_batch queries)
         (void)hipStreamSynchronize(stream);  // the old buffers are idle: searches are serialised
@@ -232,7 +234,8 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
         idx->i8_cap = 0;
         size_t fr = 0, tot = 0;
         size_t need = bytes + mbytes + ((size_t)2 << 30);
-        if (idx->use_shadow && !idx->shadow_failed && idx->shadow_cap < idx->cap_phys) need += prow * dawn::EM * 2;
+        if (!idx->i8_batched && idx->use_shadow && !idx->shadow_failed && idx->shadow_cap < idx->cap_phys)
+            need += prow * dawn::EM * 2;
         char* ns = nullptr;
         float* nm = nullptr;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need || hipMalloc((void**)&ns, bytes) != hipSuccess ||
@@ -242,6 +245,8 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
             idx->i8_failed = true;
             return false;
         }
+        (void)hipMemsetAsync(ns, 0, bytes, stream);  // sub-tiles past the last row: zeros, scale 0
+        (void)hipMemsetAsync(nm, 0, mbytes, stream);
         idx->d_i8 = ns;
         idx->d_i8meta = nm;
         idx->i8_cap = idx->cap_phys;
@@ -272,7 +277,16 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
         idx->events_used++;
     }
     const uint32_t n = (uint32_t)idx->size;
-    if ((int)B >= idx->mfma_min_batch) {
+    if ((int)B >= idx->mfma_min_batch && idx->i8_batched && i8_rows_ready(idx, stream)) {
+        // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
+        for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
+            const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
+            dawn::launch_scan_batched_i8(idx->d_x, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb,
+                                         (uint32_t)k, idx->bws, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k,
+                                         d_found + b0, idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
+                                         b0 == 0 ? e1 : nullptr);
+        }
+    } else if ((int)B >= idx->mfma_min_batch) {
         // matrix-core path, BATCH_QT queries per pass over the index
         int frt = idx->dtype;
         const void* frows = idx->d_x;  // f32 index with mfma_sched 0 / 2: the lockstep kernel converts the f32 rows
@@ -285,7 +299,7 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
                                       idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                       b0 == 0 ? e1 : nullptr);
         }
-    } else if (i8_rows_ready(idx, stream)) {
+    } else if (idx->shadow_small_batches && i8_rows_ready(idx, stream)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
         const dawn::ScanGeom& gh = idx->i8_geom();
         dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
@@ -334,6 +348,7 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     auto* idx = new dawn_index();
     idx->device = device;
     idx->dtype = dtype;
+    if (const char* e = getenv("DAWN_I8_SHADOW")) idx->use_i8 = atoi(e) != 0;  // default of the "i8_shadow" option
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
@@ -784,7 +799,7 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     int frt = idx->dtype;
     const void* frows = nullptr;
     size_t blocks;
-    if (i8_rows_ready(idx, stream)) {
+    if (idx->shadow_small_batches && i8_rows_ready(idx, stream)) {
         const dawn::ScanGeom& gh = idx->i8_geom();
         blocks = gh.blocks;
         dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
@@ -874,6 +889,10 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     if (n == "i8_shadow") {
         idx->use_i8 = value != 0;
         if (value) idx->i8_failed = false;
+        return DAWN_OK;
+    }
+    if (n == "i8_batched") {
+        idx->i8_batched = value != 0;
         return DAWN_OK;
     }
     if (n == "f16_shadow_b1") {

@@ -102,6 +102,17 @@ struct BatchPlan {
     uint32_t s2_tiles, s2_stride, m2;   // appended sample (0 = skipped), tau = m2-th largest
 };
 BatchPlan plan_batched(uint32_t n_rows);
+BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows);
+// pieces of the batched tail shared with the int8 path (scan_i8.hip)
+void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_t dense_count, uint32_t m, hipStream_t stream);
+void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
+                               const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
+                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream);
+// Batched search on the int8 shadow (scan_i8.hip): the sequence of launch_scan_batched over 128-row int8 tiles
+void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
+                            const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
+                            float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
+                            hipEvent_t ev0, hipEvent_t ev1);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);

@@ -1120,8 +1120,12 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side: pass planning + launch sequence
 // ------------------------------------------------------------------------------------------------
-BatchPlan plan_batched(uint32_t n_rows) {
+BatchPlan plan_batched(uint32_t n_rows) { return plan_batched_tiles(n_rows, TILE_ROWS); }
+
+// tile_rows: 64 (16-bit tiles) or 128 (int8 tiles, scan_i8.hip): the samples cover the same numbers of ROWS
+BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
     BatchPlan pl{};
+    const uint32_t TILE_ROWS = tile_rows;  // (shadows the constant)
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     pl.n_tiles_total = n_tiles;
     if (n_rows <= (uint32_t)BATCH_CAP) {
@@ -1142,8 +1146,8 @@ BatchPlan plan_batched(uint32_t n_rows) {
     // sample 2: n/64 rows (so that the threshold is the ~24th largest of it: the count of candidates of the full pass then
     // scatters by ~20 %), at least 16 Ki and at most 1.5M rows, appended above tau1
     uint32_t t2 = n_tiles / 64;
-    if (t2 < 256u) t2 = 256u;
-    if (t2 > 23437u) t2 = 23437u;
+    if (t2 < 16384u / TILE_ROWS) t2 = 16384u / TILE_ROWS;
+    if (t2 > 1500000u / TILE_ROWS) t2 = 1500000u / TILE_ROWS;
     pl.s2_tiles = t2;
     pl.s2_stride = n_tiles / t2;
     const double n2 = (double)t2 * TILE_ROWS;
@@ -1320,14 +1324,16 @@ void launch_batched_dense_scores(const void* d_frows, int frt, uint32_t n_rows, 
     launch_pass<true>(d_x, dtype, n_rows, 0, 1, (n + TILE_ROWS - 1) / TILE_ROWS, ws, B, grid, stream);
 }
 
+// eps_override > 0: the filter's bound when it is not the 16-bit matrix-core one (int8 upper-bound scores)
 template <bool DENSE>
 static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q,
                                   int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
-                                  uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream) {
+                                  uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
+                                  float eps_override = 0.f) {
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     // the bf16-rounded rows may exceed the is_normalized band by 2^-8: scale the bound on sum|q_i x_i| accordingly
-    const float eps = dtype == ROW_BF16 ? FILTER_EPS_BF16_MFMA : FILTER_EPS_F16;
+    const float eps = eps_override > 0.f ? eps_override : dtype == ROW_BF16 ? FILTER_EPS_BF16_MFMA : FILTER_EPS_F16;
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x,
                            d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
@@ -1336,6 +1342,26 @@ static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_
         hipLaunchKernelGGL((select_rescore_kernel<DENSE, 0>), dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x,
                            d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
                            force_fallback, eps);
+}
+
+void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
+                               const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
+                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream) {
+    if (dense_pass)
+        launch_select_rescore<true>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, force_fallback,
+                                    stream, eps);
+    else
+        launch_select_rescore<false>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, force_fallback,
+                                     stream, eps);
+}
+
+void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_t dense_count, uint32_t m, hipStream_t stream) {
+    const float* dense = reinterpret_cast<const float*>(ws.cand);
+    const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
+    if (dense_pass)
+        hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, dense_count, m, ws.tau);
+    else
+        hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, m, ws.tau);
 }
 
 // d_x/dtype: the index rows (exact rescore); d_frows/frt: the filter's row source (the same rows, or the scaled f16

@@ -21,6 +21,8 @@
 //     FILTER_EPS_I8 = 2.6e-5 on top of ub.
 //   * the hot loop never leaves the integers: the lane's list threshold tau is turned into an integer threshold once
 //     per sub-tile (5 VALU), conservatively (rows it passes are re-tested on ub itself).
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "wave_topk.hpp"
 
@@ -304,6 +306,470 @@ void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n
         else launch_filter_i8s_qb<8>(d_shadow, d_meta, n_rows, q, nb, cs, cp, g, stream);
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// matrix-core filter for 4..256 queries per pass on the int8 shadow
+// ------------------------------------------------------------------------------------------------
+// The software pipeline of scan_f16_pipe_kernel (scan_batched.hip: one wave per SIMD, 64 queries per wave, three
+// 48-KiB tile images filled by LDS-DMA, never-draining fragment ring, two accumulator sets, per-wave candidate stage)
+// on v_mfma_i32_32x32x32_i8: a 48-KiB image is FOUR 32-row sub-tiles of 12 fragments (128 rows), every MFMA covers 32
+// k instead of 16, so the matrix pipe needs half the instructions per row.  The query enters as ONE int8 image
+// (X_q = rint(q / s_q)); with the measured ||q - s_q X_q||_2 the score
+//     ub = fma(float(acc), s * s_q, E + K2),    K2 = 1.1 * ||dq||_2   (>= |(sX).dq|, see the header of this file)
+// is an upper bound of the real dot product.  The threshold test stays in the integers: per sub-tile and query group
+// one integer threshold from {s, E} of the sub-tile (6 VALU), then v_max3_i32 slices in the shadow of the MFMAs.
+// {s, E} of a tile's four sub-tiles (32 B) travel beside the DMA: two global_load_dwordx4 issued in front of the DMA
+// of tile t+2 (vmcnt is in order: the wait that publishes tile t+1 covers them), copied into the registers the tests
+// read once the last test of tile t-1 is done.
+constexpr int I8_TILE_ROWS = 128;
+constexpr int I8_TILE_BYTES = I8_TILE_ROWS * EM;  // 49152
+constexpr uint32_t I8_WCAP = 256;                 // staged candidates per wave
+constexpr uint32_t I8_SEG_CAP = (uint32_t)BATCH_CAP / (uint32_t)BATCH_CAND_SEGS;
+
+// queries -> int8 images [BATCH_QT][384] + {s_q, K2} per query; rows b >= n_q: zeros.  One wave per query.
+__global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __restrict__ q, int n_q, signed char* __restrict__ qi,
+                                                             float2* __restrict__ qmeta) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = b < n_q ? q[(size_t)b * EM + lane + 64 * j] : 0.f;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+    float e2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float t = fminf(fmaxf(rintf(v[j] / sq), -127.f), 127.f);
+        const float d = v[j] - sq * t;
+        e2 = __builtin_fmaf(d, d, e2);
+        qi[(size_t)b * EM + lane + 64 * j] = (signed char)(int)t;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o);
+    if (lane == 0) qmeta[b] = b < n_q ? float2{sq, 1.1f * 1.001f * sqrtf(e2) + 1e-9f} : float2{0.f, 0.f};
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* __restrict__ xs, const float2* __restrict__ meta,
+                                                          uint32_t n_rows, uint32_t first_tile, uint32_t tile_stride,
+                                                          uint32_t n_tiles, const i32x4_t* __restrict__ qi,
+                                                          const float2* __restrict__ qmeta, int n_q,
+                                                          const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                          uint2* __restrict__ cand, float* __restrict__ dense) {
+    constexpr int NW = 4, PD = 8, DPW = 48 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char img[3 * I8_TILE_BYTES];
+    constexpr uint32_t PLANE = NW * I8_WCAP * 4;
+    __shared__ uint32_t stage[3 * NW * I8_WCAP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const int qg0 = wave * 32 + (int)r, qg1 = (wave + NW) * 32 + (int)r;  // this lane's query in group 0 / 1
+    const bool live0 = wave * 32 < n_q, live1 = (wave + NW) * 32 < n_q;    // wave-uniform
+
+    // B operand: lane (h, query) holds k = 32s + 16h .. +15 of k-step s = 16-B chunk 2s + h of the query's image
+    i32x4_t qf[2][12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+        qf[0][s] = qi[(size_t)qg0 * 24 + 2 * s + h];
+        qf[1][s] = qi[(size_t)qg1 * 24 + 2 * s + h];
+    }
+    // per lane and group: s_q, K2, 1/s_q and the threshold lowered by K2 and by its own rounding allowance
+    float sq_l[2], k2_l[2], rsq_l[2], taum[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi_ = g == 0 ? qg0 : qg1;
+        const float2 qm = qmeta[qi_];
+        sq_l[g] = qm.x;
+        k2_l[g] = qm.y;
+        rsq_l[g] = qi_ < n_q ? 1.0f / qm.x : 0.f;
+        taum[g] = __builtin_inff();
+        if (!DENSE && qi_ < n_q) {
+            const float tk = tau[qi_] - qm.y;
+            taum[g] = tk - fabsf(tk) * 1e-6f;
+        }
+    }
+
+    const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t G = gridDim.x;
+    const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
+    const uint32_t last = n_units - 1;
+    auto unit_tile = [&](uint32_t t) { return first_tile + (blockIdx.x + t * G) * tile_stride; };
+    auto unit_row0 = [&](uint32_t t) { return unit_tile(t) * I8_TILE_ROWS; };
+    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * I8_TILE_ROWS; };
+    constexpr int NGP = DPW / 4;
+    auto dma = [&](uint32_t t, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
+        unsigned char* dst = img + image * I8_TILE_BYTES + wave * (DPW * 1024);
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)gp[j];
+            __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 4096);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 2 /* nt */);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 2);
+        }
+    };
+    auto dma_setup = [&](uint32_t t, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+    };
+    auto dma_one = [&](auto i_c, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_c)::value, J = I / 4, O = (I % 4) * 1024;
+        unsigned char* dst = img + image * I8_TILE_BYTES + wave * (DPW * 1024) + J * 4096;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[J],
+                                         (__attribute__((address_space(3))) void*)dst, 16, O, 2 /* nt */);
+    };
+    auto keep = [&](const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) asm volatile("" ::"v"(gp[j]));
+    };
+
+    // ---- candidate staging, private to the wave (as in scan_f16_pipe_kernel) ----
+    uint32_t wpos = 0;
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t q_[I8_WCAP / 64], slot[I8_WCAP / 64];
+        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;
+#pragma unroll
+        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            q_[j] = e < wpos ? stage[wave * I8_WCAP + e] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            slot[j] = 0xFFFFFFFFu;
+            if (e < wpos) slot[j] = atomicAdd(&cnt[q_[j] * BATCH_CAND_SEGS + seg], 1u);
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
+            const uint32_t e = lane + 64u * j;
+            if (slot[j] < I8_SEG_CAP)
+                cand[(size_t)q_[j] * BATCH_CAP + seg * I8_SEG_CAP + slot[j]] =
+                    make_uint2(stage[NW * I8_WCAP + wave * I8_WCAP + e], stage[2 * NW * I8_WCAP + wave * I8_WCAP + e]);
+        }
+        wpos = 0;
+    };
+    const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
+    // slow path: some lane holds an accumulator above its integer threshold.  gl / ek: the lane's s * s_q and E + K2.
+    auto tail_slow = [&](const i32x16_t& acc, uint32_t row0, uint32_t q_first, int thr_lane, float gl, float ek)
+        __attribute__((always_inline)) {
+        const uint32_t lim = n_rows > row0 + 4 * h ? n_rows - row0 - 4 * h : 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ae = acc[e];
+            const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+            unsigned long long m = __ballot(ae > thr_lane && roff < lim);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const float cf = (float)__builtin_amdgcn_readlane(ae, l);
+                const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), l));
+                const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ek), l));
+                const float sc = __builtin_fmaf(cf, g1, e1);
+                const uint32_t qidx = q_first + (uint32_t)(l & 31);
+                const uint32_t row = row0 + roff + 4u * (uint32_t)(l >> 5);
+                if (wpos >= I8_WCAP) flush_wave();
+                if (lane == 0) {
+                    const uint32_t pa = stage_base + (wave * I8_WCAP + wpos) * 4u;
+                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                                 :
+                                 : "v"(pa), "v"(qidx), "v"(__builtin_bit_cast(uint32_t, sc)), "v"(row), "n"(PLANE), "n"(2 * PLANE));
+                }
+                ++wpos;
+            }
+        }
+    };
+    i32x16_t acc[2][2];
+    int mx[2] = {0, 0}, thr[2] = {0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[1][0][e] = acc[1][1][e] = 0;
+    // {s, E} of the four sub-tiles: mu = the tile whose sub-tiles are under test, ml = the next one (in flight / landed)
+    f32x4 mu0, mu1, ml0, ml1;
+    auto sub_meta = [&](int j, float& s_, float& e_) __attribute__((always_inline)) {
+        s_ = j == 0 ? mu0.x : j == 1 ? mu0.z : j == 2 ? mu1.x : mu1.z;
+        e_ = j == 0 ? mu0.y : j == 1 ? mu0.w : j == 2 ? mu1.y : mu1.w;
+    };
+    // dense store of one finished sub-tile (accumulator set SET, sub-tile J of the tile in mu)
+    auto tail_dense = [&](auto set_c, auto nl_c, int J, uint32_t row_base, uint32_t slot_base) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
+        const uint32_t row0 = row_base + 4 * h;
+        float s_, e_;
+        sub_meta(J, s_, e_);
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            const int qidx = g == 0 ? qg0 : qg1;
+            const float gl = s_ * sq_l[g], ek = e_ + k2_l[g];
+            if (qidx < n_q) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ae = acc[SET][g][e4 * 4 + e];
+                        o[e] = (row0 + e + 8 * e4) < n_rows ? __builtin_fmaf((float)ae, gl, ek) : NEG_INF;
+                    }
+                    *reinterpret_cast<f32x4*>(dense + (size_t)qidx * BATCH_CAP + slot_base + 4 * h + 8 * e4) = o;
+                }
+            }
+        }
+    };
+    // integer thresholds of sub-tile J (of the tile in mu) for the NL live groups
+    auto set_thr = [&](auto nl_c, int J) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        float s_, e_;
+        sub_meta(J, s_, e_);
+        const float rs = __builtin_amdgcn_rcpf(s_);
+#pragma unroll
+        for (int g = 0; g < NL; ++g) {
+            const float u = __builtin_fmaf(-e_, 1.000001f, taum[g]);
+            float tf = __builtin_fmaf(u, rs * rsq_l[g], -2.0f);
+            tf = fminf(fmaxf(tf, -2.0e9f), 2.0e9f);   // (NaN from 0 * inf -> -2e9: everything is tested further)
+            if (!(taum[g] < __builtin_inff())) tf = 2.0e9f;  // padding columns never hit
+            thr[g] = (int)floorf(tf);
+            asm volatile("" : "+v"(thr[g]));
+        }
+    };
+    auto slow = [&](auto set_c, auto nl_c, int J, uint32_t row_base) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
+        float s_, e_;
+        sub_meta(J, s_, e_);
+#pragma unroll
+        for (int g = 0; g < NL; ++g)
+            if (__any(mx[g] > thr[g]))
+                tail_slow(acc[SET][g], row_base, (uint32_t)((wave + NW * g) * 32), thr[g], s_ * sq_l[g], e_ + k2_l[g]);
+    };
+
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(qf[g][s]));
+        asm volatile("" ::"v"(taum[g]), "v"(sq_l[g]), "v"(k2_l[g]), "v"(rsq_l[g]));
+    }
+    const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
+    const f32x4* meta4 = reinterpret_cast<const f32x4*>(meta);  // 2 per tile
+
+    // prologue: {s, E} of tile 0 (complete before the loop as far as hipcc can tell), tiles 0 and 1 on their way
+    ml0 = meta4[(size_t)unit_tile(0) * 2];
+    ml1 = meta4[(size_t)unit_tile(0) * 2 + 1];
+    asm volatile("" : "+v"(ml0), "+v"(ml1));
+    mu0 = ml0;
+    mu1 = ml1;
+    const unsigned char* gp0[NGP];
+    const unsigned char* gp1[NGP];
+    dma(0, 0, gp0);
+    dma(last < 1u ? last : 1u, 1, gp1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
+    keep(gp0);
+    keep(gp1);
+    i32x4_t a[PD];
+    {
+        const uint32_t ad = o0 + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[d]) : "v"(ad), "n"(d * 1024));
+    }
+
+    uint32_t t = 0;
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    auto step = [&](auto nl_c, uint32_t rd, uint32_t nx, uint32_t wr) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        const uint32_t ad = o0 + rd * I8_TILE_BYTES + (uint32_t)lane * 16u;
+        const uint32_t adn = o0 + nx * I8_TILE_BYTES + (uint32_t)lane * 16u;
+        const unsigned char* gp[NGP];
+#pragma unroll
+        for (int f = 0; f < 48; ++f) {
+            const int sub = f / 12, s = f % 12, set = sub & 1;
+            // the sub-tile whose test runs during this one: (t, sub - 1), or (t - 1, 3) while sub == 0
+            const int J = sub == 0 ? 3 : sub - 1;
+            if (NL > 0) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));  // fragment f has landed
+                __builtin_amdgcn_sched_barrier(0);
+                // asm MFMAs: accumulators and group 0's query fragments in VGPRs, group 1's in AGPRs read directly as SrcB.
+                // The kernel must stay below 256 VGPRs: hipcc would park live values in AGPRs around the slow paths, and a
+                // copy of an accumulator it cannot know to be an MFMA result in flight reads a stale register.
+#define DAWN_I8_ZERO(D, A, B, CB) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(D) : "v"(A), CB(B))
+#define DAWN_I8_ACC(D, A, B, CB) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(D) : "v"(A), CB(B))
+                if (s == 0) {
+                    DAWN_I8_ZERO(acc[set][0], a[f % PD], qf[0][0], "v");
+                    if (NL > 1) DAWN_I8_ZERO(acc[set][1], a[f % PD], qf[1][0], "a");
+                } else {
+                    DAWN_I8_ACC(acc[set][0], a[f % PD], qf[0][s], "v");
+                    if (NL > 1) DAWN_I8_ACC(acc[set][1], a[f % PD], qf[1][s], "a");
+                }
+#undef DAWN_I8_ZERO
+#undef DAWN_I8_ACC
+                __builtin_amdgcn_sched_barrier(0);
+                const bool have_prev = sub > 0 || t > 0;  // (sub is a constant: folds to `t > 0` or true)
+                if (!DENSE) {
+                    constexpr int FIRST = 2;
+                    if (s == FIRST - 1) set_thr(nl_c, J);
+                    if (s == FIRST) asm volatile("s_nop 7");
+                    if (s >= FIRST && s < FIRST + 8) {
+                        const int j = s - FIRST;
+#pragma unroll
+                        for (int g = 0; g < NL; ++g) {
+                            mx[g] = j == 0 ? max(acc[1 - set][g][0], acc[1 - set][g][1])
+                                           : max(max(mx[g], acc[1 - set][g][2 * j]), acc[1 - set][g][2 * j + 1]);
+                            asm volatile("" : "+v"(mx[g]));
+                        }
+                    }
+                    if (s == FIRST + 8 && have_prev) {
+                        bool hit = mx[0] > thr[0];
+                        if (NL > 1) hit = hit || mx[1] > thr[1];
+                        if (__any(hit)) {
+                            const uint32_t rb = sub == 0 ? unit_row0(t - 1) + 96 : unit_row0(t) + 32 * (sub - 1);
+                            if (set == 0) slow(C1(), nl_c, J, rb);
+                            else slow(C0(), nl_c, J, rb);
+                        }
+                    }
+                }
+                if (DENSE && s == 2 && have_prev) {
+                    asm volatile("s_nop 7");
+                    const uint32_t rb = sub == 0 ? unit_row0(t - 1) + 96 : unit_row0(t) + 32 * (sub - 1);
+                    const uint32_t sb = sub == 0 ? unit_slot0(t - 1) + 96 : unit_slot0(t) + 32 * (sub - 1);
+                    if (set == 0) tail_dense(C1(), nl_c, J, rb, sb);
+                    else tail_dense(C0(), nl_c, J, rb, sb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f == 11) {  // the last test of tile t-1 is done: its {s, E} make room for tile t's (landed since P2 of t-1)
+                mu0 = ml0;
+                mu1 = ml1;
+                asm volatile("" : "+v"(mu0), "+v"(mu1));
+            }
+            if (f == 12) {  // P1: every wave has left tile t-1, its image may be overwritten
+                asm volatile("s_barrier");
+                __builtin_amdgcn_sched_barrier(0);
+                // {s, E} of tile t+1, IN FRONT of the DMA of tile t+2: P2's vmcnt(DPW) covers them
+                const f32x4* mp = meta4 + (size_t)unit_tile(t + 1 < n_units ? t + 1 : last) * 2;
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                             : "=&v"(ml0), "=&v"(ml1)
+                             : "v"(mp));
+                dma_setup(t + 2 < n_units ? t + 2 : last, gp);
+            }
+            if (f == 13) dma_one(std::integral_constant<int, 0>(), wr, gp);
+            if (f == 14) dma_one(std::integral_constant<int, 1>(), wr, gp);
+            if (f == 15) dma_one(std::integral_constant<int, 2>(), wr, gp);
+            if (f == 16) dma_one(std::integral_constant<int, 3>(), wr, gp);
+            if (f == 17) dma_one(std::integral_constant<int, 4>(), wr, gp);
+            if (f == 18) dma_one(std::integral_constant<int, 5>(), wr, gp);
+            if (f == 19) dma_one(std::integral_constant<int, 6>(), wr, gp);
+            if (f == 20) dma_one(std::integral_constant<int, 7>(), wr, gp);
+            if (f == 21) dma_one(std::integral_constant<int, 8>(), wr, gp);
+            if (f == 22) dma_one(std::integral_constant<int, 9>(), wr, gp);
+            if (f == 23) dma_one(std::integral_constant<int, 10>(), wr, gp);
+            if (f == 24) dma_one(std::integral_constant<int, 11>(), wr, gp);
+            if (f == 39) {  // P2: tile t+1 and the {s, E} loads in front of tile t+2's DMA have landed
+                __builtin_amdgcn_sched_barrier(0);
+                if (DENSE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier");  // (dense stores share vmcnt)
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPW));
+                asm volatile("" : "+v"(ml0), "+v"(ml1));
+            }
+            if (NL > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (f + PD < 48)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[f % PD]) : "v"(ad), "n"((f + PD) * 1024));
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                 : "=v"(a[f % PD])
+                                 : "v"(adn), "n"((f + PD < 48 ? 0 : f + PD - 48) * 1024));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        keep(gp);
+        ++t;
+    };
+    auto run = [&](auto nl_c) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        uint32_t rd = 0, nx = 1, wr = 2;
+        while (t < n_units) {
+            step(nl_c, rd, nx, wr);
+            const uint32_t o = rd;
+            rd = nx;
+            nx = wr;
+            wr = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15");  // the ring's look-ahead reads; the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (NL > 0) {  // the last sub-tile (t = last, sub 3, accumulator set 1); mu holds tile `last` since its f == 11
+            const uint32_t rb = unit_row0(last) + 96, sb = unit_slot0(last) + 96;
+            if (DENSE) {
+                tail_dense(C1(), nl_c, 3, rb, sb);
+            } else {
+                set_thr(nl_c, 3);
+#pragma unroll
+                for (int g = 0; g < NL; ++g) {
+                    mx[g] = acc[1][g][0];
+#pragma unroll
+                    for (int e = 1; e < 16; ++e) mx[g] = max(mx[g], acc[1][g][e]);
+                }
+                slow(C1(), nl_c, 3, rb);
+            }
+        }
+    };
+    if (live1) run(C2());
+    else if (live0) run(C1());
+    else run(C0());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
+    if (!DENSE) flush_wave();
+}
+
+void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
+                            const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
+                            float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
+                            hipEvent_t ev0, hipEvent_t ev1) {
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS);
+    signed char* qi = reinterpret_cast<signed char*>(ws.qh);               // [256][384] int8
+    float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);     // [256] {s_q, K2}
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(BATCH_QT), dim3(64), 0, stream, d_q, B, qi, qm);
+    const unsigned char* xs = reinterpret_cast<const unsigned char*>(d_i8);
+    const float2* mt = reinterpret_cast<const float2*>(d_meta);
+    auto pass = [&](bool dense_pass, uint32_t stride, uint32_t n_tiles) {
+        if (n_tiles == 0) return;
+        const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
+        if (dense_pass)
+            hipLaunchKernelGGL(scan_i8_pipe_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
+                               reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
+                               reinterpret_cast<float*>(ws.cand));
+        else
+            hipLaunchKernelGGL(scan_i8_pipe_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride,
+                               n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt,
+                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+    };
+    if (pl.dense_only) {
+        if (ev0) (void)hipEventRecord(ev0, stream);
+        pass(true, 1, pl.n_tiles_total);
+        if (ev1) (void)hipEventRecord(ev1, stream);
+        launch_select_rescore_eps(true, d_x, ROW_F32, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+                                  force_fallback, FILTER_EPS_I8, stream);
+        return;
+    }
+    pass(true, pl.s1_stride, pl.s1_tiles);
+    launch_tau_select(true, B, ws, pl.s1_tiles * I8_TILE_ROWS, pl.m1, stream);
+    if (pl.s2_tiles) {
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
+        pass(false, pl.s2_stride, pl.s2_tiles);
+        launch_tau_select(false, B, ws, 0u, pl.m2, stream);
+    }
+    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    pass(false, 1, pl.n_tiles_total);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    launch_select_rescore_eps(false, d_x, ROW_F32, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+                              force_fallback, FILTER_EPS_I8, stream);
 }
 
 }  // namespace dawn

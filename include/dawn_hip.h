@@ -153,6 +153,7 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *                      41..55 = timing experiments (parts of the pipelined kernel switched off: wrong results)
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow (filters read / convert the f32 rows)
  *   "i8_shadow"        0: batches below mfma_min_batch do not use the int8 shadow (384 B/row, scan_i8.hip) of an f32 index
+ *   "i8_batched"       0: batches of mfma_min_batch and more filter on the f16 shadow instead of the int8 one
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of the shadow
  *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
  *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the 16-bit fragment stream

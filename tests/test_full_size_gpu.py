@@ -37,7 +37,7 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     idx = big
     Q, planted = _queries()
     assert idx.size() == N
-    # (1) batch-1 stream over the f16 shadow (default)
+    # (1) batch-1 stream over the int8 shadow (default)
     res1 = [idx.search(q, K) for q in Q]
     for lab, dist in res1:
         assert len(lab) == K and np.all(np.diff(dist) >= 0) and lab.min() >= 1 and lab.max() <= N
@@ -65,6 +65,16 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     assert np.array_equal(l8, labels[:8]) and np.array_equal(d8.view(np.uint32), dist[:8].view(np.uint32))
     l3, d3, f3 = idx.search_batch(Q[5:8], K)
     assert np.array_equal(l3, labels[5:8]) and np.array_equal(d3.view(np.uint32), dist[5:8].view(np.uint32))
+    # (3b) the f16 shadow instead of the int8 one: stream (batch 1) and matrix-core path (all 16)
+    idx.set_option("i8_shadow", 0)
+    try:
+        for b in (0, 7, 15):
+            lab, dd = idx.search(Q[b], K)
+            assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+        lf, df, ff = idx.search_batch(Q, K)
+        assert np.array_equal(lf, labels) and np.array_equal(df.view(np.uint32), dist.view(np.uint32))
+    finally:
+        idx.set_option("i8_shadow", 1)
     # (4) the f32 rows streamed directly (no shadow involved)
     idx.set_option("f16_shadow_b1", 0)
     try:

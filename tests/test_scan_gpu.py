@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 from dawnsearch_amd import synth  # noqa: E402
 
 
+@pytest.fixture(params=["i8", "f16"])
+def shadow(request, monkeypatch):
+    """Filter shadow of an f32 index: int8 upper-bound scores (default) or scaled f16 (DAWN_I8_SHADOW=0: the default
+    of the "i8_shadow" option, read when an index is created)."""
+    monkeypatch.setenv("DAWN_I8_SHADOW", "1" if request.param == "i8" else "0")
+    return request.param
+
+
 def _mk_index(dawn, n, seed=1, first_id=1):
     idx = dawn.VectorIndex(0)
     idx.fill_synthetic(seed, 0, n, first_id)
@@ -37,7 +45,7 @@ def test_generator_matches_oracle(dawn, oracle):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 1000, 4097, 100_003])
 @pytest.mark.parametrize("k", [1, 10, 20, 64])
-def test_scan_matches_oracle_sizes(dawn, oracle, n, k):
+def test_scan_matches_oracle_sizes(dawn, oracle, n, k, shadow):
     idx = _mk_index(dawn, n)
     x = oracle.unit_rows(1, 0, n)
     ids = np.arange(1, n + 1, dtype=np.uint64)
@@ -70,7 +78,7 @@ def test_scan_1m_batch1_and_batch(dawn, oracle):
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_exact_fallback_path_agrees(dawn, oracle):
+def test_exact_fallback_path_agrees(dawn, oracle, shadow):
     """Force the certificate to fail: the always-exact pass must give the same answer."""
     n = 50_000
     idx = _mk_index(dawn, n)
@@ -85,7 +93,7 @@ def test_exact_fallback_path_agrees(dawn, oracle):
     assert idx.stats()["fallbacks"] == 4
 
 
-def test_duplicates_and_ties(dawn, oracle):
+def test_duplicates_and_ties(dawn, oracle, shadow):
     """Duplicate rows => equal distances => earlier-added row first (KAT from SURVEY §8c).
     200 copies of the best row overflow the 64-entry shortlist band, so the certificate fails and the
     exact pass decides — results must still equal the oracle."""
@@ -204,7 +212,7 @@ def test_page_entry_file_loader(dawn, oracle, tmp_path):
     assert m == 10
 
 
-def test_remote_search_distance_limit(dawn, oracle):
+def test_remote_search_distance_limit(dawn, oracle, shadow):
     """udp_service.rs:196-199: a peer's search reports only the hits with distance < distance_limit (the asker's
     worst_distance(): 0.0 until it holds 20 results, best_results.rs:40 — which prunes everything but negative
     distances, exactly as the reference does)."""
@@ -248,7 +256,7 @@ def test_search_provider_mirror(dawn, oracle):
 @pytest.mark.parametrize("n,B,k", [(100_003, 9, 10), (100_003, 32, 20), (100_003, 33, 10), (50_000, 64, 64),
                                    (50_000, 100, 20), (31, 16, 10), (64, 40, 64), (65, 9, 64), (4097, 256, 20),
                                    (8192, 31, 10), (8193, 200, 20), (8257, 12, 1), (20_001, 256, 10)])
-def test_batched_scan_matches_oracle(dawn, oracle, n, B, k):
+def test_batched_scan_matches_oracle(dawn, oracle, n, B, k, shadow):
     idx = _mk_index(dawn, n)
     x = oracle.unit_rows(1, 0, n)
     ids = np.arange(1, n + 1, dtype=np.uint64)
@@ -267,7 +275,7 @@ def test_batched_scan_matches_oracle(dawn, oracle, n, B, k):
     assert st["fallbacks"] == 0 and st["second_chances"] == (B if (k >= 64 and n > 64) else 0)
 
 
-def test_batched_1m_batch256(dawn, oracle):
+def test_batched_1m_batch256(dawn, oracle, shadow):
     """configs[2] scan leg: 1M x 384, batch = 256 — every 5th query checked against the oracle, all 256
     against the streaming path."""
     n, B, k = 1_000_000, 256, 10
@@ -285,7 +293,7 @@ def test_batched_1m_batch256(dawn, oracle):
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_batched_two_sample_plan_3m(dawn, oracle):
+def test_batched_two_sample_plan_3m(dawn, oracle, shadow):
     """N large enough for the three-pass plan (dense sample, appended sample, full pass); k = 20; B = 300
     exercises the 256-query chunking of the device path."""
     n, B, k = 3_000_000, 300, 20
@@ -460,7 +468,7 @@ def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype)
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle):
+def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, shadow):
     base = synth.unit_rows(1, 0, 3000)
     rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])
     ids = np.arange(1, len(rows) + 1, dtype=np.uint64)
@@ -486,7 +494,7 @@ def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle):
     assert idx3.stats()["fallbacks"] == 1
 
 
-def test_batched_clustered_index_overflow_falls_back(dawn, oracle):
+def test_batched_clustered_index_overflow_falls_back(dawn, oracle, shadow):
     """An index the strided sample misrepresents: 256 tiles of 64 rows, even tiles random, odd tiles near-copies
     of one row.  The sample (every 2nd tile) sees only random rows, so a query next to the copied row collects
     > 8192 candidates -> buffer overflow -> exact pass.  Answers must still equal the oracle."""
@@ -510,7 +518,7 @@ def test_batched_clustered_index_overflow_falls_back(dawn, oracle):
     assert idx.stats()["fallbacks"] >= 1
 
 
-def test_batched_correlated_queries_burst(dawn, oracle):
+def test_batched_correlated_queries_burst(dawn, oracle, shadow):
     """256 near-identical queries (a realistic batch: one topic) hit the SAME rows, so a qualifying row appends 256
     candidates at once.  The workgroup's candidate stage must absorb or bypass such bursts without dropping
     anything or sending the batch to the exact pass."""
@@ -566,7 +574,7 @@ def test_batched_pipelined_kernel_matches(dawn, oracle, n, B, k):
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_batched_shadow_tracks_adds_and_growth(dawn, oracle):
+def test_batched_shadow_tracks_adds_and_growth(dawn, oracle, shadow):
     """The f16 shadow copy is built at the first batched search and must follow later adds / reallocation."""
     rows = oracle.unit_rows(1, 0, 30_000)
     ids = np.arange(1, 30_001, dtype=np.uint64)
