@@ -776,10 +776,15 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     *n_out = n;
     if (n == 0) return DAWN_OK;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    int frt = idx->dtype;
-    const void* frows = filter_rows(idx, &frt, idx->stream);
-    dawn::launch_batched_dense_scores(frows, frt, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
-                                      idx->stream);
+    if (idx->i8_batched && i8_rows_ready(idx, idx->stream)) {  // (upper-bound scores: scan_i8.hip)
+        dawn::launch_batched_dense_scores_i8(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws,
+                                             idx->mfma_blocks, idx->stream);
+    } else {
+        int frt = idx->dtype;
+        const void* frows = filter_rows(idx, &frt, idx->stream);
+        dawn::launch_batched_dense_scores(frows, frt, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
+                                          idx->stream);
+    }
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),
                                   n * sizeof(float), B, hipMemcpyDeviceToHost, idx->stream));
@@ -829,12 +834,17 @@ int dawn_index_debug_time_full_pass(dawn_index* idx, size_t B, int iters, double
     if (!idx || !mean_ms || iters < 1) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
     if (B == 0 || B > (size_t)dawn::BATCH_QT || !idx->bws.cand) return fail(DAWN_ERR_INVALID_ARG, "run a batched search first");
     DAWN_TRY(set_device(idx));
-    int frt = idx->dtype;
-    const void* frows = filter_rows(idx, &frt, idx->stream);
     hipEvent_t e0, e1;
     DAWN_HIP_TRY(hipEventCreate(&e0));
     DAWN_HIP_TRY(hipEventCreate(&e1));
-    dawn::launch_batched_full_pass(frows, frt, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters, idx->stream, e0, e1);
+    if (idx->i8_batched && i8_rows_ready(idx, idx->stream)) {
+        dawn::launch_batched_full_pass_i8(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters,
+                                          idx->stream, e0, e1);
+    } else {
+        int frt = idx->dtype;
+        const void* frows = filter_rows(idx, &frt, idx->stream);
+        dawn::launch_batched_full_pass(frows, frt, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters, idx->stream, e0, e1);
+    }
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     float ms = 0.f;
     DAWN_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -917,6 +927,11 @@ int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
             DAWN_HIP_TRY(hipMemset(dawn::g_batched_diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));
         }
         dawn::g_batched_sched = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "mfma_target") {
+        if (value < 64 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_target must be 64..4096");
+        dawn::g_batched_target = (int)value;
         return DAWN_OK;
     }
     if (n == "scan_threads") {

@@ -108,6 +108,10 @@ void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_
 void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                                const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
                                uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream);
+void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
+                                 int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B,
+                                    const BatchWorkspace& ws, int grid, hipStream_t stream);
 // Batched search on the int8 shadow (scan_i8.hip): the sequence of launch_scan_batched over 128-row int8 tiles
 void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
                             const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
@@ -121,6 +125,7 @@ void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int
 extern int g_batched_sched;  // 4 = default (f16 shadow: pipelined 4-wave LDS-DMA kernel for long passes, 8-wave kernel for
                              // short ones), 5 = pipelined kernel always, 1 = 8-wave kernel always, 0 = lockstep kernel on
                              // the index rows, 2 = + stamps, 41..55 = timing experiments
+extern int g_batched_target;  // candidates per query the sampled thresholds aim for (1536)
 extern unsigned long long* g_batched_diag;
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
 void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int frt, const uint64_t* d_ids, uint32_t n_rows,

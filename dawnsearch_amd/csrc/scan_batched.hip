@@ -1135,7 +1135,7 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
     // sample 1: 128 strided tiles (8192 rows), dense
     pl.s1_tiles = BATCH_CAP / TILE_ROWS;
     pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1 since n_rows > BATCH_CAP
-    const double target = 1536.0;          // expected candidates per query in the full pass
+    const double target = (double)g_batched_target;  // expected candidates per query in the full pass
     const double m_full = target * BATCH_CAP / (double)n_rows;
     if (m_full >= 8.0) {
         pl.m1 = (uint32_t)(m_full + 0.999);
@@ -1169,6 +1169,7 @@ unsigned long long* g_batched_diag = nullptr;  // device buffer [grid][8 waves][
 // 1 (default): f16 shadow rows go through the LDS-DMA kernel, other row sources through the lockstep kernel;
 // 0: lockstep kernel for every row source; 2: lockstep kernel with diagnostic stamps
 int g_batched_sched = 4;
+int g_batched_target = 512;   // option "mfma_target"
 
 template <bool DENSE, int NW, int SCHED>
 static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,

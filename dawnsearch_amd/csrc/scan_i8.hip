@@ -17,8 +17,8 @@
 //         |(sX).dq| <= ||sX||_2 ||dq||_2 <= 1.1 * sqrt(384) * 2.0e-3 s_q =: K2(q)
 //     (|dq_i| <= s_q (0.5/254 + 127 * 2^-23) < 2.0e-3 s_q; ||sX||_2 <= ||x||_2 + ||dx||_2 < 1.01 + 0.09).
 //     ub = fma(float(C), s * s_q/254, E + K2) therefore bounds the real dot product from above up to the rounding of
-//     this expression (< 5e-7) and the reference's own sequential-sum error gamma_384 * 1.0201 = 2.4e-5:
-//     FILTER_EPS_I8 = 2.6e-5 on top of ub.
+//     this expression (< 1e-6: the product s * s_q comes from a stored 1 / s through v_rcp_f32, 1 ulp each) and the
+//     reference's own sequential-sum error gamma_384 * 1.0201 = 2.34e-5: FILTER_EPS_I8 = 2.6e-5 on top of ub.
 //   * the hot loop never leaves the integers: the lane's list threshold tau is turned into an integer threshold once
 //     per sub-tile (5 VALU), conservatively (rows it passes are re-tested on ub itself).
 #include <type_traits>
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void rows_f32_to_i8s_kernel(const f32x4* __res
     if (tid == 0) {
         const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
         // 1.0101: ||q||_2 < 1.01 (gate); 1.001 + 1e-9: the f32 evaluation of dx, the sum and the square root
-        meta[sub] = float2{s, sqrtf(m) * 1.0101f * 1.001f + 1e-9f};
+        // stored: {1 / s, E}: the filters' integer thresholds need the reciprocal once per sub-tile, s itself only on a hit
+        meta[sub] = float2{1.0f / s, sqrtf(m) * 1.0101f * 1.001f + 1e-9f};
     }
 }
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     for (int f = 0; f < 12; ++f) qf[f] = i32x4_t{0, 0, 0, 0};
     const int qcol = (int)(c & 7u);
     const bool lo_part = c >= 8;
-    float sq254_l = 0.f, k2_l = 0.f;  // this lane's query: s_q / 254 and K2
+    float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;  // this lane's query: s_q / 254, K2, 254 / s_q
     if (qcol < n_q && c < 16) {
         const f32x4* qc = reinterpret_cast<const f32x4*>(q + (size_t)qcol * EM);
         float amax = 0.f;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
         }
         const float sq = fmaxf(amax, 1e-20f) / 127.0f;
         sq254_l = sq / 254.0f;
+        rsq254_l = 254.0f / sq;
         k2_l = I8_K2_PER_SQ * sq;
 #pragma unroll
         for (int f = 0; f < 12; ++f) {
@@ -207,9 +209,9 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
                 __builtin_amdgcn_sched_barrier(0);  // keep every load PD steps ahead of its use
             }
             // this lane: D[row = 32t + (e&3) + 8*(e>>2) + 4h][column c];  C = 254 acc_H + acc_L (lane c <- lane c + 8)
-            const float g_l = mt.x * sq254_l;                       // score units per unit of C
+            // mt = {1 / s, E};  units of C per unit of score = (1 / s) * (254 / s_q)
             const float u = __builtin_fmaf(-mt.y, 1.000001f, tau_m);
-            float thr_f = __builtin_fmaf(u, __builtin_amdgcn_rcpf(g_l), -2.0f);
+            float thr_f = __builtin_fmaf(u, mt.x * rsq254_l, -2.0f);
             thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
             if (!tested) thr_f = 2.0e9f;  // (0 * inf above)
             const int thr = (int)floorf(thr_f);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
 #pragma unroll
                         for (int b = 0; b < QB; ++b) {
                             if (b == qb) {
-                                const float sc = __builtin_fmaf(cf, mt.x * sq254[b], mt.y + k2[b]);
+                                const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(mt.x) * sq254[b], mt.y + k2[b]);
                                 if (sc > tau[b]) {
                                     wave_insert(ls[b], lp[b], sc, row, lane);
                                     tau[b] = read_lane63(ls[b]);
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __rest
     if (lane == 0) qmeta[b] = b < n_q ? float2{sq, 1.1f * 1.001f * sqrtf(e2) + 1e-9f} : float2{0.f, 0.f};
 }
 
-template <bool DENSE>
+// DBG (timing experiments only, results are wrong): 1 = no DMA, 2 = no barriers, 4 = no threshold tests
+template <bool DENSE, int DBG = 0>
 __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* __restrict__ xs, const float2* __restrict__ meta,
                                                           uint32_t n_rows, uint32_t first_tile, uint32_t tile_stride,
                                                           uint32_t n_tiles, const i32x4_t* __restrict__ qi,
@@ -380,18 +383,21 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
         qf[1][s] = qi[(size_t)qg1 * 24 + 2 * s + h];
     }
     // per lane and group: s_q, K2, 1/s_q and the threshold lowered by K2 and by its own rounding allowance
-    float sq_l[2], k2_l[2], rsq_l[2], taum[2];
+    float sq_l[2], k2_l[2], c1[2], c2[2];  // c1 = taum / s_q, c2 = 1.000001 / s_q (thresholds: set_thr)
+    bool pad[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int qi_ = g == 0 ? qg0 : qg1;
         const float2 qm = qmeta[qi_];
         sq_l[g] = qm.x;
         k2_l[g] = qm.y;
-        rsq_l[g] = qi_ < n_q ? 1.0f / qm.x : 0.f;
-        taum[g] = __builtin_inff();
-        if (!DENSE && qi_ < n_q) {
+        pad[g] = DENSE || qi_ >= n_q;
+        c1[g] = c2[g] = 0.f;
+        if (!pad[g]) {
             const float tk = tau[qi_] - qm.y;
-            taum[g] = tk - fabsf(tk) * 1e-6f;
+            const float rsq = 1.0f / qm.x;
+            c1[g] = (tk - fabsf(tk) * 1e-6f) * rsq;  // (tau = -inf: -inf, every row is a candidate)
+            c2[g] = 1.000001f * rsq;
         }
     }
 
@@ -496,16 +502,18 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
     for (int e = 0; e < 16; ++e) acc[1][0][e] = acc[1][1][e] = 0;
     // {s, E} of the four sub-tiles: mu = the tile whose sub-tiles are under test, ml = the next one (in flight / landed)
     f32x4 mu0, mu1, ml0, ml1;
-    auto sub_meta = [&](int j, float& s_, float& e_) __attribute__((always_inline)) {
-        s_ = j == 0 ? mu0.x : j == 1 ? mu0.z : j == 2 ? mu1.x : mu1.z;
+    // {1 / s, E} of sub-tile j
+    auto sub_meta = [&](int j, float& rs_, float& e_) __attribute__((always_inline)) {
+        rs_ = j == 0 ? mu0.x : j == 1 ? mu0.z : j == 2 ? mu1.x : mu1.z;
         e_ = j == 0 ? mu0.y : j == 1 ? mu0.w : j == 2 ? mu1.y : mu1.w;
     };
     // dense store of one finished sub-tile (accumulator set SET, sub-tile J of the tile in mu)
     auto tail_dense = [&](auto set_c, auto nl_c, int J, uint32_t row_base, uint32_t slot_base) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
         const uint32_t row0 = row_base + 4 * h;
-        float s_, e_;
-        sub_meta(J, s_, e_);
+        float rs_, e_;
+        sub_meta(J, rs_, e_);
+        const float s_ = __builtin_amdgcn_rcpf(rs_);
 #pragma unroll
         for (int g = 0; g < NL; ++g) {
             const int qidx = g == 0 ? qg0 : qg1;
@@ -525,25 +533,25 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
         }
     };
     // integer thresholds of sub-tile J (of the tile in mu) for the NL live groups
+    // thr = floor(((taum - 1.000001 E) / (s s_q)) - 2): 5 VALU per group (fma, fma, med3, floor + cvt, select)
     auto set_thr = [&](auto nl_c, int J) __attribute__((always_inline)) {
         constexpr int NL = decltype(nl_c)::value;
-        float s_, e_;
-        sub_meta(J, s_, e_);
-        const float rs = __builtin_amdgcn_rcpf(s_);
+        float rs_, e_;
+        sub_meta(J, rs_, e_);
 #pragma unroll
         for (int g = 0; g < NL; ++g) {
-            const float u = __builtin_fmaf(-e_, 1.000001f, taum[g]);
-            float tf = __builtin_fmaf(u, rs * rsq_l[g], -2.0f);
-            tf = fminf(fmaxf(tf, -2.0e9f), 2.0e9f);   // (NaN from 0 * inf -> -2e9: everything is tested further)
-            if (!(taum[g] < __builtin_inff())) tf = 2.0e9f;  // padding columns never hit
-            thr[g] = (int)floorf(tf);
+            const float u = __builtin_fmaf(-e_, c2[g], c1[g]);
+            // (NaN -- 0 * inf on a sub-tile past the end of the index -- comes out as -2e9: everything is tested further)
+            const float tf = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, rs_, -2.0f), -2.0e9f, 2.0e9f);
+            thr[g] = pad[g] ? 0x7fffffff : (int)floorf(tf);
             asm volatile("" : "+v"(thr[g]));
         }
     };
     auto slow = [&](auto set_c, auto nl_c, int J, uint32_t row_base) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
-        float s_, e_;
-        sub_meta(J, s_, e_);
+        float rs_, e_;
+        sub_meta(J, rs_, e_);
+        const float s_ = __builtin_amdgcn_rcpf(rs_);
 #pragma unroll
         for (int g = 0; g < NL; ++g)
             if (__any(mx[g] > thr[g]))
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
         for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(qf[g][s]));
-        asm volatile("" ::"v"(taum[g]), "v"(sq_l[g]), "v"(k2_l[g]), "v"(rsq_l[g]));
+        asm volatile("" ::"v"(c1[g]), "v"(sq_l[g]), "v"(k2_l[g]), "v"(c2[g]));
     }
     const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
     const f32x4* meta4 = reinterpret_cast<const f32x4*>(meta);  // 2 per tile
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
 #undef DAWN_I8_ACC
                 __builtin_amdgcn_sched_barrier(0);
                 const bool have_prev = sub > 0 || t > 0;  // (sub is a constant: folds to `t > 0` or true)
-                if (!DENSE) {
+                if (!DENSE && !(DBG & 4)) {
                     constexpr int FIRST = 2;
                     if (s == FIRST - 1) set_thr(nl_c, J);
                     if (s == FIRST) asm volatile("s_nop 7");
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
                 asm volatile("" : "+v"(mu0), "+v"(mu1));
             }
             if (f == 12) {  // P1: every wave has left tile t-1, its image may be overwritten
-                asm volatile("s_barrier");
+                if (!(DBG & 2)) asm volatile("s_barrier");
                 __builtin_amdgcn_sched_barrier(0);
                 // {s, E} of tile t+1, IN FRONT of the DMA of tile t+2: P2's vmcnt(DPW) covers them
                 const f32x4* mp = meta4 + (size_t)unit_tile(t + 1 < n_units ? t + 1 : last) * 2;
@@ -660,6 +668,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
                              : "v"(mp));
                 dma_setup(t + 2 < n_units ? t + 2 : last, gp);
             }
+            if (!(DBG & 1)) {
             if (f == 13) dma_one(std::integral_constant<int, 0>(), wr, gp);
             if (f == 14) dma_one(std::integral_constant<int, 1>(), wr, gp);
             if (f == 15) dma_one(std::integral_constant<int, 2>(), wr, gp);
@@ -672,9 +681,12 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
             if (f == 22) dma_one(std::integral_constant<int, 9>(), wr, gp);
             if (f == 23) dma_one(std::integral_constant<int, 10>(), wr, gp);
             if (f == 24) dma_one(std::integral_constant<int, 11>(), wr, gp);
+            }
             if (f == 39) {  // P2: tile t+1 and the {s, E} loads in front of tile t+2's DMA have landed
                 __builtin_amdgcn_sched_barrier(0);
                 if (DENSE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier");  // (dense stores share vmcnt)
+                else if (DBG & 1) asm volatile("s_waitcnt vmcnt(0)");
+                else if (DBG & 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW));
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPW));
                 asm volatile("" : "+v"(ml0), "+v"(ml1));
             }
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
             const uint32_t rb = unit_row0(last) + 96, sb = unit_slot0(last) + 96;
             if (DENSE) {
                 tail_dense(C1(), nl_c, 3, rb, sb);
-            } else {
+            } else if (!(DBG & 4)) {
                 set_thr(nl_c, 3);
 #pragma unroll
                 for (int g = 0; g < NL; ++g) {
@@ -725,6 +737,54 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
     else run(C0());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
     if (!DENSE) flush_wave();
+}
+
+// append pass; mfma_sched 41 / 42 / 44 / 47: timing experiments with parts switched off (results are wrong)
+static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t n_rows, uint32_t stride, uint32_t n_tiles,
+                             const i32x4_t* qi, const float2* qm, int B, const BatchWorkspace& ws, uint32_t blocks,
+                             hipStream_t stream) {
+#define DAWN_I8_PIPE(DBG_)                                                                                                   \
+    hipLaunchKernelGGL((scan_i8_pipe_kernel<false, DBG_>), dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, \
+                       qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand))
+    switch (g_batched_sched) {
+        case 41: DAWN_I8_PIPE(1); break;
+        case 42: DAWN_I8_PIPE(2); break;
+        case 44: DAWN_I8_PIPE(4); break;
+        case 47: DAWN_I8_PIPE(7); break;
+        default: DAWN_I8_PIPE(0); break;
+    }
+#undef DAWN_I8_PIPE
+}
+
+// Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
+void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
+                                 int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS);
+    const signed char* qi = reinterpret_cast<const signed char*>(ws.qh);
+    const float2* qm = reinterpret_cast<const float2*>(qi + (size_t)BATCH_QT * EM);
+    const uint32_t blocks = pl.n_tiles_total < (uint32_t)grid ? pl.n_tiles_total : (uint32_t)grid;
+    (void)hipEventRecord(ev0, stream);
+    for (int i = 0; i < iters; ++i) {
+        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
+        launch_i8_append(reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 1u,
+                         pl.n_tiles_total, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream);
+    }
+    (void)hipEventRecord(ev1, stream);
+}
+
+// Test hook: dense upper-bound scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP]
+void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B,
+                                    const BatchWorkspace& ws, int grid, hipStream_t stream) {
+    signed char* qi = reinterpret_cast<signed char*>(ws.qh);
+    float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(BATCH_QT), dim3(64), 0, stream, d_q, B, qi, qm);
+    const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
+    const uint32_t n_tiles = (n + I8_TILE_ROWS - 1) / I8_TILE_ROWS;
+    if (n_tiles == 0) return;
+    hipLaunchKernelGGL(scan_i8_pipe_kernel<true>, dim3(n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 0u, 1u,
+                       n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
+                       reinterpret_cast<float*>(ws.cand));
 }
 
 void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
@@ -745,9 +805,7 @@ void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_met
                                reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
                                reinterpret_cast<float*>(ws.cand));
         else
-            hipLaunchKernelGGL(scan_i8_pipe_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride,
-                               n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt,
-                               reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+            launch_i8_append(xs, mt, n_rows, stride, n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream);
     };
     if (pl.dense_only) {
         if (ev0) (void)hipEventRecord(ev0, stream);

@@ -322,6 +322,7 @@ def test_batched_filter_error_within_bound(dawn):
         sparse[i] = dawn.normalize(sparse[i])
     rows = np.concatenate([base, sparse])
     idx = dawn.VectorIndex(0)
+    idx.set_option("i8_shadow", 0)
     idx.add_batch(np.arange(1, len(rows) + 1, dtype=np.uint64), rows)
     Q = np.concatenate([synth.unit_rows(2, 0, 40), synth.planted_queries(1, [5, 77, 4000], 3), sparse[:5]])
     f = idx.debug_filter_scores(Q)
@@ -331,6 +332,25 @@ def test_batched_filter_error_within_bound(dawn):
     assert err < 1.25e-3 / 2, err
     # typical error is far below the worst-case bound (random roundings cancel)
     assert np.abs(f.astype(np.float64) - exact).mean() < 5e-5
+
+
+def test_int8_batched_scores_are_upper_bounds(dawn):
+    """The int8 matrix-core filter (scan_i8.hip) promises filter score >= real dot product for EVERY row (the
+    certificates need nothing else): measured against float64 on random rows, on the rows that stretch a per-sub-tile
+    quantiser (one-hot, sparse, near-duplicates: _adversarial_rows) and on queries of the same kinds.  The slack of the
+    bound stays small on ordinary rows (it decides how often the 64-row certificate holds)."""
+    rows, base, extra = _adversarial_rows(7000)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(np.arange(1, len(rows) + 1, dtype=np.uint64), rows)
+    onehot = np.zeros(384, np.float32); onehot[5] = 1.0
+    Q = np.concatenate([synth.unit_rows(2, 0, 40), synth.planted_queries(1, [9, 77, 4000], 3), extra[:12], onehot[None]])
+    f = idx.debug_filter_scores(Q)
+    assert f.shape == (len(Q), len(rows))
+    exact = Q.astype(np.float64) @ rows.astype(np.float64).T
+    slack = f.astype(np.float64) - exact
+    assert slack.min() > -1e-6, slack.min()
+    # ordinary query x sub-tile without special rows: E + K2 ~ 0.01
+    assert np.median(slack[:40]) < 0.015 and slack.max() < 0.25, (np.median(slack[:40]), slack.max())
 
 
 @pytest.mark.parametrize("shadow", ["f16", "i8"])
