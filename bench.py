@@ -176,11 +176,11 @@ def main():
                "scan_kernel_ms": scan_ms / max(n_launch, 1), "launches_timed": n_launch}
         rows_here = index.size()
         # bytes the dominant kernel has to read per row (the exact rescore touches 64 f32 rows per query on top):
-        #   "i8"  384.25: the int8 shadow of an f32 index (+ 8 B of scale/bound per 32 rows), every batch size
-        #   "f16" 768: the f16 shadow of an f32 index (i8_shadow = 0), a bf16 index
+        #   "i8"  384.25: the int8 shadow of the index rows (+ 8 B of scale/bound per 32 rows), every batch size
+        #   "f16" 768: the f16 shadow of an f32 index, or the rows of a bf16 index themselves (i8_shadow = 0)
         #   "f32" 1536: the f32 rows themselves (both shadows switched off for small batches)
         if rows_read == "default":
-            rows_read = "i8" if index.dtype == "f32" else "f16"
+            rows_read = "i8"
         row_bytes = {"i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
         leg["row_bytes_streamed"] = row_bytes
         algo = int(rows_here * row_bytes) * scan_passes(Bq)
@@ -354,6 +354,12 @@ def main():
             extra["bf16_index_batch1"] = legh
             legh2, _ = run_leg(idxh, 256, 5, 1, seed=3)
             extra["bf16_index_batch256"] = legh2
+            # ... filtering on the bf16 rows themselves (no int8 shadow: 76.8 GB in total instead of 115.2 GB)
+            idxh.set_option("i8_shadow", 0)
+            legh, _ = run_leg(idxh, 1, 5, 2, check_planted=True, rows_read="f16")
+            extra["bf16_index_batch1_own_rows"] = legh
+            legh2, _ = run_leg(idxh, 256, 3, 1, seed=3, rows_read="f16")
+            extra["bf16_index_batch256_own_rows"] = legh2
             idxh.close()
         out["extra"] = extra
         if world == 1 and rank == 0:

@@ -221,7 +221,7 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
 
 // Bring the int8 shadow up to date; false when it is disabled or does not fit.
 bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
-    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_i8 || idx->i8_failed) return false;
+    if (!idx->use_i8 || idx->i8_failed) return false;  // (a bf16 index: the int8 copy shadows its bf16 rows)
     if (idx->i8_cap < idx->cap_phys) {
         const size_t prow = padded_rows(idx->cap_phys) + 128;  // (the batched kernel moves 128-row tiles)
         const size_t bytes = prow * dawn::EM, mbytes = (prow / 32 + 1) * 8;
@@ -234,7 +234,8 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
         idx->i8_cap = 0;
         size_t fr = 0, tot = 0;
         size_t need = bytes + mbytes + ((size_t)2 << 30);
-        if (!idx->i8_batched && idx->use_shadow && !idx->shadow_failed && idx->shadow_cap < idx->cap_phys)
+        if (idx->dtype == DAWN_DTYPE_F32 && !idx->i8_batched && idx->use_shadow && !idx->shadow_failed &&
+            idx->shadow_cap < idx->cap_phys)
             need += prow * dawn::EM * 2;
         char* ns = nullptr;
         float* nm = nullptr;
@@ -253,8 +254,7 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
         idx->i8_rows = 0;  // (re-quantised from the f32 rows: 0.03 ms per million rows)
     }
     if (idx->i8_rows < idx->size) {
-        dawn::launch_rows_f32_to_i8s(reinterpret_cast<const float*>(idx->d_x), idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size,
-                                     stream);
+        dawn::launch_rows_to_i8s(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size, stream);
         idx->i8_rows = idx->size;
     }
     return true;
@@ -281,7 +281,7 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
         // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
         for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
             const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
-            dawn::launch_scan_batched_i8(idx->d_x, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb,
+            dawn::launch_scan_batched_i8(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb,
                                          (uint32_t)k, idx->bws, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k,
                                          d_found + b0, idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                          b0 == 0 ? e1 : nullptr);

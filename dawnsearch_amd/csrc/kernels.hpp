@@ -85,8 +85,8 @@ void launch_scan_filter_f16s(const void* d_rows, int rt, uint32_t n_rows, const 
 // int8 shadow (scan_i8.hip): d_meta = float2 {scale, error bound} per 32-row sub-tile
 void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                             uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-void launch_rows_f32_to_i8s(const float* d_rows, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
-                            hipStream_t stream);
+void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
+                        hipStream_t stream);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
@@ -113,10 +113,10 @@ void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t 
 void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B,
                                     const BatchWorkspace& ws, int grid, hipStream_t stream);
 // Batched search on the int8 shadow (scan_i8.hip): the sequence of launch_scan_batched over 128-row int8 tiles
-void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
-                            const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
-                            float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
-                            hipEvent_t ev0, hipEvent_t ev1);
+void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids,
+                            uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
+                            uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);

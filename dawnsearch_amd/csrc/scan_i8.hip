@@ -19,6 +19,8 @@
 //     ub = fma(float(C), s * s_q/254, E + K2) therefore bounds the real dot product from above up to the rounding of
 //     this expression (< 1e-6: the product s * s_q comes from a stored 1 / s through v_rcp_f32, 1 ulp each) and the
 //     reference's own sequential-sum error gamma_384 * 1.0201 = 2.34e-5: FILTER_EPS_I8 = 2.6e-5 on top of ub.
+//   * a bf16 index gets the same shadow of its (bf16-rounded) rows: ||x||_2 <= 1.01 (1 + 2^-8) keeps ||sX||_2 < 1.1, and
+//     the exact side's gamma_384 * 1.0201 * 1.004 = 2.35e-5 stays inside FILTER_EPS_I8.
 //   * the hot loop never leaves the integers: the lane's list threshold tau is turned into an integer threshold once
 //     per sub-tile (5 VALU), conservatively (rows it passes are re-tested on ub itself).
 #include <type_traits>
@@ -38,9 +40,11 @@ constexpr float I8_K2_PER_SQ = 1.1f * 19.6f * I8_QRES;  // K2 = I8_K2_PER_SQ * s
 // conversion: f32 rows -> int8 sub-tiles + {s, E} per sub-tile
 // ------------------------------------------------------------------------------------------------
 // One 256-thread block per sub-tile; thread = (row r = tid / 8, part = tid % 8) handles float4 chunks part + 8j.
-__global__ __launch_bounds__(256) void rows_f32_to_i8s_kernel(const f32x4* __restrict__ x, uint32_t* __restrict__ out,
-                                                               float2* __restrict__ meta, uint32_t first_sub,
-                                                               uint32_t n_valid) {
+// RT = 0: f32 rows; RT = 1: the fragment-ordered bf16 rows of a bf16 index (the int8 copy then shadows THOSE values).
+template <int RT>
+__global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict__ xv, uint32_t* __restrict__ out,
+                                                           float2* __restrict__ meta, uint32_t first_sub,
+                                                           uint32_t n_valid) {
     __shared__ float sh[4];
     const uint32_t sub = first_sub + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,8 +52,19 @@ __global__ __launch_bounds__(256) void rows_f32_to_i8s_kernel(const f32x4* __res
     const uint32_t row = sub * 32u + r;
     f32x4 v[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j)
-        v[j] = row < n_valid ? x[(size_t)row * ROW_F4 + part + 8 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 12; ++j) {
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < n_valid) {
+            const uint32_t c4 = part + 8 * j;
+            if (RT == 0) {
+                v[j] = reinterpret_cast<const f32x4*>(xv)[(size_t)row * ROW_F4 + c4];
+            } else {  // values 4 c4 .. +3 = half (c4 & 1) of 16-B chunk c4 / 2
+                const u32x4 w = reinterpret_cast<const u32x4*>(xv)[frag_chunk(row, (int)(c4 >> 1))];
+                const uint32_t w0 = (c4 & 1u) ? w.z : w.x, w1 = (c4 & 1u) ? w.w : w.y;
+                v[j] = f32x4{bf16_lo(w0), bf16_hi(w0), bf16_lo(w1), bf16_hi(w1)};
+            }
+        }
+    }
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 12; ++j)
@@ -97,14 +112,18 @@ __global__ __launch_bounds__(256) void rows_f32_to_i8s_kernel(const f32x4* __res
     }
 }
 
-void launch_rows_f32_to_i8s(const float* d_rows, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
-                            hipStream_t stream) {
+// rt: ROW_F32 (f32 rows) or ROW_BF16 (fragment-ordered bf16 rows)
+void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
+                        hipStream_t stream) {
     const uint32_t first_sub = (uint32_t)(first_row / 32);  // the sub-tile holding first_row is re-quantised whole
     const uint32_t end_sub = (uint32_t)((n_valid + 31) / 32);
     if (end_sub <= first_sub) return;
-    hipLaunchKernelGGL(rows_f32_to_i8s_kernel, dim3(end_sub - first_sub), dim3(256), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_rows), reinterpret_cast<uint32_t*>(d_shadow),
-                       reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
+    if (rt == ROW_BF16)
+        hipLaunchKernelGGL(rows_to_i8s_kernel<1>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
+    else
+        hipLaunchKernelGGL(rows_to_i8s_kernel<0>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -787,10 +806,10 @@ void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32
                        reinterpret_cast<float*>(ws.cand));
 }
 
-void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
-                            const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
-                            float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
-                            hipEvent_t ev0, hipEvent_t ev1) {
+void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids,
+                            uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
+                            uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS);
     signed char* qi = reinterpret_cast<signed char*>(ws.qh);               // [256][384] int8
     float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);     // [256] {s_q, K2}
@@ -811,7 +830,7 @@ void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_met
         if (ev0) (void)hipEventRecord(ev0, stream);
         pass(true, 1, pl.n_tiles_total);
         if (ev1) (void)hipEventRecord(ev1, stream);
-        launch_select_rescore_eps(true, d_x, ROW_F32, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+        launch_select_rescore_eps(true, d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
                                   force_fallback, FILTER_EPS_I8, stream);
         return;
     }
@@ -826,7 +845,7 @@ void launch_scan_batched_i8(const void* d_x, const void* d_i8, const void* d_met
     if (ev0) (void)hipEventRecord(ev0, stream);
     pass(false, 1, pl.n_tiles_total);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    launch_select_rescore_eps(false, d_x, ROW_F32, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
+    launch_select_rescore_eps(false, d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags,
                               force_fallback, FILTER_EPS_I8, stream);
 }
 

@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 from dawnsearch_amd import synth  # noqa: E402
 
 
+@pytest.fixture(params=["i8", "own"])
+def shadow(request, monkeypatch):
+    """Filter source of a bf16 index: the int8 shadow of its rows (default; scan_i8.hip) or the bf16 rows themselves
+    (DAWN_I8_SHADOW=0, read when an index is created)."""
+    monkeypatch.setenv("DAWN_I8_SHADOW", "1" if request.param == "i8" else "0")
+    return request.param
+
+
 def _mk(dawn, n):
     idx = dawn.VectorIndex(0, dtype="bf16")
     idx.fill_synthetic(1, 0, n, 1)
@@ -43,7 +51,7 @@ def test_bf16_rows_are_rounded_spec_rows(dawn, oracle):
 
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 255, 1000, 4097, 100_003])
 @pytest.mark.parametrize("k", [1, 10, 20])
-def test_bf16_scan_matches_oracle_sizes(dawn, oracle, n, k):
+def test_bf16_scan_matches_oracle_sizes(dawn, oracle, n, k, shadow):
     idx = _mk(dawn, n)
     x = synth.round_bf16(oracle.unit_rows(1, 0, n))
     ids = np.arange(1, n + 1, dtype=np.uint64)
@@ -57,7 +65,7 @@ def test_bf16_scan_matches_oracle_sizes(dawn, oracle, n, k):
 
 @pytest.mark.parametrize("n,B,k", [(100_003, 2, 10), (100_003, 7, 20), (50_000, 9, 10), (100_003, 33, 20), (31, 16, 10),
                                    (4097, 256, 20), (8193, 200, 10), (20_001, 256, 10)])
-def test_bf16_batches_match_oracle(dawn, oracle, n, B, k):
+def test_bf16_batches_match_oracle(dawn, oracle, n, B, k, shadow):
     idx = _mk(dawn, n)
     x = synth.round_bf16(oracle.unit_rows(1, 0, n))
     ids = np.arange(1, n + 1, dtype=np.uint64)
@@ -72,7 +80,7 @@ def test_bf16_batches_match_oracle(dawn, oracle, n, B, k):
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_bf16_1m_batch1_and_256(dawn, oracle):
+def test_bf16_1m_batch1_and_256(dawn, oracle, shadow):
     n = 1_000_000
     idx = _mk(dawn, n)
     x = synth.round_bf16(oracle.unit_rows(1, 0, n))
@@ -87,7 +95,7 @@ def test_bf16_1m_batch1_and_256(dawn, oracle):
     assert idx.stats()["fallbacks"] == 0
 
 
-def test_bf16_forced_exact_pass_and_gate_and_save_load(dawn, oracle):
+def test_bf16_forced_exact_pass_and_gate_and_save_load(dawn, oracle, shadow):
     n = 20_000
     idx = _mk(dawn, n)
     x = synth.round_bf16(oracle.unit_rows(1, 0, n))
@@ -133,7 +141,16 @@ def test_bf16_filter_errors_within_their_bounds(dawn):
     idx.add_batch(np.arange(1, len(rows) + 1, dtype=np.uint64), rows)
     stored = synth.round_bf16(rows).astype(np.float64)
     Q = np.concatenate([synth.unit_rows(2, 0, 24), synth.planted_queries(1, [5, 77, 4000], 3), rows[5000:5005]])
-    # matrix-core pass: dense scores of every row
+    # the int8 shadow of the bf16 rows (default): every filter score bounds the exact dot of the STORED row from above
+    ub = idx.debug_filter_scores(Q)
+    slack = ub.astype(np.float64) - Q.astype(np.float64) @ stored.T
+    assert slack.min() > -1e-6 and np.median(slack) < 0.015, (slack.min(), np.median(slack))
+    for q in Q[:4]:
+        sc, rr = idx.debug_stream_lists(q)
+        valid = rr != 0xFFFFFFFF
+        assert (sc[valid].astype(np.float64) - stored[rr[valid].astype(np.int64)] @ q.astype(np.float64)).min() > -1e-6
+    idx.set_option("i8_shadow", 0)
+    # matrix-core pass on the bf16 rows themselves: dense scores of every row
     f = idx.debug_filter_scores(Q)
     exact = Q.astype(np.float64) @ stored.T
     assert f.shape == exact.shape
