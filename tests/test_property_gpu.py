@@ -3,7 +3,9 @@ the oracle's, bit for bit — the certificate either proves the filtered shortli
 The generated indexes are built to stress exactly that machinery: exact duplicates (ties -> earlier row), near-ties
 below every filter bound, tight clusters around the query (more than 64 rows inside the filter's error band), sparse
 vectors with tiny components (f16 subnormal territory), antipodal and orthogonal rows, batches that mix all of them,
-any k up to 64, both index types, every batch size class (stream 1..3, matrix-core 4+, forced 8-per-pass stream)."""
+rows that stretch the int8 quantiser (one-hot / two-hot rows that set the scale of their whole sub-tile, Gaussian rows),
+any k up to 64, both index types, both filter sources (int8 upper-bound shadow, 16-bit rows), every batch size class
+(stream 1..3, matrix-core 4+, forced 8-per-pass stream)."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -40,6 +42,13 @@ def _build_rows(rng, n, kind, q0):
             v[idx] = rng.standard_normal(len(idx))
             v += 10.0 ** rng.uniform(-9, -5) * rng.standard_normal(384)
             rows[i] = _unit(v)
+    elif kind == "onehot":  # a sub-tile holding one of these is quantised with scale 1/127
+        for i in where:
+            v = np.zeros(384)
+            idx = rng.choice(384, size=int(rng.integers(1, 3)), replace=False)
+            v[idx] = rng.choice([-1.0, 1.0], size=len(idx)) * rng.uniform(0.3, 1.0, size=len(idx))
+            rows[i] = _unit(v)
+        rows[where[: max(1, m // 3)]] = np.stack([_unit(rng.standard_normal(384)) for _ in range(max(1, m // 3))])
     elif kind == "antipodal":
         rows[where] = -rows[rng.choice(n, size=m)]
         rows[where[: max(1, m // 4)]] = -q0
@@ -55,19 +64,21 @@ _EXAMPLES = int(os.environ.get("DAWN_HYP_EXAMPLES", "150"))  # soak runs: DAWN_H
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
 @given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 2500), st.integers(8000, 30000)), k=st.integers(1, 64),
        B=st.sampled_from([1, 2, 3, 4, 7, 9, 33, 70]),
-       kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal"]), dtype=st.sampled_from(["f32", "bf16"]),
-       force_stream=st.booleans(), sched=st.sampled_from([4, 5, 1]))
-def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched):
+       kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal", "onehot"]),
+       dtype=st.sampled_from(["f32", "bf16"]), force_stream=st.booleans(), sched=st.sampled_from([4, 5, 1]),
+       i8=st.booleans())
+def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched, i8):
     rng = np.random.default_rng(seed)
     Q = synth.unit_rows(int(rng.integers(1, 1 << 30)), 0, B)
     rows = _build_rows(rng, n, kind, Q[0])
-    if kind in ("duplicates", "cluster") and n >= 2:
+    if kind in ("duplicates", "cluster", "onehot") and n >= 2:
         Q[B - 1] = rows[int(rng.integers(0, n))]  # a query that IS a row
     ids = rng.permutation(np.arange(10, 10 + n)).astype(np.uint64)  # labels are arbitrary, order of insertion rules ties
     idx = dawn.VectorIndex(0, dtype=dtype)
     try:
         idx.add_batch(ids, rows)
         stored = synth.round_bf16(rows) if dtype == "bf16" else rows
+        idx.set_option("i8_shadow", int(i8))  # False: filter on the f16 shadow / the bf16 rows themselves
         if force_stream:
             idx.set_option("mfma_min_batch", 100000)
         idx.set_option("mfma_sched", sched)  # 5: the pipelined matrix-core kernel for every pass, 1: the 8-wave kernel
