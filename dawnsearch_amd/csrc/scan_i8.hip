@@ -375,7 +375,8 @@ __global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __rest
     if (lane == 0) qmeta[b] = b < n_q ? float2{sq, 1.1f * 1.001f * sqrtf(e2) + 1e-9f} : float2{0.f, 0.f};
 }
 
-// DBG (timing experiments only, results are wrong): 1 = no DMA, 2 = no barriers, 4 = no threshold tests
+// DBG (timing experiments only, results are wrong): 1 = no DMA, 2 = no barriers, 4 = no threshold tests; of the tests only:
+// 8 = no thresholds (nothing hits), 16 = no max slices, 32 = no compare / slow path
 template <bool DENSE, int DBG = 0>
 __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* __restrict__ xs, const float2* __restrict__ meta,
                                                           uint32_t n_rows, uint32_t first_tile, uint32_t tile_stride,
@@ -642,9 +643,9 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
                 const bool have_prev = sub > 0 || t > 0;  // (sub is a constant: folds to `t > 0` or true)
                 if (!DENSE && !(DBG & 4)) {
                     constexpr int FIRST = 2;
-                    if (s == FIRST - 1) set_thr(nl_c, J);
+                    if (s == FIRST - 1 && !(DBG & 8)) set_thr(nl_c, J);
                     if (s == FIRST) asm volatile("s_nop 7");
-                    if (s >= FIRST && s < FIRST + 8) {
+                    if (s >= FIRST && s < FIRST + 8 && !(DBG & 16)) {
                         const int j = s - FIRST;
 #pragma unroll
                         for (int g = 0; g < NL; ++g) {
@@ -653,10 +654,10 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
                             asm volatile("" : "+v"(mx[g]));
                         }
                     }
-                    if (s == FIRST + 8 && have_prev) {
+                    if (s == FIRST + 8 && have_prev && !(DBG & 32)) {
                         bool hit = mx[0] > thr[0];
                         if (NL > 1) hit = hit || mx[1] > thr[1];
-                        if (__any(hit)) {
+                        if (__builtin_expect(__any(hit), 0)) {  // (unlikely: keeps the slow paths out of the hot instruction stream)
                             const uint32_t rb = sub == 0 ? unit_row0(t - 1) + 96 : unit_row0(t) + 32 * (sub - 1);
                             if (set == 0) slow(C1(), nl_c, J, rb);
                             else slow(C0(), nl_c, J, rb);
@@ -770,6 +771,9 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 42: DAWN_I8_PIPE(2); break;
         case 44: DAWN_I8_PIPE(4); break;
         case 47: DAWN_I8_PIPE(7); break;
+        case 48: DAWN_I8_PIPE(8); break;    // 48 / 49 / 50: the threshold test without its thresholds / slices / branch
+        case 49: DAWN_I8_PIPE(16); break;
+        case 50: DAWN_I8_PIPE(32); break;
         default: DAWN_I8_PIPE(0); break;
     }
 #undef DAWN_I8_PIPE
