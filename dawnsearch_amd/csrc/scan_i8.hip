@@ -346,7 +346,8 @@ void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n
 // read once the last test of tile t-1 is done.
 constexpr int I8_TILE_ROWS = 128;
 constexpr int I8_TILE_BYTES = I8_TILE_ROWS * EM;  // 49152
-constexpr uint32_t I8_WCAP = 256;                 // staged candidates per wave
+constexpr uint32_t I8_ECAP = 40;                  // staged hit entries per wave ...
+constexpr uint32_t I8_EDW = 24;                   // ... of 24 dwords: 16 accumulators, query, first row, threshold, s s_q, E + K2
 constexpr uint32_t I8_SEG_CAP = (uint32_t)BATCH_CAP / (uint32_t)BATCH_CAND_SEGS;
 
 // queries -> int8 images [BATCH_QT][384] + {s_q, K2} per query; rows b >= n_q: zeros.  One wave per query.
@@ -386,8 +387,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
                                                           uint2* __restrict__ cand, float* __restrict__ dense) {
     constexpr int NW = 4, PD = 8, DPW = 48 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char img[3 * I8_TILE_BYTES];
-    constexpr uint32_t PLANE = NW * I8_WCAP * 4;
-    __shared__ uint32_t stage[3 * NW * I8_WCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[NW * I8_ECAP * I8_EDW];  // 15 KiB beside the 144-KiB ring
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -460,61 +460,88 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
         for (int j = 0; j < NGP; ++j) asm volatile("" ::"v"(gp[j]));
     };
 
-    // ---- candidate staging, private to the wave (as in scan_f16_pipe_kernel) ----
-    uint32_t wpos = 0;
+    // ---- candidate staging, private to the wave, LANE-PARALLEL: a lane whose running maximum beats its threshold dumps
+    // its 16 accumulators + {query, first row, threshold, s s_q, E + K2} as one 96-B entry (six predicated ds_write_b128,
+    // slot = popcount of the hit lanes below it: no ballot per element, no scalar loop — a hit costs ~80 clk instead of
+    // ~700, and every clock of it is a clock the other three waves wait at the next barrier); the entries are expanded
+    // into (score, row) candidates when the stage is flushed, one entry per lane.
+    uint32_t wpos = 0;  // wave-uniform fill of this wave's region
     auto flush_wave = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t q_[I8_WCAP / 64], slot[I8_WCAP / 64];
-        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;
-#pragma unroll
-        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
-            const uint32_t e = lane + 64u * j;
-            q_[j] = e < wpos ? stage[wave * I8_WCAP + e] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
-            const uint32_t e = lane + 64u * j;
-            slot[j] = 0xFFFFFFFFu;
-            if (e < wpos) slot[j] = atomicAdd(&cnt[q_[j] * BATCH_CAND_SEGS + seg], 1u);
-        }
-#pragma unroll
-        for (int j = 0; j < (int)(I8_WCAP / 64); ++j) {
-            const uint32_t e = lane + 64u * j;
-            if (slot[j] < I8_SEG_CAP)
-                cand[(size_t)q_[j] * BATCH_CAP + seg * I8_SEG_CAP + slot[j]] =
-                    make_uint2(stage[NW * I8_WCAP + wave * I8_WCAP + e], stage[2 * NW * I8_WCAP + wave * I8_WCAP + e]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores below
+        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;  // (a query belongs to ONE wave of every workgroup)
+        if ((uint32_t)lane < wpos) {
+            const uint32_t* en = stage + (wave * I8_ECAP + lane) * I8_EDW;
+            const uint32_t qidx = en[16], row0 = en[17];
+            const int th = (int)en[18];
+            const float gl = __builtin_bit_cast(float, en[19]), ek = __builtin_bit_cast(float, en[20]);
+            // (rolled loops, accumulators read again below rather than kept: the kernel has no registers to spare, and what
+            // hipcc parks in AGPRs around a slow path must never be an accumulator — see the MFMA asm in step())
+            uint32_t hits = 0;
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t row = row0 + (uint32_t)((i & 3) + 8 * (i >> 2));
+                hits |= ((int)en[i] > th && row < n_rows) ? (1u << i) : 0u;
+            }
+            // ONE slot reservation per entry (all its hits belong to one query): a single round trip to the memory-side
+            // atomic unit for the whole flush
+            uint32_t slot = hits ? atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], (uint32_t)__popc(hits)) : 0u;
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                if (hits & (1u << i)) {
+                    if (slot < I8_SEG_CAP)
+                        cand[(size_t)qidx * BATCH_CAP + seg * I8_SEG_CAP + slot] =
+                            make_uint2(__builtin_bit_cast(uint32_t, __builtin_fmaf((float)(int)en[i], gl, ek)),
+                                       row0 + (uint32_t)((i & 3) + 8 * (i >> 2)));
+                    ++slot;
+                }
+            }
         }
         wpos = 0;
     };
     const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
-    // slow path: some lane holds an accumulator above its integer threshold.  gl / ek: the lane's s * s_q and E + K2.
-    auto tail_slow = [&](const i32x16_t& acc, uint32_t row0, uint32_t q_first, int thr_lane, float gl, float ek)
+    // slow path of one query group: mxl = the lane's maximum over its 16 accumulators, thr_lane its integer threshold,
+    // gl / ek its s * s_q and E + K2; row_base: first row of the sub-tile, q_first: query of lane 0
+    auto stage_hits = [&](const i32x16_t& acc, int mxl, uint32_t row_base, uint32_t q_first, int thr_lane, float gl, float ek)
         __attribute__((always_inline)) {
-        const uint32_t lim = n_rows > row0 + 4 * h ? n_rows - row0 - 4 * h : 0u;
+        const bool hitl = mxl > thr_lane;
+        const unsigned long long hm = __ballot(hitl);
+        const uint32_t n = (uint32_t)__popcll(hm);
+        if (n > I8_ECAP) {
+            // a burst (tau = -inf, or every query of the group next to the same row): element by element, straight to the
+            // candidate buffers
+            const uint32_t lim = n_rows > row_base + 4 * h ? n_rows - row_base - 4 * h : 0u;
+            const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int ae = acc[e];
-            const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
-            unsigned long long m = __ballot(ae > thr_lane && roff < lim);
-            while (m) {
-                const int l = __builtin_ctzll(m);
-                m &= m - 1;
-                const float cf = (float)__builtin_amdgcn_readlane(ae, l);
-                const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), l));
-                const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ek), l));
-                const float sc = __builtin_fmaf(cf, g1, e1);
-                const uint32_t qidx = q_first + (uint32_t)(l & 31);
-                const uint32_t row = row0 + roff + 4u * (uint32_t)(l >> 5);
-                if (wpos >= I8_WCAP) flush_wave();
-                if (lane == 0) {
-                    const uint32_t pa = stage_base + (wave * I8_WCAP + wpos) * 4u;
-                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
-                                 :
-                                 : "v"(pa), "v"(qidx), "v"(__builtin_bit_cast(uint32_t, sc)), "v"(row), "n"(PLANE), "n"(2 * PLANE));
+            for (int e = 0; e < 16; ++e) {
+                const int ae = acc[e];
+                const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+                if (ae > thr_lane && roff < lim) {
+                    const uint32_t qidx = q_first + r;
+                    const float sc = __builtin_fmaf((float)ae, gl, ek);
+                    const uint32_t slot = atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], 1u);
+                    if (slot < I8_SEG_CAP)
+                        cand[(size_t)qidx * BATCH_CAP + seg * I8_SEG_CAP + slot] =
+                            make_uint2(__builtin_bit_cast(uint32_t, sc), row_base + 4 * h + roff);
                 }
-                ++wpos;
             }
+            return;
         }
+        if (wpos + n > I8_ECAP) flush_wave();
+        if (hitl) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            const uint32_t pa = stage_base + (wave * I8_ECAP + wpos + rank) * (I8_EDW * 4u);
+            // (sub-registers of the accumulator tuple and single registers: no copies, no extra live values)
+            const i32x4_t a0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), a1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+            const i32x4_t a2 = __builtin_shufflevector(acc, acc, 8, 9, 10, 11), a3 = __builtin_shufflevector(acc, acc, 12, 13, 14, 15);
+            asm volatile(
+                "ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\t"
+                "ds_write_b128 %0, %4 offset:48\n\tds_write_b32 %0, %5 offset:64\n\tds_write_b32 %0, %6 offset:68\n\t"
+                "ds_write_b32 %0, %7 offset:72\n\tds_write_b32 %0, %8 offset:76\n\tds_write_b32 %0, %9 offset:80"
+                :
+                : "v"(pa), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(q_first + r), "v"(row_base + 4 * h), "v"(thr_lane), "v"(gl),
+                  "v"(ek));
+        }
+        wpos += n;
     };
     i32x16_t acc[2][2];
     int mx[2] = {0, 0}, thr[2] = {0x7fffffff, 0x7fffffff};
@@ -575,7 +602,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
 #pragma unroll
         for (int g = 0; g < NL; ++g)
             if (__any(mx[g] > thr[g]))
-                tail_slow(acc[SET][g], row_base, (uint32_t)((wave + NW * g) * 32), thr[g], s_ * sq_l[g], e_ + k2_l[g]);
+                stage_hits(acc[SET][g], mx[g], row_base, (uint32_t)((wave + NW * g) * 32), thr[g], s_ * sq_l[g], e_ + k2_l[g]);
     };
 
 #pragma unroll

@@ -136,7 +136,7 @@ def test_pipelined_kernels_keep_their_accumulators_out_of_agpr_spills(tmp_path):
         for blk in notes.split("  - .agpr_count:")[1:]:
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
             seen[name] = int(blk.split("\n")[0])
-    i8 = {k: v for k, v in seen.items() if "scan_i8_pipe_kernel" in k}
+    i8 = {k: v for k, v in seen.items() if "scan_i8_pipe_kernelILb0ELi0E" in k or "scan_i8_pipe_kernelILb1ELi0E" in k}
     f16 = {k: v for k, v in seen.items() if "scan_f16_pipe_kernelILb0ELi0ELb0E" in k}  # append pass, f16 shadow
     assert len(i8) == 2 and len(f16) == 1, (i8, f16)
     assert set(i8.values()) == {48}, i8
