@@ -134,7 +134,14 @@ __device__ __forceinline__ int pack4_i8(int a, int b, int c, int d) {
 }
 
 // Lists hold ub (see the header) as the score.  q: the n_q <= QB <= 8 queries, f32 [n_q][384].
-template <int QB, int PD>
+template <bool NT>
+__device__ __forceinline__ u32x4 row_load(const u32x4* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// NT: non-temporal row loads (default) or plain ones (geometry experiments)
+template <int QB, int PD, bool NT = true>
 __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
                                                                uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                                float* __restrict__ out_s, uint32_t* __restrict__ out_p,
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
         const u32x4* p = x + (size_t)t * (12 * 64) + lane;
         u32x4 a[PD];
 #pragma unroll
-        for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+        for (int d = 0; d < PD; ++d) a[d] = row_load<NT>(p + d * 64);
         float2 mt = meta[t];
         for (;;) {
             const uint32_t tn = t + total_waves;
@@ -223,8 +230,8 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
 #pragma unroll
             for (int f = 0; f < 12; ++f) {
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
-                if (f + PD < 12) a[f % PD] = __builtin_nontemporal_load(p + (f + PD) * 64);
-                else a[f % PD] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
+                if (f + PD < 12) a[f % PD] = row_load<NT>(p + (f + PD) * 64);
+                else a[f % PD] = row_load<NT>(pn + (f + PD - 12) * 64);
                 __builtin_amdgcn_sched_barrier(0);  // keep every load PD steps ahead of its use
             }
             // this lane: D[row = 32t + (e&3) + 8*(e>>2) + 4h][column c];  C = 254 acc_H + acc_L (lane c <- lane c + 8)
@@ -308,6 +315,10 @@ static void launch_filter_i8s_qb(const void* d_shadow, const void* d_meta, uint3
         case 1: DAWN_I8S_LAUNCH(3); break;
         case 2: DAWN_I8S_LAUNCH(4); break;
         case 4: DAWN_I8S_LAUNCH(6); break;
+        case 5:  // 12 fragments, plain (temporal) loads
+            hipLaunchKernelGGL((scan_filter_i8s_kernel<QB, 12, false>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
         default: DAWN_I8S_LAUNCH(12); break;
     }
 #undef DAWN_I8S_LAUNCH
