@@ -182,7 +182,9 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     const size_t n = B * (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks}) * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
-    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, B * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, 2 * B * sizeof(uint32_t)));  // flags[B] | arrival counters of the exact pass[B]
+    DAWN_HIP_TRY(hipMemset(idx->d_flags, 0, 2 * B * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipDeviceSynchronize());  // (searches run on non-blocking streams)
     idx->ws_B = B;
     return DAWN_OK;
 }
@@ -325,10 +327,8 @@ int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint
                                        idx->force_fallback, dawn::FILTER_EPS_F32, stream);
         }
     }
-    dawn::launch_scan_exact(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
-                            stream);
-    dawn::launch_merge_exact(idx->d_ids, n, (int)B, idx->d_flags, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
-                             (uint32_t)k, d_labels, d_dist, d_found, stream);
+    dawn::launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_cand_s,
+                            idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }

@@ -133,12 +133,11 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
                          hipEvent_t ev0, hipEvent_t ev1);
 void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_row, size_t n_valid, hipStream_t stream);
-// Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK).
-void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
-                       float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream);
-void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags,
-                        const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
-                        uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+// Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK): per-workgroup exact lists, merged and written out
+// by the last workgroup to arrive (d_done[B]: arrival counters, zero before and after).
+void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+                       const uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p, int n_lists, uint32_t k,
+                       uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
 
 // Stable G-way merge of per-shard results (multi-GPU).
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,

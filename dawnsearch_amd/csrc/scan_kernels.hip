@@ -13,7 +13,7 @@
 //                           reference's sequential un-fused f32 order (bit-for-bit), sorts by
 //                           (distance, row), and certifies that no row outside the shortlist can reach
 //                           the top-k (rigorous bound FILTER_EPS_F32).
-//   3. scan_exact_kernel / merge_exact_kernel: the always-exact (slower, lane-per-row) pass, run only for
+//   3. scan_exact_kernel (its last workgroup merges): the always-exact (slower, lane-per-row) pass, run only for
 //                           queries whose certificate failed (predicated on a device flag: no host
 //                           round trip).
 //
@@ -525,14 +525,19 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
 // ------------------------------------------------------------------------------------------------
 // 3. exact fallback: lane-per-row, reference summation order, key = -distance
 // ------------------------------------------------------------------------------------------------
+// The last workgroup to finish a query merges the per-workgroup lists and writes the result (done[b]: arrival counter,
+// zero between searches): the exact pass is ONE launch, and when no flag is set — every search on ordinary data — it
+// costs one empty kernel instead of two.
 template <int RT>
-__global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, uint32_t n_rows,
-                                                        const float* __restrict__ q, int n_q,
-                                                        const uint32_t* __restrict__ flags,
+__global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, const uint64_t* __restrict__ ids,
+                                                        uint32_t n_rows, const float* __restrict__ q, int n_q,
+                                                        const uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
                                                         float* __restrict__ out_s, uint32_t* __restrict__ out_p,
-                                                        uint32_t n_lists) {
+                                                        uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
+                                                        float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
     __shared__ float sh_s[4][LIST];
     __shared__ uint32_t sh_p[4][LIST];
+    __shared__ uint32_t sh_last;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -572,57 +577,45 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
             out_s[o] = ls;
             out_p[o] = lp;
         }
-        __syncthreads();  // sh_s / sh_p are reused by the next query
+        __threadfence();  // this workgroup's list is visible device-wide before it counts itself in
+        __syncthreads();
+        if (threadIdx.x == 0) sh_last = atomicAdd(&done[b], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (sh_last) {  // block-uniform: every other workgroup's list of query b is complete
+            __threadfence();
+            float s = NEG_INF;
+            uint32_t p = NO_POS;
+            const float* cs = out_s + (size_t)b * n_lists * LIST;
+            const uint32_t* cp = out_p + (size_t)b * n_lists * LIST;
+            for (uint32_t l = wave; l < n_lists; l += nwaves)
+                merge64(s, p, cs[(size_t)l * LIST + 63 - lane], cp[(size_t)l * LIST + 63 - lane], lane);
+            block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+            if (wave == 0) {
+                const uint32_t found = n_rows < k ? n_rows : k;
+                if ((uint32_t)lane < found) {
+                    out_labels[(size_t)b * k + lane] = ids[p];
+                    out_dist[(size_t)b * k + lane] = -s;
+                }
+                if (lane == 0) {
+                    out_found[b] = found;
+                    done[b] = 0u;
+                }
+            }
+        }
+        __syncthreads();  // sh_s / sh_p / sh_last are reused by the next query
     }
 }
 
-__global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __restrict__ ids, uint32_t n_rows,
-                                                          const uint32_t* __restrict__ flags,
-                                                          const float* __restrict__ cand_s,
-                                                          const uint32_t* __restrict__ cand_p, int n_lists,
-                                                          uint32_t k, uint64_t* __restrict__ out_labels,
-                                                          float* __restrict__ out_dist,
-                                                          uint32_t* __restrict__ out_found) {
-    __shared__ float sh_s[16][LIST];
-    __shared__ uint32_t sh_p[16][LIST];
-    const int b = blockIdx.x;
-    if (flags[b] != FLAG_FALLBACK) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
-    float s = NEG_INF;
-    uint32_t p = NO_POS;
-    const float* cs = cand_s + (size_t)b * n_lists * LIST;
-    const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
-    for (int l = wave; l < n_lists; l += nwaves) {
-        merge64(s, p, cs[(size_t)l * LIST + 63 - lane], cp[(size_t)l * LIST + 63 - lane], lane);
-    }
-    block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
-    if (wave != 0) return;
-    const uint32_t found = n_rows < k ? n_rows : k;
-    if ((uint32_t)lane < found) {
-        out_labels[(size_t)b * k + lane] = ids[p];
-        out_dist[(size_t)b * k + lane] = -s;
-    }
-    if (lane == 0) out_found[b] = found;
-}
-
-void launch_scan_exact(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, const uint32_t* d_flags,
-                       float* cand_s, uint32_t* cand_p, int n_lists, hipStream_t stream) {
+void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
+                       const uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p, int n_lists, uint32_t k,
+                       uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
     const dim3 grid(n_lists, B < 16 ? B : 16);
     if (dtype == ROW_BF16)
-        hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, n_rows, d_q, B, d_flags, cand_s, cand_p,
-                           (uint32_t)n_lists);
+        hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, cand_s,
+                           cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
     else
-        hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, n_rows, d_q, B, d_flags, cand_s, cand_p,
-                           (uint32_t)n_lists);
-}
-
-void launch_merge_exact(const uint64_t* d_ids, uint32_t n_rows, int B, const uint32_t* d_flags, const float* cand_s,
-                        const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist,
-                        uint32_t* d_found, hipStream_t stream) {
-    hipLaunchKernelGGL(merge_exact_kernel, dim3(B), dim3(1024), 0, stream, d_ids, n_rows, d_flags, cand_s, cand_p,
-                       n_lists, k, d_labels, d_dist, d_found);
+        hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, cand_s,
+                           cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
 }
 
 // ------------------------------------------------------------------------------------------------
