@@ -151,12 +151,15 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "mfma_sched"       process-wide: 4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave
  *                      kernel only, 0 / 2 = lockstep converting kernel on the f32 rows (2: with phase stamps),
  *                      41..55 = timing experiments (parts of the pipelined kernel switched off: wrong results)
- *   "f16_shadow"       0: an f32 index keeps no f16 shadow (filters read / convert the f32 rows)
- *   "i8_shadow"        0: batches below mfma_min_batch do not use the int8 shadow (384 B/row, scan_i8.hip) of an f32 index
- *   "i8_batched"       0: batches of mfma_min_batch and more filter on the f16 shadow instead of the int8 one
- *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of the shadow
+ *                      (int8 pipelined kernel: 41 / 42 / 44 / 47 / 48..50, scan_i8.hip)
+ *   "mfma_target"      process-wide: candidates per query the sampled thresholds of the matrix-core path aim for (512)
+ *   "i8_shadow"        0: no int8 shadow (384 B/row, scan_i8.hip) of the index rows: the filters read the f16 shadow of
+ *                      an f32 index / the rows of a bf16 index themselves.  Default 1, or env DAWN_I8_SHADOW at creation
+ *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
+ *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
+ *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow
  *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
- *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the 16-bit fragment stream
+ *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the shadow fragment streams
  *   "force_fallback"   1: every query also takes the exact pass (tests) */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
 
