@@ -93,7 +93,7 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
                           int force_fallback, float eps, hipStream_t stream);
-// Batched search on the matrix cores (9 <= B <= BATCH_QT): f16 MFMA filter with sampled thresholds,
+// Batched search on the matrix cores (mfma_min_batch <= B <= BATCH_QT) over 16-bit rows: f16 / bf16 MFMA filter with sampled thresholds,
 // candidate append, exact rescore + certificate (scan_batched.hip).  ev0/ev1 bracket the full pass.
 struct BatchPlan {
     bool dense_only;          // n_rows <= BATCH_CAP: one dense pass, no thresholds
