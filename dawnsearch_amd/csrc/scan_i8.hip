@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
         sq_l[g] = qm.x;
         k2_l[g] = qm.y;
         pad[g] = DENSE || qi_ >= n_q;
-        c1[g] = c2[g] = 0.f;
+        c1[g] = 3.0e38f;  // padding column: threshold +2e9
+        c2[g] = 0.f;
         if (!pad[g]) {
             const float tk = tau[qi_] - qm.y;
             const float rsq = 1.0f / qm.x;
@@ -591,18 +592,23 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
         }
     };
     // integer thresholds of sub-tile J (of the tile in mu) for the NL live groups
-    // thr = floor(((taum - 1.000001 E) / (s s_q)) - 2): 5 VALU per group (fma, fma, med3, floor + cvt, select)
+    // thr = floor(((taum - 1.000001 E) / (s s_q)) - 2), both groups at once: two packed fmas (v_pk_fma_f32), then med3 +
+    // floor-convert per group.  Padding columns carry c1 = 3e38, c2 = 0: their threshold saturates at +2e9 (never hit).
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
     auto set_thr = [&](auto nl_c, int J) __attribute__((always_inline)) {
         constexpr int NL = decltype(nl_c)::value;
         float rs_, e_;
         sub_meta(J, rs_, e_);
+        const f32x2_t u = __builtin_elementwise_fma(f32x2_t{-e_, -e_}, f32x2_t{c2[0], c2[1]}, f32x2_t{c1[0], c1[1]});
+        const f32x2_t t2 = __builtin_elementwise_fma(u, f32x2_t{rs_, rs_}, f32x2_t{-2.0f, -2.0f});
 #pragma unroll
         for (int g = 0; g < NL; ++g) {
-            const float u = __builtin_fmaf(-e_, c2[g], c1[g]);
-            // (NaN -- 0 * inf on a sub-tile past the end of the index -- comes out as -2e9: everything is tested further)
-            const float tf = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, rs_, -2.0f), -2.0e9f, 2.0e9f);
-            thr[g] = pad[g] ? 0x7fffffff : (int)floorf(tf);
-            asm volatile("" : "+v"(thr[g]));
+            // (NaN -- 0 * inf on a sub-tile past the end of the index -- comes out as -2e9: everything is tested further,
+            // and the rows do not exist)
+            const float tf = __builtin_amdgcn_fmed3f(g == 0 ? t2.x : t2.y, -2.0e9f, 2.0e9f);
+            int ti;
+            asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(ti) : "v"(tf));
+            thr[g] = ti;
         }
     };
     auto slow = [&](auto set_c, auto nl_c, int J, uint32_t row_base) __attribute__((always_inline)) {
