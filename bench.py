@@ -275,6 +275,7 @@ def main():
                      "speedup_vs_f32_row_stream_at_hbm_peak": (rows_local * ROW_BYTES * scan_passes(B) / (HBM_PEAK_GBS * 1e9)
                                                                / (scan_avg_ms * 1e-3) if scan_avg_ms > 0 else 0.0)},
         "checks": {"planted_top1_ok": head["planted_top1_ok"], "fallbacks": idx.stats()["fallbacks"]},
+        "hbm_bytes_per_gpu": idx.memory(),  # rows / filter shadows built so far / labels + workspaces
         "fill_seconds": fill_s,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")

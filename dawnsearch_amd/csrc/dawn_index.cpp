@@ -767,6 +767,29 @@ int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_c
     return DAWN_OK;
 }
 
+int dawn_index_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    const uint64_t rows = idx->d_x ? (uint64_t)padded_rows(idx->cap_phys) * idx->row_bytes() : 0;
+    uint64_t shadows = 0;
+    if (idx->d_shadow) shadows += (uint64_t)padded_rows(idx->shadow_cap) * dawn::EM * 2;
+    if (idx->d_i8) {
+        const uint64_t prow = padded_rows(idx->i8_cap) + 128;
+        shadows += prow * dawn::EM + (prow / 32 + 1) * 8;
+    }
+    uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
+    if (idx->d_cand_s)
+        other += (uint64_t)idx->ws_B * std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks}) *
+                     dawn::LIST * 8 + 2 * idx->ws_B * 4;
+    if (idx->bws.cand)
+        other += (uint64_t)dawn::BATCH_QT * (dawn::EM * 2 + 4 + dawn::BATCH_CAND_SEGS * 4 + (uint64_t)dawn::BATCH_CAP * 8);
+    if (idx->d_stage) other += (uint64_t)idx->stage_rows * dawn::EM * 4;
+    other += kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 12 + 4) + 4;  // host-API staging
+    if (rows_bytes) *rows_bytes = rows;
+    if (shadow_bytes) *shadow_bytes = shadows;
+    if (other_bytes) *other_bytes = other;
+    return DAWN_OK;
+}
+
 int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t B, float* out, size_t* n_out) {
     if (!idx || !queries || !out || !n_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (B == 0 || B > (size_t)dawn::BATCH_QT) return fail(DAWN_ERR_INVALID_ARG, "B must be 1..%d", dawn::BATCH_QT);

@@ -122,6 +122,14 @@ class VectorIndex:
         check(lib.dawn_index_stats_ext(self._h, C.byref(s), C.byref(c2), C.byref(f)))
         return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value}
 
+    def memory(self):
+        """HBM bytes held by the index: rows, filter shadows built so far, everything else."""
+        r = C.c_uint64(0)
+        sh = C.c_uint64(0)
+        o = C.c_uint64(0)
+        check(lib.dawn_index_memory(self._h, C.byref(r), C.byref(sh), C.byref(o)))
+        return {"rows": r.value, "shadows": sh.value, "other": o.value}
+
     def set_option(self, name: str, value: int):
         check(lib.dawn_index_set_option(self._h, name.encode(), value))
 

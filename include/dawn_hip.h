@@ -134,6 +134,9 @@ int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_m
 int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
 /* ... and searches whose 64-row certificate failed but whose 1024-row second certificate held (no exact pass). */
 int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_chances, uint64_t *fallbacks);
+/* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
+ * so far (int8: 384 B/row + 8 B per 32 rows; f16: 768 B/row), everything else (labels, search workspaces, staging). */
+int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
  * rows [0, n), n = min(size, 8192): out [B][n].  Lets a test check the bound the certificate relies on. */
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);

@@ -610,3 +610,22 @@ def test_batched_shadow_tracks_adds_and_growth(dawn, oracle, shadow):
     for b in (0, 7, 39):
         _assert_same(l[b], d[b], *oracle.scan_topk(rows, ids, Q[b], 10, threads=4))
     assert l[7][0] == 30_000 and idx.stats()["fallbacks"] == 0
+
+
+def test_memory_accounting(dawn):
+    """dawn_index_memory: 1536 B per reserved f32 row; after the first searches + 384 B per row (+ 8 B per 32 rows) of int8
+    shadow, and + 768 B per row once the f16 shadow is asked for."""
+    n = 100_000
+    idx = _mk_index(dawn, n)
+    m0 = idx.memory()
+    assert m0["rows"] >= n * 1536 and m0["rows"] < 1.6 * n * 1536 and m0["shadows"] == 0
+    q = synth.unit_rows(2, 0, 1)[0]
+    idx.search(q, 10)
+    m1 = idx.memory()
+    per_row = m1["shadows"] / (m1["rows"] / 1536)
+    assert 384 <= per_row < 386, per_row
+    idx.set_option("i8_shadow", 0)
+    idx.search(q, 10)
+    m2 = idx.memory()
+    assert m2["shadows"] - m1["shadows"] == (m1["rows"] // 1536) * 768
+    assert m2["other"] > n * 8
