@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "common.hpp"
@@ -57,11 +58,31 @@ struct dawn_embedder {
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
+    // hipGraph replay of launch-bound forwards (one text = 45 kernels of 3-6 us): the launch sequence depends only on
+    // (B, total tokens, longest sequence) and on the buffer addresses, so an instantiated graph is kept per such key and
+    // replayed; the token ids / offsets are read on the device at run time.  Larger batches are GPU-bound: no graphs.
+    struct GraphKey {
+        int B, T, max_len;
+        const void *ids, *off, *out;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(B, T, max_len, ids, off, out) < std::tie(o.B, o.T, o.max_len, o.ids, o.off, o.out);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, int> graph_seen;  // a shape is captured the second time it shows up
+    int use_graphs = 1;                  // option "graphs"
+    int graph_max_tokens = 512;
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+        graph_seen.clear();
+    }
 };
 
 namespace {
 
 int ensure_ws(dawn_embedder* e, int T, int B) {
+    if (T > e->cap_T || B > e->cap_B) e->drop_graphs();  // (they hold the old buffer addresses)
     if (T > e->cap_T) {
         float** bufs[] = {&e->x, &e->qkv, &e->ctx, &e->tmp, &e->attn, &e->ff};
         for (float** b : bufs)
@@ -309,6 +330,7 @@ void dawn_embedder_destroy(dawn_embedder* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->drop_graphs();
     void* ptrs[] = {e->d_weights, e->x, e->qkv, e->ctx, e->tmp, e->attn, e->ff, e->d_ids, e->d_off, e->d_pos, e->d_out};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -323,6 +345,16 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
         dawn::g_skinny_max_m = (int)value;
         return DAWN_OK;
     }
+    if (std::string(name) == "graphs") {  // 0: never replay hipGraphs (every forward is ~45 plain launches)
+        e->use_graphs = value != 0;
+        if (!value) e->drop_graphs();
+        return DAWN_OK;
+    }
+    if (std::string(name) == "graph_max_tokens") {
+        if (value < 0 || value > 65536) return fail(DAWN_ERR_INVALID_ARG, "graph_max_tokens out of range");
+        e->graph_max_tokens = (int)value;
+        return DAWN_OK;
+    }
     return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
 }
 
@@ -334,6 +366,33 @@ int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, 
     DAWN_HIP_TRY(hipSetDevice(e->device));
     DAWN_TRY(ensure_ws(e, total_tokens, B));
     hipStream_t s = (hipStream_t)stream;
+    if (e->use_graphs && total_tokens <= e->graph_max_tokens) {
+        const dawn_embedder::GraphKey key{B, total_tokens, max_len, d_token_ids, d_seq_offsets, d_out};
+        auto it = e->graphs.find(key);
+        if (it != e->graphs.end()) {
+            DAWN_HIP_TRY(hipGraphLaunch(it->second, s));
+            return DAWN_OK;
+        }
+        if (++e->graph_seen[key] >= 2 && e->graphs.size() < 512) {
+            // second sighting (the first, plain, run did every one-time initialisation): capture, instantiate, replay
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s);
+                dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);
+                const hipError_t ce = hipStreamEndCapture(s, &g);
+                if (ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(g);
+                    e->graphs[key] = ge;
+                    DAWN_HIP_TRY(hipGraphLaunch(ge, s));
+                    return DAWN_OK;
+                }
+                if (g) (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();
+            e->use_graphs = 0;  // capture is not available here: plain launches from now on
+        }
+    }
     encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s);
     dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);  // embedding_service.rs:126-136
     DAWN_HIP_TRY(hipGetLastError());

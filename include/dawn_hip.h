@@ -205,7 +205,8 @@ int dawn_embedder_forward(dawn_embedder *e, const uint32_t *token_ids, const int
 int dawn_embedder_forward_device(dawn_embedder *e, const uint32_t *d_token_ids, const int32_t *d_seq_offsets,
                                  int B, int total_tokens, int max_len, float *d_out, void *stream);
 /* Tuning knobs (defaults are the tuned values): "skinny_max_rows" = total tokens up to which the GEMMs use the
- * split-K latency form. */
+ * split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
+ * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
 int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);
 /* BertModel::forward hidden states (model.rs:565-570) for tests: out [total_tokens][384]. */
 int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,

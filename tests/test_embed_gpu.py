@@ -187,3 +187,30 @@ def test_any_batch_composition_matches_the_oracle(provider, oracle):
             assert np.abs(e - ref(s)).max() < TOL_EMB
 
     run()
+
+
+def test_graph_replay_is_bit_identical_to_plain_launches(provider):
+    """Launch-bound forwards (a lone text: ~45 kernels of a few microseconds) are replayed as hipGraphs from the second
+    sighting of a (batch, tokens, longest sequence) shape on: first call plain, second captured, later ones replayed —
+    all bit-identical to the plain-launch result, for changing token contents under one shape and across shapes."""
+    shapes = [synth.token_sequences(31 + i, 1, n, n)[0] for i, n in enumerate((2, 5, 17, 32, 33, 64, 100, 128))]
+    provider.set_option("graphs", 0)
+    plain = [provider.calculate_embedding([s])[0] for s in shapes]
+    pair_plain = provider.calculate_embedding([shapes[1], shapes[2]])
+    provider.set_option("graphs", 1)
+    try:
+        for rounds in range(4):  # plain, capture, replay, replay
+            for s, ref in zip(shapes, plain):
+                got = provider.calculate_embedding([s])[0]
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+            got = provider.calculate_embedding([shapes[1], shapes[2]])
+            assert np.array_equal(got.view(np.uint32), pair_plain.view(np.uint32))
+        # same shape, other tokens: the graph reads the ids at run time
+        other = synth.token_sequences(77, 1, 17, 17)[0]
+        provider.set_option("graphs", 0)
+        ref = provider.calculate_embedding([other])[0]
+        provider.set_option("graphs", 1)
+        for _ in range(3):
+            assert np.array_equal(provider.calculate_embedding([other])[0].view(np.uint32), ref.view(np.uint32))
+    finally:
+        provider.set_option("graphs", 1)
