@@ -629,3 +629,24 @@ def test_memory_accounting(dawn):
     m2 = idx.memory()
     assert m2["shadows"] - m1["shadows"] == (m1["rows"] // 1536) * 768
     assert m2["other"] > n * 8
+
+
+@pytest.mark.parametrize("n", [127, 128, 129, 255, 257, 8191, 8192, 8193, 8320, 8321, 16385, 40_001])
+@pytest.mark.parametrize("B", [4, 130, 256])
+def test_int8_batched_tile_edges(dawn, oracle, n, B):
+    """Index sizes around the 128-row tiles and 32-row sub-tiles of the int8 matrix-core pass, around the dense-only
+    limit (8192 rows) and the smallest sampled plans; query counts that use one wave, five waves / both groups, all of
+    them.  Bit-identical to the oracle; the rows past the end of the last tile never show up."""
+    idx = _mk_index(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, B)
+    Q[B - 1] = x[n - 1]          # the very last row
+    Q[0] = synth.planted_queries(1, [n - (n % 32 or 32)], 3)[0]  # first row of the last sub-tile
+    labels, dist, found = idx.search_batch(Q, 10)
+    for b in list(range(0, B, max(1, B // 12))) + [B - 1]:
+        olab, odist = oracle.scan_topk(x, ids, Q[b], 10, threads=8)
+        assert found[b] == min(10, n)
+        _assert_same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
+    assert labels[B - 1][0] == n and labels.max() <= n
+    assert idx.stats()["fallbacks"] == 0
