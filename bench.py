@@ -148,7 +148,7 @@ def main():
 
     def scan_passes(Bq):
         """Passes over the index rows made by the dominant kernel for a batch of Bq queries."""
-        if Bq >= 4:
+        if Bq >= 2:
             return -(-Bq // 256)          # matrix-core path: 256 queries per pass (scan_batched.hip)
         return -(-Bq // 8)                # streaming path over 16-bit fragments: 8 queries per pass
 
@@ -187,7 +187,7 @@ def main():
         if leg["scan_kernel_ms"] > 0:
             leg["scan_GBps"] = algo / (leg["scan_kernel_ms"] * 1e-3) / 1e9
             leg["hbm_frac"] = leg["scan_GBps"] / HBM_PEAK_GBS
-            if Bq >= 4:
+            if Bq >= 2:
                 # 256 query columns are multiplied whatever Bq is; dense peaks: 2.5 PFLOP/s f16/bf16, int8 twice that
                 # (MI355X_MICROARCH.md: the i8 MFMA has the cycles of the bf16 form at 2x the K)
                 leg["mfma_TFLOPs"] = 2.0 * 256 * rows_here * 384 / (leg["scan_kernel_ms"] * 1e-3) / 1e12
@@ -247,7 +247,7 @@ def main():
     elapsed_ms = head["ms_per_step"]
     scan_avg_ms = head["scan_kernel_ms"]
     achieved = head.get("scan_GBps", 0.0)
-    if B >= 4:
+    if B >= 2:
         kernel = "scan_i8_pipe_kernel<append> (int8 shadow tiles by LDS-DMA, 4 waves x 64 queries, v_mfma_i32_32x32x32_i8)"
     else:
         kernel = "scan_filter_i8s_kernel (int8 shadow fragments, global load -> integer MFMA; scores are upper bounds)"

@@ -92,7 +92,9 @@ struct dawn_index {
     // streaming filter keeps per-wave top-64 lists, whose warm-up grows with every extra query
     // (tools/small_batch_paths.py, stream vs matrix-core ms — 1M rows: B=2 0.22 / 0.21, B=4 0.33 / 0.22, B=8 0.74 / 0.23;
     // 100M rows: B=2 11.00 / 11.15, B=4 11.20 / 11.19, B=8 11.96 / 11.18; B=1 0.176 / 0.199 and 10.93 / 11.15)
-    int mfma_min_batch = 4;
+    // int8 shadow (tools/small_batch_paths.py, stream / matrix-core ms): 1M rows B=1 0.136 / 0.166, B=2 0.199 / 0.170,
+    // B=3 0.251 / 0.169; 40M rows B=1 2.27 / 2.33, B=2 2.36 / 2.35, B=3 2.42 / 2.34: two queries and more take the pass
+    int mfma_min_batch = 2;
     // host-API staging
     float* d_q = nullptr;
     uint64_t* d_labels = nullptr;

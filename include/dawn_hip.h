@@ -149,7 +149,7 @@ int dawn_index_debug_time_full_pass(dawn_index *idx, size_t B, int iters, double
 int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *out_scores, uint32_t *out_rows,
                                   size_t cap_blocks, size_t *n_blocks);
 /* Tuning knobs (tests and tools sweep them; the defaults are the tuned values):
- *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 4)
+ *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 2)
  *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
  *   "mfma_sched"       process-wide: 4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave
  *                      kernel only, 0 / 2 = lockstep converting kernel on the f32 rows (2: with phase stamps),

@@ -56,12 +56,12 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     for b in range(len(Q)):
         assert found[b] == K
         assert np.array_equal(labels[b], res1[b][0]) and np.array_equal(dist[b].view(np.uint32), res1[b][1].view(np.uint32))
-    # (3) 8 queries in ONE streaming pass (batches of 4+ take the matrix-core path unless told otherwise), and 3 by default
+    # (3) 8 queries in ONE streaming pass (batches of 2+ take the matrix-core path unless told otherwise); 3 on the default path
     idx.set_option("mfma_min_batch", 100000)
     try:
         l8, d8, f8 = idx.search_batch(Q[:8], K)
     finally:
-        idx.set_option("mfma_min_batch", 4)
+        idx.set_option("mfma_min_batch", 2)
     assert np.array_equal(l8, labels[:8]) and np.array_equal(d8.view(np.uint32), dist[:8].view(np.uint32))
     l3, d3, f3 = idx.search_batch(Q[5:8], K)
     assert np.array_equal(l3, labels[5:8]) and np.array_equal(d3.view(np.uint32), dist[5:8].view(np.uint32))

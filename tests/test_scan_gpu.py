@@ -465,7 +465,7 @@ def test_int8_shadow_tracks_adds_and_growth(dawn, oracle):
 @pytest.mark.parametrize("dtype", ["f32", "f32-f16shadow", "bf16"])
 @pytest.mark.parametrize("n,B", [(4097, 2), (100_003, 3), (100_003, 5), (300_001, 8), (20_001, 13)])
 def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype):
-    """The streaming filter serves 1..3 queries by default; forced (mfma_min_batch) it takes any batch, 8 queries per
+    """The streaming filter serves single queries by default; forced (mfma_min_batch) it takes any batch, 8 queries per
     pass (QB = 1 / 4 / 8 variants; int8 shadow, f16 shadow or bf16 index): same results as the oracle and as the
     default path."""
     idx = dawn.VectorIndex(0, dtype=dtype.split("-")[0])
