@@ -60,9 +60,10 @@ struct dawn_index {
         return geom_h_pinned ? geom_h : size < kShadowSmallRows ? geom_h_small : geom_i8;
     }
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
-    // f32 index only: int8 shadow (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows) read by the streaming filter of
-    // batches below mfma_min_batch — a quarter of the f32 bytes.  Built lazily at the first such search, and only while
-    // the f16 shadow of the matrix-core path still fits beside it.
+    // int8 shadow of the index rows (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows; f32 and bf16 indexes alike) read by
+    // every filter — the streaming one of single queries and the matrix-core pass — instead of the rows: a quarter of the
+    // f32 bytes.  Built lazily at the first search, extended on add, re-quantised on growth; if it cannot be allocated
+    // (or "i8_shadow" = 0) the filters fall back to the f16 shadow / the rows.
     char* d_i8 = nullptr;
     float* d_i8meta = nullptr;
     size_t i8_cap = 0, i8_rows = 0;

@@ -1,4 +1,5 @@
-// scan_i8.hip — int8 FILTER shadow of an f32 index (ROW_I8S, kernels.hpp) and its streaming filter for 1..8 queries.
+// scan_i8.hip — int8 FILTER shadow of the index rows (ROW_I8S, kernels.hpp), its streaming filter (1..8 queries per pass;
+// single queries by default) and its matrix-core pass (up to 256 queries; second half of this file).
 //
 // The filter stage of a search only has to produce, for every row, an UPPER BOUND on its exact score that is tight
 // enough for the 64-row shortlist to contain the true top-k (the exact rescore and the certificate of
