@@ -1137,7 +1137,10 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
     pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1 since n_rows > BATCH_CAP
     const double target = (double)g_batched_target;  // expected candidates per query in the full pass
     const double m_full = target * BATCH_CAP / (double)n_rows;
-    if (m_full >= 8.0) {
+    // one sample is enough while the threshold can be read from at least the 4th largest sample score (n <= 1 M rows at
+    // target 512): the candidate count of the full pass then follows target/4 x Gamma(4) — below the 64 the shortlist
+    // wants for 0.2 % of the queries (their certificate then rests on tau itself), never near the buffers' capacity
+    if (m_full >= 4.0) {
         pl.m1 = (uint32_t)(m_full + 0.999);
         if (pl.m1 > (uint32_t)LIST) pl.m1 = LIST;
         pl.s2_tiles = 0;
