@@ -539,7 +539,10 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
             }
             return;
         }
-        if (wpos + n > I8_ECAP) flush_wave();
+        if (wpos + n > I8_ECAP) {
+            flush_wave();
+            asm volatile("" ::: "memory");  // the flush's reads of the stage stay in front of the stores below
+        }
         if (hitl) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
             const uint32_t pa = stage_base + (wave * I8_ECAP + wpos + rank) * (I8_EDW * 4u);
