@@ -56,8 +56,9 @@ struct dawn_index {
     // int8 shadow stream: 4 waves per CU, whole sub-tiles (12 KiB) in flight per wave (tools/scan_sweep_shadow.py, 80M
     // rows: 7.01 TB/s against 6.97 with 2 waves; everything with >= 24 KiB in flight per CU lands within 2 %)
     dawn::ScanGeom geom_i8{256, 256, 3};
+    // ... and 8 waves per CU below 16 M rows (12.5 M rows — one shard of 100 M on 8 GPUs —: 723 vs 731 us; 25 M: a tie)
     const dawn::ScanGeom& i8_geom() const {
-        return geom_h_pinned ? geom_h : size < kShadowSmallRows ? geom_h_small : geom_i8;
+        return geom_h_pinned ? geom_h : size < ((size_t)16 << 20) ? geom_h_small : geom_i8;
     }
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
     // int8 shadow of the index rows (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows; f32 and bf16 indexes alike) read by
