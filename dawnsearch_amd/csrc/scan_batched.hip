@@ -980,10 +980,11 @@ __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, c
 
 // tau[b] = m-th largest score of query b's sample (dense scores or appended candidates); fewer than m
 // samples -> the smallest one; none -> -inf.  Rows scoring <= tau are NOT appended by the next pass.
+// Leaves the query's segment counters at zero for the append pass that follows (no memset launch in between).
 template <bool DENSE>
 __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restrict__ dense,
                                                          const uint2* __restrict__ cand,
-                                                         const uint32_t* __restrict__ cnt, uint32_t dense_count,
+                                                         uint32_t* __restrict__ cnt, uint32_t dense_count,
                                                          uint32_t m, float* __restrict__ tau) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
@@ -1004,6 +1005,8 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
         t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)pick));
     }
     if (lane == 0) tau[b] = t;
+    // (every wave read its segment's count before the first barrier of block_top64's merge)
+    if (lane < BATCH_CAND_SEGS) cnt[(size_t)b * BATCH_CAND_SEGS + lane] = 0u;
 }
 
 // Final: shortlist = top-64 candidates by filter score; exact rescore in the reference order; certificate.
@@ -1391,13 +1394,11 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
     launch_pass<true>(d_frows, frt, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
     hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
                        pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
-    if (pl.s2_tiles) {
-        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
+    if (pl.s2_tiles) {  // (the counters were left at zero by tau_select)
         launch_pass<false>(d_frows, frt, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
         hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
                            ws.tau);
     }
-    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
     if (ev1) (void)hipEventRecord(ev1, stream);

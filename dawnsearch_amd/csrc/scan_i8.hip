@@ -888,12 +888,10 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
     }
     pass(true, pl.s1_stride, pl.s1_tiles);
     launch_tau_select(true, B, ws, pl.s1_tiles * I8_TILE_ROWS, pl.m1, stream);
-    if (pl.s2_tiles) {
-        (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
+    if (pl.s2_tiles) {  // (tau_select leaves the segment counters at zero)
         pass(false, pl.s2_stride, pl.s2_tiles);
         launch_tau_select(false, B, ws, 0u, pl.m2, stream);
     }
-    (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
     pass(false, 1, pl.n_tiles_total);
     if (ev1) (void)hipEventRecord(ev1, stream);
