@@ -79,20 +79,65 @@ def cpu_baseline(sample_rows: int, k: int, total_rows: int):
     }
 
 
+def launch_ranks(args) -> int:
+    """A bare `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment): start N fresh ranks — one process
+    per GPU, torch.distributed.run, RCCL — BEFORE this process touches the GPU (it never does), relay rank 0's JSON line
+    as the last line of stdout and exit with the job's code.  (Never re-exec a process that has initialised HIP.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is None:
+        print(json.dumps({"error": f"the {args.gpus}-rank job printed no result line", "returncode": proc.returncode}))
+        return proc.returncode or 1
+    print(line, flush=True)
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...), "
+                         "or run `python bench.py --gpus N` without WORLD_SIZE and let it start the ranks")
+    n_dev = torch.cuda.device_count()  # (does not initialise the GPU)
+    if n_dev < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    # fewer GPUs than ranks (a 1-GPU box asked for --gpus 2): ranks share devices and exchange their result blobs
+    # through gloo — RCCL cannot put two ranks on one device.  The line is then marked "oversubscribed": a functional
+    # check of the N-rank flow, not a measurement.
+    oversub = world > n_dev
+    dev_index = local_rank % n_dev
+    backend = "gloo" if oversub else "nccl"
     if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if oversub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), rank=rank, world_size=world)
+    local_rank = dev_index
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -127,8 +172,14 @@ def main():
 
         def step():
             index.search_device(d_q.data_ptr(), Bq, k, p, p + off_d, p + off_f, stream)
-            if collective:
+            if collective and oversub:  # shared device: the blobs travel through host memory (gloo)
+                hb = blob.cpu()
+                hg = torch.empty((world * nbytes,), dtype=torch.uint8)
+                dist.all_gather_into_tensor(hg, hb)
+                g_blob.copy_(hg)
+            elif collective:
                 dist.all_gather_into_tensor(g_blob, blob)
+            if collective:
                 dawn.topk_merge_packed_device(local_rank, world, Bq, k, g_blob.data_ptr(), o_lab.data_ptr(),
                                               o_dist.data_ptr(), o_found.data_ptr(), stream)
 
@@ -142,6 +193,7 @@ def main():
         return step, result
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -167,7 +219,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if oversub else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         n_launch, scan_ms = index.profile_read()
@@ -261,7 +313,9 @@ def main():
                                "(int8 upper-bound filter over a shadow copy of every row + "
                                "exact f32 rescore + certificate: results bit-identical to the f32 scan)",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
-                   "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else "")},
+                   "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else ""),
+                   "ranks": world, "collective_backend": (backend if (world > 1 or args.force_collective) else None),
+                   "oversubscribed": oversub},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,

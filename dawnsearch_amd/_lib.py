@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdawn_hip.so")
+# DAWN_LIB: another build of the same library (tools only: the `make EXPERIMENTS=1` build with the timing-experiment kernels)
+LIB_PATH = os.environ.get("DAWN_LIB") or os.path.join(_HERE, "libdawn_hip.so")
 
 DAWN_OK = 0
 ERR_INVALID_ARG, ERR_NOT_NORMALIZED, ERR_HIP, ERR_IO, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6, -7
@@ -56,6 +57,8 @@ _SIGS = {
     "dawn_version": (_i32, []),
     "dawn_device_count": (_i32, [C.POINTER(_i32)]),
     "dawn_index_create": (_i32, [_sz, _i32, _i32, _pp]),
+    "dawn_index_create_sharded": (_i32, [_sz, _i32, _i32, C.POINTER(_i32), _pp]),
+    "dawn_index_shard_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _sz]),
     "dawn_index_destroy": (None, [_vp]),
     "dawn_index_reserve": (_i32, [_vp, _sz]),
     "dawn_index_size": (_sz, [_vp]),

@@ -3,117 +3,32 @@
 // Replaces usearch::ffi::Index as used by src/search/search_provider.rs (new_index :102, reserve
 // :133/:282, add :149/:284, search :214, size/capacity :246/:280, save/load :115-117/:178) with an
 // exact brute-force index: rows [N][384] f32 + ids [N] u64 live in one HBM allocation each, appended in
-// insertion order; search = scan_kernels.hip.
-#include <algorithm>
+// insertion order; search = scan_i8.hip / scan_kernels.hip / scan_batched.hip.
+//
+// Division of labour: every MUTATION (create, reserve, add*, fill, load*, set_option) leaves the index ready to be
+// searched — workspaces allocated, the filter shadow of the current rows built — and synchronises its own stream; a
+// SEARCH of up to 256 queries is then a fixed sequence of kernel launches on the caller's stream: no allocation, no
+// synchronisation, no host decision that depends on device data (graph-capturable).  Callers that search on a stream
+// of their own must have that stream idle before they mutate the index (the reference's actor never overlaps the two).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <cstdlib>
-#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include <vector>
+#include <thread>
 
-#include "common.hpp"
-#include "kernels.hpp"
+#include "index_internal.hpp"
 
 using dawn::fail;
 
 namespace {
-constexpr size_t kMaxBatch = 256;        // queries per internal pass of the host API
-constexpr size_t kMaxProfile = 4096;     // kept event pairs
-constexpr size_t kZeroCopyBatch = 8;      // host API: up to this many queries get their results by zero-copy stores
-constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
 constexpr char kMagic[8] = {'D', 'A', 'W', 'N', 'I', 'D', 'X', '1'};
-}  // namespace
-
-struct dawn_index {
-    int device = 0;
-    size_t dims = DAWN_EM_LEN;
-    hipStream_t stream = nullptr;
-
-    int dtype = DAWN_DTYPE_F32;  // row storage: f32 (1536 B/row) or bf16 (768 B/row)
-    char* d_x = nullptr;         // [(cap_phys + ROW_PAD)][384] of dtype
-    // f32 index only: scaled-f16 shadow copy of the rows (f16(2^8 x), 768 B/row, tiles in MFMA-fragment order: ROW_F16S
-    // in kernels.hpp) read by the matrix-core
-    // FILTER instead of the f32 rows: half the bytes and no conversion work in the scan.  Built lazily at the first
-    // batched search, extended on add; results stay exact (the rescore reads the f32 rows).  Costs +50 % HBM; if
-    // the allocation fails the filter converts f32 rows on the fly as before.
-    char* d_shadow = nullptr;
-    size_t shadow_cap = 0;       // rows allocated
-    size_t shadow_rows = 0;      // rows converted so far (prefix)
-    int use_shadow = 1;          // option "f16_shadow"
-    int shadow_small_batches = 1;  // option "f16_shadow_b1": batches of 1..8 queries also filter on the shadow
-    // geometry of the shadow stream (MFMA from registers): one 2-wave block per CU, `unroll` picks the load schedule
-    // (launch_filter_f16s_qb: 3 = ring of 12 fragments = 12 KiB in flight per wave).  tools/scan_sweep_shadow.py,
-    // 80M rows: 7.02-7.07 TB/s; every schedule with 2-4 waves per CU lands within 1 % of it
-    dawn::ScanGeom geom_h{256, 128, 3};
-    // ... and below kShadowSmallRows rows (a few dozen sub-tiles per wave: start-up, tail and load balance count)
-    // one 8-wave block per CU: 1M rows 154 -> 130 us.  Setting any shadow_scan_* option pins geom_h for every size.
-    dawn::ScanGeom geom_h_small{256, 512, 3};
-    bool geom_h_pinned = false;
-    const dawn::ScanGeom& shadow_geom() const {
-        return (!geom_h_pinned && size < kShadowSmallRows) ? geom_h_small : geom_h;
-    }
-    // int8 shadow stream: 4 waves per CU, whole sub-tiles (12 KiB) in flight per wave (tools/scan_sweep_shadow.py, 80M
-    // rows: 7.01 TB/s against 6.97 with 2 waves; everything with >= 24 KiB in flight per CU lands within 2 %)
-    dawn::ScanGeom geom_i8{256, 256, 3};
-    // ... and 8 waves per CU below 16 M rows (12.5 M rows — one shard of 100 M on 8 GPUs —: 723 vs 731 us; 25 M: a tie)
-    const dawn::ScanGeom& i8_geom() const {
-        return geom_h_pinned ? geom_h : size < ((size_t)16 << 20) ? geom_h_small : geom_i8;
-    }
-    bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
-    // int8 shadow of the index rows (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows; f32 and bf16 indexes alike) read by
-    // every filter — the streaming one of single queries and the matrix-core pass — instead of the rows: a quarter of the
-    // f32 bytes.  Built lazily at the first search, extended on add, re-quantised on growth; if it cannot be allocated
-    // (or "i8_shadow" = 0) the filters fall back to the f16 shadow / the rows.
-    char* d_i8 = nullptr;
-    float* d_i8meta = nullptr;
-    size_t i8_cap = 0, i8_rows = 0;
-    int use_i8 = 1;              // option "i8_shadow"
-    int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
-    bool i8_failed = false;
-    float* d_stage = nullptr;    // bf16 index: f32 staging rows for add / get_rows / fill ([stage_rows][384])
-    size_t stage_rows = 0;
-    size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }
-    uint64_t* d_ids = nullptr;  // [cap_phys]
-    size_t size = 0;
-    size_t cap_reported = 0;  // what reserve() promised (usearch semantics)
-    size_t cap_phys = 0;      // rows actually allocated (geometric growth)
-
-    // search workspaces
-    // batch-1..8 streaming scan: one 4-wave block per CU, 3 row pairs (9 KiB) in flight per wave.  Measured on
-    // MI355X (tools/scan_sweep.py, 40M rows): 36 KiB in flight per CU reads 7.17 TB/s; the full-occupancy
-    // geometry (32 waves, 192 KiB per CU) only 6.55 TB/s.
-    dawn::ScanGeom geom{256, 256, 3};
-    size_t ws_B = 0;
-    float* d_cand_s = nullptr;
-    uint32_t* d_cand_p = nullptr;
-    uint32_t* d_flags = nullptr;
-    dawn::BatchWorkspace bws{nullptr, nullptr, nullptr, nullptr};  // matrix-core batched path
-    int mfma_blocks = 256;   // one 8-wave workgroup per CU
-    // B >= this goes to the matrix-core filter (sampled thresholds, one candidate buffer per query); below it the
-    // streaming filter keeps per-wave top-64 lists, whose warm-up grows with every extra query
-    // (tools/small_batch_paths.py, stream vs matrix-core ms — 1M rows: B=2 0.22 / 0.21, B=4 0.33 / 0.22, B=8 0.74 / 0.23;
-    // 100M rows: B=2 11.00 / 11.15, B=4 11.20 / 11.19, B=8 11.96 / 11.18; B=1 0.176 / 0.199 and 10.93 / 11.15)
-    // int8 shadow (tools/small_batch_paths.py, stream / matrix-core ms): 1M rows B=1 0.136 / 0.166, B=2 0.199 / 0.170,
-    // B=3 0.251 / 0.169; 40M rows B=1 2.27 / 2.33, B=2 2.36 / 2.35, B=3 2.42 / 2.34: two queries and more take the pass
-    int mfma_min_batch = 2;
-    // host-API staging
-    float* d_q = nullptr;
-    uint64_t* d_labels = nullptr;
-    float* d_dist = nullptr;
-    uint32_t* d_found = nullptr;
-    uint32_t* d_bad = nullptr;
-    void* h_pinned = nullptr;  // kMaxBatch * (384*4 + 64*8 + 64*4 + 4 + 4)
-    size_t h_pinned_bytes = 0;
-
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    size_t events_used = 0;
-    uint64_t n_searches = 0, n_fallbacks = 0, n_second = 0;
-    int force_fallback = 0;
-};
-
-namespace {
+constexpr size_t kPageEntryBytes = 1568;  // src/index/warc.rs:35-43 (repr(C)): 8 + 8 + 384*4 + 8 + 8
+constexpr size_t kBulkChunkRows = 32768;  // rows per pinned staging buffer of the bulk loaders (48 MiB)
 
 int set_device(const dawn_index* idx) {
     DAWN_HIP_TRY(hipSetDevice(idx->device));
@@ -122,7 +37,7 @@ int set_device(const dawn_index* idx) {
 
 size_t padded_rows(size_t rows) { return ((rows + dawn::ROW_PAD - 1) / dawn::ROW_PAD) * dawn::ROW_PAD + dawn::ROW_PAD; }
 
-// Make room for at least `rows` rows (physical).  Existing rows are preserved.
+// Make room for at least `rows` rows (physical).  Live and pending rows are preserved.
 int grow_phys(dawn_index* idx, size_t rows) {
     if (rows <= idx->cap_phys) return DAWN_OK;
     if (rows >= 0xFFFFFF00ull) return fail(DAWN_ERR_UNSUPPORTED, "index limited to 2^32-256 rows per device");
@@ -136,16 +51,17 @@ int grow_phys(dawn_index* idx, size_t rows) {
         (void)hipFree(nx);
         return fail(DAWN_ERR_OOM, "hipMalloc(ids): %s", hipGetErrorString(e));
     }
+    const size_t keep = idx->size + idx->pending;
     // (a bf16 index is stored in 64-row tiles: copy and clear whole tiles)
-    const size_t live = idx->dtype == DAWN_DTYPE_BF16 ? (idx->size + dawn::ROW_PAD - 1) / dawn::ROW_PAD * dawn::ROW_PAD : idx->size;
-    if (idx->size) {
+    const size_t live = idx->dtype == DAWN_DTYPE_BF16 ? (keep + dawn::ROW_PAD - 1) / dawn::ROW_PAD * dawn::ROW_PAD : keep;
+    if (keep) {
         DAWN_HIP_TRY(hipMemcpyAsync(nx, idx->d_x, live * rb, hipMemcpyDeviceToDevice, idx->stream));
-        DAWN_HIP_TRY(hipMemcpyAsync(nid, idx->d_ids, idx->size * sizeof(uint64_t), hipMemcpyDeviceToDevice,
-                                    idx->stream));
+        DAWN_HIP_TRY(hipMemcpyAsync(nid, idx->d_ids, keep * sizeof(uint64_t), hipMemcpyDeviceToDevice, idx->stream));
     }
     // zero everything past the live rows: the scan may read (never use) up to ROW_PAD rows past size
     DAWN_HIP_TRY(hipMemsetAsync(nx + live * rb, 0, (prow - live) * rb, idx->stream));
-    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    // the old rows may still be read by a search a caller issued on a stream of its own
+    DAWN_HIP_TRY(hipDeviceSynchronize());
     if (idx->d_x) (void)hipFree(idx->d_x);
     if (idx->d_ids) (void)hipFree(idx->d_ids);
     idx->d_x = nx;
@@ -155,7 +71,7 @@ int grow_phys(dawn_index* idx, size_t rows) {
 }
 
 int ensure_room(dawn_index* idx, size_t extra) {
-    const size_t need = idx->size + extra;
+    const size_t need = idx->size + idx->pending + extra;
     if (need > idx->cap_phys) {
         size_t target = std::max(need, idx->cap_phys + idx->cap_phys / 2);
         target = std::max<size_t>(target, 1024);
@@ -165,17 +81,29 @@ int ensure_room(dawn_index* idx, size_t extra) {
     return DAWN_OK;
 }
 
+size_t ws_lists_needed(const dawn_index* idx) {
+    return (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks});
+}
+
+// Search workspaces for batches of up to B queries (creation: kMaxBatch; a search_device call with more queries in one
+// call grows them — the one case where a search allocates).
 int ensure_workspace(dawn_index* idx, size_t B) {
-    // the batched workspace also serves the f16-shadow streaming filter of small batches (scaled query images)
-    const bool shadow_possible = idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed;
-    if ((B >= (size_t)idx->mfma_min_batch || shadow_possible) && !idx->bws.cand) {
+    if (!idx->bws.cand) {
         if (int e = dawn::batched_init()) return fail(DAWN_ERR_HIP, "hipFuncSetAttribute(LDS): %s", hipGetErrorString((hipError_t)e));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * dawn::EM * sizeof(_Float16)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.tau, dawn::BATCH_QT * sizeof(float)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMalloc(&idx->bws.cand, (size_t)dawn::BATCH_QT * dawn::BATCH_CAP * 8));
+        DAWN_HIP_TRY(hipMemset(idx->bws.cnt, 0, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
     }
-    if (B <= idx->ws_B) return DAWN_OK;
+    if (!idx->d_stats) {
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, 4 * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMemset(idx->d_stats, 0, 4 * sizeof(uint32_t)));
+    }
+    const size_t lists = ws_lists_needed(idx);
+    if (B <= idx->ws_B && lists <= idx->ws_lists) return DAWN_OK;
+    B = std::max(B, idx->ws_B);
+    DAWN_HIP_TRY(hipDeviceSynchronize());  // nothing may still be using the old buffers
     if (idx->d_cand_s) (void)hipFree(idx->d_cand_s);
     if (idx->d_cand_p) (void)hipFree(idx->d_cand_p);
     if (idx->d_flags) (void)hipFree(idx->d_flags);
@@ -183,34 +111,38 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
     idx->ws_B = 0;
-    const size_t n = B * (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks}) * dawn::LIST;
+    const size_t n = B * lists * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, 2 * B * sizeof(uint32_t)));  // flags[B] | arrival counters of the exact pass[B]
     DAWN_HIP_TRY(hipMemset(idx->d_flags, 0, 2 * B * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipDeviceSynchronize());  // (searches run on non-blocking streams)
     idx->ws_B = B;
+    idx->ws_lists = lists;
     return DAWN_OK;
 }
 
-// Bring the f16 shadow up to date with the f32 rows (no-op when disabled / not an f32 index / out of memory).
-// Returns the filter's row source.
-const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
-    *frt = idx->dtype;
-    if (idx->dtype != DAWN_DTYPE_F32 || !idx->use_shadow || idx->shadow_failed) return idx->d_x;
+bool enough_free(size_t bytes) {
+    size_t fr = 0, tot = 0;
+    return hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= bytes + ((size_t)2 << 30);
+}
+
+// Bring the f16 shadow up to date with the f32 rows (no-op when it cannot be allocated).
+void f16_shadow_sync(dawn_index* idx) {
+    hipStream_t stream = idx->stream;
     if (idx->shadow_cap < idx->cap_phys) {
         char* ns = nullptr;
         const size_t prow = padded_rows(idx->cap_phys);
-        if (hipMalloc((void**)&ns, prow * dawn::EM * 2) != hipSuccess) {
+        if (!enough_free(prow * dawn::EM * 2) || hipMalloc((void**)&ns, prow * dawn::EM * 2) != hipSuccess) {
             (void)hipGetLastError();
             idx->shadow_failed = true;
-            return idx->d_x;
+            return;
         }
         (void)hipMemsetAsync(ns, 0, prow * dawn::EM * 2, stream);
-        if (idx->d_shadow) {  // keep what is converted already (the old buffer is idle: searches are serialised)
+        if (idx->d_shadow) {  // keep what is converted already
             (void)hipMemcpyAsync(ns, idx->d_shadow, padded_rows(idx->shadow_rows) * dawn::EM * 2, hipMemcpyDeviceToDevice,
                                  stream);  // whole tiles
-            (void)hipStreamSynchronize(stream);
+            (void)hipDeviceSynchronize();
             (void)hipFree(idx->d_shadow);
         }
         idx->d_shadow = ns;
@@ -221,31 +153,24 @@ const void* filter_rows(dawn_index* idx, int* frt, hipStream_t stream) {
                                       stream);
         idx->shadow_rows = idx->size;
     }
-    *frt = dawn::ROW_F16S;
-    return idx->d_shadow;
 }
 
-// Bring the int8 shadow up to date; false when it is disabled or does not fit.
-bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
-    if (!idx->use_i8 || idx->i8_failed) return false;  // (a bf16 index: the int8 copy shadows its bf16 rows)
+// Bring the int8 shadow up to date; false when it does not fit.
+bool i8_shadow_sync(dawn_index* idx) {
+    hipStream_t stream = idx->stream;
     if (idx->i8_cap < idx->cap_phys) {
         const size_t prow = padded_rows(idx->cap_phys) + 128;  // (the batched kernel moves 128-row tiles)
         const size_t bytes = prow * dawn::EM, mbytes = (prow / 32 + 1) * 8;
-        // leave room for the f16 shadow of the matrix-core path (allocated at the first batch of mfma_min_batch queries)
-        (void)hipStreamSynchronize(stream);  // the old buffers are idle: searches are serialised
+        (void)hipDeviceSynchronize();  // nothing reads the old buffers any more
         if (idx->d_i8) (void)hipFree(idx->d_i8);
         if (idx->d_i8meta) (void)hipFree(idx->d_i8meta);
         idx->d_i8 = nullptr;
         idx->d_i8meta = nullptr;
         idx->i8_cap = 0;
-        size_t fr = 0, tot = 0;
-        size_t need = bytes + mbytes + ((size_t)2 << 30);
-        if (idx->dtype == DAWN_DTYPE_F32 && !idx->i8_batched && idx->use_shadow && !idx->shadow_failed &&
-            idx->shadow_cap < idx->cap_phys)
-            need += prow * dawn::EM * 2;
+        idx->i8_rows = 0;
         char* ns = nullptr;
         float* nm = nullptr;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need || hipMalloc((void**)&ns, bytes) != hipSuccess ||
+        if (!enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
             hipMalloc((void**)&nm, mbytes) != hipSuccess) {
             (void)hipGetLastError();
             if (ns) (void)hipFree(ns);
@@ -256,8 +181,7 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
         (void)hipMemsetAsync(nm, 0, mbytes, stream);
         idx->d_i8 = ns;
         idx->d_i8meta = nm;
-        idx->i8_cap = idx->cap_phys;
-        idx->i8_rows = 0;  // (re-quantised from the f32 rows: 0.03 ms per million rows)
+        idx->i8_cap = idx->cap_phys;  // (re-quantised from the rows: 0.03 ms per million rows)
     }
     if (idx->i8_rows < idx->size) {
         dawn::launch_rows_to_i8s(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size, stream);
@@ -266,76 +190,611 @@ bool i8_rows_ready(dawn_index* idx, hipStream_t stream) {
     return true;
 }
 
+bool i8_live(const dawn_index* idx) {
+    return idx->use_i8 && !idx->i8_failed && idx->i8_rows == idx->size && (idx->d_i8 || idx->size == 0);
+}
+bool f16_live(const dawn_index* idx) {
+    return idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed && idx->d_shadow &&
+           idx->shadow_rows == idx->size;
+}
+
+int ensure_stage(dawn_index* idx, size_t bytes) {
+    if (bytes <= idx->stage_bytes) return DAWN_OK;
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));  // earlier chunks may still be passing through it
+    if (idx->d_stage) (void)hipFree(idx->d_stage);
+    idx->d_stage = nullptr;
+    idx->stage_bytes = 0;
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stage, bytes));
+    idx->stage_bytes = bytes;
+    return DAWN_OK;
+}
+
+}  // namespace
+
+namespace dawn {
+
+// Which filter source the searches of this index will read, given its options (mirrors index_search_on_device), built on
+// idx->stream.  An option that needs a shadow the index does not hold yet builds it here — never inside a search.
+int index_prepare_search(dawn_index* idx) {
+    DAWN_TRY(ensure_workspace(idx, std::max(idx->ws_B, kMaxBatch)));
+    if (idx->size == 0) return DAWN_OK;
+    bool i8_ok = false;
+    if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
+    if (idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed) {
+        const bool batched_needs = !(i8_ok && idx->i8_batched);
+        const bool small_needs = idx->shadow_small_batches && !i8_ok;
+        if (batched_needs || small_needs) f16_shadow_sync(idx);
+    }
+    DAWN_HIP_TRY(hipGetLastError());
+    return DAWN_OK;
+}
+
 // The whole search as a fixed launch sequence on `stream` (no host decisions in between).
-int search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
-                     uint32_t* d_found, hipStream_t stream) {
-    DAWN_TRY(ensure_workspace(idx, B));
+int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
+                           uint32_t* d_found, hipStream_t stream) {
+    if (B > idx->ws_B) DAWN_TRY(ensure_workspace(idx, B));  // more than kMaxBatch queries in one device call
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (idx->profiling && idx->events_used < kMaxProfile) {
-        if (idx->events_used == idx->events.size()) {
-            hipEvent_t a, b;
-            DAWN_HIP_TRY(hipEventCreate(&a));
-            DAWN_HIP_TRY(hipEventCreate(&b));
-            idx->events.emplace_back(a, b);
-        }
+    if (idx->profiling && idx->events_used < idx->events.size()) {
         e0 = idx->events[idx->events_used].first;
         e1 = idx->events[idx->events_used].second;
         idx->events_used++;
     }
     const uint32_t n = (uint32_t)idx->size;
-    if ((int)B >= idx->mfma_min_batch && idx->i8_batched && i8_rows_ready(idx, stream)) {
+    const bool batched = (int)B >= idx->mfma_min_batch;
+    if (batched && idx->i8_batched && i8_live(idx)) {
         // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
-        for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
-            const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
-            dawn::launch_scan_batched_i8(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb,
-                                         (uint32_t)k, idx->bws, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k,
-                                         d_found + b0, idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
-                                         b0 == 0 ? e1 : nullptr);
+        for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
+            const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
+            launch_scan_batched_i8(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * EM, (int)nb,
+                                   (uint32_t)k, idx->bws, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
+                                   idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
+                                   b0 == 0 ? e1 : nullptr);
         }
-    } else if ((int)B >= idx->mfma_min_batch) {
-        // matrix-core path, BATCH_QT queries per pass over the index
+    } else if (batched) {
+        // matrix-core path on 16-bit rows: the f16 shadow of an f32 index, a bf16 index itself; an f32 index without a
+        // shadow (or mfma_sched 0 / 2): the lockstep kernel converts the f32 rows on the fly
         int frt = idx->dtype;
-        const void* frows = idx->d_x;  // f32 index with mfma_sched 0 / 2: the lockstep kernel converts the f32 rows
-        if (idx->dtype == DAWN_DTYPE_BF16 || (dawn::g_batched_sched != 0 && dawn::g_batched_sched != 2))
-            frows = filter_rows(idx, &frt, stream);  // (a bf16 index is its own fragment-ordered filter source)
-        for (size_t b0 = 0; b0 < B; b0 += dawn::BATCH_QT) {
-            const size_t nb = std::min<size_t>(dawn::BATCH_QT, B - b0);
-            dawn::launch_scan_batched(idx->d_x, idx->dtype, frows, frt, idx->d_ids, n, d_q + b0 * dawn::EM, (int)nb, (uint32_t)k, idx->bws,
-                                      idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
-                                      idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
-                                      b0 == 0 ? e1 : nullptr);
+        const void* frows = idx->d_x;
+        if (idx->dtype == DAWN_DTYPE_F32 && idx->bws.sched != 0 && idx->bws.sched != 2 && f16_live(idx)) {
+            frows = idx->d_shadow;
+            frt = ROW_F16S;
         }
-    } else if (idx->shadow_small_batches && i8_rows_ready(idx, stream)) {
+        for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
+            const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
+            launch_scan_batched(idx->d_x, idx->dtype, frows, frt, idx->d_ids, n, d_q + b0 * EM, (int)nb, (uint32_t)k, idx->bws,
+                                idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0, idx->d_flags + b0,
+                                idx->force_fallback, stream, b0 == 0 ? e0 : nullptr, b0 == 0 ? e1 : nullptr);
+        }
+    } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
-        const dawn::ScanGeom& gh = idx->i8_geom();
-        dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
-        dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh.blocks,
-                                   (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback,
-                                   dawn::FILTER_EPS_I8, stream);
+        const ScanGeom& gh = idx->i8_geom();
+        launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
+        launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh.blocks,
+                             (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_I8, stream);
+    } else if (idx->dtype == DAWN_DTYPE_BF16 || (idx->shadow_small_batches && f16_live(idx))) {
+        // 1..8 queries: stream the 16-bit fragments (768 B/row: the f16 shadow instead of the f32 rows, or the bf16
+        // index itself) through the matrix cores
+        const bool own = idx->dtype == DAWN_DTYPE_BF16;
+        const ScanGeom& gh = idx->shadow_geom();
+        launch_scan_filter_f16s(own ? idx->d_x : idx->d_shadow, own ? ROW_BF16 : ROW_F16S, n, d_q, (int)B, idx->d_cand_s,
+                                idx->d_cand_p, gh, stream, e0, e1);
+        launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh.blocks,
+                             (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback,
+                             own ? FILTER_EPS_BF16_STREAM : FILTER_EPS_F16, stream);
     } else {
-        int frt = idx->dtype;
-        const void* frows = filter_rows(idx, &frt, stream);
-        if (frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
-            // 1..8 queries: stream the 16-bit fragments (768 B/row: the f16 shadow instead of the f32 rows, or the
-            // bf16 index itself) through the matrix cores
-            const dawn::ScanGeom& gh = idx->shadow_geom();
-            dawn::launch_scan_filter_f16s(frows, frt, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, gh, stream, e0, e1);
-            dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                       gh.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback,
-                                       frt == dawn::ROW_BF16 ? dawn::FILTER_EPS_BF16_STREAM : dawn::FILTER_EPS_F16, stream);
-        } else {
-            dawn::launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream,
-                                     e0, e1);
-            dawn::launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p,
-                                       idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                                       idx->force_fallback, dawn::FILTER_EPS_F32, stream);
-        }
+        // the f32 rows themselves (1536 B/row)
+        launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
+        launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
+                             (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_F32, stream);
     }
-    dawn::launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_cand_s,
-                            idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
+    launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
+                      idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }
+
+int index_create_single(int dtype, int device, dawn_index** out) {
+    *out = nullptr;
+    DAWN_TRY(require_device(device));
+    DAWN_HIP_TRY(hipSetDevice(device));
+    auto* idx = new dawn_index();
+    idx->device = device;
+    idx->dtype = dtype;
+    if (const char* e = getenv("DAWN_I8_SHADOW")) idx->use_i8 = atoi(e) != 0;  // default of the "i8_shadow" option
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
+        idx->geom_h.blocks = prop.multiProcessorCount;
+        idx->geom_h_small.blocks = prop.multiProcessorCount;
+        idx->geom_i8.blocks = prop.multiProcessorCount;
+        idx->mfma_blocks = prop.multiProcessorCount;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(DAWN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    const size_t hb = kMaxBatch * (EM * 4 + DAWN_MAX_K * 8 + DAWN_MAX_K * 4 + 8);
+    if (hipHostMalloc(&idx->h_pinned, hb, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&idx->d_q, kMaxBatch * EM * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_labels, kMaxBatch * DAWN_MAX_K * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_dist, kMaxBatch * DAWN_MAX_K * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_found, kMaxBatch * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&idx->d_bad, sizeof(uint32_t)) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_slot[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_slot[1], hipEventDisableTiming) != hipSuccess) {
+        index_destroy_single(idx);
+        return fail(DAWN_ERR_OOM, "allocating index staging buffers failed");
+    }
+    idx->h_pinned_bytes = hb;
+    int rc = index_prepare_search(idx);
+    if (rc == DAWN_OK && hipStreamSynchronize(idx->stream) != hipSuccess) rc = fail(DAWN_ERR_HIP, "index creation failed");
+    if (rc != DAWN_OK) {
+        index_destroy_single(idx);
+        return rc;
+    }
+    *out = idx;
+    return DAWN_OK;
+}
+
+void index_destroy_single(dawn_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& ev : idx->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    for (hipEvent_t ev : idx->ev_slot)
+        if (ev) (void)hipEventDestroy(ev);
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
+                    idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->d_q,
+                    idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int index_reserve_single(dawn_index* idx, size_t capacity) {
+    DAWN_TRY(set_device(idx));
+    if (capacity > idx->cap_phys) {
+        DAWN_TRY(grow_phys(idx, capacity));
+        DAWN_TRY(index_prepare_search(idx));  // the shadows move with the rows
+        DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    }
+    if (capacity > idx->cap_reported) idx->cap_reported = capacity;
+    return DAWN_OK;
+}
+
+int index_append_async(dawn_index* idx, RowSrc kind, const void* h_src, const uint64_t* h_ids, uint64_t first_label, size_t m,
+                       int slot) {
+    if (idx->shards) return sharded_append_async(idx, kind, h_src, h_ids, first_label, m, slot);
+    if (m == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_room(idx, m));
+    hipStream_t st = idx->stream;
+    if (idx->pending == 0) DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), st));
+    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
+    const size_t at = idx->size + idx->pending;
+    const size_t rb = idx->row_bytes();
+    // rows land past `size` (invisible to searches) and become live only after validation
+    if (kind == RowSrc::HostRows && !bf16) {
+        float* dst = reinterpret_cast<float*>(idx->d_x + at * rb);
+        DAWN_HIP_TRY(hipMemcpyAsync(dst, h_src, m * rb, hipMemcpyHostToDevice, st));
+        launch_validate_rows(dst, (uint32_t)m, idx->d_bad, st);
+    } else {
+        // through device staging: PageEntry records are cut down to their vectors on the GPU (the host only moves
+        // bytes), a bf16 index gates the f32 input and rounds it into its tiles
+        const size_t rec = kind == RowSrc::HostPageEntries ? kPageEntryBytes : EM * sizeof(float);
+        const size_t sub_rows = std::min(m, kStageChunk);
+        const size_t raw_bytes = kind == RowSrc::HostPageEntries ? (sub_rows * rec + 255) / 256 * 256 : 0;
+        const size_t f32_bytes = bf16 ? sub_rows * EM * sizeof(float) : 0;
+        DAWN_TRY(ensure_stage(idx, raw_bytes + f32_bytes));
+        for (size_t o = 0; o < m; o += sub_rows) {
+            const size_t mm = std::min(sub_rows, m - o);
+            char* d_raw = reinterpret_cast<char*>(idx->d_stage);
+            float* d_f32 = bf16 ? reinterpret_cast<float*>(d_raw + raw_bytes) : reinterpret_cast<float*>(idx->d_x + (at + o) * rb);
+            const char* src = reinterpret_cast<const char*>(h_src) + o * rec;
+            if (kind == RowSrc::HostPageEntries) {
+                DAWN_HIP_TRY(hipMemcpyAsync(d_raw, src, mm * rec, hipMemcpyHostToDevice, st));
+                launch_page_entries_to_rows(d_raw, (uint32_t)mm, d_f32, st);
+            } else {
+                DAWN_HIP_TRY(hipMemcpyAsync(d_f32, src, mm * rec, hipMemcpyHostToDevice, st));
+            }
+            launch_validate_rows(d_f32, (uint32_t)mm, idx->d_bad, st);  // gate on the f32 input
+            if (bf16) launch_rows_f32_to_bf16(d_f32, idx->d_x, at + o, mm, st);
+        }
+    }
+    if (h_ids) DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + at, h_ids, m * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    else launch_iota_u64(idx->d_ids + at, first_label, (uint32_t)m, st);
+    DAWN_HIP_TRY(hipGetLastError());
+    idx->pending += m;
+    if (slot >= 0) {
+        DAWN_HIP_TRY(hipEventRecord(idx->ev_slot[slot], st));
+        idx->ev_slot_used[slot] = true;
+    }
+    return DAWN_OK;
+}
+
+int index_append_wait(dawn_index* idx, int slot) {
+    if (idx->shards) return sharded_append_wait(idx, slot);
+    if (!idx->ev_slot_used[slot]) return DAWN_OK;
+    DAWN_HIP_TRY(hipEventSynchronize(idx->ev_slot[slot]));
+    idx->ev_slot_used[slot] = false;
+    return DAWN_OK;
+}
+
+int index_append_check(dawn_index* idx, uint32_t* bad) {
+    *bad = 0;
+    if (idx->pending == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    uint32_t* hb = reinterpret_cast<uint32_t*>(idx->h_pinned);
+    DAWN_HIP_TRY(hipMemcpyAsync(hb, idx->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->ev_slot_used[0] = idx->ev_slot_used[1] = false;
+    *bad = *hb;
+    return DAWN_OK;
+}
+
+int index_append_finish(dawn_index* idx, bool keep) {
+    if (idx->pending == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    if (!keep) {
+        // (a bf16 index keeps the rejected rows' fragments: rows >= size are masked by position in every kernel)
+        if (idx->dtype != DAWN_DTYPE_BF16)
+            (void)hipMemsetAsync(idx->d_x + idx->size * idx->row_bytes(), 0, idx->pending * idx->row_bytes(), idx->stream);
+        idx->pending = 0;
+        DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+        return DAWN_OK;
+    }
+    idx->size += idx->pending;
+    idx->pending = 0;
+    DAWN_TRY(index_prepare_search(idx));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return DAWN_OK;
+}
+
+int index_append_commit(dawn_index* idx) {
+    if (idx->shards) return sharded_append_commit(idx);
+    uint32_t bad = 0;
+    const size_t n = idx->pending;
+    DAWN_TRY(index_append_check(idx, &bad));
+    DAWN_TRY(index_append_finish(idx, bad == 0));
+    if (bad) return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized (%u of %zu rows)", bad, n);
+    return DAWN_OK;
+}
+
+void index_append_abort(dawn_index* idx) {
+    if (idx->shards) return sharded_append_abort(idx);
+    (void)hipSetDevice(idx->device);
+    (void)hipStreamSynchronize(idx->stream);
+    idx->ev_slot_used[0] = idx->ev_slot_used[1] = false;
+    (void)index_append_finish(idx, false);
+}
+
+int index_clear(dawn_index* idx) {
+    if (idx->shards) return sharded_clear(idx);
+    DAWN_TRY(set_device(idx));
+    DAWN_HIP_TRY(hipDeviceSynchronize());
+    idx->size = 0;
+    idx->pending = 0;
+    idx->shadow_rows = 0;
+    idx->i8_rows = 0;
+    return DAWN_OK;
+}
+
+// Synthetic unit rows appended as pending rows: rows first_row.. of stream `seed`; labels first_id + i, or
+// (a shard of a sharded index) the global positions first_pos + i.
+int index_fill_async(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, bool ids_are_positions,
+                     uint64_t first_pos) {
+    if (n == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    DAWN_TRY(ensure_room(idx, n));
+    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
+    const size_t rb = idx->row_bytes();
+    const size_t chunk = bf16 ? kStageChunk : (size_t)1u << 22;  // rows per generator launch
+    const size_t m0 = std::min(n, chunk);
+    // staging: [m0] f32 lengths (+ [m0][384] f32 rows for a bf16 index)
+    const size_t len_bytes = (m0 * sizeof(float) + 255) / 256 * 256;
+    DAWN_TRY(ensure_stage(idx, len_bytes + (bf16 ? m0 * EM * sizeof(float) : 0)));
+    float* d_len = idx->d_stage;
+    float* d_f32 = reinterpret_cast<float*>(reinterpret_cast<char*>(idx->d_stage) + len_bytes);
+    const size_t at = idx->size + idx->pending;
+    for (size_t o = 0; o < n; o += chunk) {
+        const size_t m = std::min(chunk, n - o);
+        char* dst = idx->d_x + (at + o) * rb;
+        if (bf16) {  // f32 unit rows of the spec, then rounded: the bf16 index holds round_bf16(spec row)
+            launch_fill_synth(seed, first_row + o, (uint32_t)m, d_f32, d_len, idx->stream);
+            launch_rows_f32_to_bf16(d_f32, idx->d_x, at + o, m, idx->stream);
+        } else {
+            launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->stream);
+        }
+        launch_iota_u64(idx->d_ids + at + o, (ids_are_positions ? first_pos : first_id) + o, (uint32_t)m, idx->stream);
+    }
+    DAWN_HIP_TRY(hipGetLastError());
+    if (idx->pending == 0) DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), idx->stream));
+    idx->pending += n;
+    return DAWN_OK;
+}
+
+// Rows come back as f32 whatever the storage type (bf16 rows widened exactly).
+int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids) {
+    if (first + n > idx->size) return fail(DAWN_ERR_INVALID_ARG, "rows [%zu, %zu) out of range (size %zu)", first, first + n, idx->size);
+    if (n == 0) return DAWN_OK;
+    DAWN_TRY(set_device(idx));
+    const size_t rb = idx->row_bytes();
+    if (out_rows && idx->dtype == DAWN_DTYPE_BF16) {
+        DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk) * EM * sizeof(float)));
+        for (size_t o = 0; o < n; o += kStageChunk) {
+            const size_t m = std::min(kStageChunk, n - o);
+            launch_rows_bf16_to_f32(idx->d_x, first + o, idx->d_stage, m, idx->stream);
+            DAWN_HIP_TRY(hipMemcpyAsync(out_rows + o * EM, idx->d_stage, m * EM * sizeof(float), hipMemcpyDeviceToHost,
+                                        idx->stream));
+            DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+        }
+    } else if (out_rows) {
+        DAWN_HIP_TRY(hipMemcpy(out_rows, idx->d_x + first * rb, n * rb, hipMemcpyDeviceToHost));
+    }
+    if (out_ids) DAWN_HIP_TRY(hipMemcpy(out_ids, idx->d_ids + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return DAWN_OK;
+}
+
+int index_profile_enable_single(dawn_index* idx, int enable) {
+    DAWN_TRY(set_device(idx));
+    if (enable) {  // the event pairs exist before the first profiled search: a search creates nothing
+        idx->events.reserve(kMaxProfile);
+        while (idx->events.size() < kMaxProfile) {
+            hipEvent_t a, b;
+            DAWN_HIP_TRY(hipEventCreate(&a));
+            if (hipEventCreate(&b) != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return fail(DAWN_ERR_HIP, "hipEventCreate failed");
+            }
+            idx->events.emplace_back(a, b);
+        }
+    }
+    idx->profiling = enable != 0;
+    idx->events_used = 0;
+    return DAWN_OK;
+}
+
+int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total_ms) {
+    DAWN_TRY(set_device(idx));
+    DAWN_HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0;
+    for (size_t i = 0; i < idx->events_used; ++i) {
+        float ms = 0.f;
+        DAWN_HIP_TRY(hipEventElapsedTime(&ms, idx->events[i].first, idx->events[i].second));
+        sum += ms;
+    }
+    *launches = idx->events_used;
+    *total_ms = sum;
+    idx->events_used = 0;
+    return DAWN_OK;
+}
+
+// The certificate counters live on the device (scan_exact_kernel bumps them at the end of every search, whichever entry
+// point issued it); reading them synchronises the device.
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks) {
+    DAWN_TRY(set_device(idx));
+    uint32_t st[4] = {0, 0, 0, 0};
+    DAWN_HIP_TRY(hipDeviceSynchronize());
+    if (idx->d_stats) DAWN_HIP_TRY(hipMemcpy(st, idx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+    if (searches) *searches = idx->n_searches;
+    if (second) *second = st[FLAG_SECOND];
+    if (fallbacks) *fallbacks = st[FLAG_FALLBACK];
+    return DAWN_OK;
+}
+
+int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes) {
+    const uint64_t rows = idx->d_x ? (uint64_t)padded_rows(idx->cap_phys) * idx->row_bytes() : 0;
+    uint64_t shadows = 0;
+    if (idx->d_shadow) shadows += (uint64_t)padded_rows(idx->shadow_cap) * EM * 2;
+    if (idx->d_i8) {
+        const uint64_t prow = padded_rows(idx->i8_cap) + 128;
+        shadows += prow * EM + (prow / 32 + 1) * 8;
+    }
+    uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
+    if (idx->d_cand_s) other += (uint64_t)idx->ws_B * idx->ws_lists * LIST * 8 + 2 * idx->ws_B * 4 + 16;
+    if (idx->bws.cand) other += (uint64_t)BATCH_QT * (EM * 2 + 4 + BATCH_CAND_SEGS * 4 + (uint64_t)BATCH_CAP * 8);
+    other += idx->stage_bytes;
+    other += kMaxBatch * (EM * 4 + DAWN_MAX_K * 12 + 4) + 4;  // host-API staging
+    if (rows_bytes) *rows_bytes = rows;
+    if (shadow_bytes) *shadow_bytes = shadows;
+    if (other_bytes) *other_bytes = other;
+    return DAWN_OK;
+}
+
+int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
+    const std::string n(name);
+    DAWN_TRY(set_device(idx));
+    auto reprepare = [&]() -> int {  // options that change which shadow / workspace the searches need
+        DAWN_TRY(index_prepare_search(idx));
+        DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+        return DAWN_OK;
+    };
+    if (n == "force_fallback") {
+        idx->force_fallback = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "scan_blocks") {
+        if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "scan_blocks out of range");
+        idx->geom.blocks = (int)value;
+        return reprepare();  // candidate buffers are sized by the grid
+    }
+    if (n == "mfma_min_batch") {
+        if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
+        idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (n == "mfma_blocks") {
+        if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
+        idx->mfma_blocks = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "scan_unroll") {
+        if (value < 1 || value > 4) return fail(DAWN_ERR_INVALID_ARG, "scan_unroll must be 1..4");
+        idx->geom.unroll = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "f16_shadow") {
+        idx->use_shadow = value != 0;
+        return reprepare();
+    }
+    if (n == "i8_shadow") {
+        idx->use_i8 = value != 0;
+        if (value) idx->i8_failed = false;
+        return reprepare();
+    }
+    if (n == "i8_batched") {
+        idx->i8_batched = value != 0;
+        return reprepare();
+    }
+    if (n == "f16_shadow_b1") {
+        idx->shadow_small_batches = value != 0;
+        return reprepare();
+    }
+    if (n == "shadow_scan_blocks" || n == "shadow_scan_threads" || n == "shadow_scan_unroll") {
+        if (n == "shadow_scan_blocks") {
+            if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_blocks out of range");
+            idx->geom_h.blocks = (int)value;
+        } else if (n == "shadow_scan_threads") {
+            if (value != 64 && value != 128 && value != 256 && value != 512)
+                return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_threads must be 64/128/256/512");
+            idx->geom_h.threads = (int)value;
+        } else {
+            if (value < 1 || value > 8) return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_unroll must be 1..8");
+            idx->geom_h.unroll = (int)value;
+        }
+        idx->geom_h_pinned = true;
+        return reprepare();
+    }
+    if (n == "mfma_sched") {
+#ifdef DAWN_EXPERIMENTS
+        const bool ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 5 || (value >= 41 && value <= 55);
+#else
+        const bool ok = value == 0 || value == 1 || value == 4 || value == 5;
+#endif
+        if (!ok) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 4 or 5");
+#ifdef DAWN_EXPERIMENTS
+        if (value == 2 && !idx->bws.diag) {
+            DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.diag, 4096 * 8 * 8 * sizeof(unsigned long long)));
+            DAWN_HIP_TRY(hipMemset(idx->bws.diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));
+        }
+#endif
+        idx->bws.sched = (int)value;
+        return reprepare();
+    }
+    if (n == "mfma_target") {
+        if (value < 64 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_target must be 64..4096");
+        idx->bws.target = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "scan_threads") {
+        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return fail(DAWN_ERR_INVALID_ARG, "scan_threads must be 64/128/256/512/1024");
+        idx->geom.threads = (int)value;
+        return DAWN_OK;
+    }
+    return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
+}
+
+}  // namespace dawn
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bulk file I/O: parallel pread / pwrite of large extents (the page cache copies at a few GB/s per thread)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+bool rw_all(int fd, char* buf, size_t bytes, off_t off, bool write) {
+    while (bytes) {
+        const ssize_t r = write ? ::pwrite(fd, buf, bytes, off) : ::pread(fd, buf, bytes, off);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;  // error, or a file shorter than its header promised
+        buf += r;
+        off += r;
+        bytes -= (size_t)r;
+    }
+    return true;
+}
+
+bool parallel_rw(int fd, void* buf, size_t bytes, off_t off, bool write) {
+    unsigned T = std::thread::hardware_concurrency();
+    T = std::max(1u, std::min(T ? T : 1u, 8u));
+    if (bytes < ((size_t)8 << 20)) T = 1;
+    if (T == 1) return rw_all(fd, (char*)buf, bytes, off, write);
+    const size_t per = ((bytes + T - 1) / T + 4095) / 4096 * 4096;
+    std::vector<std::thread> th;
+    std::vector<char> ok(T, 1);
+    for (unsigned t = 0; t < T; ++t) {
+        const size_t b0 = std::min(bytes, (size_t)t * per), b1 = std::min(bytes, b0 + per);
+        if (b0 == b1) break;
+        th.emplace_back([=, &ok]() { ok[t] = rw_all(fd, (char*)buf + b0, b1 - b0, off + (off_t)b0, write) ? 1 : 0; });
+    }
+    for (auto& x : th) x.join();
+    for (char c : ok)
+        if (!c) return false;
+    return true;
+}
+
+struct PinnedPair {
+    void* buf[2] = {nullptr, nullptr};
+    int init(size_t bytes) {
+        for (auto& b : buf)
+            if (hipHostMalloc(&b, bytes, hipHostMallocDefault) != hipSuccess) {
+                b = nullptr;
+                return fail(DAWN_ERR_OOM, "hipHostMalloc(%zu) for the bulk staging buffers failed", bytes);
+            }
+        return DAWN_OK;
+    }
+    ~PinnedPair() {
+        for (void* b : buf)
+            if (b) (void)hipHostFree(b);
+    }
+};
+
+// n_rows records of `kind` at rows_off of fd (+ their labels at ids_off, or first_label + i) -> pending rows of idx,
+// through two pinned buffers: the parallel read of chunk c+1 overlaps the DMA (and the GPU-side unpacking /
+// validation) of chunk c.  The caller commits or aborts.
+int ingest_file_rows(dawn_index* idx, int fd, dawn::RowSrc kind, size_t n_rows, off_t rows_off, off_t ids_off,
+                     uint64_t first_label, const char* path) {
+    const size_t rec = kind == dawn::RowSrc::HostPageEntries ? kPageEntryBytes : dawn::EM * sizeof(float);
+    const size_t ch = std::min(kBulkChunkRows, std::max<size_t>(n_rows, 1));
+    const size_t rows_bytes = (ch * rec + 255) / 256 * 256;
+    PinnedPair pp;
+    DAWN_TRY(pp.init(rows_bytes + (ids_off >= 0 ? ch * sizeof(uint64_t) : 0)));
+    auto run = [&]() -> int {
+        size_t c = 0;
+        for (size_t o = 0; o < n_rows; o += ch, ++c) {
+            const int slot = (int)(c & 1);
+            const size_t m = std::min(ch, n_rows - o);
+            DAWN_TRY(dawn::index_append_wait(idx, slot));  // the copies out of this buffer two chunks ago
+            char* hb = reinterpret_cast<char*>(pp.buf[slot]);
+            if (!parallel_rw(fd, hb, m * rec, rows_off + (off_t)(o * rec), false))
+                return fail(DAWN_ERR_IO, "%s: truncated row data", path);
+            uint64_t* hid = nullptr;
+            if (ids_off >= 0) {
+                hid = reinterpret_cast<uint64_t*>(hb + rows_bytes);
+                if (!rw_all(fd, (char*)hid, m * 8, ids_off + (off_t)(o * 8), false))
+                    return fail(DAWN_ERR_IO, "%s: truncated id table", path);
+            }
+            DAWN_TRY(dawn::index_append_async(idx, kind, hb, hid, first_label + o, m, slot));
+        }
+        return DAWN_OK;
+    };
+    const int rc = run();
+    // the pinned buffers go away with this frame: every copy out of them must have finished, error or not
+    const std::string msg = dawn::last_error();
+    (void)dawn::index_append_wait(idx, 0);
+    (void)dawn::index_append_wait(idx, 1);
+    if (rc != DAWN_OK) dawn::last_error() = msg;
+    return rc;
+}
+
+int root_device(const dawn_index* idx) { return idx->shards ? dawn::sharded_root_device(idx) : idx->device; }
+int index_dtype(const dawn_index* idx) { return idx->shards ? dawn::sharded_dtype(idx) : idx->dtype; }
 
 }  // namespace
 
@@ -347,141 +806,46 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
     if (dims != DAWN_EM_LEN) return fail(DAWN_ERR_UNSUPPORTED, "dims must be %d (EM_LEN)", DAWN_EM_LEN);
     if (dtype != DAWN_DTYPE_F32 && dtype != DAWN_DTYPE_BF16)
         return fail(DAWN_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
-    DAWN_TRY(dawn::require_device(device));
-    DAWN_HIP_TRY(hipSetDevice(device));
-    auto* idx = new dawn_index();
-    idx->device = device;
-    idx->dtype = dtype;
-    if (const char* e = getenv("DAWN_I8_SHADOW")) idx->use_i8 = atoi(e) != 0;  // default of the "i8_shadow" option
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-        idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
-    if (prop.multiProcessorCount > 0) {
-        idx->geom_h.blocks = prop.multiProcessorCount;
-        idx->geom_h_small.blocks = prop.multiProcessorCount;
-        idx->geom_i8.blocks = prop.multiProcessorCount;
-    }
-    if (prop.multiProcessorCount > 0) idx->mfma_blocks = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete idx;
-        return fail(DAWN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-    }
-    const size_t hb = kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8 + DAWN_MAX_K * 4 + 8);
-    if (hipHostMalloc(&idx->h_pinned, hb, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void**)&idx->d_q, kMaxBatch * dawn::EM * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&idx->d_labels, kMaxBatch * DAWN_MAX_K * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void**)&idx->d_dist, kMaxBatch * DAWN_MAX_K * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&idx->d_found, kMaxBatch * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&idx->d_bad, sizeof(uint32_t)) != hipSuccess) {
-        dawn_index_destroy(idx);
-        return fail(DAWN_ERR_OOM, "allocating index staging buffers failed");
-    }
-    idx->h_pinned_bytes = hb;
-    *out = idx;
-    return DAWN_OK;
+    return dawn::guarded([&] { return dawn::index_create_single(dtype, device, out); });
 }
 
 void dawn_index_destroy(dawn_index* idx) {
     if (!idx) return;
-    (void)hipSetDevice(idx->device);
-    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    for (auto& ev : idx->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p, idx->d_flags, idx->bws.qh, idx->bws.tau,
-                    idx->bws.cnt, idx->bws.cand, idx->d_q, idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-    if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
-    if (idx->stream) (void)hipStreamDestroy(idx->stream);
-    delete idx;
+    if (idx->shards) return dawn::sharded_destroy(idx);
+    dawn::index_destroy_single(idx);
 }
 
 int dawn_index_reserve(dawn_index* idx, size_t capacity) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    DAWN_TRY(set_device(idx));
-    if (capacity > idx->cap_phys) DAWN_TRY(grow_phys(idx, capacity));
-    if (capacity > idx->cap_reported) idx->cap_reported = capacity;
-    return DAWN_OK;
+    return dawn::guarded([&] { return idx->shards ? dawn::sharded_reserve(idx, capacity) : dawn::index_reserve_single(idx, capacity); });
 }
 
-size_t dawn_index_size(const dawn_index* idx) { return idx ? idx->size : 0; }
-size_t dawn_index_capacity(const dawn_index* idx) { return idx ? idx->cap_reported : 0; }
-
-// bf16 index: f32 rows pass through a device staging buffer (validated there, then rounded into the index)
-static int ensure_stage(dawn_index* idx, size_t rows) {
-    if (rows <= idx->stage_rows) return DAWN_OK;
-    if (idx->d_stage) (void)hipFree(idx->d_stage);
-    idx->d_stage = nullptr;
-    idx->stage_rows = 0;
-    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stage, rows * dawn::EM * sizeof(float)));
-    idx->stage_rows = rows;
-    return DAWN_OK;
+size_t dawn_index_size(const dawn_index* idx) { return !idx ? 0 : idx->shards ? dawn::sharded_size(idx) : idx->size; }
+size_t dawn_index_capacity(const dawn_index* idx) {
+    return !idx ? 0 : idx->shards ? dawn::sharded_capacity(idx) : idx->cap_reported;
 }
-constexpr size_t kStageChunk = 1u << 18;  // 256 Ki rows = 384 MiB of f32 staging at most
 
 int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const float* v) {
     if (!idx || (!ids && n) || (!v && n)) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (n == 0) return DAWN_OK;
-    DAWN_TRY(set_device(idx));
-    DAWN_TRY(ensure_room(idx, n));
-    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
-    const size_t rb = idx->row_bytes();
-    // rows land past `size` (invisible to searches) and become live only after validation
-    DAWN_HIP_TRY(hipMemsetAsync(idx->d_bad, 0, sizeof(uint32_t), idx->stream));
-    if (!bf16) {
-        float* dst = reinterpret_cast<float*>(idx->d_x + idx->size * rb);
-        DAWN_HIP_TRY(hipMemcpyAsync(dst, v, n * rb, hipMemcpyHostToDevice, idx->stream));
-        dawn::launch_validate_rows(dst, (uint32_t)n, idx->d_bad, idx->stream);
-    } else {
-        DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk)));
-        for (size_t o = 0; o < n; o += kStageChunk) {
-            const size_t m = std::min(kStageChunk, n - o);
-            DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, v + o * dawn::EM, m * dawn::EM * sizeof(float),
-                                        hipMemcpyHostToDevice, idx->stream));
-            dawn::launch_validate_rows(idx->d_stage, (uint32_t)m, idx->d_bad, idx->stream);  // gate on the f32 input
-            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size + o, m, idx->stream);
-            if (o + kStageChunk < n) DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));  // staging buffer reuse
+    return dawn::guarded([&] {
+        // (the caller's buffers are pageable: the runtime stages them; every call ends synchronised in commit)
+        for (size_t o = 0; o < n; o += dawn::kStageChunk) {
+            const size_t m = std::min(dawn::kStageChunk, n - o);
+            int rc = dawn::index_append_async(idx, dawn::RowSrc::HostRows, v + o * dawn::EM, ids + o, 0, m, -1);
+            if (rc != DAWN_OK) {
+                dawn::index_append_abort(idx);
+                return rc;
+            }
         }
-    }
-    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, ids, n * sizeof(uint64_t), hipMemcpyHostToDevice,
-                                idx->stream));
-    uint32_t bad = 0;
-    DAWN_HIP_TRY(hipMemcpyAsync(&bad, idx->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
-    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
-    if (bad) {
-        // (a bf16 index keeps the rejected rows' fragments: rows >= size are masked by position in every kernel)
-        if (!bf16) (void)hipMemsetAsync(idx->d_x + idx->size * rb, 0, n * rb, idx->stream);
-        (void)hipStreamSynchronize(idx->stream);
-        return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized (%u of %zu rows)", bad, n);
-    }
-    idx->size += n;
-    return DAWN_OK;
+        return dawn::index_append_commit(idx);
+    });
 }
 
 int dawn_index_add(dawn_index* idx, uint64_t id, const float* v) {
     if (!idx || !v) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (!dawn::host_is_normalized(v)) return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized");
-    DAWN_TRY(set_device(idx));
-    DAWN_TRY(ensure_room(idx, 1));
-    float* hp = (float*)idx->h_pinned;
-    std::memcpy(hp, v, dawn::EM * sizeof(float));
-    uint64_t* hid = (uint64_t*)(hp + dawn::EM);
-    *hid = id;
-    const size_t rb = idx->row_bytes();
-    if (idx->dtype == DAWN_DTYPE_BF16) {
-        DAWN_TRY(ensure_stage(idx, 1));
-        DAWN_HIP_TRY(hipMemcpyAsync(idx->d_stage, hp, dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-        dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size, 1, idx->stream);
-    } else {
-        DAWN_HIP_TRY(hipMemcpyAsync(idx->d_x + idx->size * rb, hp, rb, hipMemcpyHostToDevice, idx->stream));
-    }
-    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_ids + idx->size, hid, sizeof(uint64_t), hipMemcpyHostToDevice, idx->stream));
-    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
-    idx->size += 1;
-    return DAWN_OK;
+    return dawn_index_add_batch(idx, 1, &id, v);
 }
 
 int dawn_index_search_device(dawn_index* idx, const float* d_queries, size_t B, size_t count, uint64_t* d_labels,
@@ -489,9 +853,12 @@ int dawn_index_search_device(dawn_index* idx, const float* d_queries, size_t B, 
     if (!idx || !d_queries || !d_labels || !d_distances || !d_found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (count == 0 || count > DAWN_MAX_K) return fail(DAWN_ERR_UNSUPPORTED, "count must be 1..%d", DAWN_MAX_K);
     if (B == 0) return DAWN_OK;
+    if (idx->shards)
+        return dawn::guarded(
+            [&] { return dawn::sharded_search_device(idx, d_queries, B, count, d_labels, d_distances, d_found, (hipStream_t)stream); });
     DAWN_TRY(set_device(idx));
     idx->n_searches += B;
-    return search_on_device(idx, d_queries, B, count, d_labels, d_distances, d_found, (hipStream_t)stream);
+    return dawn::index_search_on_device(idx, d_queries, B, count, d_labels, d_distances, d_found, (hipStream_t)stream);
 }
 
 int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, size_t count, uint64_t* labels,
@@ -501,7 +868,10 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
     for (size_t b = 0; b < B; ++b)  // search_provider.rs:206-208
         if (!dawn::host_is_normalized(queries + b * dawn::EM))
             return fail(DAWN_ERR_NOT_NORMALIZED, "Search vector is not normalized");
+    if (idx->shards)
+        return dawn::guarded([&] { return dawn::sharded_search_batch(idx, queries, B, count, labels, distances, found); });
     DAWN_TRY(set_device(idx));
+    using dawn::kMaxBatch;
     for (size_t b0 = 0; b0 < B; b0 += kMaxBatch) {
         const size_t nb = std::min(kMaxBatch, B - b0);
         char* hp = (char*)idx->h_pinned;
@@ -509,29 +879,23 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
         uint64_t* hl = (uint64_t*)(hp + kMaxBatch * dawn::EM * 4);
         float* hd = (float*)(hp + kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8));
         uint32_t* hf = (uint32_t*)(hp + kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 8 + DAWN_MAX_K * 4));
-        uint32_t* hflag = hf + kMaxBatch;
         std::memcpy(hq, queries + b0 * dawn::EM, nb * dawn::EM * sizeof(float));
         DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, hq, nb * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
         idx->n_searches += nb;
-        if (nb <= kZeroCopyBatch) {
+        if (nb <= dawn::kZeroCopyBatch) {
             // few queries: the tail kernels store the results straight into the pinned host block (coherent,
             // device-visible): no copy commands between the last kernel and the host's wake-up
-            DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, hl, hd, hf, idx->stream));
+            DAWN_TRY(dawn::index_search_on_device(idx, idx->d_q, nb, count, hl, hd, hf, idx->stream));
         } else {
-            DAWN_TRY(search_on_device(idx, idx->d_q, nb, count, idx->d_labels, idx->d_dist, idx->d_found, idx->stream));
+            DAWN_TRY(dawn::index_search_on_device(idx, idx->d_q, nb, count, idx->d_labels, idx->d_dist, idx->d_found, idx->stream));
             DAWN_HIP_TRY(hipMemcpyAsync(hl, idx->d_labels, nb * count * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
             DAWN_HIP_TRY(hipMemcpyAsync(hd, idx->d_dist, nb * count * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
             DAWN_HIP_TRY(hipMemcpyAsync(hf, idx->d_found, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
         }
-        DAWN_HIP_TRY(hipMemcpyAsync(hflag, idx->d_flags, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
         DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
         std::memcpy(labels + b0 * count, hl, nb * count * sizeof(uint64_t));
         std::memcpy(distances + b0 * count, hd, nb * count * sizeof(float));
-        for (size_t b = 0; b < nb; ++b) {
-            found[b0 + b] = hf[b];
-            if (hflag[b] == dawn::FLAG_FALLBACK) idx->n_fallbacks++;
-            else if (hflag[b] == dawn::FLAG_SECOND) idx->n_second++;
-        }
+        for (size_t b = 0; b < nb; ++b) found[b0 + b] = hf[b];
     }
     return DAWN_OK;
 }
@@ -559,7 +923,7 @@ int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const u
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
     if (B == 0) return DAWN_OK;
-    dawn::launch_shard_merge(G, B, count, d_in_labels, d_in_distances, d_in_found, B * count, B * count, B, d_labels,
+    dawn::launch_shard_merge(G, B, count, d_in_labels, d_in_distances, d_in_found, B * count, B * count, B, nullptr, d_labels,
                              d_distances, d_found, (hipStream_t)stream);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
@@ -577,7 +941,7 @@ int dawn_topk_merge_packed_device(int device, size_t G, size_t B, size_t count, 
     const size_t stride = dawn_result_blob_bytes(B, count);
     const char* base = (const char*)d_blobs;
     dawn::launch_shard_merge(G, B, count, (const uint64_t*)base, (const float*)(base + B * count * 8),
-                             (const uint32_t*)(base + B * count * 12), stride / 8, stride / 4, stride / 4, d_labels,
+                             (const uint32_t*)(base + B * count * 12), stride / 8, stride / 4, stride / 4, nullptr, d_labels,
                              d_distances, d_found, (hipStream_t)stream);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
@@ -586,231 +950,191 @@ int dawn_topk_merge_packed_device(int device, size_t G, size_t B, size_t count, 
 int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (n == 0) return DAWN_OK;
-    DAWN_TRY(set_device(idx));
-    DAWN_TRY(ensure_room(idx, n));
-    const bool bf16 = idx->dtype == DAWN_DTYPE_BF16;
-    const size_t rb = idx->row_bytes();
-    const size_t chunk = bf16 ? kStageChunk : (size_t)1u << 22;  // rows per generator launch
-    if (bf16) DAWN_TRY(ensure_stage(idx, std::min(n, chunk)));
-    float* d_len = nullptr;
-    DAWN_HIP_TRY(hipMalloc((void**)&d_len, std::min(n, chunk) * sizeof(float)));
-    for (size_t o = 0; o < n; o += chunk) {
-        const size_t m = std::min(chunk, n - o);
-        char* dst = idx->d_x + (idx->size + o) * rb;
-        if (bf16) {  // f32 unit rows of the spec, then rounded: the bf16 index holds round_bf16(spec row)
-            dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, idx->d_stage, d_len, idx->stream);
-            dawn::launch_rows_f32_to_bf16(idx->d_stage, idx->d_x, idx->size + o, m, idx->stream);
-        } else {
-            dawn::launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->stream);
+    return dawn::guarded([&] {
+        if (idx->shards) return dawn::sharded_fill_synthetic(idx, seed, first_row, n, first_id);
+        int rc = dawn::index_fill_async(idx, seed, first_row, n, first_id, false, 0);
+        if (rc != DAWN_OK) {
+            dawn::index_append_abort(idx);
+            return rc;
         }
-        dawn::launch_iota_u64(idx->d_ids + idx->size + o, first_id + o, (uint32_t)m, idx->stream);
-    }
-    hipError_t e = hipStreamSynchronize(idx->stream);
-    (void)hipFree(d_len);
-    if (e != hipSuccess) return fail(DAWN_ERR_HIP, "fill_synthetic: %s", hipGetErrorString(e));
-    idx->size += n;
-    return DAWN_OK;
+        return dawn::index_append_finish(idx, true);  // (generated rows are unit rows by construction: no gate)
+    });
 }
 
-// Rows come back as f32 whatever the storage type (bf16 rows widened exactly).
 int dawn_index_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    if (first + n > idx->size) return fail(DAWN_ERR_INVALID_ARG, "rows [%zu, %zu) out of range (size %zu)", first, first + n, idx->size);
-    if (n == 0) return DAWN_OK;
-    DAWN_TRY(set_device(idx));
-    const size_t rb = idx->row_bytes();
-    if (out_rows && idx->dtype == DAWN_DTYPE_BF16) {
-        DAWN_TRY(ensure_stage(idx, std::min(n, kStageChunk)));
-        for (size_t o = 0; o < n; o += kStageChunk) {
-            const size_t m = std::min(kStageChunk, n - o);
-            dawn::launch_rows_bf16_to_f32(idx->d_x, first + o, idx->d_stage, m, idx->stream);
-            DAWN_HIP_TRY(hipMemcpyAsync(out_rows + o * dawn::EM, idx->d_stage, m * dawn::EM * sizeof(float),
-                                        hipMemcpyDeviceToHost, idx->stream));
-            DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
-        }
-    } else if (out_rows) {
-        DAWN_HIP_TRY(hipMemcpy(out_rows, idx->d_x + first * rb, n * rb, hipMemcpyDeviceToHost));
-    }
-    if (out_ids) DAWN_HIP_TRY(hipMemcpy(out_ids, idx->d_ids + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    return DAWN_OK;
+    return dawn::guarded([&] {
+        return idx->shards ? dawn::sharded_get_rows(idx, first, n, out_rows, out_ids)
+                           : dawn::index_get_rows_single(idx, first, n, out_rows, out_ids);
+    });
 }
 
 // File layout: "DAWNIDX1" | u32 dims | u32 dtype | u64 n | ids[n] u64 | rows[n][384] f32 (little endian).  Rows are
-// written as f32 for both storage types (a bf16 index widens exactly and re-rounds to the same bits on load).
+// written as f32 for both storage types (a bf16 index widens exactly and re-rounds to the same bits on load); a sharded
+// index writes its rows in insertion order: the file does not depend on how many devices hold the index.
+// Written to `path`.tmp, flushed to disk and renamed over `path`: an interrupted save (the reference saves on shutdown,
+// src/bin/dawnsearch.rs:151) leaves the previous file, never a truncated one.
 int dawn_index_save(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    DAWN_TRY(set_device(idx));
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return fail(DAWN_ERR_IO, "cannot open %s for writing", path);
-    const uint32_t dims = DAWN_EM_LEN, dtype = (uint32_t)idx->dtype;
-    const uint64_t n = idx->size;
-    bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(&dims, 4, 1, f) == 1 &&
-              std::fwrite(&dtype, 4, 1, f) == 1 && std::fwrite(&n, 8, 1, f) == 1;
-    const size_t chunk = 1u << 16;
-    std::vector<char> buf(chunk * dawn::EM * sizeof(float));
-    for (size_t o = 0; ok && o < n; o += chunk) {
-        const size_t m = std::min<size_t>(chunk, n - o);
-        if (hipMemcpy(buf.data(), idx->d_ids + o, m * 8, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-        else ok = std::fwrite(buf.data(), 8, m, f) == m;
-    }
-    for (size_t o = 0; ok && o < n; o += chunk) {
-        const size_t m = std::min<size_t>(chunk, n - o);
-        if (dawn_index_get_rows(idx, o, m, reinterpret_cast<float*>(buf.data()), nullptr) != DAWN_OK) ok = false;
-        else ok = std::fwrite(buf.data(), dawn::EM * 4, m, f) == m;
-    }
-    if (std::fclose(f) != 0) ok = false;
-    if (!ok) return fail(DAWN_ERR_IO, "writing %s failed", path);
-    return DAWN_OK;
+    return dawn::guarded([&] {
+        DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        const std::string tmp = std::string(path) + ".tmp";
+        const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s for writing", tmp.c_str());
+        const uint64_t n = dawn_index_size(idx);
+        char header[24];
+        const uint32_t dims = DAWN_EM_LEN, dtype = (uint32_t)index_dtype(idx);
+        std::memcpy(header, kMagic, 8);
+        std::memcpy(header + 8, &dims, 4);
+        std::memcpy(header + 12, &dtype, 4);
+        std::memcpy(header + 16, &n, 8);
+        bool ok = rw_all(fd, header, 24, 0, true);
+        const size_t ch = std::min<size_t>(kBulkChunkRows, std::max<uint64_t>(n, 1));
+        PinnedPair pp;
+        int rc = ok ? pp.init(ch * dawn::EM * sizeof(float)) : DAWN_OK;
+        const off_t rows_off = 24 + (off_t)(n * 8);
+        for (size_t o = 0; ok && rc == DAWN_OK && o < n; o += ch) {
+            const size_t m = std::min<size_t>(ch, n - o);
+            // D2H into pinned memory runs at the link rate; the parallel pwrite behind it is the slower half
+            rc = dawn_index_get_rows(idx, o, m, reinterpret_cast<float*>(pp.buf[0]), reinterpret_cast<uint64_t*>(pp.buf[1]));
+            if (rc != DAWN_OK) break;
+            ok = rw_all(fd, (char*)pp.buf[1], m * 8, 24 + (off_t)(o * 8), true) &&
+                 parallel_rw(fd, pp.buf[0], m * dawn::EM * sizeof(float), rows_off + (off_t)(o * dawn::EM * sizeof(float)), true);
+        }
+        if (ok && rc == DAWN_OK && ::fsync(fd) != 0) ok = false;
+        if (::close(fd) != 0) ok = false;
+        if (rc == DAWN_OK && ok && ::rename(tmp.c_str(), path) != 0) ok = false;
+        if (rc != DAWN_OK || !ok) {
+            ::unlink(tmp.c_str());
+            return rc != DAWN_OK ? rc : fail(DAWN_ERR_IO, "writing %s failed", path);
+        }
+        return DAWN_OK;
+    });
 }
 
+// index.load(path): replaces the contents.  All or nothing: the header is checked against the file's size before the
+// index is touched, and any later failure (I/O error, a row that fails the is_normalized gate) leaves the index EMPTY,
+// never partially filled — the reference's start-up flow then rebuilds from the database
+// (`if !load(path).is_ok() { fill_index_from_db(); save() }`, search_provider.rs:115-117) onto a clean index.
 int dawn_index_load(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    DAWN_TRY(set_device(idx));
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return fail(DAWN_ERR_IO, "cannot open %s", path);
-    char magic[8];
-    uint32_t dims = 0, dtype = 0;
-    uint64_t n = 0;
-    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kMagic, 8) != 0 || std::fread(&dims, 4, 1, f) != 1 ||
-        std::fread(&dtype, 4, 1, f) != 1 || std::fread(&n, 8, 1, f) != 1 || dims != DAWN_EM_LEN ||
-        (dtype != DAWN_DTYPE_F32 && dtype != DAWN_DTYPE_BF16)) {
-        std::fclose(f);
-        return fail(DAWN_ERR_IO, "%s is not a dawn index file", path);
-    }
-    std::vector<uint64_t> ids(n);
-    if (n && std::fread(ids.data(), 8, n, f) != n) {
-        std::fclose(f);
-        return fail(DAWN_ERR_IO, "%s: truncated id table", path);
-    }
-    idx->size = 0;  // load replaces the contents (usearch load semantics)
-    idx->shadow_rows = 0;
-    idx->i8_rows = 0;
-    const size_t chunk = 1u << 16;
-    std::vector<float> buf(chunk * dawn::EM);
-    for (size_t o = 0; o < n; o += chunk) {
-        const size_t m = std::min<size_t>(chunk, n - o);
-        if (std::fread(buf.data(), dawn::EM * 4, m, f) != m) {
-            std::fclose(f);
-            return fail(DAWN_ERR_IO, "%s: truncated row data", path);
+    return dawn::guarded([&] {
+        DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s", path);
+        struct stat stt;
+        char header[24];
+        uint32_t dims = 0, dtype = 0;
+        uint64_t n = 0;
+        int rc = DAWN_OK;
+        if (::fstat(fd, &stt) != 0 || !rw_all(fd, header, 24, 0, false) || std::memcmp(header, kMagic, 8) != 0) {
+            rc = fail(DAWN_ERR_IO, "%s is not a dawn index file", path);
+        } else {
+            std::memcpy(&dims, header + 8, 4);
+            std::memcpy(&dtype, header + 12, 4);
+            std::memcpy(&n, header + 16, 8);
+            if (dims != DAWN_EM_LEN || (dtype != DAWN_DTYPE_F32 && dtype != DAWN_DTYPE_BF16))
+                rc = fail(DAWN_ERR_IO, "%s is not a dawn index file", path);
+            else if (n > ((uint64_t)stt.st_size - 24) / (8 + dawn::EM * sizeof(float)))
+                rc = fail(DAWN_ERR_IO, "%s: truncated (header promises %llu rows, the file holds %llu bytes)", path,
+                          (unsigned long long)n, (unsigned long long)stt.st_size);
         }
-        int rc = dawn_index_add_batch(idx, m, ids.data() + o, buf.data());
-        if (rc != DAWN_OK) {
-            std::fclose(f);
-            return rc;
+        if (rc == DAWN_OK) rc = dawn::index_clear(idx);  // load replaces the contents (usearch load semantics)
+        if (rc == DAWN_OK && n) {
+            rc = dawn_index_reserve(idx, n);
+            if (rc == DAWN_OK)
+                rc = ingest_file_rows(idx, fd, dawn::RowSrc::HostRows, n, 24 + (off_t)(n * 8), 24, 0, path);
+            if (rc == DAWN_OK) rc = dawn::index_append_commit(idx);
+            else dawn::index_append_abort(idx);
+            if (rc != DAWN_OK) {
+                const std::string msg = dawn::last_error();
+                (void)dawn::index_clear(idx);
+                dawn::last_error() = msg;
+            }
         }
-    }
-    std::fclose(f);
-    return DAWN_OK;
+        ::close(fd);
+        return rc;
+    });
 }
 
 // src/index/warc.rs:35-43 PageEntry (repr(C)): u64 url_pos, u64 title_pos, f32 vector[384], u64 url_len,
-// u64 title_len = 1568 bytes; read as examples_old/document_embeddings.rs:60-71 does.
+// u64 title_len = 1568 bytes; read as examples_old/document_embeddings.rs:60-71 does (entries = len / 1568).  Appends;
+// on any failure nothing is added.  The records go to the GPU as they are on disk (pinned staging, DMA overlapped with
+// the next read) and are cut down to their vectors there.
 int dawn_index_load_page_entries(dawn_index* idx, const char* emb_path, uint64_t first_id) {
     if (!idx || !emb_path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    FILE* f = std::fopen(emb_path, "rb");
-    if (!f) return fail(DAWN_ERR_IO, "cannot open %s", emb_path);
-    constexpr size_t REC = 1568, OFF = 16;
-    const size_t chunk = 1u << 14;
-    std::vector<unsigned char> raw(chunk * REC);
-    std::vector<float> rows(chunk * dawn::EM);
-    std::vector<uint64_t> ids(chunk);
-    uint64_t next = first_id;
-    for (;;) {
-        const size_t m = std::fread(raw.data(), REC, chunk, f);  // entries() = len / size_of::<PageEntry>()
-        if (m == 0) break;
-        for (size_t i = 0; i < m; ++i) {
-            std::memcpy(rows.data() + i * dawn::EM, raw.data() + i * REC + OFF, dawn::EM * 4);
-            ids[i] = next++;
+    return dawn::guarded([&] {
+        DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        const int fd = ::open(emb_path, O_RDONLY);
+        if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s", emb_path);
+        struct stat stt;
+        int rc = DAWN_OK;
+        if (::fstat(fd, &stt) != 0) rc = fail(DAWN_ERR_IO, "cannot stat %s", emb_path);
+        const size_t n = rc == DAWN_OK ? (size_t)stt.st_size / kPageEntryBytes : 0;
+        if (rc == DAWN_OK && n) {
+            rc = dawn_index_reserve(idx, dawn_index_size(idx) + n);
+            if (rc == DAWN_OK) rc = ingest_file_rows(idx, fd, dawn::RowSrc::HostPageEntries, n, 0, -1, first_id, emb_path);
+            if (rc == DAWN_OK) rc = dawn::index_append_commit(idx);
+            else dawn::index_append_abort(idx);
         }
-        int rc = dawn_index_add_batch(idx, m, ids.data(), rows.data());
-        if (rc != DAWN_OK) {
-            std::fclose(f);
-            return rc;
-        }
-    }
-    std::fclose(f);
-    return DAWN_OK;
+        ::close(fd);
+        return rc;
+    });
 }
 
 int dawn_index_profile_enable(dawn_index* idx, int enable) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    idx->profiling = enable != 0;
-    idx->events_used = 0;
-    return DAWN_OK;
+    return dawn::guarded(
+        [&] { return idx->shards ? dawn::sharded_profile_enable(idx, enable) : dawn::index_profile_enable_single(idx, enable); });
 }
 
 int dawn_index_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms) {
     if (!idx || !launches || !total_ms) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    DAWN_TRY(set_device(idx));
-    DAWN_HIP_TRY(hipDeviceSynchronize());
-    double sum = 0.0;
-    for (size_t i = 0; i < idx->events_used; ++i) {
-        float ms = 0.f;
-        DAWN_HIP_TRY(hipEventElapsedTime(&ms, idx->events[i].first, idx->events[i].second));
-        sum += ms;
-    }
-    *launches = idx->events_used;
-    *total_ms = sum;
-    idx->events_used = 0;
-    return DAWN_OK;
+    return idx->shards ? dawn::sharded_profile_read(idx, launches, total_ms)
+                       : dawn::index_profile_read_single(idx, launches, total_ms);
 }
 
 int dawn_index_stats(dawn_index* idx, uint64_t* searches, uint64_t* fallbacks) {
-    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    if (searches) *searches = idx->n_searches;
-    if (fallbacks) *fallbacks = idx->n_fallbacks;
-    return DAWN_OK;
+    return dawn_index_stats_ext(idx, searches, nullptr, fallbacks);
 }
 
 // ... plus the queries whose first certificate failed and whose 1024-deep second one held (no exact pass needed)
 int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_chances, uint64_t* fallbacks) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    if (searches) *searches = idx->n_searches;
-    if (second_chances) *second_chances = idx->n_second;
-    if (fallbacks) *fallbacks = idx->n_fallbacks;
-    return DAWN_OK;
+    return idx->shards ? dawn::sharded_stats(idx, searches, second_chances, fallbacks)
+                       : dawn::index_stats_single(idx, searches, second_chances, fallbacks);
 }
 
 int dawn_index_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    const uint64_t rows = idx->d_x ? (uint64_t)padded_rows(idx->cap_phys) * idx->row_bytes() : 0;
-    uint64_t shadows = 0;
-    if (idx->d_shadow) shadows += (uint64_t)padded_rows(idx->shadow_cap) * dawn::EM * 2;
-    if (idx->d_i8) {
-        const uint64_t prow = padded_rows(idx->i8_cap) + 128;
-        shadows += prow * dawn::EM + (prow / 32 + 1) * 8;
-    }
-    uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
-    if (idx->d_cand_s)
-        other += (uint64_t)idx->ws_B * std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks}) *
-                     dawn::LIST * 8 + 2 * idx->ws_B * 4;
-    if (idx->bws.cand)
-        other += (uint64_t)dawn::BATCH_QT * (dawn::EM * 2 + 4 + dawn::BATCH_CAND_SEGS * 4 + (uint64_t)dawn::BATCH_CAP * 8);
-    if (idx->d_stage) other += (uint64_t)idx->stage_rows * dawn::EM * 4;
-    other += kMaxBatch * (dawn::EM * 4 + DAWN_MAX_K * 12 + 4) + 4;  // host-API staging
-    if (rows_bytes) *rows_bytes = rows;
-    if (shadow_bytes) *shadow_bytes = shadows;
-    if (other_bytes) *other_bytes = other;
-    return DAWN_OK;
+    return idx->shards ? dawn::sharded_memory(idx, rows_bytes, shadow_bytes, other_bytes)
+                       : dawn::index_memory_single(idx, rows_bytes, shadow_bytes, other_bytes);
 }
+
+int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
+    if (!idx || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    return dawn::guarded(
+        [&] { return idx->shards ? dawn::sharded_set_option(idx, name, value) : dawn::index_set_option_single(idx, name, value); });
+}
+
+// ---- test / timing hooks (single-device indexes only) ------------------------------------------------------------------
 
 int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t B, float* out, size_t* n_out) {
     if (!idx || !queries || !out || !n_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
     if (B == 0 || B > (size_t)dawn::BATCH_QT) return fail(DAWN_ERR_INVALID_ARG, "B must be 1..%d", dawn::BATCH_QT);
     DAWN_TRY(set_device(idx));
-    DAWN_TRY(ensure_workspace(idx, std::max<size_t>(B, idx->mfma_min_batch)));
     const size_t n = std::min<size_t>(idx->size, dawn::BATCH_CAP);
     *n_out = n;
     if (n == 0) return DAWN_OK;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    if (idx->i8_batched && i8_rows_ready(idx, idx->stream)) {  // (upper-bound scores: scan_i8.hip)
+    if (idx->i8_batched && i8_live(idx)) {  // (upper-bound scores: scan_i8.hip)
         dawn::launch_batched_dense_scores_i8(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws,
                                              idx->mfma_blocks, idx->stream);
     } else {
-        int frt = idx->dtype;
-        const void* frows = filter_rows(idx, &frt, idx->stream);
-        dawn::launch_batched_dense_scores(frows, frt, (uint32_t)idx->size, idx->d_q, (int)B, idx->bws, idx->mfma_blocks,
-                                          idx->stream);
+        const bool sh = f16_live(idx);
+        dawn::launch_batched_dense_scores(sh ? idx->d_shadow : idx->d_x, sh ? dawn::ROW_F16S : idx->dtype, (uint32_t)idx->size,
+                                          idx->d_q, (int)B, idx->bws, idx->mfma_blocks, idx->stream);
     }
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),
@@ -824,23 +1148,22 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
 int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* out_scores, uint32_t* out_rows,
                                   size_t cap_blocks, size_t* n_blocks) {
     if (!idx || !query || !out_scores || !out_rows || !n_blocks) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
     DAWN_TRY(set_device(idx));
-    DAWN_TRY(ensure_workspace(idx, 1));
     hipStream_t stream = idx->stream;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
-    int frt = idx->dtype;
-    const void* frows = nullptr;
     size_t blocks;
-    if (idx->shadow_small_batches && i8_rows_ready(idx, stream)) {
+    if (idx->shadow_small_batches && i8_live(idx)) {
         const dawn::ScanGeom& gh = idx->i8_geom();
         blocks = gh.blocks;
         dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
                                      stream, nullptr, nullptr);
-    } else if ((frows = filter_rows(idx, &frt, stream)), frt == dawn::ROW_BF16 || (frt == dawn::ROW_F16S && idx->shadow_small_batches)) {
+    } else if (idx->dtype == DAWN_DTYPE_BF16 || (idx->shadow_small_batches && f16_live(idx))) {
+        const bool own = idx->dtype == DAWN_DTYPE_BF16;
         const dawn::ScanGeom& gh = idx->shadow_geom();
         blocks = gh.blocks;
-        dawn::launch_scan_filter_f16s(frows, frt, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,
-                                      stream, nullptr, nullptr);
+        dawn::launch_scan_filter_f16s(own ? idx->d_x : idx->d_shadow, own ? dawn::ROW_BF16 : dawn::ROW_F16S, (uint32_t)idx->size,
+                                      idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh, stream, nullptr, nullptr);
     } else {
         blocks = idx->geom.blocks;
         dawn::launch_scan_filter(idx->d_x, idx->dtype, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p,
@@ -859,18 +1182,19 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
 // thresholds of the last batched search (run one first) and the current mfma_sched variant; results are discarded.
 int dawn_index_debug_time_full_pass(dawn_index* idx, size_t B, int iters, double* mean_ms) {
     if (!idx || !mean_ms || iters < 1) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
     if (B == 0 || B > (size_t)dawn::BATCH_QT || !idx->bws.cand) return fail(DAWN_ERR_INVALID_ARG, "run a batched search first");
     DAWN_TRY(set_device(idx));
     hipEvent_t e0, e1;
     DAWN_HIP_TRY(hipEventCreate(&e0));
     DAWN_HIP_TRY(hipEventCreate(&e1));
-    if (idx->i8_batched && i8_rows_ready(idx, idx->stream)) {
+    if (idx->i8_batched && i8_live(idx)) {
         dawn::launch_batched_full_pass_i8(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters,
                                           idx->stream, e0, e1);
     } else {
-        int frt = idx->dtype;
-        const void* frows = filter_rows(idx, &frt, idx->stream);
-        dawn::launch_batched_full_pass(frows, frt, (uint32_t)idx->size, (int)B, idx->bws, idx->mfma_blocks, iters, idx->stream, e0, e1);
+        const bool sh = f16_live(idx);
+        dawn::launch_batched_full_pass(sh ? idx->d_shadow : idx->d_x, sh ? dawn::ROW_F16S : idx->dtype, (uint32_t)idx->size, (int)B,
+                                       idx->bws, idx->mfma_blocks, iters, idx->stream, e0, e1);
     }
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     float ms = 0.f;
@@ -881,93 +1205,15 @@ int dawn_index_debug_time_full_pass(dawn_index* idx, size_t B, int iters, double
     return DAWN_OK;
 }
 
-// Diagnostic: per-wave phase cycle sums of the last batched full pass run with mfma_sched = 2: out [blocks][8][8].
+// Diagnostic (builds with -DDAWN_EXPERIMENTS): per-wave phase cycle sums of the last batched full pass run with
+// mfma_sched = 2: out [blocks][8][8].
 int dawn_index_debug_read_diag(dawn_index* idx, unsigned long long* out, size_t blocks) {
     if (!idx || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    if (!dawn::g_batched_diag || blocks > 4096) return fail(DAWN_ERR_INVALID_ARG, "no diagnostic buffer");
+    if (idx->shards || !idx->bws.diag || blocks > 4096) return fail(DAWN_ERR_INVALID_ARG, "no diagnostic buffer");
     DAWN_TRY(set_device(idx));
     DAWN_HIP_TRY(hipDeviceSynchronize());
-    DAWN_HIP_TRY(hipMemcpy(out, dawn::g_batched_diag, blocks * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DAWN_HIP_TRY(hipMemcpy(out, idx->bws.diag, blocks * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DAWN_OK;
-}
-
-int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
-    if (!idx || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    const std::string n(name);
-    if (n == "force_fallback") {
-        idx->force_fallback = value != 0;
-        return DAWN_OK;
-    }
-    if (n == "scan_blocks") {
-        if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "scan_blocks out of range");
-        idx->geom.blocks = (int)value;
-        idx->ws_B = 0;  // candidate buffers are sized by the grid
-        return DAWN_OK;
-    }
-    if (n == "mfma_min_batch") {
-        if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
-        idx->mfma_min_batch = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "mfma_blocks") {
-        if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
-        idx->mfma_blocks = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "scan_unroll") {
-        if (value < 1 || value > 4) return fail(DAWN_ERR_INVALID_ARG, "scan_unroll must be 1..4");
-        idx->geom.unroll = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "f16_shadow") {
-        idx->use_shadow = value != 0;
-        return DAWN_OK;
-    }
-    if (n == "i8_shadow") {
-        idx->use_i8 = value != 0;
-        if (value) idx->i8_failed = false;
-        return DAWN_OK;
-    }
-    if (n == "i8_batched") {
-        idx->i8_batched = value != 0;
-        return DAWN_OK;
-    }
-    if (n == "f16_shadow_b1") {
-        idx->shadow_small_batches = value != 0;
-        return DAWN_OK;
-    }
-    if (n == "shadow_scan_blocks" || n == "shadow_scan_threads" || n == "shadow_scan_unroll") {
-        idx->geom_h_pinned = true;
-        if (n == "shadow_scan_blocks") idx->geom_h.blocks = (int)value, idx->ws_B = 0;
-        else if (n == "shadow_scan_threads") {
-            if (value != 64 && value != 128 && value != 256 && value != 512)
-                return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_threads must be 64/128/256/512");
-            idx->geom_h.threads = (int)value;
-        } else idx->geom_h.unroll = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "mfma_sched") {
-        if (value < 0 || value == 3 || (value > 5 && value < 41) || value > 55)
-            return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 2, 4 or 5 (41..55: timing experiments)");
-        if (value == 2 && !dawn::g_batched_diag) {
-            DAWN_HIP_TRY(hipMalloc((void**)&dawn::g_batched_diag, 4096 * 8 * 8 * sizeof(unsigned long long)));
-            DAWN_HIP_TRY(hipMemset(dawn::g_batched_diag, 0, 4096 * 8 * 8 * sizeof(unsigned long long)));
-        }
-        dawn::g_batched_sched = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "mfma_target") {
-        if (value < 64 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_target must be 64..4096");
-        dawn::g_batched_target = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "scan_threads") {
-        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
-            return fail(DAWN_ERR_INVALID_ARG, "scan_threads must be 64/128/256/512/1024");
-        idx->geom.threads = (int)value;
-        return DAWN_OK;
-    }
-    return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
 }
 
 }  // extern "C"

@@ -1,0 +1,197 @@
+// index_internal.hpp — the index object behind the dawn_index_* C ABI and the pieces dawn_index.cpp (one device) and
+// dawn_sharded.cpp (one process, several devices) share.  Not part of the ABI.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <exception>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace dawn {
+struct ShardSet;  // dawn_sharded.cpp
+
+constexpr size_t kMaxBatch = 256;        // queries per internal pass of the host API
+constexpr size_t kMaxProfile = 4096;     // kept event pairs
+constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
+constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
+constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
+}  // namespace dawn
+
+struct dawn_index {
+    int device = 0;
+    size_t dims = DAWN_EM_LEN;
+    hipStream_t stream = nullptr;
+
+    int dtype = DAWN_DTYPE_F32;  // row storage: f32 (1536 B/row) or bf16 (768 B/row)
+    char* d_x = nullptr;         // [(cap_phys + ROW_PAD)][384] of dtype
+    // f32 index only: scaled-f16 shadow copy of the rows (f16(2^8 x), 768 B/row, tiles in MFMA-fragment order: ROW_F16S
+    // in kernels.hpp) read by the 16-bit matrix-core FILTER instead of the f32 rows.  Only kept when the int8 shadow is
+    // switched off or does not fit; results stay exact (the rescore reads the f32 rows).
+    char* d_shadow = nullptr;
+    size_t shadow_cap = 0;       // rows allocated
+    size_t shadow_rows = 0;      // rows converted so far (prefix)
+    int use_shadow = 1;          // option "f16_shadow"
+    int shadow_small_batches = 1;  // option "f16_shadow_b1": batches of 1..8 queries also filter on a shadow
+    // geometry of the shadow stream (MFMA from registers): one 2-wave block per CU, `unroll` picks the load schedule
+    // (launch_filter_f16s_qb: 3 = ring of 12 fragments = 12 KiB in flight per wave).  tools/scan_sweep_shadow.py,
+    // 80M rows: 7.02-7.07 TB/s; every schedule with 2-4 waves per CU lands within 1 % of it
+    dawn::ScanGeom geom_h{256, 128, 3};
+    // ... and below kShadowSmallRows rows (a few dozen sub-tiles per wave: start-up, tail and load balance count)
+    // one 8-wave block per CU: 1M rows 154 -> 130 us.  Setting any shadow_scan_* option pins geom_h for every size.
+    dawn::ScanGeom geom_h_small{256, 512, 3};
+    bool geom_h_pinned = false;
+    const dawn::ScanGeom& shadow_geom() const {
+        return (!geom_h_pinned && size < dawn::kShadowSmallRows) ? geom_h_small : geom_h;
+    }
+    // int8 shadow stream: 4 waves per CU, whole sub-tiles (12 KiB) in flight per wave (tools/scan_sweep_shadow.py, 80M
+    // rows: 7.01 TB/s against 6.97 with 2 waves; everything with >= 24 KiB in flight per CU lands within 2 %)
+    dawn::ScanGeom geom_i8{256, 256, 3};
+    // ... and 8 waves per CU below 16 M rows (12.5 M rows — one shard of 100 M on 8 GPUs —: 723 vs 731 us; 25 M: a tie)
+    const dawn::ScanGeom& i8_geom() const {
+        return geom_h_pinned ? geom_h : size < ((size_t)16 << 20) ? geom_h_small : geom_i8;
+    }
+    bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
+    // int8 shadow of the index rows (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows; f32 and bf16 indexes alike) read by
+    // every filter — the streaming one of single queries and the matrix-core pass — instead of the rows: a quarter of the
+    // f32 bytes.  Kept current by every mutation (add / add_batch / fill / load / reserve: the last sub-tile is
+    // re-quantised on add, everything on growth), so a search is launches only; if it cannot be allocated (or
+    // "i8_shadow" = 0) the filters fall back to the f16 shadow / the rows.
+    char* d_i8 = nullptr;
+    float* d_i8meta = nullptr;
+    size_t i8_cap = 0, i8_rows = 0;
+    int use_i8 = 1;              // option "i8_shadow"
+    int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
+    bool i8_failed = false;
+    float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records
+    size_t stage_bytes = 0;
+    size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }
+    uint64_t* d_ids = nullptr;  // [cap_phys]
+    size_t size = 0;
+    size_t pending = 0;       // rows enqueued by index_append_async past `size`, not committed yet
+    size_t cap_reported = 0;  // what reserve() promised (usearch semantics)
+    size_t cap_phys = 0;      // rows actually allocated (geometric growth)
+
+    // search workspaces (allocated at creation for batches of up to kMaxBatch queries: a search is launches only)
+    // batch-1..8 streaming scan: one 4-wave block per CU, 3 row pairs (9 KiB) in flight per wave.  Measured on
+    // MI355X (tools/scan_sweep.py, 40M rows): 36 KiB in flight per CU reads 7.17 TB/s; the full-occupancy
+    // geometry (32 waves, 192 KiB per CU) only 6.55 TB/s.
+    dawn::ScanGeom geom{256, 256, 3};
+    size_t ws_B = 0;
+    size_t ws_lists = 0;      // candidate lists per query the workspace was sized for
+    float* d_cand_s = nullptr;
+    uint32_t* d_cand_p = nullptr;
+    uint32_t* d_flags = nullptr;   // [ws_B] certificate flags | [ws_B] arrival counters of the exact pass
+    uint32_t* d_stats = nullptr;   // [4]: queries that ended with FLAG_FALLBACK ([1]) / FLAG_SECOND ([2]), counted on the device
+    dawn::BatchWorkspace bws{};    // matrix-core batched path (+ per-index "mfma_sched" / "mfma_target")
+    int mfma_blocks = 256;   // one 8-wave workgroup per CU
+    // B >= this goes to the matrix-core filter (sampled thresholds, one candidate buffer per query); below it the
+    // streaming filter keeps per-wave top-64 lists, whose warm-up grows with every extra query
+    // int8 shadow (tools/small_batch_paths.py, stream / matrix-core ms): 1M rows B=1 0.136 / 0.166, B=2 0.199 / 0.170,
+    // B=3 0.251 / 0.169; 40M rows B=1 2.27 / 2.33, B=2 2.36 / 2.35, B=3 2.42 / 2.34: two queries and more take the pass
+    int mfma_min_batch = 2;
+    // host-API staging
+    float* d_q = nullptr;
+    uint64_t* d_labels = nullptr;
+    float* d_dist = nullptr;
+    uint32_t* d_found = nullptr;
+    uint32_t* d_bad = nullptr;
+    void* h_pinned = nullptr;  // kMaxBatch * (384*4 + 64*8 + 64*4 + 4 + 4)
+    size_t h_pinned_bytes = 0;
+
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    uint64_t n_searches = 0;
+    int force_fallback = 0;
+
+    // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,
+    // recorded behind the last copy out of it
+    hipEvent_t ev_slot[2] = {nullptr, nullptr};
+    bool ev_slot_used[2] = {false, false};
+
+    // one process, several devices (dawn_index_create_sharded): this handle owns no rows itself and routes every call
+    dawn::ShardSet* shards = nullptr;
+    bool pos_ids = false;  // this index is a shard of such a handle: d_ids hold global insertion positions
+};
+
+namespace dawn {
+
+// A C ABI must not let C++ exceptions through (the callers are Rust / C): every entry point that can allocate runs
+// inside guarded().
+template <class F>
+int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(DAWN_ERR_OOM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DAWN_ERR_INVALID_ARG, "%s", e.what());
+    } catch (...) {
+        return fail(DAWN_ERR_HIP, "unexpected exception");
+    }
+}
+
+// ---- single-device pieces used by the sharded router -------------------------------------------------------------
+int index_create_single(int dtype, int device, dawn_index** out);
+void index_destroy_single(dawn_index* idx);
+int index_reserve_single(dawn_index* idx, size_t capacity);
+// The whole search as a fixed launch sequence on `stream` (no allocation, no host decisions for B <= kMaxBatch).
+int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
+                           uint32_t* d_found, hipStream_t stream);
+// Bulk append in two phases.  async: enqueue, on idx->stream, the transfer of m rows into the slots behind size + pending
+// (invisible to searches) and their is_normalized check; nothing is synchronised, the host buffers must stay valid
+// until the stream has passed (bulk callers hand pinned buffers and wait on an event).  commit: wait, and either make
+// all pending rows live (shadows brought up to date) or — a row failed the gate — drop them all.
+enum class RowSrc { HostRows, HostPageEntries };
+// h_src: m rows of 384 f32, or m PageEntry records of 1568 B.  h_ids: m labels; NULL = labels are first_label + i.
+// slot 0/1: record the index's event of that slot behind the copies (index_append_wait(slot) then tells when the host
+// buffer may be overwritten); -1: none.
+int index_append_async(dawn_index* idx, RowSrc kind, const void* h_src, const uint64_t* h_ids, uint64_t first_label, size_t m,
+                       int slot);
+int index_append_wait(dawn_index* idx, int slot);
+int index_append_check(dawn_index* idx, uint32_t* bad);  // wait for the pending rows; *bad = rows that failed the gate
+int index_append_finish(dawn_index* idx, bool keep);     // make the pending rows live (shadows updated) or drop them
+int index_append_commit(dawn_index* idx);   // check + finish: DAWN_OK / DAWN_ERR_NOT_NORMALIZED (nothing added) / error
+void index_append_abort(dawn_index* idx);   // drop the pending rows (I/O error half way)
+int index_clear(dawn_index* idx);           // size = 0 (load replaces the contents)
+int index_fill_async(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, bool ids_are_positions,
+                     uint64_t first_pos);
+// Workspaces + filter shadows for the current rows and options, on idx->stream (callers synchronise).
+int index_prepare_search(dawn_index* idx);
+int index_set_option_single(dawn_index* idx, const char* name, int64_t value);
+int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
+int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks);
+int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total_ms);
+int index_profile_enable_single(dawn_index* idx, int enable);
+
+// ---- the router (dawn_sharded.cpp) -------------------------------------------------------------------------------
+void sharded_destroy(dawn_index* idx);
+int sharded_reserve(dawn_index* idx, size_t capacity);
+size_t sharded_size(const dawn_index* idx);
+size_t sharded_capacity(const dawn_index* idx);
+int sharded_append_async(dawn_index* idx, RowSrc kind, const void* h_src, const uint64_t* h_ids, uint64_t first_label, size_t m,
+                         int slot);
+int sharded_append_wait(dawn_index* idx, int slot);
+int sharded_append_commit(dawn_index* idx);
+void sharded_append_abort(dawn_index* idx);
+int sharded_clear(dawn_index* idx);
+int sharded_search_device(dawn_index* idx, const float* d_q, size_t B, size_t k, uint64_t* d_labels, float* d_dist,
+                          uint32_t* d_found, hipStream_t stream);
+int sharded_search_batch(dawn_index* idx, const float* queries, size_t B, size_t count, uint64_t* labels, float* distances,
+                         size_t* found);
+int sharded_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id);
+int sharded_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
+int sharded_set_option(dawn_index* idx, const char* name, int64_t value);
+int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
+int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks);
+int sharded_profile_enable(dawn_index* idx, int enable);
+int sharded_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms);
+int sharded_dtype(const dawn_index* idx);
+int sharded_root_device(const dawn_index* idx);
+
+}  // namespace dawn

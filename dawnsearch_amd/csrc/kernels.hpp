@@ -65,6 +65,12 @@ struct BatchWorkspace {
     uint32_t* cnt;   // [BATCH_QT][BATCH_CAND_SEGS] candidates appended per segment
     void* cand;      // [BATCH_QT][BATCH_CAND_SEGS][BATCH_CAP / BATCH_CAND_SEGS] uint2 (score bits, row); first half doubles
                      // as the dense f32 score matrix [BATCH_QT][BATCH_CAP]
+    // per-index tuning (dawn_index_set_option "mfma_sched" / "mfma_target")
+    int sched = 4;    // 4 = default (16-bit rows: pipelined 4-wave LDS-DMA kernel for long passes, 8-wave kernel for short
+                      // ones), 5 = pipelined kernel always, 1 = 8-wave kernel always, 0 = lockstep converting kernel on the
+                      // f32 rows; builds with -DDAWN_EXPERIMENTS only: 2 = + stamps, 41..55 = timing experiments
+    int target = 512; // candidates per query the sampled thresholds aim for
+    unsigned long long* diag = nullptr;  // DAWN_EXPERIMENTS, sched 2: [grid][8 waves][8] phase stamps
 };
 struct ScanGeom {
     int blocks;           // scan grid (== number of candidate lists per query)
@@ -101,8 +107,8 @@ struct BatchPlan {
     uint32_t s1_tiles, s1_stride, m1;   // dense sample, tau = m1-th largest
     uint32_t s2_tiles, s2_stride, m2;   // appended sample (0 = skipped), tau = m2-th largest
 };
-BatchPlan plan_batched(uint32_t n_rows);
-BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows);
+BatchPlan plan_batched(uint32_t n_rows, int target);
+BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target);
 // pieces of the batched tail shared with the int8 path (scan_i8.hip)
 void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_t dense_count, uint32_t m, hipStream_t stream);
 void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
@@ -122,11 +128,6 @@ void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, co
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);
 void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                               int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-extern int g_batched_sched;  // 4 = default (f16 shadow: pipelined 4-wave LDS-DMA kernel for long passes, 8-wave kernel for
-                             // short ones), 5 = pipelined kernel always, 1 = 8-wave kernel always, 0 = lockstep kernel on
-                             // the index rows, 2 = + stamps, 41..55 = timing experiments
-extern int g_batched_target;  // candidates per query the sampled thresholds aim for (1536)
-extern unsigned long long* g_batched_diag;
 int batched_init();  // raises the dynamic-LDS limit of the scan kernels; 0 or a hipError_t
 void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int frt, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
@@ -136,13 +137,16 @@ void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_r
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK): per-workgroup exact lists, merged and written out
 // by the last workgroup to arrive (d_done[B]: arrival counters, zero before and after).
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
-                       const uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p, int n_lists, uint32_t k,
-                       uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+                       const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
+                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
 
-// Stable G-way merge of per-shard results (multi-GPU).
+// Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
+// positions — ties go to the lower position and the winners are translated through the table.
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
-                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, uint64_t* out_labels,
-                        float* out_dist, uint32_t* out_found, hipStream_t stream);
+                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, const uint64_t* pos_to_label,
+                        uint64_t* out_labels, float* out_dist, uint32_t* out_found, hipStream_t stream);
+// PageEntry records (1568 B, vector at byte 16: src/index/warc.rs:35-43) -> packed f32 rows
+void launch_page_entries_to_rows(const void* d_records, uint32_t n, float* d_rows, hipStream_t stream);
 
 // is_normalized (vector.rs:185-192) over n rows; *d_bad_count += number of failing rows.
 void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count, hipStream_t stream);

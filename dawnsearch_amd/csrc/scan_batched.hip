@@ -1123,10 +1123,10 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side: pass planning + launch sequence
 // ------------------------------------------------------------------------------------------------
-BatchPlan plan_batched(uint32_t n_rows) { return plan_batched_tiles(n_rows, TILE_ROWS); }
+BatchPlan plan_batched(uint32_t n_rows, int target) { return plan_batched_tiles(n_rows, TILE_ROWS, target); }
 
 // tile_rows: 64 (16-bit tiles) or 128 (int8 tiles, scan_i8.hip): the samples cover the same numbers of ROWS
-BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
+BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per_query) {
     BatchPlan pl{};
     const uint32_t TILE_ROWS = tile_rows;  // (shadows the constant)
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
@@ -1138,7 +1138,7 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
     // sample 1: 128 strided tiles (8192 rows), dense
     pl.s1_tiles = BATCH_CAP / TILE_ROWS;
     pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1 since n_rows > BATCH_CAP
-    const double target = (double)g_batched_target;  // expected candidates per query in the full pass
+    const double target = (double)target_per_query;  // expected candidates per query in the full pass (option "mfma_target")
     const double m_full = target * BATCH_CAP / (double)n_rows;
     // one sample is enough while the threshold can be read from at least the 4th largest sample score (n <= 1 M rows at
     // target 512): the candidate count of the full pass then follows target/4 x Gamma(4) — below the 64 the shortlist
@@ -1173,11 +1173,10 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows) {
 static bool g_lds_attr_set = false;
 
 
-unsigned long long* g_batched_diag = nullptr;  // device buffer [grid][8 waves][8] for the SCHED == 2 diagnostic build
-// 1 (default): f16 shadow rows go through the LDS-DMA kernel, other row sources through the lockstep kernel;
-// 0: lockstep kernel for every row source; 2: lockstep kernel with diagnostic stamps
-int g_batched_sched = 4;
-int g_batched_target = 512;   // option "mfma_target"
+// Kernel choice and threshold target travel in the index's BatchWorkspace (ws.sched / ws.target / ws.diag: per index, not
+// per process).  The timing experiments (parts of the pipelined kernels switched off: wrong results by design) and the
+// stamped diagnostic kernel only exist in builds with -DDAWN_EXPERIMENTS (make EXPERIMENTS=1); the release library does
+// not contain them.
 
 template <bool DENSE, int NW, int SCHED>
 static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
@@ -1185,16 +1184,19 @@ static void launch_pass_nw(const void* d_x, uint32_t n_rows, uint32_t first, uin
     const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
     hipLaunchKernelGGL((scan_f16_kernel<DENSE, NW, SCHED>), dim3(blocks), dim3(NW * 64), LDS_BYTES, stream, d_x, n_rows,
                        first, stride, n_tiles, reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt,
-                       reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), g_batched_diag);
+                       reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), ws.diag);
 }
 
 template <bool DENSE>
 static void launch_pass_rt(const void* d_rows, uint32_t n_rows, uint32_t first, uint32_t stride, uint32_t n_tiles,
                            const BatchWorkspace& ws, int n_q, int grid, hipStream_t stream) {
-    if (g_batched_sched == 2 && !DENSE)  // lockstep kernel with diagnostic stamps (full append pass only)
+#ifdef DAWN_EXPERIMENTS
+    if (ws.sched == 2 && !DENSE) {  // lockstep kernel with diagnostic stamps (full append pass only)
         launch_pass_nw<false, 8, 2>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
-    else
-        launch_pass_nw<DENSE, 8, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
+        return;
+    }
+#endif
+    launch_pass_nw<DENSE, 8, 0>(d_rows, n_rows, first, stride, n_tiles, ws, n_q, grid, stream);
 }
 
 // Fragment-ordered 16-bit tiles (f16 shadow of an f32 index, or a bf16 index): the LDS-DMA kernels.
@@ -1212,13 +1214,14 @@ static void launch_pass_dma(const void* d_rows, uint32_t n_rows, uint32_t first,
     // paths, and go to the 8-wave kernel like the sample passes (measured full pass, 256 queries: 40M rows 7.43 vs
     // 7.82 ms, 12.5M 2.47 vs 2.53, 4M 0.91 vs 0.87, 1M 0.34 vs 0.28 ms).  5: pipelined kernel for every pass (tests).
     // 1: 8-wave kernel only.
-    const int v = g_batched_sched;
+    const int v = ws.sched;
     const bool pipe = v >= 5 || (v != 1 && !DENSE && n_tiles >= (1u << 17));
     if (!pipe)
         hipLaunchKernelGGL((scan_f16_dma_kernel<DENSE, 8, BF16>), dim3(blocks), dim3(512), 0, stream,
                            reinterpret_cast<const unsigned char*>(d_rows), n_rows, first, stride, n_tiles,
                            reinterpret_cast<const half8*>(ws.qh), n_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
                            reinterpret_cast<float*>(ws.cand));
+#ifdef DAWN_EXPERIMENTS
     else if (!BF16 && !DENSE && v == 41) DAWN_PIPE_LAUNCH(1);   // 41..55: timing experiments, parts switched off
     else if (!BF16 && !DENSE && v == 42) DAWN_PIPE_LAUNCH(2);
     else if (!BF16 && !DENSE && v == 43) DAWN_PIPE_LAUNCH(3);
@@ -1227,6 +1230,7 @@ static void launch_pass_dma(const void* d_rows, uint32_t n_rows, uint32_t first,
     else if (!BF16 && !DENSE && v == 48) DAWN_PIPE_LAUNCH(8);
     else if (!BF16 && !DENSE && v == 55) DAWN_PIPE_LAUNCH(15);
     else if (!BF16 && !DENSE && v == 54) DAWN_PIPE_LAUNCH(16);
+#endif
     else DAWN_PIPE_LAUNCH(0);
 #undef DAWN_PIPE_LAUNCH
 }
@@ -1244,8 +1248,10 @@ static void launch_pass(const void* d_rows, int rt, uint32_t n_rows, uint32_t fi
 
 static hipError_t set_lds_attr_rt() {
     const void* fns[] = {reinterpret_cast<const void*>(scan_f16_kernel<true, 8, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 0>),
-                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 2>)};
+#ifdef DAWN_EXPERIMENTS
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 2>),
+#endif
+                         reinterpret_cast<const void*>(scan_f16_kernel<false, 8, 0>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1315,7 +1321,7 @@ void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipS
 // Timing hook: the full append pass alone (thresholds ws.tau as left by the last search), `iters` times.
 void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                               int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched(n_rows);
+    const BatchPlan pl = plan_batched(n_rows, ws.target);
     (void)hipEventRecord(ev0, stream);
     for (int i = 0; i < iters; ++i) {
         (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
@@ -1379,7 +1385,7 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
                          const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
                          hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched(n_rows);
+    const BatchPlan pl = plan_batched(n_rows, ws.target);
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     prep_queries(d_q, B, ws, frt, stream);

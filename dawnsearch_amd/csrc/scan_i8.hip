@@ -814,7 +814,8 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
 #define DAWN_I8_PIPE(DBG_)                                                                                                   \
     hipLaunchKernelGGL((scan_i8_pipe_kernel<false, DBG_>), dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, \
                        qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand))
-    switch (g_batched_sched) {
+    switch (ws.sched) {
+#ifdef DAWN_EXPERIMENTS  // (make EXPERIMENTS=1: not in the release library)
         case 41: DAWN_I8_PIPE(1); break;
         case 42: DAWN_I8_PIPE(2); break;
         case 44: DAWN_I8_PIPE(4); break;
@@ -822,6 +823,7 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 48: DAWN_I8_PIPE(8); break;    // 48 / 49 / 50: the threshold test without its thresholds / slices / branch
         case 49: DAWN_I8_PIPE(16); break;
         case 50: DAWN_I8_PIPE(32); break;
+#endif
         default: DAWN_I8_PIPE(0); break;
     }
 #undef DAWN_I8_PIPE
@@ -830,7 +832,7 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
 // Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
 void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                                  int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS);
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target);
     const signed char* qi = reinterpret_cast<const signed char*>(ws.qh);
     const float2* qm = reinterpret_cast<const float2*>(qi + (size_t)BATCH_QT * EM);
     const uint32_t blocks = pl.n_tiles_total < (uint32_t)grid ? pl.n_tiles_total : (uint32_t)grid;
@@ -862,7 +864,7 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
                             uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
                             uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS);
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target);
     signed char* qi = reinterpret_cast<signed char*>(ws.qh);               // [256][384] int8
     float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);     // [256] {s_q, K2}
     hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(BATCH_QT), dim3(64), 0, stream, d_q, B, qi, qm);

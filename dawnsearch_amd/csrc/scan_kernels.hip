@@ -532,6 +532,7 @@ template <int RT>
 __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, const uint64_t* __restrict__ ids,
                                                         uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                         const uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
+                                                        uint32_t* __restrict__ stats,
                                                         float* __restrict__ out_s, uint32_t* __restrict__ out_p,
                                                         uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
                                                         float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
@@ -545,7 +546,11 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
     const uint32_t total_waves = gridDim.x * nwaves;
     // grid.y <= 16 query slots: the common launch (no flag set) costs a few thousand workgroups less than one per query
     for (int b = blockIdx.y; b < n_q; b += gridDim.y) {
-        if (flags[b] != FLAG_FALLBACK) continue;  // block-uniform
+        const uint32_t flag = flags[b];
+        // certificate statistics of the index (dawn_index_stats*): this kernel closes every search and sees every
+        // query's final flag, so the counters also cover searches issued through dawn_index_search_device
+        if (stats && flag != FLAG_OK && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[flag], 1u);
+        if (flag != FLAG_FALLBACK) continue;  // block-uniform
         const float* qv = q + (size_t)b * EM;
 
         float ls = NEG_INF, tau = NEG_INF;
@@ -607,15 +612,15 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
 }
 
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
-                       const uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p, int n_lists, uint32_t k,
-                       uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
+                       const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
+                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
     const dim3 grid(n_lists, B < 16 ? B : 16);
     if (dtype == ROW_BF16)
-        hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, cand_s,
-                           cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
+        hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, d_stats,
+                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
     else
-        hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, cand_s,
-                           cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
+        hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, d_stats,
+                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -623,14 +628,20 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 // ------------------------------------------------------------------------------------------------
 // Shard g's lists start at in_labels + g*sl, in_dist + g*sd, in_found + g*sf (element strides): separate
 // [G][B][k] arrays (sl = sd = B*k, sf = B) or one packed blob per shard as all-gathered by the ranks.
+// Ties: lower shard, then shard-local order (contiguous row shards: that IS insertion order).  POS = true (the
+// single-process sharded index of dawn_sharded.cpp, whose rows are dealt to the shards chunk by chunk): the "labels" coming
+// in are global insertion positions, ties go to the lower position, and pos_to_label[] turns the winners into labels.
+template <bool POS>
 __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B, uint32_t k,
                                                          const uint64_t* __restrict__ in_labels,
                                                          const float* __restrict__ in_dist,
                                                          const uint32_t* __restrict__ in_found, size_t sl, size_t sd,
-                                                         size_t sf, uint64_t* __restrict__ out_labels,
+                                                         size_t sf, const uint64_t* __restrict__ pos_to_label,
+                                                         uint64_t* __restrict__ out_labels,
                                                          float* __restrict__ out_dist,
                                                          uint32_t* __restrict__ out_found) {
     __shared__ float sh_d[512];
+    __shared__ uint64_t sh_l[POS ? 512 : 1];
     const uint32_t b = blockIdx.x;
     const uint32_t t = threadIdx.x;
     const uint32_t total = G * k;  // <= 512
@@ -646,16 +657,18 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
         }
     }
     sh_d[t] = d;
+    if (POS) sh_l[t] = valid ? label : ~0ull;
     __syncthreads();
     if (valid) {
         // rank = number of candidates ordered before (d, g, i); t = g*k+i is that lexicographic index
         uint32_t rank = 0;
         for (uint32_t o = 0; o < total; ++o) {
             const float od = sh_d[o];
-            rank += (od < d || (od == d && o < t)) ? 1u : 0u;
+            const bool before = POS ? sh_l[o] < label : o < t;
+            rank += (od < d || (od == d && before)) ? 1u : 0u;
         }
         if (rank < k) {
-            out_labels[(size_t)b * k + rank] = label;
+            out_labels[(size_t)b * k + rank] = POS ? pos_to_label[label] : label;
             out_dist[(size_t)b * k + rank] = d;
         }
     }
@@ -667,10 +680,14 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
 }
 
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
-                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, uint64_t* out_labels,
-                        float* out_dist, uint32_t* out_found, hipStream_t stream) {
-    hipLaunchKernelGGL(shard_merge_kernel, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
-                       (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, out_labels, out_dist, out_found);
+                        const uint32_t* in_found, size_t sl, size_t sd, size_t sf, const uint64_t* pos_to_label,
+                        uint64_t* out_labels, float* out_dist, uint32_t* out_found, hipStream_t stream) {
+    if (pos_to_label)
+        hipLaunchKernelGGL(shard_merge_kernel<true>, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
+                           (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, pos_to_label, out_labels, out_dist, out_found);
+    else
+        hipLaunchKernelGGL(shard_merge_kernel<false>, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
+                           (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, pos_to_label, out_labels, out_dist, out_found);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,6 +706,25 @@ __global__ void validate_rows_kernel(const float* __restrict__ rows, uint32_t n,
     const float l = sqrtf(s);  // correctly rounded (HIP default)
     const bool ok = __builtin_isfinite(l) && l > (1.0f - 0.01f) && l < (1.0f + 0.01f);
     if (!ok) atomicAdd(bad, 1u);
+}
+
+// src/index/warc.rs:35-43 PageEntry records (1568 B: u64 url_pos, u64 title_pos, f32 vector[384], u64 url_len, u64
+// title_len) as they sit in an .emb file -> packed f32 rows.  The records arrive by DMA exactly as on disk; the vector of
+// record r is the 96 16-B chunks starting at byte 1568 r + 16 (16-B aligned: 1568 = 98 x 16).
+__global__ void page_entries_to_rows_kernel(const f32x4* __restrict__ rec, uint32_t n, f32x4* __restrict__ rows) {
+    const size_t total = (size_t)n * ROW_F4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / ROW_F4, c = i % ROW_F4;
+        rows[i] = rec[r * 98 + 1 + c];
+    }
+}
+
+void launch_page_entries_to_rows(const void* d_records, uint32_t n, float* d_rows, hipStream_t stream) {
+    if (n == 0) return;
+    size_t blocks = ((size_t)n * ROW_F4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(page_entries_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_records), n, reinterpret_cast<f32x4*>(d_rows));
 }
 
 void launch_validate_rows(const float* d_rows, uint32_t n, uint32_t* d_bad_count, hipStream_t stream) {

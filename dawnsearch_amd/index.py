@@ -15,15 +15,30 @@ def _ptr(a: np.ndarray) -> C.c_void_p:
 
 
 class VectorIndex:
-    """usearch::ffi::Index replacement (search_provider.rs:102-284) living in HBM on one MI355X."""
+    """usearch::ffi::Index replacement (search_provider.rs:102-284) living in HBM on one MI355X — or, with
+    `devices=[...]`, dealt over several GPUs of the node behind the same calls (dawn_index_create_sharded)."""
 
-    def __init__(self, device: int = 0, dims: int = EM_LEN, dtype: str = "f32"):
+    def __init__(self, device: int = 0, dims: int = EM_LEN, dtype: str = "f32", devices=None):
         h = C.c_void_p()
         code = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[dtype]
-        check(lib.dawn_index_create(dims, code, device, C.byref(h)))
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*devices)
+            check(lib.dawn_index_create_sharded(dims, code, len(devices), devs, C.byref(h)))
+            device = devices[0]
+        else:
+            check(lib.dawn_index_create(dims, code, device, C.byref(h)))
         self._h = h
         self.device = device
         self.dtype = dtype
+
+    def shard_info(self):
+        """-> {"n_shards", "gather" (1 RCCL all-gather, -1 RCCL selected / not initialised yet, 2 peer copies, 0 none),
+        "sizes"}."""
+        n = C.c_int(0)
+        g = C.c_int(0)
+        sizes = np.zeros(64, dtype=np.uintp)
+        check(lib.dawn_index_shard_info(self._h, C.byref(n), C.byref(g), _ptr(sizes), 64))
+        return {"n_shards": n.value, "gather": g.value, "sizes": sizes[:n.value].astype(np.int64).tolist()}
 
     def close(self):
         if getattr(self, "_h", None):

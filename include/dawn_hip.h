@@ -56,6 +56,20 @@ typedef struct dawn_index dawn_index;
 /* new_index(&INDEX_OPTIONS) — search_provider.rs:35-42,102.  dims must be 384, metric is IP
  * (distance = 1 - sum(q_i*x_i)), dtype DAWN_DTYPE_F32 or DAWN_DTYPE_BF16.  `device` = HIP device ordinal. */
 int dawn_index_create(size_t dims, int dtype, int device, dawn_index **out);
+/* The same index with its rows dealt over n_gpus devices of one node (dawn_index_create(dim, dtype, n_gpus)):
+ * devices[i] = HIP ordinal of shard i (NULL = 0..n_gpus-1; devices[0] is the root, where queries arrive and results
+ * leave).  EVERY dawn_index_* call below takes the handle unchanged: add / add_batch deal chunks of 4096 consecutive rows
+ * round robin, search runs all shards concurrently, gathers the per-shard top-k blobs (one grouped ncclAllGather over
+ * RCCL/xGMI; peer copies when "shard_gather" = 2 or a device holds several shards) and merges them on the root — ties go to
+ * the earlier-added row, so the answer is bit-identical to the single-device index; save / load files are the same
+ * files.  This is the multi-GPU counterpart of search_remote's fan-out + BestResults merge (search_service.rs:201-277)
+ * for ONE process driving the GPUs of a node (the one-process-per-GPU form is dawn_index_search_device +
+ * dawn_topk_merge_packed_device around the caller's own collective).  Extra options: "shard_chunk" (while empty),
+ * "shard_gather" 0 auto / 1 RCCL / 2 peer copies. */
+int dawn_index_create_sharded(size_t dims, int dtype, int n_gpus, const int *devices, dawn_index **out);
+/* *n_shards (1 for a plain index); *gather: 1 RCCL all-gather in use, -1 RCCL selected and not initialised yet (first
+ * search), 2 peer copies, 0 nothing to gather; shard_sizes[min(n_shards, cap)] rows per shard.  NULL = not wanted. */
+int dawn_index_shard_info(dawn_index *idx, int *n_shards, int *gather, size_t *shard_sizes, size_t cap);
 void dawn_index_destroy(dawn_index *idx); /* drop of UniquePtr<Index> */
 
 int dawn_index_reserve(dawn_index *idx, size_t capacity);      /* index.reserve(n)  :133,282 */
@@ -86,16 +100,25 @@ int dawn_index_search_limited(dawn_index *idx, const float *query, size_t count,
 int dawn_index_search_batch(dawn_index *idx, const float *queries, size_t B, size_t count,
                             uint64_t *labels, float *distances, size_t *found);
 
-int dawn_index_save(dawn_index *idx, const char *path); /* index.save(path) :117,178 */
-int dawn_index_load(dawn_index *idx, const char *path); /* index.load(path) :115     */
+/* index.save(path) :117,178.  Atomic: written to `path`.tmp, fsync'ed, renamed — an interrupted save leaves the old file. */
+int dawn_index_save(dawn_index *idx, const char *path);
+/* index.load(path) :115.  Replaces the contents; all or nothing: a truncated / corrupt file or a row failing the
+ * is_normalized gate leaves the index EMPTY (never partially filled), so the reference's
+ * `if !load(path).is_ok() { fill_index_from_db() }` (:115-117) rebuilds onto a clean index.  The file streams through
+ * pinned host staging, reads overlapped with the DMA into HBM. */
+int dawn_index_load(dawn_index *idx, const char *path);
 /* Bulk-load the packed PageEntry file of src/index/warc.rs:35-43 (1568-B records, vector at
- * byte 16) as read by examples_old/document_embeddings.rs:56-71; ids = first_id + record index. */
+ * byte 16) as read by examples_old/document_embeddings.rs:56-71; ids = first_id + record index.  Appends; all or
+ * nothing.  Records go to the GPU as they are on disk and are cut down to their vectors there. */
 int dawn_index_load_page_entries(dawn_index *idx, const char *emb_path, uint64_t first_id);
 
 /* ---- device-resident forms (queries/results already in HBM; nothing is synchronised) -------- */
 /* d_queries [B][384] f32, d_labels [B][count] u64, d_distances [B][count] f32, d_found [B] u32 are
- * DEVICE pointers on the index's device; `stream` is a hipStream_t (NULL = default stream).
- * Queries are assumed validated.  Launch-only: graph-capturable, no host round trip. */
+ * DEVICE pointers on the index's (root) device; `stream` is a hipStream_t (NULL = default stream).
+ * Queries are assumed validated.  For B <= 256 on a single-device index this is kernel launches only — no allocation, no
+ * synchronisation, no host decision on device data: graph-capturable.  (Workspaces and the filter shadow of the current rows
+ * are prepared by create / add / load / reserve / set_option, which synchronise; a caller searching on its own stream
+ * must have that stream idle before it mutates the index.  B > 256 in one call grows the workspaces once.) */
 int dawn_index_search_device(dawn_index *idx, const float *d_queries, size_t B, size_t count,
                              uint64_t *d_labels, float *d_distances, uint32_t *d_found, void *stream);
 /* Stable G-way merge of per-shard results (each ascending by (distance, shard-local order)) —
@@ -130,7 +153,8 @@ int dawn_index_get_rows(dawn_index *idx, size_t first, size_t n, float *out_rows
  * count and summed milliseconds since the last reset and resets. Synchronises the device. */
 int dawn_index_profile_enable(dawn_index *idx, int enable);
 int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_ms);
-/* Counters: searches that needed the exact fallback pass (certificate failed). */
+/* Counters: searches that needed the exact fallback pass (certificate failed).  Counted on the device at the end of every
+ * search, whichever entry point issued it (host API or dawn_index_search_device); reading synchronises the device. */
 int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
 /* ... and searches whose 64-row certificate failed but whose 1024-row second certificate held (no exact pass). */
 int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_chances, uint64_t *fallbacks);
@@ -151,11 +175,11 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
 /* Tuning knobs (tests and tools sweep them; the defaults are the tuned values):
  *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 2)
  *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
- *   "mfma_sched"       process-wide: 4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave
- *                      kernel only, 0 / 2 = lockstep converting kernel on the f32 rows (2: with phase stamps),
- *                      41..55 = timing experiments (parts of the pipelined kernel switched off: wrong results)
- *                      (int8 pipelined kernel: 41 / 42 / 44 / 47 / 48..50, scan_i8.hip)
- *   "mfma_target"      process-wide: candidates per query the sampled thresholds of the matrix-core path aim for (512)
+ *   "mfma_sched"       4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave kernel only,
+ *                      0 = lockstep converting kernel on the f32 rows.  (The timing experiments 2 / 41..55 — parts of the
+ *                      pipelined kernels switched off, wrong results by design — only exist in `make EXPERIMENTS=1`
+ *                      builds; the release library rejects them.)
+ *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (512)
  *   "i8_shadow"        0: no int8 shadow (384 B/row, scan_i8.hip) of the index rows: the filters read the f16 shadow of
  *                      an f32 index / the rows of a bf16 index themselves.  Default 1, or env DAWN_I8_SHADOW at creation
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow

@@ -141,3 +141,41 @@ def test_pipelined_kernels_keep_their_accumulators_out_of_agpr_spills(tmp_path):
     assert len(i8) == 2 and len(f16) == 1, (i8, f16)
     assert set(i8.values()) == {48}, i8
     assert set(f16.values()) == {96}, f16
+
+
+def test_release_library_holds_no_experiment_kernels(tmp_path):
+    """The timing-experiment variants of the pipelined kernels (DBG != 0: parts switched off, wrong results by design) and
+    the stamped diagnostic kernel only exist in `make EXPERIMENTS=1` builds (libdawn_hip_exp.so); the shipped library must
+    not contain them — nothing reachable through dawn_index_set_option may return wrong results."""
+    import glob
+    import shutil
+    import subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "dawnsearch_amd", "libdawn_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(lib)):
+        pytest.skip("ROCm binutils or the built library not present")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    names = set()
+    for f in glob.glob(str(tmp_path / "lib.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
+        names.update(re.findall(r"\.name:\s+(\S+)", notes))
+    i8 = [n for n in names if "scan_i8_pipe_kernel" in n and not n.endswith(".kd")]
+    f16 = [n for n in names if "scan_f16_pipe_kernel" in n and not n.endswith(".kd")]
+    assert i8 and f16
+    # template arguments <DENSE, DBG, ...>: ILb?ELi<DBG>E
+    assert all(re.search(r"scan_i8_pipe_kernelILb[01]ELi0E", n) for n in i8), i8
+    assert all(re.search(r"scan_f16_pipe_kernelILb[01]ELi0E", n) for n in f16), f16
+    assert not [n for n in names if re.search(r"scan_f16_kernelILb[01]ELi8ELi2E", n)], "stamped diagnostic kernel present"
+
+
+def test_sharded_create_needs_devices_and_checks_arguments(dawn):
+    import ctypes as C
+    from dawnsearch_amd import _lib
+    h = C.c_void_p()
+    assert _lib.lib.dawn_index_create_sharded(384, 0, 0, None, C.byref(h)) == _lib.ERR_INVALID_ARG
+    assert _lib.lib.dawn_index_create_sharded(128, 0, 2, None, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert _lib.lib.dawn_index_create_sharded(384, 7, 2, None, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    if dawn.device_count() == 0:
+        assert _lib.lib.dawn_index_create_sharded(384, 0, 2, None, C.byref(h)) == _lib.ERR_NO_DEVICE
+        assert not h.value and "no CPU fallback" in dawn.last_error()

@@ -185,6 +185,49 @@ def test_add_reserve_growth_and_save_load(dawn, oracle, tmp_path):
     _assert_same(*idx2.search(q, 20), *want)
     with pytest.raises(dawn.DawnError):
         idx2.load(str(tmp_path / "missing.dawn"))
+    assert idx2.size() == 3000  # a file that cannot be opened leaves the index alone
+    import os
+    assert not os.path.exists(p + ".tmp")  # save writes path.tmp, fsyncs and renames
+
+
+def test_load_is_all_or_nothing(dawn, oracle, tmp_path):
+    """A truncated file (an interrupted save of an older build, a full disk) or a row that fails the is_normalized gate must
+    leave the index EMPTY, never partially filled: the reference then runs fill_index_from_db() onto it
+    (search_provider.rs:115-117) and duplicates would show up in every search."""
+    n = 70_000  # more than two staging chunks of the pipelined loader
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    p = str(tmp_path / "index.dawn")
+    idx.save(p)
+    data = open(p, "rb").read()
+    assert len(data) == 24 + n * (8 + 1536)
+    q = synth.unit_rows(2, 0, 1)[0]
+    want = idx.search(q, 10)
+    t = str(tmp_path / "truncated.dawn")
+    for cut in (len(data) - 1, 24 + n * 8 + 40_000 * 1536 + 17, 24 + 100, 10):
+        open(t, "wb").write(data[:cut])
+        idx2 = dawn.VectorIndex(0)
+        idx2.fill_synthetic(3, 0, 100, 1)
+        with pytest.raises(dawn.DawnError):
+            idx2.load(t)
+        assert idx2.size() == 100  # the header is checked against the file size before the index is touched
+        assert len(idx2.search(q, 10)[0]) == min(10, idx2.size())
+    # a bad row far into the file: the rows in front of it were already on the device
+    bad = bytearray(data)
+    off = 24 + n * 8 + 50_000 * 1536
+    bad[off:off + 1536] = (np.frombuffer(data[off:off + 1536], dtype=np.float32) * 3).tobytes()
+    open(t, "wb").write(bytes(bad))
+    idx3 = dawn.VectorIndex(0)
+    with pytest.raises(dawn.NotNormalizedError):
+        idx3.load(t)
+    assert idx3.size() == 0 and len(idx3.search(q, 10)[0]) == 0
+    idx3.load(p)  # ... and the index is still usable
+    assert idx3.size() == n
+    got = idx3.search(q, 10)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    rows, ids = idx3.get_rows(n - 5, 5)
+    assert np.array_equal(rows.view(np.uint32), oracle.unit_rows(1, n - 5, 5).view(np.uint32))
+    assert np.array_equal(ids, np.arange(n - 4, n + 1, dtype=np.uint64))
 
 
 def test_page_entry_file_loader(dawn, oracle, tmp_path):
@@ -210,6 +253,22 @@ def test_page_entry_file_loader(dawn, oracle, tmp_path):
     sc = np.zeros(10, dtype=np.float32)
     m = oracle.lib().orc_scan_examples_old(rec.reshape(-1), n, q, ent, sc)
     assert m == 10
+    # ... its ranking is the IP ranking (sum (a-b)^2 = 2 - 2 a.b on unit vectors), entry e = label e + 1, scores 2 x distance
+    lab, dist = idx.search(q, 10)
+    assert np.array_equal(ent.astype(np.uint64) + 1, lab), (ent, lab)
+    assert np.all(np.diff(sc) >= 0) and np.allclose(sc, 2.0 * dist, rtol=0, atol=1e-5)
+    # a file with a trailing partial record: entries() = len / size_of::<PageEntry>() (document_embeddings.rs:60-62)
+    with open(p, "ab") as f:
+        f.write(b"\x01" * 700)
+    idx2 = dawn.VectorIndex(0, dtype="bf16")
+    idx2.load_page_entries(p, first_id=1)
+    assert idx2.size() == n
+    # a non-unit vector anywhere in the file: nothing is added
+    rec[n // 2, 16:16 + 1536] = (rows[n // 2] * 2).view(np.uint8)
+    rec.tofile(p)
+    with pytest.raises(dawn.NotNormalizedError):
+        idx.load_page_entries(p, first_id=10_000)
+    assert idx.size() == n
 
 
 def test_remote_search_distance_limit(dawn, oracle, shadow):
@@ -613,20 +672,24 @@ def test_batched_shadow_tracks_adds_and_growth(dawn, oracle, shadow):
 
 
 def test_memory_accounting(dawn):
-    """dawn_index_memory: 1536 B per reserved f32 row; after the first searches + 384 B per row (+ 8 B per 32 rows) of int8
-    shadow, and + 768 B per row once the f16 shadow is asked for."""
+    """dawn_index_memory: 1536 B per reserved f32 row + 384 B per row (+ 8 B per 32 rows) of int8 shadow, which every
+    mutation keeps current (a search allocates nothing), and + 768 B per row once the f16 shadow is asked for."""
     n = 100_000
-    idx = _mk_index(dawn, n)
+    idx = dawn.VectorIndex(0)
+    idx.reserve(n)
     m0 = idx.memory()
     assert m0["rows"] >= n * 1536 and m0["rows"] < 1.6 * n * 1536 and m0["shadows"] == 0
+    idx.fill_synthetic(1, 0, n, 1)
     q = synth.unit_rows(2, 0, 1)[0]
-    idx.search(q, 10)
     m1 = idx.memory()
+    idx.search(q, 10)
+    assert idx.memory() == m1
     per_row = m1["shadows"] / (m1["rows"] / 1536)
     assert 384 <= per_row < 386, per_row
     idx.set_option("i8_shadow", 0)
-    idx.search(q, 10)
     m2 = idx.memory()
+    idx.search(q, 10)
+    assert idx.memory() == m2
     assert m2["shadows"] - m1["shadows"] == (m1["rows"] // 1536) * 768
     assert m2["other"] > n * 8
 

@@ -1,0 +1,170 @@
+"""The sharded index behind the C ABI (dawn_index_create_sharded): ONE handle, G shards, the unchanged dawn_index_* calls.
+On the 1-GPU test box the G shards are logical (all on device 0: the gather is then G device-to-device copies instead of the
+RCCL all-gather, everything else — chunked dealing of rows, per-shard searches on their own streams, events, merge by
+insertion position, label translation — is the code the 8-GPU node runs).  Bar: bit-identical to the single-device index
+and to the oracle, ties included."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+
+def _same(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("G,chunk,n", [(2, 4096, 40_000), (8, 64, 40_000), (5, 128, 10_007), (8, 4096, 3000), (3, 64, 100)])
+def test_sharded_handle_equals_single_index_and_oracle(dawn, oracle, G, chunk, n):
+    full = dawn.VectorIndex(0)
+    full.fill_synthetic(1, 0, n, 1000)
+    sh = dawn.VectorIndex(devices=[0] * G)
+    sh.set_option("shard_chunk", chunk)
+    sh.fill_synthetic(1, 0, n, 1000)
+    info = sh.shard_info()
+    assert info["n_shards"] == G and sum(info["sizes"]) == n == sh.size()
+    assert max(info["sizes"]) - min(info["sizes"]) <= chunk
+    rows, ids = sh.get_rows(0, n)
+    frows, fids = full.get_rows(0, n)
+    assert np.array_equal(rows.view(np.uint32), frows.view(np.uint32)) and np.array_equal(ids, fids)
+    Q = np.concatenate([synth.unit_rows(2, 0, 12), synth.planted_queries(1, [0, n // 2, n - 1], 3)])
+    Q[1] = rows[min(chunk, n - 1)]  # an exact hit on the first row of the second chunk
+    for k in (1, 10, 20, 64):
+        a = sh.search_batch(Q, k)
+        b = full.search_batch(Q, k)
+        assert np.array_equal(a[2], b[2])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    for b in (0, 1, 13):
+        ol, od = oracle.scan_topk(frows, fids, Q[b], 20, threads=4)
+        l, d = sh.search(Q[b], 20)  # one query: the streaming filter on every shard
+        assert np.array_equal(l, ol) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    st = sh.stats()
+    assert st["searches"] == 4 * len(Q) + 3 and st["fallbacks"] == 0
+
+
+def test_sharded_ties_follow_insertion_order_across_shards(dawn, oracle):
+    """Duplicates of one row land on different shards (chunk 64, 4 shards): equal distances must come out in insertion
+    order — the merge compares insertion positions, not shard numbers."""
+    base = synth.unit_rows(1, 0, 700)
+    rows = np.concatenate([base, np.repeat(base[7:8], 40, axis=0), base[:200], np.repeat(base[7:8], 5, axis=0)])
+    ids = np.arange(5000, 5000 + len(rows), dtype=np.uint64)[::-1].copy()  # labels unrelated to positions (descending)
+    q = synth.planted_queries(1, [7], 3)[0]
+    sh = dawn.VectorIndex(devices=[0, 0, 0, 0])
+    sh.set_option("shard_chunk", 64)
+    sh.add_batch(ids, rows)
+    single = dawn.VectorIndex(0)
+    single.add_batch(ids, rows)
+    for k in (10, 20, 64):
+        ol, od = oracle.scan_topk(rows, ids, q, k)
+        assert _same(sh.search(q, k), (ol, od))
+        assert _same(single.search(q, k), (ol, od))
+    l, d = sh.search(q, 64)
+    assert l[0] == ids[7] and list(l[1:41]) == list(ids[700:740])  # the copies, in the order they were added
+
+
+def test_sharded_adds_one_by_one_reserve_and_errors(dawn, oracle):
+    rows = synth.unit_rows(5, 0, 700)
+    sh = dawn.VectorIndex(devices=[0, 0, 0])
+    sh.set_option("shard_chunk", 64)
+    assert sh.capacity() == 0
+    sh.reserve(10)
+    assert sh.capacity() == 10 and sh.size() == 0
+    for i in range(200):  # the reference's insert path: one row per call, reserve(+16) when full (search_provider.rs:280-284)
+        if sh.size() == sh.capacity():
+            sh.reserve(sh.size() + 16)
+        sh.add(100 + i, rows[i])
+    sh.add_batch(np.arange(300, 800, dtype=np.uint64), rows[200:])
+    assert sh.size() == 700 and sh.shard_info()["sizes"] == [256, 252, 192]
+    ids = np.concatenate([np.arange(100, 300), np.arange(300, 800)]).astype(np.uint64)
+    q = synth.unit_rows(2, 3, 1)[0]
+    assert _same(sh.search(q, 20), oracle.scan_topk(rows, ids, q, 20))
+    with pytest.raises(dawn.DawnError):
+        sh.set_option("shard_chunk", 128)  # not on a filled index
+    bad = synth.unit_rows(1, 0, 300)
+    bad[290] *= 2.0  # lands on another shard than row 0: all shards must drop their part
+    with pytest.raises(dawn.NotNormalizedError):
+        sh.add_batch(np.arange(300, dtype=np.uint64), bad)
+    assert sh.size() == 700 and sh.shard_info()["sizes"] == [256, 252, 192]
+    assert _same(sh.search(q, 20), oracle.scan_topk(rows, ids, q, 20))
+    sh.add(999, rows[0])  # still in step after the rolled-back batch
+    assert sh.size() == 701
+    with pytest.raises(dawn.NotNormalizedError):
+        sh.search(q * 1.5, 10)
+    empty = dawn.VectorIndex(devices=[0, 0])
+    assert len(empty.search(q, 10)[0]) == 0
+
+
+def test_sharded_files_are_the_single_index_files(dawn, oracle, tmp_path):
+    n = 9000
+    rows = synth.unit_rows(7, 0, n)
+    ids = (np.arange(n, dtype=np.uint64) * 3 + 11)
+    sh = dawn.VectorIndex(devices=[0, 0, 0])
+    sh.set_option("shard_chunk", 256)
+    sh.add_batch(ids, rows)
+    single = dawn.VectorIndex(0)
+    single.add_batch(ids, rows)
+    p1, p2 = str(tmp_path / "sharded.dawn"), str(tmp_path / "single.dawn")
+    sh.save(p1)
+    single.save(p2)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    q = synth.unit_rows(2, 9, 1)[0]
+    want = oracle.scan_topk(rows, ids, q, 20)
+    a = dawn.VectorIndex(devices=[0, 0, 0, 0, 0])  # another shard count reads the same file
+    a.load(p2)
+    b = dawn.VectorIndex(0)
+    b.load(p1)
+    assert a.size() == n == b.size()
+    assert _same(a.search(q, 20), want) and _same(b.search(q, 20), want)
+    # PageEntry records into a sharded index
+    rec = np.zeros((n, 1568), dtype=np.uint8)
+    rec[:, 16:16 + 1536] = rows.view(np.uint8).reshape(n, 1536)
+    pe = str(tmp_path / "x.warc.emb")
+    rec.tofile(pe)
+    c = dawn.VectorIndex(devices=[0, 0])
+    c.load_page_entries(pe, first_id=1)
+    assert c.size() == n
+    assert _same(c.search(q, 10), oracle.scan_topk(rows, np.arange(1, n + 1, dtype=np.uint64), q, 10))
+
+
+def test_sharded_bf16_and_device_resident_search(dawn, oracle):
+    import torch
+    n = 30_000
+    sh = dawn.VectorIndex(devices=[0, 0], dtype="bf16")
+    sh.set_option("shard_chunk", 1024)
+    sh.fill_synthetic(1, 0, n, 1)
+    single = dawn.VectorIndex(0, dtype="bf16")
+    single.fill_synthetic(1, 0, n, 1)
+    Q = synth.unit_rows(2, 0, 40)
+    a, b = sh.search_batch(Q, 10), single.search_batch(Q, 10)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # device-resident form on the caller's (torch) stream
+    dev = torch.device("cuda", 0)
+    dq = torch.from_numpy(Q).to(dev)
+    lab = torch.zeros((40, 10), dtype=torch.int64, device=dev)
+    dist = torch.zeros((40, 10), dtype=torch.float32, device=dev)
+    fnd = torch.zeros((40,), dtype=torch.int32, device=dev)
+    for _ in range(3):  # back-to-back searches reuse the per-shard blobs and the gather buffer
+        sh.search_device(dq.data_ptr(), 40, 10, lab.data_ptr(), dist.data_ptr(), fnd.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(lab.cpu().numpy().view(np.uint64), b[0])
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), b[1].view(np.uint32))
+
+
+def test_rccl_all_gather_path_on_one_device(dawn, oracle):
+    """"shard_gather" = 1 forces the RCCL collective (librccl loaded on first use, ncclCommInitAll, grouped ncclAllGather
+    on the shard's stream) even for a single shard: the library path of the 8-GPU node, exercised with world size 1."""
+    n = 20_000
+    sh = dawn.VectorIndex(devices=[0])
+    sh.set_option("shard_gather", 1)
+    sh.fill_synthetic(1, 0, n, 1)
+    assert sh.shard_info()["gather"] == 1
+    single = dawn.VectorIndex(0)
+    single.fill_synthetic(1, 0, n, 1)
+    Q = synth.unit_rows(2, 0, 9)
+    for _ in range(2):
+        a, b = sh.search_batch(Q, 20), single.search_batch(Q, 20)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    with pytest.raises(dawn.DawnError):  # two shards on one device cannot form an RCCL communicator
+        dawn.VectorIndex(devices=[0, 0]).set_option("shard_gather", 1)
