@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip batch-256 / 1M / latency / cpu legs")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-capi-sharded", action="store_true",
+                    help="N > 1: skip the single-process leg (tools/sharded_capi_bench.py: one process, N GPUs, C ABI only)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather + packed merge even at world size 1 (exercises the N>1 code path)")
     return ap.parse_args()
@@ -77,6 +79,34 @@ def cpu_baseline(sample_rows: int, k: int, total_rows: int):
                   f"scaled to {total_rows} rows ({rows_per_s / 1e6:.2f} M rows/s)",
         "all_cores": {"value": nq2 * sample_rows / t2 / total_rows, "cores": cores},
     }
+
+
+def capi_sharded_leg(n_gpus: int, rows: int, k: int, timeout_s: float = 240.0):
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_capi_bench.py"), "--gpus", str(n_gpus), "--rows", str(rows),
+           "--k", str(k)]
+    env = {kk: v for kk, v in os.environ.items()
+           if kk not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                         "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    res = {"command": " ".join(cmd[1:]), "modes": []}
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+        try:
+            stdout, _ = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            stdout, _ = proc.communicate()
+            res["error"] = f"timed out after {timeout_s:.0f} s"
+        res["returncode"] = proc.returncode
+        for ln in (stdout or "").splitlines():
+            if ln.startswith("{"):
+                try:
+                    res["modes"].append(json.loads(ln))
+                except Exception:
+                    pass
+    except Exception as e:
+        res["error"] = repr(e)
+    return res
 
 
 def launch_ranks(args) -> int:
@@ -431,9 +461,17 @@ def main():
     # RCCL writes a version banner to C stdout; get every rank's C buffers out before rank 0 prints the ONE JSON
     # line, so that the line is the last thing on stdout.
     import ctypes
+    try:
+        idx.close()
+    except Exception:
+        pass
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and rank == 0 and not args.no_capi_sharded and not oversub:
+        # The same index behind the C ABI alone: ONE process, N GPUs (dawn_index_create_sharded, RCCL all-gather / peer
+        # copies inside the library).  A child process, bounded in time; the ranks have released their indexes.
+        out.setdefault("extra", {})["single_process_sharded"] = capi_sharded_leg(world, args.rows, k)
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     if rank == 0:
