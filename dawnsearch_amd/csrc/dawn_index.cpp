@@ -90,7 +90,8 @@ size_t ws_lists_needed(const dawn_index* idx) {
 int ensure_workspace(dawn_index* idx, size_t B) {
     if (!idx->bws.cand) {
         if (int e = dawn::batched_init()) return fail(DAWN_ERR_HIP, "hipFuncSetAttribute(LDS): %s", hipGetErrorString((hipError_t)e));
-        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * dawn::EM * sizeof(_Float16)));
+        // (16-bit paths: f16 / bf16 query images; int8 path: H images | {s_q, K2} | L images)
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.qh, (size_t)dawn::BATCH_QT * (dawn::EM * sizeof(_Float16) + 16)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.tau, dawn::BATCH_QT * sizeof(float)));
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMalloc(&idx->bws.cand, (size_t)dawn::BATCH_QT * dawn::BATCH_CAP * 8));
@@ -506,10 +507,10 @@ int index_fill_async(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t 
         const size_t m = std::min(chunk, n - o);
         char* dst = idx->d_x + (at + o) * rb;
         if (bf16) {  // f32 unit rows of the spec, then rounded: the bf16 index holds round_bf16(spec row)
-            launch_fill_synth(seed, first_row + o, (uint32_t)m, d_f32, d_len, idx->stream);
+            launch_fill_synth(seed, first_row + o, (uint32_t)m, d_f32, d_len, idx->synth_dist, idx->stream);
             launch_rows_f32_to_bf16(d_f32, idx->d_x, at + o, m, idx->stream);
         } else {
-            launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->stream);
+            launch_fill_synth(seed, first_row + o, (uint32_t)m, reinterpret_cast<float*>(dst), d_len, idx->synth_dist, idx->stream);
         }
         launch_iota_u64(idx->d_ids + at + o, (ids_are_positions ? first_pos : first_id) + o, (uint32_t)m, idx->stream);
     }
@@ -577,14 +578,15 @@ int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total
 
 // The certificate counters live on the device (scan_exact_kernel bumps them at the end of every search, whichever entry
 // point issued it); reading them synchronises the device.
-int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks) {
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened) {
     DAWN_TRY(set_device(idx));
     uint32_t st[4] = {0, 0, 0, 0};
     DAWN_HIP_TRY(hipDeviceSynchronize());
     if (idx->d_stats) DAWN_HIP_TRY(hipMemcpy(st, idx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
     if (searches) *searches = idx->n_searches;
-    if (second) *second = st[FLAG_SECOND];
+    if (second) *second = (uint64_t)st[FLAG_SECOND] + st[FLAG_DEEP];
     if (fallbacks) *fallbacks = st[FLAG_FALLBACK];
+    if (deepened) *deepened = st[FLAG_DEEP];
     return DAWN_OK;
 }
 
@@ -617,6 +619,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     };
     if (n == "force_fallback") {
         idx->force_fallback = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "synth_dist") {  // dawn_index_fill_synthetic: 0 the spec's uniform rows, 1 Gaussian, 2 / 3 heavy-tailed
+        if (value < 0 || value > 3) return fail(DAWN_ERR_INVALID_ARG, "synth_dist must be 0..3");
+        idx->synth_dist = (int)value;
         return DAWN_OK;
     }
     if (n == "scan_blocks") {
@@ -1101,8 +1108,15 @@ int dawn_index_stats(dawn_index* idx, uint64_t* searches, uint64_t* fallbacks) {
 // ... plus the queries whose first certificate failed and whose 1024-deep second one held (no exact pass needed)
 int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_chances, uint64_t* fallbacks) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    return idx->shards ? dawn::sharded_stats(idx, searches, second_chances, fallbacks)
-                       : dawn::index_stats_single(idx, searches, second_chances, fallbacks);
+    return idx->shards ? dawn::sharded_stats(idx, searches, second_chances, fallbacks, nullptr)
+                       : dawn::index_stats_single(idx, searches, second_chances, fallbacks, nullptr);
+}
+
+// ... and, of those, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled
+int dawn_index_stats_deep(dawn_index* idx, uint64_t* deepened) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, deepened)
+                       : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, deepened);
 }
 
 int dawn_index_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes) {

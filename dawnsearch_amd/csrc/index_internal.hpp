@@ -85,7 +85,7 @@ struct dawn_index {
     float* d_cand_s = nullptr;
     uint32_t* d_cand_p = nullptr;
     uint32_t* d_flags = nullptr;   // [ws_B] certificate flags | [ws_B] arrival counters of the exact pass
-    uint32_t* d_stats = nullptr;   // [4]: queries that ended with FLAG_FALLBACK ([1]) / FLAG_SECOND ([2]), counted on the device
+    uint32_t* d_stats = nullptr;   // [4]: queries that ended with FLAG_FALLBACK ([1]) / FLAG_SECOND ([2]) / FLAG_DEEP ([3]), counted on the device
     dawn::BatchWorkspace bws{};    // matrix-core batched path (+ per-index "mfma_sched" / "mfma_target")
     int mfma_blocks = 256;   // one 8-wave workgroup per CU
     // B >= this goes to the matrix-core filter (sampled thresholds, one candidate buffer per query); below it the
@@ -107,6 +107,7 @@ struct dawn_index {
     size_t events_used = 0;
     uint64_t n_searches = 0;
     int force_fallback = 0;
+    int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)
 
     // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,
     // recorded behind the last copy out of it
@@ -165,7 +166,7 @@ int index_prepare_search(dawn_index* idx);
 int index_set_option_single(dawn_index* idx, const char* name, int64_t value);
 int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
-int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks);
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened);
 int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total_ms);
 int index_profile_enable_single(dawn_index* idx, int enable);
 
@@ -188,7 +189,7 @@ int sharded_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row, s
 int sharded_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int sharded_set_option(dawn_index* idx, const char* name, int64_t value);
 int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
-int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks);
+int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened);
 int sharded_profile_enable(dawn_index* idx, int enable);
 int sharded_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms);
 int sharded_dtype(const dawn_index* idx);

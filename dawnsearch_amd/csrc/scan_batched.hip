@@ -925,11 +925,12 @@ __global__ __launch_bounds__(256) void scan_f16_pipe_kernel(const unsigned char*
 // keep: only the best `keep` (<= 64) entries of the result are needed (tau_select wants the m-th largest): after its
 // first chunk a wave then inserts just the elements that beat its keep-th best (a handful per chunk) instead of
 // sorting and merging every chunk of 64.
+// excl: only entries strictly worse than (ex_s, ex_p) in (score desc, row asc) order count (the certificate's deeper rounds)
 template <bool DENSE>
 __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, const uint2* __restrict__ cand_q,
                                             const uint32_t* __restrict__ seg_cnt_q, uint32_t count, float& s, uint32_t& p,
                                             float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave, int lane, int nwaves,
-                                            uint32_t keep = LIST) {
+                                            uint32_t keep = LIST, bool excl = false, float ex_s = 0.f, uint32_t ex_p = 0u) {
     s = NEG_INF;
     p = NO_POS;
     bool first = true;
@@ -954,6 +955,10 @@ __device__ __forceinline__ void block_top64(const float* __restrict__ dense_q, c
                 const uint2 v = cand_q[e];
                 d = -__builtin_bit_cast(float, v.x);
                 row = v.y;
+            }
+            if (excl && row != NO_POS && !better(ex_s, ex_p, -d, row)) {
+                d = POS_INF;
+                row = NO_POS;
             }
         }
         if (!first && keep <= 32) {
@@ -1037,55 +1042,31 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
             count += c > SEG_CAP ? SEG_CAP : c;
         }
     }
-    float s;
-    uint32_t p;
-    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
-                       s, p, sh_s, sh_p, wave, lane, 16);
-    const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
+    __shared__ uint32_t sh_ctl[4];
+    auto select = [&](bool first, float ex_s, uint32_t ex_p, float& s, uint32_t& p) {
+        block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
+                           s, p, sh_s, sh_p, wave, lane, 16, LIST, !first, ex_s, ex_p);
+    };
+    // rows that never became candidates scored <= tau in the pass (DENSE: every row is a candidate)
+    const float base = DENSE ? NEG_INF : tau[b];
     const uint32_t found = n_rows < k ? n_rows : k;
-    __shared__ uint32_t sh_second;
+    float bs;
+    uint32_t bp;
+    bool heavy;
+    const uint32_t flag = certify_rounds<RT>(select, base, !overflow, n_rows, found, eps, force_fallback, q + (size_t)b * EM, x,
+                                             rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
     if (wave == 0) {
-        float m = read_lane63(s);  // -inf when fewer than 64 candidates
-        if (!DENSE) {
-            const float t = tau[b];
-            m = (count >= (uint32_t)LIST) ? m : t;
-        }
-        const bool valid = p != NO_POS;
-        float d = POS_INF;
-        if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133
-        sort64_asc(d, p, lane);
-
-        uint32_t flag = FLAG_OK;
-        bool second = false;
-        if (n_rows > (uint32_t)LIST && found > 0) {
-            const uint32_t have = __popcll(__ballot(p != NO_POS));
-            if (have < found || overflow) {
-                flag = FLAG_FALLBACK;
-            } else {
-                // see merge_rescore_kernel: rows outside the shortlist have distance >= fl(1 - up(m + eps))
-                const float t = round_up_f32((double)m + (double)eps);
-                const float d_bound = __fsub_rn(1.0f, t);
-                const float dk =
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
-                if (!(d_bound > dk)) {
-                    flag = FLAG_FALLBACK;
-                    second = !force_fallback;  // the candidates are complete (no overflow): worth a second look
-                }
-            }
-        }
-        if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
-        if ((uint32_t)lane < found && p != NO_POS) {
-            out_labels[(size_t)b * k + lane] = ids[p];
-            out_dist[(size_t)b * k + lane] = d;
+        if ((uint32_t)lane < found && bp != NO_POS) {
+            out_labels[(size_t)b * k + lane] = ids[bp];
+            out_dist[(size_t)b * k + lane] = -bs;
         }
         if (lane == 0) {
             out_found[b] = found;
             out_flags[b] = flag;
-            sh_second = second ? 1u : 0u;
         }
     }
+    if (!heavy) return;
     __syncthreads();
-    if (!sh_second) return;
 
     // ---- second chance (wave_topk.hpp): every row scoring above tau is a candidate (DENSE: every row is one); the
     // 1024 best are rescored exactly
@@ -1123,10 +1104,10 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side: pass planning + launch sequence
 // ------------------------------------------------------------------------------------------------
-BatchPlan plan_batched(uint32_t n_rows, int target) { return plan_batched_tiles(n_rows, TILE_ROWS, target); }
+BatchPlan plan_batched(uint32_t n_rows, int target, uint32_t k) { return plan_batched_tiles(n_rows, TILE_ROWS, target, k); }
 
 // tile_rows: 64 (16-bit tiles) or 128 (int8 tiles, scan_i8.hip): the samples cover the same numbers of ROWS
-BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per_query) {
+BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per_query, uint32_t k) {
     BatchPlan pl{};
     const uint32_t TILE_ROWS = tile_rows;  // (shadows the constant)
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
@@ -1135,17 +1116,30 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per
         pl.dense_only = true;
         return pl;
     }
-    // sample 1: 128 strided tiles (8192 rows), dense
-    pl.s1_tiles = BATCH_CAP / TILE_ROWS;
-    pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1 since n_rows > BATCH_CAP
-    const double target = (double)target_per_query;  // expected candidates per query in the full pass (option "mfma_target")
+    // sample 1: up to 8192 strided rows, dense; tau = the m1-th largest sample score, m1 <= 64 (tau_select reads it off a
+    // top-64 list).  A small index (m_full > 64) samples fewer rows instead, so that the 64th largest of the sample still
+    // sits at the target depth: the candidates' depth is what the certificates rest on (rows that never became candidates
+    // are only known to score <= tau in the pass's own bound — int8: E + K2 ~ 0.017 of slack on unit vectors — so tau has
+    // to lie c_min ~ k exp(slack z / sigma) ranks deep: 75 .. 120 candidates for k = 20 on 1 M .. 100 M rows, 250 .. 390
+    // for k = 64; the sampled estimate of that depth scatters like target x Gamma(m) / m, m = the rank tau is read from).
+    // expected candidates per query in the full pass (option "mfma_target"; twice that for k > 32)
+    const double target = (double)target_per_query * (k > 32 ? 2.0 : 1.0);
     const double m_full = target * BATCH_CAP / (double)n_rows;
-    // one sample is enough while the threshold can be read from at least the 4th largest sample score (n <= 1 M rows at
-    // target 512): the candidate count of the full pass then follows target/4 x Gamma(4) — below the 64 the shortlist
-    // wants for 0.2 % of the queries (their certificate then rests on tau itself), never near the buffers' capacity
-    if (m_full >= 4.0) {
-        pl.m1 = (uint32_t)(m_full + 0.999);
+    uint32_t s1_rows = BATCH_CAP;
+    if (m_full > (double)LIST) {
+        s1_rows = (uint32_t)((double)BATCH_CAP * (double)LIST / m_full);
+        if (s1_rows < 8u * TILE_ROWS) s1_rows = 8u * TILE_ROWS;
+    }
+    pl.s1_tiles = (s1_rows + TILE_ROWS - 1) / TILE_ROWS;
+    if (pl.s1_tiles > n_tiles) pl.s1_tiles = n_tiles;
+    pl.s1_stride = n_tiles / pl.s1_tiles;  // >= 1
+    // one sample is enough while the threshold can be read from at least the 8th largest sample score (n <= 1 M rows at
+    // target 1024): the candidate count of the full pass then follows target/8 x Gamma(8) — below c_min once in > 10^5
+    if (m_full >= 8.0) {
+        const double m_s = target * (double)(pl.s1_tiles * TILE_ROWS) / (double)n_rows;
+        pl.m1 = (uint32_t)(m_s + 0.999);
         if (pl.m1 > (uint32_t)LIST) pl.m1 = LIST;
+        if (pl.m1 < 1) pl.m1 = 1;
         pl.s2_tiles = 0;
         return pl;
     }
@@ -1166,7 +1160,7 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per
     double m2 = target * n2 / (double)n_rows;
     pl.m2 = (uint32_t)(m2 + 0.999);
     if (pl.m2 < 8) pl.m2 = 8;
-    if (pl.m2 > (uint32_t)LIST) pl.m2 = LIST;
+    if (pl.m2 > (uint32_t)LIST) pl.m2 = LIST;  // (target 1024: m2 = 16 while sample 2 is n / 64 rows)
     return pl;
 }
 
@@ -1321,7 +1315,7 @@ void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipS
 // Timing hook: the full append pass alone (thresholds ws.tau as left by the last search), `iters` times.
 void launch_batched_full_pass(const void* d_frows, int frt, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                               int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched(n_rows, ws.target);
+    const BatchPlan pl = plan_batched(n_rows, ws.target, 10);
     (void)hipEventRecord(ev0, stream);
     for (int i = 0; i < iters; ++i) {
         (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
@@ -1385,7 +1379,7 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
                          const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels,
                          float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
                          hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched(n_rows, ws.target);
+    const BatchPlan pl = plan_batched(n_rows, ws.target, k);
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     prep_queries(d_q, B, ws, frt, stream);

@@ -24,6 +24,19 @@
 //     the exact side's gamma_384 * 1.0201 * 1.004 = 2.35e-5 stays inside FILTER_EPS_I8.
 //   * the hot loop never leaves the integers: the lane's list threshold tau is turned into an integer threshold once
 //     per sub-tile (5 VALU), conservatively (rows it passes are re-tested on ub itself).
+//   * THE SHADOW LIVES IN A ROTATED BASIS.  E grows with max|x| of a sub-tile (s = max|x| / 127), and sentence embeddings
+//     are heavy-tailed: a few dimensions are several times larger than the rest.  Measured on 100 M synthetic rows with 4
+//     dimensions x5 (tools/cert_stats.py, profiles/r02/cert_stats_*.log): without the rotation 73-94 % of the queries of a
+//     256-batch failed both certificates and took the exact pass — 7-9 SECONDS per batch instead of 10 ms.  Rows and
+//     queries are therefore multiplied by one fixed orthogonal matrix R before they are quantised (the filter only needs
+//     x.q = (Rx).(Rq)):  R = (H_128 / sqrt(128) (x) I_3) . (M_3 (x) I_128) . diag(+-1)  — pseudo-random signs, the
+//     orthogonal 3x3 mix M_3 = (2/3) J - I across the three 128-blocks, a 128-point Walsh-Hadamard transform in each block:
+//     every output is a signed sum of all 384 inputs, so one large dimension is spread evenly (x a / sqrt(384)) and
+//     whatever the data looked like, the quantiser sees near-Gaussian components with max|x'| ~ 4 / sqrt(384).  13 adds
+//     per element, in registers (DPP / permlane butterflies across lanes), at conversion and query-preparation time; the
+//     scans themselves are unchanged.  Its f32 rounding (<= 1.1e-6 ||x|| per vector: 7 butterfly stages, the 3x3 mix, the
+//     scale) is part of FILTER_EPS_I8.  Correctness never depends on what the rotation achieves: E and K2 are measured on
+//     the rotated values.
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -33,6 +46,98 @@ namespace dawn {
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+// ---- the rotation R -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rot_neg(uint32_t k) { return ((k * 0x9E3779B1u) >> 19) & 1u; }  // sign of element k
+constexpr float ROT_SCALE = 0.08838834764831845f;  // 1 / sqrt(128)
+
+// One wavefront, lane l holds v[j] = element l + 64 j (j = 0..5) of a 384-vector: v <- R v.  Block b = elements
+// 128 b .. 128 b + 127 = v[2b], v[2b+1]; index inside the block = l + 64 (j & 1): bit 6 in-thread, bits 0..5 across lanes.
+__device__ __forceinline__ void rotate384_wave(float (&v)[6], int lane) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (rot_neg((uint32_t)(lane + 64 * j))) v[j] = -v[j];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // M_3 = (2/3) J - I on (block 0, block 1, block 2), element by element
+        const float m = (v[t] + v[t + 2] + v[t + 4]) * (2.0f / 3.0f);
+        v[t] = m - v[t];
+        v[t + 2] = m - v[t + 2];
+        v[t + 4] = m - v[t + 4];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float a0 = v[2 * b], a1 = v[2 * b + 1];
+        v[2 * b] = a0 + a1;
+        v[2 * b + 1] = a0 - a1;
+    }
+    auto stage = [&](auto st) {
+        constexpr int O = decltype(st)::value;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float o = lane_xor_f32<O>(v[j], lane);
+            v[j] = (lane & O) ? o - v[j] : v[j] + o;
+        }
+    };
+    stage(std::integral_constant<int, 1>());
+    stage(std::integral_constant<int, 2>());
+    stage(std::integral_constant<int, 4>());
+    stage(std::integral_constant<int, 8>());
+    stage(std::integral_constant<int, 16>());
+    stage(std::integral_constant<int, 32>());
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] *= ROT_SCALE;
+}
+
+// The conversion kernel's layout: thread (row r, part = tid & 7) holds v[j] = elements 32 j + 4 part + {0,1,2,3}
+// (j = 0..11).  Block b = v[4b .. 4b+3]; index inside the block = 32 (j & 3) + 4 part + i: bits 0-1 in the float4, bits 2-4
+// across the 8 neighbouring lanes, bits 5-6 in-thread.
+__device__ __forceinline__ void rotate384_rowpart(f32x4 (&v)[12], uint32_t part, int lane) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const uint32_t k = 32u * j + 4u * part;
+        if (rot_neg(k + 0)) v[j].x = -v[j].x;
+        if (rot_neg(k + 1)) v[j].y = -v[j].y;
+        if (rot_neg(k + 2)) v[j].z = -v[j].z;
+        if (rot_neg(k + 3)) v[j].w = -v[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 m = (v[j] + v[j + 4] + v[j + 8]) * (2.0f / 3.0f);
+        v[j] = m - v[j];
+        v[j + 4] = m - v[j + 4];
+        v[j + 8] = m - v[j + 8];
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {  // bits 0, 1: inside the float4
+        f32x4 a = v[j];
+        a = f32x4{a.x + a.y, a.x - a.y, a.z + a.w, a.z - a.w};
+        v[j] = f32x4{a.x + a.z, a.y + a.w, a.x - a.z, a.y - a.w};
+    }
+    auto stage = [&](auto st) {  // bits 2..4: lanes part ^ 1, 2, 4
+        constexpr int O = decltype(st)::value;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            f32x4 o;
+            o.x = lane_xor_f32<O>(v[j].x, lane);
+            o.y = lane_xor_f32<O>(v[j].y, lane);
+            o.z = lane_xor_f32<O>(v[j].z, lane);
+            o.w = lane_xor_f32<O>(v[j].w, lane);
+            v[j] = (lane & O) ? o - v[j] : v[j] + o;
+        }
+    };
+    stage(std::integral_constant<int, 1>());
+    stage(std::integral_constant<int, 2>());
+    stage(std::integral_constant<int, 4>());
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {  // bits 5, 6: v[4b + (0..3)]
+        f32x4 a0 = v[4 * b], a1 = v[4 * b + 1], a2 = v[4 * b + 2], a3 = v[4 * b + 3];
+        const f32x4 b0 = a0 + a1, b1 = a0 - a1, b2 = a2 + a3, b3 = a2 - a3;
+        v[4 * b] = (b0 + b2) * ROT_SCALE;
+        v[4 * b + 1] = (b1 + b3) * ROT_SCALE;
+        v[4 * b + 2] = (b0 - b2) * ROT_SCALE;
+        v[4 * b + 3] = (b1 - b3) * ROT_SCALE;
+    }
+}
 
 constexpr float I8_QRES = 2.0e-3f;                   // |dq_i| <= I8_QRES * s_q
 constexpr float I8_K2_PER_SQ = 1.1f * 19.6f * I8_QRES;  // K2 = I8_K2_PER_SQ * s_q  (sqrt(384) < 19.6)
@@ -66,6 +171,7 @@ __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict
             }
         }
     }
+    rotate384_rowpart(v, part, lane);  // (rows past n_valid stay zero)
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 12; ++j)
@@ -165,8 +271,19 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const int qcol = (int)(c & 7u);
     const bool lo_part = c >= 8;
     float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;  // this lane's query: s_q / 254, K2, 254 / s_q
+    // the queries in the shadow's basis: wave w rotates queries w, w + nwaves, ... into LDS
+    __shared__ __attribute__((aligned(16))) float sh_q[QB * EM];
+    for (int b = wave; b < n_q; b += nwaves) {
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = q[(size_t)b * EM + lane + 64 * j];
+        rotate384_wave(v, lane);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sh_q[b * EM + lane + 64 * j] = v[j];
+    }
+    __syncthreads();
     if (qcol < n_q && c < 16) {
-        const f32x4* qc = reinterpret_cast<const f32x4*>(q + (size_t)qcol * EM);
+        const f32x4* qc = reinterpret_cast<const f32x4*>(sh_q + (size_t)qcol * EM);
         float amax = 0.f;
         for (int i = 0; i < ROW_F4; ++i) {
             const f32x4 v = qc[i];
@@ -369,6 +486,7 @@ __global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __rest
     float v[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) v[j] = b < n_q ? q[(size_t)b * EM + lane + 64 * j] : 0.f;
+    rotate384_wave(v, lane);  // the shadow's basis (header of this file)
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
@@ -832,7 +950,7 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
 // Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
 void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                                  int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target);
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target, 10);
     const signed char* qi = reinterpret_cast<const signed char*>(ws.qh);
     const float2* qm = reinterpret_cast<const float2*>(qi + (size_t)BATCH_QT * EM);
     const uint32_t blocks = pl.n_tiles_total < (uint32_t)grid ? pl.n_tiles_total : (uint32_t)grid;
@@ -864,7 +982,7 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
                             uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
                             uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target);
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target, k);
     signed char* qi = reinterpret_cast<signed char*>(ws.qh);               // [256][384] int8
     float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);     // [256] {s_q, K2}
     hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(BATCH_QT), dim3(64), 0, stream, d_q, B, qi, qm);

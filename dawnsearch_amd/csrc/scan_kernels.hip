@@ -416,73 +416,74 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
 
-    float s = NEG_INF;
-    uint32_t p = NO_POS;
     const float* cs = cand_s + (size_t)b * n_lists * LIST;
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
-    constexpr int INF = 16;  // lists in flight per wave: the usual 256 lists are ONE round of loads
-    for (int l0 = wave; l0 < n_lists; l0 += INF * nwaves) {
-        float os[INF];
-        uint32_t op[INF];
+    __shared__ uint32_t sh_ctl[4];
+    // the next 64 candidates by filter score among the per-workgroup lists
+    auto select = [&](bool first, float ex_s, uint32_t ex_p, float& s, uint32_t& p) {
+        s = NEG_INF;
+        p = NO_POS;
+        constexpr int INF = 16;  // lists in flight per wave: the usual 256 lists are ONE round of loads
+        for (int l0 = wave; l0 < n_lists; l0 += INF * nwaves) {
+            float os[INF];
+            uint32_t op[INF];
 #pragma unroll
-        for (int j = 0; j < INF; ++j) {
-            const int l = l0 + j * nwaves;
-            os[j] = l < n_lists ? cs[(size_t)l * LIST + 63 - lane] : NEG_INF;
-            op[j] = l < n_lists ? cp[(size_t)l * LIST + 63 - lane] : NO_POS;
-        }
+            for (int j = 0; j < INF; ++j) {
+                const int l = l0 + j * nwaves;
+                os[j] = l < n_lists ? cs[(size_t)l * LIST + 63 - lane] : NEG_INF;
+                op[j] = l < n_lists ? cp[(size_t)l * LIST + 63 - lane] : NO_POS;
+            }
 #pragma unroll
-        for (int j = 0; j < INF; ++j)
-            if (l0 + j * nwaves < n_lists) merge64(s, p, os[j], op[j], lane);  // wave-uniform
-    }
-    block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
-    // shortlist (wave 0): 64 best rows by filter score; every wave helps to fetch them for the exact rescore
-    const float dot = block_exact_dots<RT>(q + (size_t)b * EM, x, p, rescore_stage, sh_rows, wave, lane);
-    const uint32_t found = n_rows < k ? n_rows : k;
-    __shared__ uint32_t sh_second;
-    if (wave == 0) {
-        // m (the worst score that made it) bounds the filter score of every row NOT in the shortlist.
-        const float m = read_lane63(s);
-        const bool valid = p != NO_POS;
-        float d = POS_INF;
-        if (valid) d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
-        sort64_asc(d, p, lane);
-
-        uint32_t flag = FLAG_OK;
-        if (n_rows > LIST && found > 0) {
-            // Any row r outside the shortlist has filter score <= m, hence exact dot <= m + eps, hence
-            // distance fl(1 - dot_r) >= fl(1 - up(m + eps)) =: d_bound.  If d_bound > d_k (strictly, so that
-            // not even a tie on the rounded distance is possible) the exact top-k lies inside the shortlist.
-            const float t = round_up_f32((double)m + (double)eps);
-            const float d_bound = __fsub_rn(1.0f, t);
-            const float dk = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), (int)found - 1));
-            if (!(d_bound > dk)) flag = FLAG_FALLBACK;
+            for (int j = 0; j < INF; ++j) {
+                if (l0 + j * nwaves >= n_lists) continue;  // wave-uniform
+                if (!first) {
+                    // entries down to the last one already rescored drop out: they are a prefix of the (descending) list,
+                    // so the survivors are sorted again with the fillers moved behind them
+                    float d = POS_INF;
+                    uint32_t row = NO_POS;
+                    if (op[j] != NO_POS && better(ex_s, ex_p, os[j], op[j])) {
+                        d = -os[j];
+                        row = op[j];
+                    }
+                    sort64_asc(d, row, lane);
+                    os[j] = -__shfl(d, 63 - lane);
+                    op[j] = __shfl(row, 63 - lane);
+                }
+                merge64(s, p, os[j], op[j], lane);
+            }
         }
-        const bool second = flag == FLAG_FALLBACK && !force_fallback;
-        if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
-        if ((uint32_t)lane < found) {
-            out_labels[(size_t)b * k + lane] = ids[p];
-            out_dist[(size_t)b * k + lane] = d;
-        }
-        if (lane == 0) {
-            out_found[b] = found;
-            out_flags[b] = flag;
-            sh_second = second ? 1u : 0u;
-        }
-    }
-    __syncthreads();
-    if (!sh_second) return;
-
-    // ---- second chance (wave_topk.hpp): the union of the workgroup lists holds every row whose filter score exceeds
-    // T = the largest 64th entry of any list; its 1024 best are rescored exactly
+        block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+    };
+    // rows in no list scored <= T = the largest 64th entry of any list (round 1: the merged 64th entry is >= T anyway)
     float tmax = NEG_INF;
     for (int l = threadIdx.x; l < n_lists; l += blockDim.x) tmax = fmaxf(tmax, cs[(size_t)l * LIST + 63]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-    if (lane == 0) sh_s[wave][0] = tmax;
+    __shared__ float sh_t[16];
+    if (lane == 0) sh_t[wave] = tmax;
     __syncthreads();
     float T = NEG_INF;
-    for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_s[w][0]);
+    for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_t[w]);
+    const uint32_t found = n_rows < k ? n_rows : k;
+    float bs;
+    uint32_t bp;
+    bool heavy;
+    const uint32_t flag = certify_rounds<RT>(select, T, true, n_rows, found, eps, force_fallback, q + (size_t)b * EM, x,
+                                             rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
+    if (wave == 0) {
+        if ((uint32_t)lane < found && bp != NO_POS) {
+            out_labels[(size_t)b * k + lane] = ids[bp];
+            out_dist[(size_t)b * k + lane] = -bs;
+        }
+        if (lane == 0) {
+            out_found[b] = found;
+            out_flags[b] = flag;
+        }
+    }
+    if (!heavy) return;
+
+    // ---- second chance (wave_topk.hpp): the union of the workgroup lists holds every row whose filter score exceeds T;
+    // its 1024 best are rescored exactly
     __syncthreads();
     auto load = [&](uint32_t e, float& sc, uint32_t& row) {
         sc = cs[e];
@@ -746,33 +747,56 @@ __device__ __forceinline__ float synth_uniform(uint64_t key, uint64_t idx) {
     return __fmul_rn((float)nn, 1.0f / 16777216.0f);
 }
 
+// Bench / test distributions other than the spec's uniform rows (option "synth_dist"; device-generated, NOT restated on the
+// CPU: the bench legs that use them check planted rows fetched back from the index, not an oracle scan):
+//   1  Gaussian components (Box-Muller over two uniforms of the stream): what a random rotation makes of any embedding
+//   2  heavy-tailed, fixed dimensions: Gaussian with dimensions {7, 101, 213, 340} scaled x5 — sentence-embedding models
+//      have a handful of dimensions that are large in every vector
+//   3  heavy-tailed, per-row dimensions: Gaussian with 4 pseudo-random dimensions per row scaled x5
+template <int DIST>
+__device__ __forceinline__ float synth_value(uint64_t key, uint64_t row, uint32_t col) {
+    const uint64_t idx = row * (uint64_t)EM + col;
+    if (DIST == 0) return synth_uniform(key, idx);
+    const float u1 = synth_uniform(key, 2 * idx), u2 = synth_uniform(key, 2 * idx + 1);
+    const float a = 0.5f * u1 + 0.5f;  // (0, 1)
+    float g = sqrtf(-2.0f * __logf(a)) * __cosf(3.14159265f * u2);
+    if (DIST == 2 && (col == 7u || col == 101u || col == 213u || col == 340u)) g *= 5.0f;
+    if (DIST == 3) {
+        const uint64_t hsh = splitmix64(key ^ (row * 0xD1B54A32D192ED03ULL));
+        if (col == (uint32_t)(hsh % EM) || col == (uint32_t)((hsh >> 16) % EM) || col == (uint32_t)((hsh >> 32) % EM) ||
+            col == (uint32_t)((hsh >> 48) % EM))
+            g *= 5.0f;
+    }
+    return g;
+}
+
 // pass 1: per-row length, sequential sum of squares (vector.rs:195)
+template <int DIST>
 __global__ void synth_len_kernel(uint64_t key, uint64_t first_row, uint32_t n, float* __restrict__ len) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint64_t base = (first_row + r) * (uint64_t)EM;
     float s = 0.0f;
     for (int c = 0; c < EM; ++c) {
-        const float v = synth_uniform(key, base + c);
+        const float v = synth_value<DIST>(key, first_row + r, (uint32_t)c);
         s = __fadd_rn(s, __fmul_rn(v, v));
     }
     len[r] = sqrtf(s);
 }
 
 // pass 2: coalesced write of v / len (vector.rs:196)
+template <int DIST>
 __global__ void synth_write_kernel(uint64_t key, uint64_t first_row, uint32_t n, const float* __restrict__ len,
                                    f32x4* __restrict__ out) {
     const size_t total = (size_t)n * ROW_F4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(i / ROW_F4);
         const uint32_t c = (uint32_t)(i % ROW_F4);
-        const uint64_t base = (first_row + r) * (uint64_t)EM + c * 4u;
         const float l = len[r];
         f32x4 v;
-        v.x = synth_uniform(key, base + 0) / l;
-        v.y = synth_uniform(key, base + 1) / l;
-        v.z = synth_uniform(key, base + 2) / l;
-        v.w = synth_uniform(key, base + 3) / l;
+        v.x = synth_value<DIST>(key, first_row + r, c * 4u + 0u) / l;
+        v.y = synth_value<DIST>(key, first_row + r, c * 4u + 1u) / l;
+        v.z = synth_value<DIST>(key, first_row + r, c * 4u + 2u) / l;
+        v.w = synth_value<DIST>(key, first_row + r, c * 4u + 3u) / l;
         out[i] = v;
     }
 }
@@ -830,16 +854,26 @@ static uint64_t host_splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_out, float* d_len,
-                       hipStream_t stream) {
-    if (n == 0) return;
-    const uint64_t key = host_splitmix64(seed);
-    hipLaunchKernelGGL(synth_len_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, first_row, n, d_len);
+template <int DIST>
+static void fill_synth_dist(uint64_t key, uint64_t first_row, uint32_t n, float* d_out, float* d_len, hipStream_t stream) {
+    hipLaunchKernelGGL(synth_len_kernel<DIST>, dim3((n + 255) / 256), dim3(256), 0, stream, key, first_row, n, d_len);
     const size_t total = (size_t)n * ROW_F4;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(synth_write_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, key, first_row, n, d_len,
+    hipLaunchKernelGGL(synth_write_kernel<DIST>, dim3((unsigned)blocks), dim3(256), 0, stream, key, first_row, n, d_len,
                        reinterpret_cast<f32x4*>(d_out));
+}
+
+void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_out, float* d_len, int dist,
+                       hipStream_t stream) {
+    if (n == 0) return;
+    const uint64_t key = host_splitmix64(seed);
+    switch (dist) {
+        case 1: fill_synth_dist<1>(key, first_row, n, d_out, d_len, stream); break;
+        case 2: fill_synth_dist<2>(key, first_row, n, d_out, d_len, stream); break;
+        case 3: fill_synth_dist<3>(key, first_row, n, d_out, d_len, stream); break;
+        default: fill_synth_dist<0>(key, first_row, n, d_out, d_len, stream); break;
+    }
 }
 
 __global__ void iota_u64_kernel(uint64_t* out, uint64_t first, uint32_t n) {

@@ -297,6 +297,109 @@ __device__ __forceinline__ float round_up_f32(double t) {
 
 
 // ------------------------------------------------------------------------------------------------
+// The certificate loop shared by the search tails (merge_rescore_kernel: streaming filters; select_rescore_kernel:
+// matrix-core passes).
+//
+// Round 1: the 64 best candidates by FILTER score are rescored exactly (reference order); every other row is known to
+// score <= m = the 64th filter score (or `base`, the bound the filter pass itself gives for rows that never became
+// candidates), hence to lie at distance >= fl(1 - up(m + eps)); if that exceeds the k-th exact distance strictly, the
+// exact top-k is inside the shortlist.  The int8 filters' scores are upper bounds with E (+ K2) ~ 0.009 .. 0.017 of slack
+// on unit vectors — the order of the gap between the 20th and the 64th best score of a large index — so a marginal
+// failure is ordinary there (tools/cert_stats.py: k = 20 on 100 M rows fails round 1 for 10 .. 100 % of the queries).
+// Instead of the 1024-row second chance below (a radix selection and 1024 uncoalesced row walks: 0.1 - 0.2 ms) the loop
+// DEEPENS: round r + 1 takes the next 64 candidates by filter score (selection repeated with everything down to the last
+// entry of round r excluded), rescores them the same cooperative way (block_exact_dots: ~4 us), merges the exact results
+// and tries the certificate with the bound 64 ranks further down — up to CERT_ROUNDS x 64 rows.  Same mathematics as
+// round 1, each round ~10 us.
+//   select(first, ex_s, ex_p, s, p): called by every thread; leaves in wave 0 the (up to) 64 best candidates by filter
+//   score (descending, ties -> lower row; fillers (-inf, NO_POS) last) among those strictly worse than (ex_s, ex_p)
+//   (first: among all).
+// Returns the flag; wave 0 holds the result in (bs = -distance descending, bp = row).  heavy: the rounds are used up (or
+// the candidates ran out above `base`) — the caller may still try second_chance().
+// ------------------------------------------------------------------------------------------------
+constexpr int CERT_ROUNDS = 4;
+
+template <int RT, class SelectFn>
+__device__ __forceinline__ uint32_t certify_rounds(SelectFn select, float base, bool complete, uint32_t n_rows, uint32_t found,
+                                                   float eps, int force_fallback, const float* __restrict__ qv,
+                                                   const void* __restrict__ x, unsigned char* rescore_stage, uint32_t* sh_rows,
+                                                   uint32_t* sh_ctl, int wave, int lane, float& bs, uint32_t& bp, bool& heavy) {
+    float s;
+    uint32_t p;
+    select(true, 0.f, 0u, s, p);
+    bs = NEG_INF;
+    bp = NO_POS;
+    uint32_t flag = FLAG_OK;
+    heavy = false;
+    for (int r = 0;; ++r) {
+        const float dot = block_exact_dots<RT>(qv, x, p, rescore_stage, sh_rows, wave, lane);
+        if (wave == 0) {
+            const uint32_t have_r = __popcll(__ballot(p != NO_POS));
+            const float s_last = read_lane63(s);
+            const uint32_t p_last = (uint32_t)__builtin_amdgcn_readlane((int)p, 63);
+            float d = POS_INF;
+            uint32_t pr = p;
+            if (p != NO_POS) {
+                d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+                if (!(d == d)) {
+                    d = POS_INF;
+                    pr = NO_POS;
+                }
+            }
+            sort64_asc(d, pr, lane);
+            if (r == 0) {
+                bs = -d;
+                bp = pr;
+            } else {
+                const float os = -__shfl(d, 63 - lane);
+                const uint32_t op = __shfl(pr, 63 - lane);
+                merge64(bs, bp, os, op, lane);
+            }
+            // bound on the filter score of everything not rescored so far
+            const float m = have_r == (uint32_t)LIST ? fmaxf(s_last, base) : base;
+            uint32_t next = 0;
+            flag = FLAG_OK;
+            if (n_rows > (uint32_t)LIST && found > 0) {
+                const uint32_t have = __popcll(__ballot(bp != NO_POS));
+                if (have < found || !complete) {
+                    flag = FLAG_FALLBACK;  // not enough candidates / candidates were dropped: only the exact pass can tell
+                } else if (m > NEG_INF) {
+                    const float t = round_up_f32((double)m + (double)eps);
+                    const float d_bound = __fsub_rn(1.0f, t);
+                    const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bs), (int)found - 1));
+                    if (!(d_bound > dk)) {
+                        flag = FLAG_FALLBACK;
+                        // worth another round: there are candidates left above `base`
+                        if (!force_fallback && have_r == (uint32_t)LIST && s_last > base) next = (r + 1 < CERT_ROUNDS) ? 1u : 2u;
+                        else if (!force_fallback) next = 2u;
+                    }
+                }
+            }
+            if (flag == FLAG_OK && r > 0) flag = FLAG_DEEP;
+            if (lane == 0) {
+                sh_ctl[0] = next;
+                sh_ctl[1] = __builtin_bit_cast(uint32_t, s_last);
+                sh_ctl[2] = p_last;
+                sh_ctl[3] = flag;
+            }
+        }
+        __syncthreads();
+        const uint32_t next = sh_ctl[0];
+        const float ex_s = __builtin_bit_cast(float, sh_ctl[1]);
+        const uint32_t ex_p = sh_ctl[2];
+        flag = sh_ctl[3];
+        __syncthreads();
+        if (next != 1u) {
+            heavy = next == 2u;
+            break;
+        }
+        select(false, ex_s, ex_p, s, p);
+    }
+    if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
+    return flag;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Second chance of a failed certificate.  The first certificate bounds everything outside a 64-row shortlist by the
 // 64th filter score; it fails when more than ~54 rows crowd the top of a query within the filter's error band (near-
 // duplicate pages, k = 64).  Before the whole index is rescanned exactly, the candidates the filter pass left behind are

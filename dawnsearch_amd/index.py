@@ -135,7 +135,10 @@ class VectorIndex:
         f = C.c_uint64(0)
         c2 = C.c_uint64(0)
         check(lib.dawn_index_stats_ext(self._h, C.byref(s), C.byref(c2), C.byref(f)))
-        return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value}
+        dp = C.c_uint64(0)
+        check(lib.dawn_index_stats_deep(self._h, C.byref(dp)))
+        # second_chances: the 64-row certificate failed, no exact pass needed; deepened: those settled by a deeper round
+        return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value}
 
     def memory(self):
         """HBM bytes held by the index: rows, filter shadows built so far, everything else."""

@@ -156,8 +156,11 @@ int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_m
 /* Counters: searches that needed the exact fallback pass (certificate failed).  Counted on the device at the end of every
  * search, whichever entry point issued it (host API or dawn_index_search_device); reading synchronises the device. */
 int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
-/* ... and searches whose 64-row certificate failed but whose 1024-row second certificate held (no exact pass). */
+/* ... and searches whose 64-row certificate failed but a deeper one held (no exact pass): deeper rounds of the same
+ * certificate (128 .. 256 rows) or, after those, the 1024-row second chance. */
 int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_chances, uint64_t *fallbacks);
+/* ... of the second_chances, those a deeper round settled (the cheap kind: ~10 us per round). */
+int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
  * so far (int8: 384 B/row + 8 B per 32 rows; f16: 768 B/row), everything else (labels, search workspaces, staging). */
 int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
@@ -179,7 +182,7 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *                      0 = lockstep converting kernel on the f32 rows.  (The timing experiments 2 / 41..55 — parts of the
  *                      pipelined kernels switched off, wrong results by design — only exist in `make EXPERIMENTS=1`
  *                      builds; the release library rejects them.)
- *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (512)
+ *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (1024; twice that for count > 32)
  *   "i8_shadow"        0: no int8 shadow (384 B/row, scan_i8.hip) of the index rows: the filters read the f16 shadow of
  *                      an f32 index / the rows of a bf16 index themselves.  Default 1, or env DAWN_I8_SHADOW at creation
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
@@ -187,7 +190,9 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow
  *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
  *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the shadow fragment streams
- *   "force_fallback"   1: every query also takes the exact pass (tests) */
+ *   "force_fallback"   1: every query also takes the exact pass (tests)
+ *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
+ *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -144,11 +144,11 @@ def test_bf16_filter_errors_within_their_bounds(dawn):
     # the int8 shadow of the bf16 rows (default): every filter score bounds the exact dot of the STORED row from above
     ub = idx.debug_filter_scores(Q)
     slack = ub.astype(np.float64) - Q.astype(np.float64) @ stored.T
-    assert slack.min() > -1e-6 and np.median(slack) < 0.015, (slack.min(), np.median(slack))
+    assert slack.min() > -4e-6 and np.median(slack) < 0.02 and slack.max() < 0.03, (slack.min(), np.median(slack), slack.max())
     for q in Q[:4]:
         sc, rr = idx.debug_stream_lists(q)
         valid = rr != 0xFFFFFFFF
-        assert (sc[valid].astype(np.float64) - stored[rr[valid].astype(np.int64)] @ q.astype(np.float64)).min() > -1e-6
+        assert (sc[valid].astype(np.float64) - stored[rr[valid].astype(np.int64)] @ q.astype(np.float64)).min() > -4e-6
     idx.set_option("i8_shadow", 0)
     # matrix-core pass on the bf16 rows themselves: dense scores of every row
     f = idx.debug_filter_scores(Q)

@@ -331,7 +331,16 @@ def test_batched_scan_matches_oracle(dawn, oracle, n, B, k, shadow):
     # k == shortlist length (64) leaves no margin for the 64-row certificate: those searches are decided by the
     # 1024-row second certificate (every candidate above the threshold rescored exactly), not by the exact pass
     st = idx.stats()
-    assert st["fallbacks"] == 0 and st["second_chances"] == (B if (k >= 64 and n > 64) else 0)
+    # k = 64 leaves the 64-row certificate no room: every query takes the 1024-row one.  k = 20: the int8 bound's slack
+    # (E ~ 0.009 in the rotated basis, + K2 on a dense-only index) is of the order of the gap between the 20th and the
+    # 64th best score, so some queries do; k <= 10: none.  Never an exact pass.
+    assert st["fallbacks"] == 0
+    if k >= 64 and n > 64:
+        assert st["second_chances"] == B
+    elif k <= 10 or shadow != "i8":
+        assert st["second_chances"] == 0
+    else:
+        assert st["second_chances"] <= B and st["deepened"] == st["second_chances"]  # settled by a deeper round
 
 
 def test_batched_1m_batch256(dawn, oracle, shadow):
@@ -407,9 +416,10 @@ def test_int8_batched_scores_are_upper_bounds(dawn):
     assert f.shape == (len(Q), len(rows))
     exact = Q.astype(np.float64) @ rows.astype(np.float64).T
     slack = f.astype(np.float64) - exact
-    assert slack.min() > -1e-6, slack.min()
-    # ordinary query x sub-tile without special rows: E + K2 ~ 0.01
-    assert np.median(slack[:40]) < 0.015 and slack.max() < 0.25, (np.median(slack[:40]), slack.max())
+    assert slack.min() > -4e-6, slack.min()  # (-: the f32 rounding of the rotation the shadow lives in, scan_i8.hip)
+    # E + K2 ~ 0.017 in the rotated basis — for EVERY kind of row and query: one-hot / sparse rows no longer stretch the
+    # quantiser of their sub-tile (before the rotation: up to 0.25)
+    assert np.median(slack[:40]) < 0.02 and slack.max() < 0.03, (np.median(slack[:40]), slack.max())
 
 
 @pytest.mark.parametrize("shadow", ["f16", "i8"])
@@ -436,7 +446,7 @@ def test_stream_filter_lists_hold_the_top64(dawn, n, shadow):
         if shadow == "f16":
             assert np.abs(diff).max() < 1.25e-3 / 2
         else:
-            assert diff.min() > -1e-6 and diff.max() < 0.02, (diff.min(), diff.max())
+            assert diff.min() > -4e-6 and diff.max() < 0.02, (diff.min(), diff.max())
         for b in range(len(sc)):  # descending inside a list, fillers last
             nv = int(valid[b].sum())
             assert np.all(valid[b][:nv]) and np.all(np.diff(sc[b][:nv]) <= 0)
@@ -447,7 +457,7 @@ def test_stream_filter_lists_hold_the_top64(dawn, n, shadow):
                 need = need[exact[need] > exact[order[63]] + 2 * 1.25e-3]
             else:
                 T = sc[:, 63].max()
-                need = np.nonzero(exact > T + 1e-6)[0]
+                need = np.nonzero(exact > T + 4e-6)[0]
         assert set(need.tolist()) <= set(got.tolist())
 
 
@@ -490,7 +500,7 @@ def test_int8_shadow_bounds_and_results_on_adversarial_rows(dawn, oracle, n_base
         valid = lr != 0xFFFFFFFF
         got = lr[valid].astype(np.int64)
         exact = rows[got].astype(np.float64) @ q.astype(np.float64)
-        assert (sc[valid].astype(np.float64) - exact).min() > -1e-6
+        assert (sc[valid].astype(np.float64) - exact).min() > -4e-6
     for k in (10, 20):
         for B in (1, 2, 3):
             for j in range(0, len(Q), B):
@@ -561,7 +571,7 @@ def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, sha
     assert labels[3][0] == 12 and list(labels[3][1:4]) == [3001, 3002, 3003]
     # 301 identical rows at the top: the 64-row certificate cannot hold, the 1024-row one does — no exact pass
     st = idx.stats()
-    assert st["fallbacks"] == 0 and st["second_chances"] == 1
+    assert st["fallbacks"] == 0 and (st["second_chances"] == 1 if shadow != "i8" else 1 <= st["second_chances"] <= 8)
     # 1500 identical rows are more than the second certificate looks at: the exact pass decides, same answer
     rows3 = np.concatenate([base, np.repeat(base[11:12], 1500, axis=0)])
     ids3 = np.arange(1, len(rows3) + 1, dtype=np.uint64)
