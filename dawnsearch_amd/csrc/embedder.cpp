@@ -427,4 +427,46 @@ int dawn_embedder_hidden_states(dawn_embedder* e, const uint32_t* token_ids, con
     return DAWN_OK;
 }
 
+// Test hook: ONE kernel of the forward in isolation, so that a3 / a5 / a7 of SURVEY 8(a) have their own parity tests:
+//   op 0  BertEmbeddings (model.rs:266-281): token_ids [T] (one sequence, positions 0..T-1) -> out [T][384]
+//   op 1  LayerNorm(a + r) with layer 0's attention-output LayerNorm (model.rs:86-104,378): in = a [T][384] | r [T][384]
+//   op 2  layer 0's intermediate dense + activation (model.rs:425-430, HiddenActLayer :28-37): in [T][384] -> [T][1536]
+//   op 3  the same GEMM through the 64x64 tile kernel regardless of T (op 2 takes the skinny form for T <= 640)
+int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, float* out) {
+    if (!e || !in || !out || T <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
+    const Config& c = e->cfg;
+    if (T > c.max_position_embeddings) return fail(DAWN_ERR_INVALID_ARG, "T exceeds max_position_embeddings");
+    DAWN_HIP_TRY(hipSetDevice(e->device));
+    DAWN_TRY(ensure_ws(e, 2 * T, 1));
+    hipStream_t s = e->stream;
+    const size_t H = c.hidden_size, I = c.intermediate_size;
+    const LayerW& L = e->layers[0];
+    const float eps = (float)c.layer_norm_eps;
+    size_t out_elems = (size_t)T * H;
+    if (op == 0) {
+        const int off[2] = {0, T};
+        DAWN_HIP_TRY(hipMemcpyAsync(e->d_ids, in, (size_t)T * 4, hipMemcpyHostToDevice, s));
+        DAWN_HIP_TRY(hipMemcpyAsync(e->d_off, off, sizeof(off), hipMemcpyHostToDevice, s));
+        dawn::launch_tok_pos(e->d_off, 1, e->d_pos, s);
+        dawn::launch_embed_ln(e->d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s);
+    } else if (op == 1) {
+        DAWN_HIP_TRY(hipMemcpyAsync(e->tmp, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
+        DAWN_HIP_TRY(hipMemcpyAsync(e->attn, (const float*)in + (size_t)T * H, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
+        dawn::launch_add_ln(e->tmp, e->attn, T, L.ao_g, L.ao_beta, eps, e->x, s);
+    } else if (op == 2 || op == 3) {
+        DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
+        const int keep = dawn::g_skinny_max_m;
+        if (op == 3) dawn::g_skinny_max_m = 0;
+        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s);
+        dawn::g_skinny_max_m = keep;
+        out_elems = (size_t)T * I;
+    } else {
+        return fail(DAWN_ERR_INVALID_ARG, "unknown op %d", op);
+    }
+    DAWN_HIP_TRY(hipGetLastError());
+    DAWN_HIP_TRY(hipMemcpyAsync(out, op >= 2 ? e->ff : e->x, out_elems * 4, hipMemcpyDeviceToHost, s));
+    DAWN_HIP_TRY(hipStreamSynchronize(s));
+    return DAWN_OK;
+}
+
 }  // extern "C"

@@ -75,16 +75,24 @@ class EmbeddingProvider:
     def set_option(self, name: str, value: int):
         check(lib.dawn_embedder_set_option(self._h, name.encode(), value))
 
+    def debug_op(self, op: int, data: np.ndarray, T: int, out_cols: int = EM_LEN) -> np.ndarray:
+        """Test hook (dawn_embedder_debug_op): one kernel of the forward in isolation."""
+        data = np.ascontiguousarray(data)
+        out = np.zeros((T, out_cols), dtype=np.float32)
+        check(lib.dawn_embedder_debug_op(self._h, op, _ptr(data), T, _ptr(out)))
+        return out
+
     def forward_device(self, d_token_ids: int, d_seq_offsets: int, B: int, total_tokens: int, max_len: int,
                        d_out: int, stream: int = 0):
         check(lib.dawn_embedder_forward_device(self._h, d_token_ids, d_seq_offsets, B, total_tokens, max_len, d_out,
                                                stream))
 
 
-def write_synthetic_model(dirpath: str, seed: int = 3, prefix: str = "", gamma_beta: bool = False):
-    """Write model.safetensors + config.json with the seeded synthetic weights."""
+def write_synthetic_model(dirpath: str, seed: int = 3, prefix: str = "", gamma_beta: bool = False, style: int = 0):
+    """Write model.safetensors + config.json with the seeded synthetic weights (style 1: the "wide"
+    bell-shaped weights with large LayerNorm gains of synth.bert_tensor_specs_wide)."""
     from safetensors.numpy import save_file
-    w = synth.bert_weights(seed)
+    w = synth.bert_weights(seed, style=style)
     out = {}
     for k, v in w.items():
         if gamma_beta and ".LayerNorm." in k:

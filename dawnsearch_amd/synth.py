@@ -60,6 +60,16 @@ def unit_rows(seed: int, first_row: int, n: int) -> np.ndarray:
     return normalize_rows(uniform(seed, idx))
 
 
+def unit_rows_normal(seed: int, first_row: int, n: int, heavy_dims=(), heavy_scale: float = 5.0) -> np.ndarray:
+    """[n, 384] unit rows with bell-shaped components (scaled_normal's g over stream `seed`), optionally with the
+    dimensions `heavy_dims` scaled up before normalisation — the score distribution of real embeddings, and what the
+    int8 shadow's quantiser has to cope with (tests; identical values wherever numpy runs)."""
+    g = scaled_normal(seed, (first_row + n) * EM_LEN, 1.0, 0.0)[first_row * EM_LEN:].reshape(n, EM_LEN).copy()
+    for d in heavy_dims:
+        g[:, d] = (g[:, d] * np.float32(heavy_scale)).astype(np.float32)
+    return normalize_rows(g)
+
+
 def round_bf16(a: np.ndarray) -> np.ndarray:
     """f32 -> nearest-even bf16 -> f32 (what a DAWN_DTYPE_BF16 index stores and scores)."""
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
@@ -124,11 +134,64 @@ def bert_tensor_specs(cfg: dict = MINILM_CONFIG):
     return specs
 
 
-def bert_weights(seed: int, cfg: dict = MINILM_CONFIG) -> dict:
+def scaled_normal(seed: int, n: int, scale: float, offset: float) -> np.ndarray:
+    """offset + scale * g, g = ((u0 + u1) + u2 + u3) * sqrt(3)/2 over four consecutive uniforms of the stream: a
+    bell-shaped value of unit variance (|g| <= 3.46) with f32 arithmetic in a fixed order (identical in numpy and C)."""
+    i = np.arange(n, dtype=np.uint64) * np.uint64(4)
+    u0, u1, u2, u3 = (uniform(seed, i + np.uint64(j)) for j in range(4))
+    g = (((u0 + u1).astype(np.float32) + u2).astype(np.float32) + u3).astype(np.float32)
+    g = (g * np.float32(0.8660254)).astype(np.float32)
+    m = (np.float32(scale) * g).astype(np.float32)
+    return (np.float32(offset) + m).astype(np.float32)
+
+
+# style 1 ("wide"): bell-shaped weights, LayerNorm gains 1 +- 0.5 (some near 0, some beyond 2), biases of 0.1-0.2 —
+# further from the uniform style-0 weights than a trained checkpoint is: a second, independent pin of the embedder
+_WIDE = {"word": 0.06, "pos": 0.03, "type": 0.03, "ln_g": 0.5, "ln_b": 0.2, "qkv_w": 0.06, "bias": 0.1, "ao_w": 0.05,
+         "i_w": 0.04, "o_w": 0.03}
+
+
+def bert_tensor_specs_wide(cfg: dict = MINILM_CONFIG):
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    W = _WIDE
+    specs = [
+        ("embeddings.word_embeddings.weight", (cfg["vocab_size"], H), W["word"], 0.0),
+        ("embeddings.position_embeddings.weight", (cfg["max_position_embeddings"], H), W["pos"], 0.0),
+        ("embeddings.token_type_embeddings.weight", (cfg["type_vocab_size"], H), W["type"], 0.0),
+        ("embeddings.LayerNorm.weight", (H,), W["ln_g"], 1.0),
+        ("embeddings.LayerNorm.bias", (H,), W["ln_b"], 0.0),
+    ]
+    for L in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{L}."
+        specs += [
+            (p + "attention.self.query.weight", (H, H), W["qkv_w"], 0.0),
+            (p + "attention.self.query.bias", (H,), W["bias"], 0.0),
+            (p + "attention.self.key.weight", (H, H), W["qkv_w"], 0.0),
+            (p + "attention.self.key.bias", (H,), W["bias"], 0.0),
+            (p + "attention.self.value.weight", (H, H), W["qkv_w"], 0.0),
+            (p + "attention.self.value.bias", (H,), W["bias"], 0.0),
+            (p + "attention.output.dense.weight", (H, H), W["ao_w"], 0.0),
+            (p + "attention.output.dense.bias", (H,), W["bias"], 0.0),
+            (p + "attention.output.LayerNorm.weight", (H,), W["ln_g"], 1.0),
+            (p + "attention.output.LayerNorm.bias", (H,), W["ln_b"], 0.0),
+            (p + "intermediate.dense.weight", (I, H), W["i_w"], 0.0),
+            (p + "intermediate.dense.bias", (I,), W["bias"], 0.0),
+            (p + "output.dense.weight", (H, I), W["o_w"], 0.0),
+            (p + "output.dense.bias", (H,), W["bias"], 0.0),
+            (p + "output.LayerNorm.weight", (H,), W["ln_g"], 1.0),
+            (p + "output.LayerNorm.bias", (H,), W["ln_b"], 0.0),
+        ]
+    return specs
+
+
+def bert_weights(seed: int, cfg: dict = MINILM_CONFIG, style: int = 0) -> dict:
+    """style 0: uniform values (the DESIGN.md §5 spec); style 1: the "wide" bell-shaped weights above."""
     out = {}
-    for t, (name, shape, scale, offset) in enumerate(bert_tensor_specs(cfg)):
+    specs = bert_tensor_specs(cfg) if style == 0 else bert_tensor_specs_wide(cfg)
+    for t, (name, shape, scale, offset) in enumerate(specs):
         n = int(np.prod(shape))
-        out[name] = scaled(seed * 1000 + t, n, scale, offset).reshape(shape)
+        gen = scaled if style == 0 else scaled_normal
+        out[name] = gen(seed * 1000 + t, n, scale, offset).reshape(shape)
     return out
 
 

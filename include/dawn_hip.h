@@ -240,6 +240,11 @@ int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);
 /* BertModel::forward hidden states (model.rs:565-570) for tests: out [total_tokens][384]. */
 int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,
                                 int B, float *out);
+/* Test hook: one kernel of the forward in isolation — op 0 BertEmbeddings (model.rs:266-281: in = T token ids of one
+ * sequence, out [T][384]); 1 LayerNorm(a + r) with layer 0's attention-output LayerNorm (:86-104,378: in = a | r, each
+ * [T][384]); 2 / 3 layer 0's intermediate dense + activation (:425-430, :28-37: in [T][384], out [T][1536]; 2 = the form
+ * the forward would take for T rows, 3 = the 64x64 tile kernel). */
+int dawn_embedder_debug_op(dawn_embedder *e, int op, const void *in, int T, float *out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host tokenizer — the `tokenizers` crate calls of EmbeddingProvider (embedding_service.rs:88,     */

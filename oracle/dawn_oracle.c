@@ -343,6 +343,18 @@ void orc_synth_scaled(uint64_t seed, size_t n, float scale, float offset, float 
     }
 }
 
+/* style 1 ("wide", dawnsearch_amd/synth.py: scaled_normal): offset + scale * ((u0 + u1) + u2 + u3) * sqrt(3)/2 */
+void orc_synth_scaled_normal(uint64_t seed, size_t n, float scale, float offset, float *out) {
+    for (size_t i = 0; i < n; i++) {
+        float g = orc_synth_uniform(seed, 4 * i) + orc_synth_uniform(seed, 4 * i + 1);
+        g = g + orc_synth_uniform(seed, 4 * i + 2);
+        g = g + orc_synth_uniform(seed, 4 * i + 3);
+        g = g * 0.8660254f;
+        float m = scale * g;
+        out[i] = offset + m;
+    }
+}
+
 /* ======================================================================================= */
 /* src/embedding/model.rs                                                                    */
 /* ======================================================================================= */
@@ -521,7 +533,11 @@ size_t orc_bert_param_count(const orc_bert_config *c) {
  *   +12/+13 output.dense.{weight [H,I] 0.03, bias [H] 0.02}
  *   +14/+15 output.LayerNorm.{weight 0.10+1, bias 0.05}
  */
-orc_bert_weights *orc_bert_synth(uint64_t seed) {
+orc_bert_weights *orc_bert_synth(uint64_t seed) { return orc_bert_synth_style(seed, 0); }
+
+/* style 0: the uniform weights of the list above; style 1: the "wide" bell-shaped weights of
+ * dawnsearch_amd/synth.py:bert_tensor_specs_wide (LayerNorm gains 1 +- 0.5, biases 0.1 - 0.2) — same tensor order */
+orc_bert_weights *orc_bert_synth_style(uint64_t seed, int style) {
     orc_bert_weights *w = (orc_bert_weights *)calloc(1, sizeof(*w));
     orc_bert_config c = {30522, 384, 6, 12, 1536, 512, 2, 1e-12f}; /* model.rs:160-180 */
     w->cfg = c;
@@ -530,13 +546,18 @@ orc_bert_weights *orc_bert_synth(uint64_t seed) {
     float *p = blk;
     const size_t H = 384, I = 1536;
     int t = 0;
-#define TENSOR(field, n, scale, off)                                        \
-    do {                                                                    \
-        orc_synth_scaled(seed * 1000 + (uint64_t)t, (n), (scale), (off), p); \
-        field = p;                                                          \
-        p += (n);                                                           \
-        t++;                                                                \
+#define TENSOR(field, n, scale, off)                                                              \
+    do {                                                                                          \
+        if (style == 0) orc_synth_scaled(seed * 1000 + (uint64_t)t, (n), (scale), (off), p);      \
+        else orc_synth_scaled_normal(seed * 1000 + (uint64_t)t, (n), wide[t < 5 ? t : 5 + (t - 5) % 16], (off), p); \
+        field = p;                                                                                \
+        p += (n);                                                                                 \
+        t++;                                                                                      \
     } while (0)
+    /* scales of style 1, tensors 0..4 and the 16 of a layer */
+    static const float wide[21] = {0.06f, 0.03f, 0.03f, 0.5f, 0.2f,
+                                   0.06f, 0.1f, 0.06f, 0.1f, 0.06f, 0.1f, 0.05f, 0.1f, 0.5f, 0.2f,
+                                   0.04f, 0.1f, 0.03f, 0.1f, 0.5f, 0.2f};
     TENSOR(w->word_emb, (size_t)c.vocab_size * H, 0.05f, 0.0f);
     TENSOR(w->pos_emb, (size_t)c.max_pos * H, 0.02f, 0.0f);
     TENSOR(w->type_emb, (size_t)c.type_vocab * H, 0.02f, 0.0f);

@@ -117,6 +117,8 @@ void orc_embed_padded_batch(const orc_bert_weights *w, const uint32_t *ids, cons
  * orc_bert_free_synth.  Tensor order/names documented in dawn_oracle.c (same as the safetensors
  * writer in tests/synth_weights.py). */
 orc_bert_weights *orc_bert_synth(uint64_t seed);
+orc_bert_weights *orc_bert_synth_style(uint64_t seed, int style); /* 1: "wide" weights (synth.py) */
+void orc_synth_scaled_normal(uint64_t seed, size_t n, float scale, float offset, float *out);
 void orc_bert_free_synth(orc_bert_weights *w);
 size_t orc_bert_param_count(const orc_bert_config *c);
 

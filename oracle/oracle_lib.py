@@ -82,6 +82,9 @@ def lib():
     L.orc_synth_scaled.argtypes = [C.c_uint64, C.c_size_t, C.c_float, C.c_float, _f32p]
     L.orc_bert_synth.argtypes = [C.c_uint64]
     L.orc_bert_synth.restype = C.c_void_p
+    L.orc_bert_synth_style.argtypes = [C.c_uint64, C.c_int]
+    L.orc_bert_synth_style.restype = C.c_void_p
+    L.orc_synth_scaled_normal.argtypes = [C.c_uint64, C.c_size_t, C.c_float, C.c_float, _f32p]
     L.orc_bert_free_synth.argtypes = [C.c_void_p]
     L.orc_bert_forward.argtypes = [C.c_void_p, _u32p, C.c_int, _f32p]
     L.orc_embed.argtypes = [C.c_void_p, _u32p, C.c_int, _f32p]
@@ -143,8 +146,8 @@ class BestResults:
 
 
 class SynthBert:
-    def __init__(self, seed: int):
-        self._w = lib().orc_bert_synth(seed)
+    def __init__(self, seed: int, style: int = 0):
+        self._w = lib().orc_bert_synth_style(seed, style)
 
     def forward(self, ids: np.ndarray) -> np.ndarray:
         ids = np.ascontiguousarray(ids, dtype=np.uint32)

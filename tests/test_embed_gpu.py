@@ -214,3 +214,70 @@ def test_graph_replay_is_bit_identical_to_plain_launches(provider):
             assert np.array_equal(provider.calculate_embedding([other])[0].view(np.uint32), ref.view(np.uint32))
     finally:
         provider.set_option("graphs", 1)
+
+
+def test_second_golden_pin_wide_weights_and_512_tokens(dawn, oracle, tmp_path):
+    """HF transformers fixture on the "wide" style-1 weights (bell-shaped, LayerNorm gains 1 +- 0.5, biases 0.1-0.2) with
+    sequences of 2 .. 512 tokens in ONE packed batch: the HIP forward within 1e-5 of the fixture and of the C oracle."""
+    import json
+    g = np.load(os.path.join(GOLD, "minilm_wide_seed5.npz"))
+    meta = json.load(open(os.path.join(GOLD, "minilm_wide_seed5.json")))
+    st, cj = dawn.write_synthetic_model(str(tmp_path), seed=meta["weight_seed"], style=meta["weight_style"])
+    ep = dawn.EmbeddingProvider(st, cj, 0)
+    try:
+        offs, toks = g["seq_offsets"], g["token_ids"]
+        seqs = [toks[offs[b]:offs[b + 1]] for b in range(len(offs) - 1)]
+        assert max(len(s) for s in seqs) == 512
+        emb = ep.calculate_embedding(seqs)
+        assert np.abs(emb - g["embeddings"]).max() < TOL_EMB
+        for i in (0, 3, 7):  # each also alone (skinny GEMMs / long-sequence attention)
+            assert np.abs(ep.calculate_embedding([seqs[i]])[0] - g["embeddings"][i]).max() < TOL_EMB
+        hs = ep.hidden_states([seqs[2]])[0]
+        assert np.abs(hs - g["hidden_states_seq2"]).max() < 2e-4  # values up to 5.6: 4e-5 relative
+        sb = oracle.SynthBert(meta["weight_seed"], meta["weight_style"])
+        assert np.abs(emb[5] - sb.embed(seqs[5])).max() < TOL_EMB
+    finally:
+        ep.close()
+
+
+def test_single_kernels_in_isolation(provider, oracle):
+    """SURVEY 8(a) rows a3 (BertEmbeddings), a5 (LayerNorm), a7 (tanh-GELU behind the dense) each on its own, against
+    float64 numpy restatements of model.rs:266-281, :86-104, :28-37 + :53-64 on the seed-3 weights."""
+    w = synth.bert_weights(3)
+    T = 37
+    ids = synth.token_sequences(77, 1, T, T)[0]
+
+    def ln(v, gam, bet):
+        v = v.astype(np.float64)
+        m = v.mean(-1, keepdims=True)
+        xc = v - m
+        var = (xc * xc).mean(-1, keepdims=True)
+        return xc / np.sqrt(var + 1e-12) * gam + bet
+
+    # a3: word[id] + type[0] + pos[t] -> LayerNorm
+    e = (w["embeddings.word_embeddings.weight"][ids].astype(np.float64) + w["embeddings.token_type_embeddings.weight"][0]
+         + w["embeddings.position_embeddings.weight"][:T])
+    want = ln(e, w["embeddings.LayerNorm.weight"], w["embeddings.LayerNorm.bias"])
+    got = provider.debug_op(0, ids.astype(np.uint32), T)
+    assert np.abs(got - want).max() < 2e-6
+    # a5: LayerNorm(a + r), inputs of very different scales per row (1e-3 .. 1e3) and a constant row (variance 0 -> eps)
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((T, 384)) * np.logspace(-3, 3, T)[:, None]).astype(np.float32)
+    r = (rng.standard_normal((T, 384)) * 0.1).astype(np.float32)
+    a[5] = 2.5
+    r[5] = -0.5
+    want = ln(a.astype(np.float64) + r, w["encoder.layer.0.attention.output.LayerNorm.weight"],
+              w["encoder.layer.0.attention.output.LayerNorm.bias"])
+    got = provider.debug_op(1, np.concatenate([a, r]), T)
+    err = np.abs(got - want)
+    assert np.isfinite(got).all() and err[np.arange(T) != 5].max() < 5e-6
+    assert np.abs(got[5] - w["encoder.layer.0.attention.output.LayerNorm.bias"]).max() < 1e-6  # (x - mean) = 0 exactly
+    # a7 (+ a4): dense 384 -> 1536 + tanh-GELU, inputs spanning the GELU's flat, curved and linear ranges
+    x = (rng.standard_normal((T, 384)) * np.linspace(0.05, 6, T)[:, None]).astype(np.float32)
+    z = x.astype(np.float64) @ w["encoder.layer.0.intermediate.dense.weight"].astype(np.float64).T \
+        + w["encoder.layer.0.intermediate.dense.bias"]
+    want = 0.5 * z * (1 + np.tanh(np.sqrt(2 / np.pi) * z * (1 + 0.044715 * z * z)))
+    assert np.abs(z).max() > 4 and (np.abs(z) < 0.1).any()
+    for op in (2, 3):  # the skinny form and the 64x64 tile kernel
+        got = provider.debug_op(op, x, T, out_cols=1536)
+        assert np.abs(got - want).max() < 3e-6 * max(1.0, np.abs(want).max())

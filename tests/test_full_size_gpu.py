@@ -2,8 +2,12 @@
 need the CPU oracle to scan 153.6 GB: independent GPU paths must agree bit for bit (f16-shadow MFMA stream, f32-row
 stream, matrix-core batched pass, forced exact pass: four different kernels over the same rows), planted rows must
 come back first with the distance the oracle computes for that ONE row, results are ascending, in range, idempotent,
-and equal to the merge of two half-index searches (the sharded identity).  Skipped when the card cannot hold the index.
+and equal to the merge of two half-index searches (the sharded identity).  The card must hold the index: on a GPU with
+less than 245 GB of free HBM these tests FAIL (this is the only 100 M evidence of the suite — a skip would hide its absence);
+DAWN_ALLOW_SMALL_GPU=1 turns that into a skip for development boxes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -20,7 +24,10 @@ def big(dawn):
     import torch
     free, total = torch.cuda.mem_get_info(0)
     if free < 245e9:
-        pytest.skip("needs ~235 GB of free HBM (100 M f32 rows + f16 shadow)")
+        msg = f"needs ~235 GB of free HBM (100 M f32 rows + int8 and f16 shadows); this card has {free / 1e9:.0f} GB free"
+        if os.environ.get("DAWN_ALLOW_SMALL_GPU") == "1":
+            pytest.skip(msg)
+        pytest.fail(msg)
     idx = dawn.VectorIndex(0)
     idx.fill_synthetic(1, 0, N, 1)
     yield idx
@@ -95,6 +102,43 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     assert idx.stats()["fallbacks"] == before + 2
 
 
+def test_100m_batch256_all_paths_agree(dawn, big):
+    """configs[3]'s per-shard workload at B = 256, k = 20 (the service's count): ALL 256 queries over 100 M rows through
+    the int8 matrix-core pass (default), the f16-shadow matrix-core pass and the int8 streaming filter (8 queries per pass)
+    — three kernels, two shadows — bit-identical; a sample also against the f32-row stream; no exact pass anywhere."""
+    idx = big
+    k = 20
+    Q = synth.unit_rows(3, 0, 256)
+    Q[:10] = _queries()[0][6:16]  # the planted ones
+    before = idx.stats()
+    labels, dist, found = idx.search_batch(Q, k)
+    assert np.all(found == k) and np.all(np.diff(dist, axis=1) >= 0) and labels.min() >= 1 and labels.max() <= N
+    assert np.array_equal(labels[:10, 0], _queries()[1] + 1)
+    idx.set_option("mfma_min_batch", 100000)  # the streaming filter, 8 queries per pass over the int8 shadow
+    try:
+        ls, ds, fs = idx.search_batch(Q, k)
+    finally:
+        idx.set_option("mfma_min_batch", 2)
+    assert np.array_equal(ls, labels) and np.array_equal(ds.view(np.uint32), dist.view(np.uint32))
+    idx.set_option("i8_shadow", 0)  # f16 shadow: scan_f16_pipe_kernel
+    try:
+        lf, df, ff = idx.search_batch(Q, k)
+    finally:
+        idx.set_option("i8_shadow", 1)
+    assert np.array_equal(lf, labels) and np.array_equal(df.view(np.uint32), dist.view(np.uint32))
+    idx.set_option("f16_shadow_b1", 0)  # the f32 rows themselves, a sample of the batch
+    try:
+        for b in (0, 17, 130, 255):
+            lab, dd = idx.search(Q[b], k)
+            assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    finally:
+        idx.set_option("f16_shadow_b1", 1)
+    after = idx.stats()
+    assert after["fallbacks"] == before["fallbacks"]
+    # the first certificate's misses were all settled by a deeper round of the same certificate
+    assert after["second_chances"] - before["second_chances"] == after["deepened"] - before["deepened"]
+
+
 def test_100m_k_edge_and_sharded_identity(dawn, big):
     """k = 1 and k = 64 (no certificate margin: exact pass) agree on the common prefix with k = 10; the top-k of the
     whole index equals the stable merge of the top-k of its two halves (what the multi-GPU path computes)."""
@@ -125,6 +169,20 @@ def test_100m_k_edge_and_sharded_identity(dawn, big):
     dd = np.concatenate([p[1] for p in parts])
     order = np.lexsort((np.arange(20), dd))[:10]  # stable: ties -> lower shard / earlier rows
     assert np.array_equal(lab[order], l10) and np.array_equal(dd[order].view(np.uint32), d10.view(np.uint32))
+    # ... and the same 100 M rows behind ONE sharded handle (dawn_index_create_sharded, 4 logical shards of 25 M rows on
+    # this device: chunked dealing, per-shard searches on their own streams, gather, merge by insertion position) — the
+    # C-ABI form of configs[3], at full size
+    sh = dawn.VectorIndex(devices=[0, 0, 0, 0])
+    sh.fill_synthetic(1, 0, N, 1)
+    assert sh.size() == N and max(sh.shard_info()["sizes"]) - min(sh.shard_info()["sizes"]) <= 4096
+    ls, ds = sh.search(q, 10)
+    assert np.array_equal(ls, l10) and np.array_equal(ds.view(np.uint32), d10.view(np.uint32))
+    Q16 = Q[:16]
+    lb, db, fb = sh.search_batch(Q16, 10)
+    planted = _queries()[1]
+    assert np.array_equal(lb[6:16, 0], planted + 1) and np.array_equal(lb[3], l10) and np.all(fb == 10)
+    assert sh.stats()["fallbacks"] == 0
+    sh.close()
 
 
 def test_125m_bf16_shard_paths_agree(dawn, oracle):

@@ -189,3 +189,39 @@ def test_embedder_oracle_vs_golden(oracle):
     for b in range(3):
         same = np.abs(padded[b] - g["embeddings"][b]).max() < 2e-6
         assert same == (lens[b] == lens[longest])
+
+
+def test_embedder_oracle_vs_second_golden_pin(oracle):
+    """Second, independent pin of the embedder restatement: HF transformers on the "wide" style-1 weights (bell-shaped
+    values, LayerNorm gains 1 +- 0.5, biases 0.1-0.2: activations up to 5.6) and sequences of 2 .. 512 tokens (512 =
+    max_position_embeddings).  tests/golden/minilm_wide_seed5.npz, generator tests/golden/make_golden.py."""
+    g = np.load(os.path.join(GOLD, "minilm_wide_seed5.npz"))
+    meta = json.load(open(os.path.join(GOLD, "minilm_wide_seed5.json")))
+    sb = oracle.SynthBert(meta["weight_seed"], meta["weight_style"])
+    offs, toks = g["seq_offsets"], g["token_ids"]
+    assert [int(offs[i + 1] - offs[i]) for i in range(len(offs) - 1)] == meta["lengths"] and meta["lengths"][-1] == 512
+    for b in range(len(offs) - 1):
+        emb = sb.embed(toks[offs[b]:offs[b + 1]])
+        assert np.abs(emb - g["embeddings"][b]).max() < 2e-6
+    hs = sb.forward(toks[offs[2]:offs[3]])
+    assert np.abs(hs - g["hidden_states_seq2"]).max() < 5e-5 and np.abs(g["hidden_states_seq2"]).max() > 3
+    # the generators of the style agree between numpy and C bit for bit
+    from dawnsearch_amd import synth
+    a = np.empty(5000, np.float32)
+    oracle.lib().orc_synth_scaled_normal(5003, 5000, 0.5, 1.0, a)
+    assert np.array_equal(a, synth.scaled_normal(5003, 5000, 0.5, 1.0))
+
+
+def test_scan_oracle_vs_heavy_tailed_golden(oracle):
+    """Scan fixture on bell-shaped unit rows with four heavy dimensions (what real embeddings look like): the C oracle
+    reproduces the numpy restatement's top-20 bit for bit."""
+    from dawnsearch_amd import synth
+    g = np.load(os.path.join(GOLD, "scan_normal_seed4.npz"))
+    n = int(g["n_rows"])
+    X = synth.unit_rows_normal(int(g["index_seed"]), 0, n, heavy_dims=tuple(int(d) for d in g["heavy_dims"]))
+    assert np.abs(X).max() > 0.4  # heavy-tailed indeed (uniform spec rows: 0.09)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    for q, lab, dist in zip(g["queries"], g["labels"], g["distances"]):
+        l, d = oracle.scan_topk(X, ids, q, 20)
+        assert np.array_equal(l, lab) and np.array_equal(d.view(np.uint32), dist.view(np.uint32))
+    assert g["labels"][3][0] == 1235

@@ -723,3 +723,31 @@ def test_int8_batched_tile_edges(dawn, oracle, n, B):
         _assert_same(labels[b][:found[b]], dist[b][:found[b]], olab, odist)
     assert labels[B - 1][0] == n and labels.max() <= n
     assert idx.stats()["fallbacks"] == 0
+
+
+def test_heavy_tailed_golden_fixture_all_paths(dawn, oracle):
+    """The committed scan fixture on bell-shaped rows with four heavy dimensions (tests/golden/scan_normal_seed4.npz, by
+    the numpy restatement): streaming filter, matrix-core pass, both shadows, a bf16-free f32 index — bit-identical, and
+    without an exact pass: the rotation of the int8 shadow takes the heavy dimensions out of the quantiser's way
+    (scan_i8.hip; without it these rows sent most queries to the exact pass)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "scan_normal_seed4.npz"))
+    n = int(g["n_rows"])
+    X = synth.unit_rows_normal(int(g["index_seed"]), 0, n, heavy_dims=tuple(int(d) for d in g["heavy_dims"]))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(ids, X)
+    Q = g["queries"]
+    for i8 in (1, 0):
+        idx.set_option("i8_shadow", i8)
+        lab, dist, found = idx.search_batch(Q, 20)
+        assert np.array_equal(lab, g["labels"]) and np.array_equal(dist.view(np.uint32), g["distances"].view(np.uint32))
+        for b in (0, 3):
+            l, d = idx.search(Q[b], 20)
+            assert np.array_equal(l, g["labels"][b]) and np.array_equal(d.view(np.uint32), g["distances"][b].view(np.uint32))
+    assert idx.stats()["fallbacks"] == 0
+    # the bound's slack on these rows equals the slack on any others (what the rotation is for)
+    idx.set_option("i8_shadow", 1)
+    f = idx.debug_filter_scores(Q)
+    slack = f.astype(np.float64) - Q.astype(np.float64) @ X[:f.shape[1]].astype(np.float64).T
+    assert slack.min() > -4e-6 and slack.max() < 0.03, (slack.min(), slack.max())
