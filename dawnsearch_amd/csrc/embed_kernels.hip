@@ -274,6 +274,105 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
     }
 }
 
+// The same with LayerNorm(a + r) as a PROLOGUE (K = 384 = the hidden size, 8 waves): the two dense layers that follow a
+// residual LayerNorm (FFN1 after attention-output, Q|K|V of the next layer after output) normalise the 16 rows they load
+// anyway — every block recomputes the statistics of its strip (16 x 384 values it reads in any case) and the blocks of
+// column 0 also write the normalised rows out (they are the next residual).  One launch less per LayerNorm: 11 of the 45
+// dependent launches of a one-text forward (model.rs:374-379, 458-463 + :86-104 arithmetic: mean = sum / H; xc = x - mean;
+// var = sum xc^2 / H; xc / sqrt(var + eps) * gamma + beta — the sums run over the block's lanes and waves in a fixed
+// order of their own, f32 throughout).
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __restrict__ Aa, const float* __restrict__ Ar,
+                                                              const float* __restrict__ gam, const float* __restrict__ bet,
+                                                              float eps, float* __restrict__ Xout,
+                                                              const float* __restrict__ W, const float* __restrict__ bias,
+                                                              float* __restrict__ Y, int M, int N) {
+    constexpr int NWV = 8, K = H, STEPS = K / NWV / 16;  // 48 k-values per wave and row: 3 steps of 16
+    __shared__ __attribute__((aligned(16))) float part[NWV * 4 * 64];
+    __shared__ float red[NWV][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    const int k_begin = wave * (K / NWV) + 4 * kq;
+    const bool a_ok = m0 + r < M;
+    f32x4 av[STEPS], bv[STEPS];
+    const float* wrow = W + (size_t)(n0 + r) * K + k_begin;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const size_t o = (size_t)(m0 + r) * K + k_begin + 16 * st;
+        av[st] = a_ok ? *reinterpret_cast<const f32x4*>(Aa + o) + *reinterpret_cast<const f32x4*>(Ar + o)
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[st] = *reinterpret_cast<const f32x4*>(wrow + 16 * st);
+    }
+    // row statistics: this lane holds 12 of row r's 384 values; lanes r, r+16, r+32, r+48 of the 8 waves hold the rest
+    auto row_total = [&](float v) {
+        v += lane_xor_f32<16>(v, lane);
+        v += lane_xor_f32<32>(v, lane);
+        if (kq == 0) red[wave][r] = v;
+        __syncthreads();
+        float t = red[0][r];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) t += red[w][r];
+        __syncthreads();
+        return t;
+    };
+    float s1 = 0.f;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) s1 += (av[st].x + av[st].y) + (av[st].z + av[st].w);
+    const float inv_h = 1.0f / (float)H;
+    const float mean = row_total(s1) * inv_h;
+    float s2 = 0.f;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        av[st] = av[st] - mean;
+        s2 += (av[st].x * av[st].x + av[st].y * av[st].y) + (av[st].z * av[st].z + av[st].w * av[st].w);
+    }
+    const float den = sqrtf(row_total(s2) * inv_h + eps);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int k = k_begin + 16 * st;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam + k), b4 = *reinterpret_cast<const f32x4*>(bet + k);
+        av[st] = (av[st] / den) * g4 + b4;
+        if (blockIdx.x == 0 && a_ok) *reinterpret_cast<f32x4*>(Xout + (size_t)(m0 + r) * K + k) = av[st];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st].x, bv[st].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st].y, bv[st].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st].z, bv[st].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st].w, bv[st].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[(wave * 4 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    if (tid < 256) {
+        const int e = tid >> 6, l = tid & 63;
+        float sum = part[e * 64 + l];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) sum += part[(w * 4 + e) * 64 + l];
+        const int row = m0 + 4 * (l >> 4) + e;
+        const int n = n0 + (l & 15);
+        if (row < M) Y[(size_t)row * N + n] = act_apply(sum + bias[n], ACT);
+    }
+}
+
+// Y = act(LN(a + r) . W^T + bias), x_out = LN(a + r); false: this shape does not take the fused form (the caller then
+// runs add_ln + gemm)
+bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
+                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s) {
+    if (M <= 0) return true;
+    // measured (tools/embed_latency.py, device-resident loop): 12 tokens 0.170 -> 0.164 ms, 27 tokens 0.194 -> 0.189 ms per
+    // forward; at 128 tokens the N/16 blocks of a strip each redoing its statistics cost more than the launch saves
+    // (0.290 -> 0.310 ms): fused up to 64 rows only
+    if (K != H || M > 64 || M > g_skinny_max_m || N % 16 != 0) return false;
+    dim3 grid(N / 16, (M + 15) / 16), block(512);
+    if (act == 1) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<1>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
+    else if (act == 2) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<2>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
+    else hipLaunchKernelGGL(gemm_skinny16_ln_kernel<0>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
+    return true;
+}
+
 template <int NWV>
 static void launch_skinny16(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
                             hipStream_t s) {

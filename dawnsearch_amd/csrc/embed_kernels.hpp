@@ -12,6 +12,10 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
 // Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
                     hipStream_t s);
+// Y = act(LN(a + r) . W^T + bias) and x_out = LN(a + r) in ONE launch (latency form: M <= skinny limit, K = 384); false =
+// not applicable to this shape
+bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
+                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s);
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s);
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s);
 int attention_set_max_lds();

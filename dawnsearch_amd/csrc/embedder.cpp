@@ -54,7 +54,7 @@ struct dawn_embedder {
     std::vector<LayerW> layers;
     // workspaces (grown on demand)
     int cap_T = 0, cap_B = 0;
-    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *attn = nullptr, *ff = nullptr;
+    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *tmp2 = nullptr, *attn = nullptr, *ff = nullptr;
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
@@ -84,7 +84,7 @@ namespace {
 int ensure_ws(dawn_embedder* e, int T, int B) {
     if (T > e->cap_T || B > e->cap_B) e->drop_graphs();  // (they hold the old buffer addresses)
     if (T > e->cap_T) {
-        float** bufs[] = {&e->x, &e->qkv, &e->ctx, &e->tmp, &e->attn, &e->ff};
+        float** bufs[] = {&e->x, &e->qkv, &e->ctx, &e->tmp, &e->tmp2, &e->attn, &e->ff};
         for (float** b : bufs)
             if (*b) {
                 (void)hipFree(*b);
@@ -101,6 +101,7 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
         DAWN_HIP_TRY(hipMalloc((void**)&e->qkv, cap * 3 * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->tmp, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->tmp2, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->attn, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ff, cap * I * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->d_ids, cap * sizeof(uint32_t)));
@@ -129,15 +130,28 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
     const float eps = (float)c.layer_norm_eps;
     dawn::launch_tok_pos(d_off, B, e->d_pos, s);
     dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s);
+    // Latency form (few tokens: the reference's one text per call): the residual LayerNorms run as the prologue of the dense
+    // layer that consumes them (launch_gemm_ln_nt) — `pending` = the output LayerNorm of the previous layer not applied
+    // yet: x = LN(tmp2 + attn) is produced by this layer's Q|K|V launch.
+    const LayerW* pending = nullptr;
     for (const LayerW& L : e->layers) {  // BertLayer::forward model.rs:487-498
-        dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s);          // :327-329 (Q|K|V fused)
+        // :327-329 (Q|K|V fused)
+        if (!(pending && dawn::launch_gemm_ln_nt(e->tmp2, e->attn, pending->o_g, pending->o_beta, eps, e->x, L.qkv_w, L.qkv_b,
+                                                 e->qkv, T, 3 * H, H, 0, s))) {
+            if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
+            dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s);
+        }
         dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s);                      // :331-346
         dawn::launch_gemm_nt(e->ctx, L.ao_w, L.ao_b, e->tmp, T, H, H, 0, s);               // :376
-        dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s);          // :378
-        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s);             // :427-428
-        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp, T, H, I, 0, s);                  // :460
-        dawn::launch_add_ln(e->tmp, e->attn, T, L.o_g, L.o_beta, eps, e->x, s);            // :462
+        // :378 LayerNorm(dense + x) -> attn, then :427-428 intermediate dense + activation
+        if (!dawn::launch_gemm_ln_nt(e->tmp, e->x, L.ao_g, L.ao_beta, eps, e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s)) {
+            dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s);
+            dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s);
+        }
+        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s);                 // :460
+        pending = &L;                                                                      // :462 LayerNorm(dense + attn)
     }
+    if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
 }
 
 int check_sequences(const dawn_embedder* e, const uint32_t* ids, const int32_t* off, int B, int* T_out, int* max_len) {
@@ -331,7 +345,7 @@ void dawn_embedder_destroy(dawn_embedder* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->drop_graphs();
-    void* ptrs[] = {e->d_weights, e->x, e->qkv, e->ctx, e->tmp, e->attn, e->ff, e->d_ids, e->d_off, e->d_pos, e->d_out};
+    void* ptrs[] = {e->d_weights, e->x, e->qkv, e->ctx, e->tmp, e->tmp2, e->attn, e->ff, e->d_ids, e->d_off, e->d_pos, e->d_out};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
