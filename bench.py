@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip batch-256 / 1M / latency / cpu legs")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1: all-gather + merge of a step finish before the next search starts (no overlap)")
     ap.add_argument("--no-capi-sharded", action="store_true",
                     help="N > 1: skip the single-process leg (tools/sharded_capi_bench.py: one process, N GPUs, C ABI only)")
     ap.add_argument("--force-collective", action="store_true",
@@ -235,37 +237,60 @@ def main():
         if Bq >= 1:  # planted: query 0 is a noisy copy of global row 4242 (checked after the run)
             q_host[0] = synth.planted_queries(1, [4242 % args.rows], 5)[0]
         d_q = torch.from_numpy(q_host).to(dev)
-        # per-rank result blob: labels | distances | found (dawn_hip.h) — one all-gather per search
+        # per-rank result blob: labels | distances | found (dawn_hip.h) — one all-gather per search.  Two sets of buffers:
+        # with RCCL the all-gather + merge of step i run (NCCL stream) under the scan of step i + 1 (double buffering; a
+        # search server pipelines its batches the same way) — `value` is a throughput; latency is reported by the host_api legs
         nbytes = dawn.result_blob_bytes(Bq, k)
         off_d, off_f = Bq * k * 8, Bq * k * 12
-        blob = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
-        p = blob.data_ptr()
+        collective = world > 1 or args.force_collective
+        pipelined = collective and not oversub and not args.no_pipeline
+        nbuf = 2 if pipelined else 1
+        blobs = [torch.zeros((nbytes,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        g_blobs = [torch.zeros((world * nbytes,), dtype=torch.uint8, device=dev) if collective else None for _ in range(nbuf)]
         o_lab = torch.zeros((Bq, k), dtype=torch.int64, device=dev)
         o_dist = torch.zeros((Bq, k), dtype=torch.float32, device=dev)
         o_found = torch.zeros((Bq,), dtype=torch.int32, device=dev)
-        collective = world > 1 or args.force_collective
-        g_blob = torch.zeros((world * nbytes,), dtype=torch.uint8, device=dev) if collective else None
+        state = {"i": 0, "pending": None}
+
+        def merge(j):
+            dawn.topk_merge_packed_device(local_rank, world, Bq, k, g_blobs[j].data_ptr(), o_lab.data_ptr(),
+                                          o_dist.data_ptr(), o_found.data_ptr(), stream)
+
+        def drain():
+            if state["pending"] is not None:
+                j, work = state["pending"]
+                work.wait()  # the current stream waits for the collective (long finished: it ran under the next scan)
+                merge(j)
+                state["pending"] = None
 
         def step():
+            j = state["i"] % nbuf
+            state["i"] += 1
+            p = blobs[j].data_ptr()
             index.search_device(d_q.data_ptr(), Bq, k, p, p + off_d, p + off_f, stream)
             if collective and oversub:  # shared device: the blobs travel through host memory (gloo)
-                hb = blob.cpu()
+                hb = blobs[j].cpu()
                 hg = torch.empty((world * nbytes,), dtype=torch.uint8)
                 dist.all_gather_into_tensor(hg, hb)
-                g_blob.copy_(hg)
+                g_blobs[j].copy_(hg)
+                merge(j)
+            elif pipelined:
+                work = dist.all_gather_into_tensor(g_blobs[j], blobs[j], async_op=True)
+                drain()  # the previous step's gather + merge, behind this step's scan on the stream
+                state["pending"] = (j, work)
             elif collective:
-                dist.all_gather_into_tensor(g_blob, blob)
-            if collective:
-                dawn.topk_merge_packed_device(local_rank, world, Bq, k, g_blob.data_ptr(), o_lab.data_ptr(),
-                                              o_dist.data_ptr(), o_found.data_ptr(), stream)
+                dist.all_gather_into_tensor(g_blobs[j], blobs[j])
+                merge(j)
 
         def result():
+            drain()
             torch.cuda.synchronize()
             if collective:
                 return o_lab.cpu().numpy(), o_dist.cpu().numpy()
-            raw = blob.cpu().numpy()
+            raw = blobs[0].cpu().numpy()
             return (raw[:off_d].view(np.int64).reshape(Bq, k), raw[off_d:off_f].view(np.float32).reshape(Bq, k))
 
+        step.drain = drain
         return step, result
 
     def barrier():
@@ -287,11 +312,13 @@ def main():
         index.profile_enable(True)
         for _ in range(warmup):
             step()
+        step.drain()
         barrier()
         index.profile_read()  # drop warm-up launches
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        step.drain()  # (pipelined ranks: the last step's gather + merge)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -460,6 +487,7 @@ def main():
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
                    "sharding": f"row-sharded x{world}" + (", one RCCL all-gather of packed per-shard top-k + merge" if world > 1 else ""),
                    "ranks": world, "collective_backend": (backend if (world > 1 or args.force_collective) else None),
+                   "pipelined": bool((world > 1 or args.force_collective) and not oversub and not args.no_pipeline),
                    "oversubscribed": oversub},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
