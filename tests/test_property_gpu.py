@@ -49,6 +49,12 @@ def _build_rows(rng, n, kind, q0):
             v[idx] = rng.choice([-1.0, 1.0], size=len(idx)) * rng.uniform(0.3, 1.0, size=len(idx))
             rows[i] = _unit(v)
         rows[where[: max(1, m // 3)]] = np.stack([_unit(rng.standard_normal(384)) for _ in range(max(1, m // 3))])
+    elif kind == "heavy":  # bell-shaped rows with a few dimensions far larger than the rest (sentence embeddings); the
+        # whole index, not a subset: top scores then crowd within the int8 bound's slack (deepening rounds)
+        g = rng.standard_normal((n, 384))
+        dims = rng.choice(384, size=int(rng.integers(1, 6)), replace=False)
+        g[:, dims] *= rng.uniform(3, 20)
+        rows = np.stack([_unit(v) for v in g])
     elif kind == "antipodal":
         rows[where] = -rows[rng.choice(n, size=m)]
         rows[where[: max(1, m // 4)]] = -q0
@@ -64,18 +70,23 @@ _EXAMPLES = int(os.environ.get("DAWN_HYP_EXAMPLES", "150"))  # soak runs: DAWN_H
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
 @given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 2500), st.integers(8000, 30000)), k=st.integers(1, 64),
        B=st.sampled_from([1, 2, 3, 4, 7, 9, 33, 70]),
-       kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal", "onehot"]),
+       kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal", "onehot", "heavy"]),
        dtype=st.sampled_from(["f32", "bf16"]), force_stream=st.booleans(), sched=st.sampled_from([4, 5, 1]),
-       i8=st.booleans())
-def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched, i8):
+       i8=st.booleans(), shards=st.sampled_from([0, 0, 2, 3]))
+def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched, i8, shards):
     rng = np.random.default_rng(seed)
     Q = synth.unit_rows(int(rng.integers(1, 1 << 30)), 0, B)
     rows = _build_rows(rng, n, kind, Q[0])
+    if kind == "heavy":  # queries of the same kind
+        Q = _build_rows(rng, B, "heavy", Q[0]) if B >= 4 else Q
     if kind in ("duplicates", "cluster", "onehot") and n >= 2:
         Q[B - 1] = rows[int(rng.integers(0, n))]  # a query that IS a row
     ids = rng.permutation(np.arange(10, 10 + n)).astype(np.uint64)  # labels are arbitrary, order of insertion rules ties
-    idx = dawn.VectorIndex(0, dtype=dtype)
+    # shards > 0: the same index behind one sharded handle (logical shards on this device, small chunks)
+    idx = dawn.VectorIndex(0, dtype=dtype) if not shards else dawn.VectorIndex(devices=[0] * shards, dtype=dtype)
     try:
+        if shards:
+            idx.set_option("shard_chunk", 64 * int(rng.integers(1, 9)))
         idx.add_batch(ids, rows)
         stored = synth.round_bf16(rows) if dtype == "bf16" else rows
         idx.set_option("i8_shadow", int(i8))  # False: filter on the f16 shadow / the bf16 rows themselves
@@ -89,5 +100,4 @@ def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kin
             assert np.array_equal(labels[b][:found[b]], olab), (kind, dtype, n, k, B, b)
             assert np.array_equal(dist[b][:found[b]].view(np.uint32), odist.view(np.uint32)), (kind, dtype, n, k, B, b)
     finally:
-        idx.set_option("mfma_sched", 4)  # process-wide
         idx.close()
