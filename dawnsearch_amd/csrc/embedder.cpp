@@ -10,7 +10,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -185,10 +187,24 @@ int upload_inputs(dawn_embedder* e, const uint32_t* ids, const int32_t* off, int
 
 extern "C" {
 
+static int embedder_create_impl(const char* safetensors_path, const char* config_json_path, int device, dawn_embedder** out);
+
 int dawn_embedder_create(const char* safetensors_path, const char* config_json_path, int device,
                          dawn_embedder** out) {
     if (!out || !safetensors_path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
+    try {  // (std::vector / std::map / std::string allocations on file-sized data)
+        return embedder_create_impl(safetensors_path, config_json_path, device, out);
+    } catch (const std::bad_alloc&) {
+        return fail(DAWN_ERR_OOM, "out of host memory while loading %s", safetensors_path);
+    } catch (const std::exception& ex) {
+        return fail(DAWN_ERR_IO, "%s: %s", safetensors_path, ex.what());
+    } catch (...) {
+        return fail(DAWN_ERR_IO, "%s: unexpected exception", safetensors_path);
+    }
+}
+
+static int embedder_create_impl(const char* safetensors_path, const char* config_json_path, int device, dawn_embedder** out) {
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
 
@@ -224,6 +240,12 @@ int dawn_embedder_create(const char* safetensors_path, const char* config_json_p
         cfg.num_hidden_layers < 1 || cfg.num_hidden_layers > 48 || cfg.max_position_embeddings > 512)
         return fail(DAWN_ERR_UNSUPPORTED,
                     "kernels are built for hidden 384 / 12 heads / intermediate %%64 / <=512 positions (all-MiniLM-L6-v2)");
+    // every size below comes from a file: bound it before it sizes an allocation (a C ABI must not throw / terminate)
+    if (cfg.vocab_size < 1 || cfg.vocab_size > (1 << 22) || cfg.type_vocab_size < 1 || cfg.type_vocab_size > 1024 ||
+        cfg.intermediate_size < 64 || cfg.intermediate_size > 65536 || cfg.max_position_embeddings < 1 ||
+        !(cfg.layer_norm_eps >= 0.0) || cfg.layer_norm_eps > 1.0)
+        return fail(DAWN_ERR_UNSUPPORTED, "config.json: vocab_size / type_vocab_size / intermediate_size / "
+                                          "max_position_embeddings / layer_norm_eps out of range");
 
     std::vector<char> file;
     if (!read_file(safetensors_path, file) || file.size() < 8) return fail(DAWN_ERR_IO, "cannot read %s", safetensors_path);

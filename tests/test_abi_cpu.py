@@ -179,3 +179,4 @@ def test_sharded_create_needs_devices_and_checks_arguments(dawn):
     if dawn.device_count() == 0:
         assert _lib.lib.dawn_index_create_sharded(384, 0, 2, None, C.byref(h)) == _lib.ERR_NO_DEVICE
         assert not h.value and "no CPU fallback" in dawn.last_error()
+

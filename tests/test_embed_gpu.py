@@ -281,3 +281,23 @@ def test_single_kernels_in_isolation(provider, oracle):
     for op in (2, 3):  # the skinny form and the 64x64 tile kernel
         got = provider.debug_op(op, x, T, out_cols=1536)
         assert np.abs(got - want).max() < 3e-6 * max(1.0, np.abs(want).max())
+
+
+def test_create_rejects_hostile_config_before_allocating(dawn, tmp_path):
+    """Sizes read from config.json are bounded before they size an allocation (a C ABI must not throw through extern "C")."""
+    import ctypes as C
+    import json
+    from dawnsearch_amd import _lib
+    st = tmp_path / "model.safetensors"
+    st.write_bytes(b"\x02\x00\x00\x00\x00\x00\x00\x00{}")
+    for bad in ({"vocab_size": -5}, {"vocab_size": 2 ** 31 - 1}, {"type_vocab_size": 0}, {"intermediate_size": 1 << 30},
+                {"max_position_embeddings": 0}, {"layer_norm_eps": -1.0}):
+        cj = tmp_path / "config.json"
+        cj.write_text(json.dumps({**synth.MINILM_CONFIG, **bad}))
+        h = C.c_void_p()
+        rc = _lib.lib.dawn_embedder_create(str(st).encode(), str(cj).encode(), 0, C.byref(h))
+        assert rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_IO) and not h.value, (bad, rc)
+    # a sane config with an empty safetensors file: a clean IO error, not a crash
+    (tmp_path / "config.json").write_text(json.dumps(synth.MINILM_CONFIG))
+    h = C.c_void_p()
+    assert _lib.lib.dawn_embedder_create(str(st).encode(), str(tmp_path / "config.json").encode(), 0, C.byref(h)) == _lib.ERR_IO
