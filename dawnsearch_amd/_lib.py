@@ -107,6 +107,7 @@ _SIGS = {
     "dawn_embedder_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "dawn_embedder_hidden_states": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "dawn_embedder_debug_op": (_i32, [_vp, _i32, _vp, _i32, _vp]),
+    "dawn_embedder_debug_gemm_time": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dawn_tokenizer_create": (_i32, [C.c_char_p, _pp]),
     "dawn_tokenizer_destroy": (None, [_vp]),
     "dawn_tokenizer_set_max_length": (_i32, [_vp, _sz]),

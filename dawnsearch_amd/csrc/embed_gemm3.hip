@@ -1,0 +1,393 @@
+// embed_gemm3.hip — f32-accurate dense layers on the bf16 matrix cores (3-way split, 6 products).
+//
+// model.rs:53-64  y = x . W^T + b  is an f32 contraction.  v_mfma_f32_32x32x2_f32 does it at 157 TFLOP/s peak; the bf16
+// matrix cores run 16x that.  Every f32 value is the exact sum of three bf16 values up to 2^-24 of its magnitude:
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)        (the subtractions are exact)
+// so  a b = sum_{i,j} a_i b_j, and the six products with i + j <= 4 carry everything down to 3 x 2^-24 |a b| — the size
+// of one f32 rounding.  Each of them is an EXACT f32 number (8-bit x 8-bit significands), accumulated in f32 by
+// v_mfma_f32_32x32x16_bf16: six MFMAs of 8 passes (192 cycles) do the work of eight f32 MFMAs of 16 passes (512 cycles)
+// for one 32x32 tile and 16 values of k.  The result differs from the f32-MFMA kernel (embed_kernels.hip) by the order of
+// the f32 additions and the three dropped product classes: ~1e-7 relative — the parity bar is 1e-5 on the unit embeddings.
+//
+// Operands travel as PLANES: three bf16 arrays [rows][K] per matrix (weights are split once at load time; activations are
+// written as planes by the kernel that produces them — a consumer tile would otherwise re-split every element N/64 times).
+// A 64x64 block tile, four waves of 32x32; per K-step of 32 each operand is three 4-KiB plane tiles that go HBM/L2 -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; 6 instructions per wave and step) into a double
+// buffer; 16-B chunk c of row r sits at slot c ^ ((r >> 1) & 3) of its 64-B row, so that the ds_read_b128 of an MFMA
+// operand (32 rows x one chunk) touches every bank group once.
+#include "embed_kernels.hpp"
+#include "wave_topk.hpp"
+
+namespace dawn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {  // finite inputs
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+
+// f32 -> three bf16 planes (plane p at planes + p * plane_stride, element index unchanged)
+__device__ __forceinline__ void split3(float a, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    b1 = bf16_rne_bits(a);
+    const float r1 = a - bf16_bits_to_f32(b1);  // exact
+    b2 = bf16_rne_bits(r1);
+    const float r2 = r1 - bf16_bits_to_f32(b2);  // exact
+    b3 = bf16_rne_bits(r2);
+}
+
+__global__ void split_planes_kernel(const float* __restrict__ in, uint16_t* __restrict__ planes, size_t n, size_t plane_stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t b1, b2, b3;
+        split3(in[i], b1, b2, b3);
+        planes[i] = (uint16_t)b1;
+        planes[plane_stride + i] = (uint16_t)b2;
+        planes[2 * plane_stride + i] = (uint16_t)b3;
+    }
+}
+
+void launch_split_planes(const float* in, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t s) {
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, planes, n, plane_stride);
+}
+
+constexpr int G3T = 64;                 // block tile (rows of A, rows of W)
+constexpr int G3K = 32;                 // K-step
+constexpr int G3_PLANE = G3T * G3K * 2;  // 4096 B: one plane tile
+constexpr int G3_BUF = 6 * G3_PLANE;    // A planes | W planes
+
+__device__ __forceinline__ float act_apply3(float v, int act) {
+    if (act == 1) {  // tanh-GELU, model.rs:31-35 (see act_apply in embed_kernels.hip)
+        const float k = 0.7978845608028654f;
+        const float u = k * v * (1.0f + 0.044715f * v * v);
+        const float t = fminf(fmaxf(-2.0f * u, -80.0f), 80.0f);
+        return v / (1.0f + __expf(t));
+    }
+    if (act == 2) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// Y[M,N] (f32, may be NULL) and / or Yp (planes [3][y_rows][N], may be NULL) = act(A . W^T + bias)
+//   Ap: planes [3][a_rows][K] (a_plane = elements per plane), Wp: planes [3][N][K]
+// M arbitrary (rows past M are clamped on load and not stored), N % 64 == 0, K % 32 == 0.
+// A ring of STAGES K-step images: the DMA of step i + STAGES - 1 is issued at step i (after the barrier that says
+// everyone left step i - 1, whose image it overwrites), so a transfer has STAGES - 1 steps of matrix time to land — one
+// step (12 MFMAs = 384 cycles) is shorter than an L2 round trip.  hipcc waits for EVERY LDS-DMA in flight in front of an
+// LDS read it can see, so the fragment reads are inline asm under a hand-counted vmcnt.
+template <int ACT, int STAGES>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __restrict__ Ap, size_t a_plane,
+                                                         const uint16_t* __restrict__ Wp, size_t w_plane,
+                                                         const float* __restrict__ bias, float* __restrict__ Y,
+                                                         uint16_t* __restrict__ Yp, size_t y_plane, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // STAGES x 24 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile order (see gemm_nt_kernel): consecutive tiles of one strip of A on one XCD
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int tiles_n = N / G3T;
+    if (tile >= tiles_n * ((M + G3T - 1) / G3T)) return;
+    const int m0 = (tile / tiles_n) * G3T, n0 = (tile % tiles_n) * G3T;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+    // DMA: this lane fills slot s = wave * 64 + lane of every plane tile: row s >> 2, physical chunk s & 3
+    const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
+    const int s_c = s_cp ^ ((s_row >> 1) & 3);  // logical 16-B chunk (8 values of k) it has to fetch
+    const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
+    const uint16_t* ga = Ap + (size_t)a_row * K + s_c * 8;
+    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * K + s_c * 8;
+    auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
+        unsigned char* base = lds + stage * G3_BUF + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + k0),
+                                             (__attribute__((address_space(3))) void*)(base + p * G3_PLANE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (3 + p) * G3_PLANE), 16, 0, 0);
+        }
+    };
+    // operand reads: lane (r = lane & 31, kh = lane >> 5) wants chunk 2 j + kh of row wm + r (A) / wn + r (W)
+    const int ra = wm + (lane & 31), rb = wn + (lane & 31), kh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    uint32_t a_ad[2], b_ad[2];  // LDS byte offsets (stage 0) of this lane's chunk in k16 half j, plane 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 1) & 3)) << 4));
+        b_ad[j] = lds0 + (uint32_t)(3 * G3_PLANE + rb * 64 + (((2 * j + kh) ^ ((rb >> 1) & 3)) << 4));
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int n_steps = K / G3K;
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < n_steps) dma(st * G3K, st);
+    int stage = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        // this wave's share of step i has landed: at most the DMAs of the (up to STAGES - 2) younger steps are in flight
+        const int younger = n_steps - 1 - i < STAGES - 2 ? n_steps - 1 - i : STAGES - 2;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");  // ... everyone's; and everyone has left step i - 1
+        if (i + STAGES - 1 < n_steps) {
+            int ws = stage + STAGES - 1;
+            if (ws >= STAGES) ws -= STAGES;
+            dma((i + STAGES - 1) * G3K, ws);  // into the image of step i - 1
+        }
+        const uint32_t so = (uint32_t)(stage * G3_BUF);
+        u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j][p]) : "v"(a_ad[j] + so), "n"(p * G3_PLANE));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j][p]) : "v"(b_ad[j] + so), "n"(p * G3_PLANE));
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // (reads are issued in j order, 6 per k16 half: the first half is complete when 6 are still outstanding)
+            // (the fragments are operands of the wait: the MFMAs that read them cannot be scheduled in front of it)
+            if (j == 0)
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]));
+            auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
+                                                              __builtin_bit_cast(bf16x8, fb[j][pb]), acc, 0, 0, 0);
+            };
+            mm(2, 0);  // smallest classes first
+            mm(0, 2);
+            mm(1, 1);
+            mm(1, 0);
+            mm(0, 1);
+            mm(0, 0);
+        }
+        if (++stage == STAGES) stage = 0;
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int n = n0 + wn + (lane & 31);
+    const float bvv = bias[n];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm + row;
+        if (m < M) {
+            const float v = act_apply3(acc[reg] + bvv, ACT);
+            if (Y) Y[(size_t)m * N + n] = v;
+            if (Yp) {
+                uint32_t b1, b2, b3;
+                split3(v, b1, b2, b3);
+                Yp[(size_t)m * N + n] = (uint16_t)b1;
+                Yp[y_plane + (size_t)m * N + n] = (uint16_t)b2;
+                Yp[2 * y_plane + (size_t)m * N + n] = (uint16_t)b3;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 128 x 128 block tile, 8 waves (two per SIMD), wave tile 32 x 64: an A fragment feeds two MFMA columns, so a k16 step is 9
+// fragment reads for 12 MFMAs instead of 6 for 6 — the 64x64 kernel above is bound by the LDS read port (4 SIMDs x 6 KiB per
+// 192 cycles = the port's 128 B/clk), this one needs 73 % of it.  K-step 32, double buffer of 48-KiB images (one workgroup
+// per CU; the second wave of a SIMD covers the first one's waits).  Large M only (M >= 2048: below that there are not
+// enough 128 x 128 tiles for the chip).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int G3B = 128;
+constexpr int G3B_PLANE = G3B * G3K * 2;  // 8192 B
+constexpr int G3B_BUF = 6 * G3B_PLANE;    // 48 KiB
+constexpr int G3B_STAGE_RS = 136;                        // epilogue staging: bytes per 64-column bf16 row (+ 8 B of padding)
+constexpr int G3B_STAGE = 8 * 3 * 32 * G3B_STAGE_RS;     // 8 waves x 3 planes x 32 rows
+constexpr int G3B_LDS = 2 * G3B_BUF > G3B_STAGE ? 2 * G3B_BUF : G3B_STAGE;  // 102 KiB
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __restrict__ Ap, size_t a_plane,
+                                                             const uint16_t* __restrict__ Wp, size_t w_plane,
+                                                             const float* __restrict__ bias, float* __restrict__ Y,
+                                                             uint16_t* __restrict__ Yp, size_t y_plane, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 x 48 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int tiles_n = N / G3B;
+    if (tile >= tiles_n * ((M + G3B - 1) / G3B)) return;
+    const int m0 = (tile / tiles_n) * G3B, n0 = (tile % tiles_n) * G3B;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;  // 4 x 2 waves
+
+    // DMA: 512 lanes fill the 512 16-B slots of every 128-row plane tile: slot s = wave * 64 + lane: row s >> 2, chunk s & 3
+    const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
+    const int s_c = s_cp ^ ((s_row >> 1) & 3);
+    const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
+    const uint16_t* ga = Ap + (size_t)a_row * K + s_c * 8;
+    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * K + s_c * 8;
+    auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
+        unsigned char* base = lds + stage * G3B_BUF + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + k0),
+                                             (__attribute__((address_space(3))) void*)(base + p * G3B_PLANE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (3 + p) * G3B_PLANE), 16, 0, 0);
+        }
+    };
+    const int ra = wm + (lane & 31), rb0 = wn + (lane & 31), rb1 = rb0 + 32, kh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    uint32_t a_ad[2], b_ad[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 1) & 3)) << 4));
+        b_ad[0][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb0 * 64 + (((2 * j + kh) ^ ((rb0 >> 1) & 3)) << 4));
+        b_ad[1][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb1 * 64 + (((2 * j + kh) ^ ((rb1 >> 1) & 3)) << 4));
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+
+    const int n_steps = K / G3K;
+    dma(0, 0);
+    int stage = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (i + 1 < n_steps) dma((i + 1) * G3K, stage ^ 1);
+        const uint32_t so = (uint32_t)(stage * G3B_BUF);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 fa[3], fb0[3], fb1[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb1[0]),
+                           "+v"(fb1[1]), "+v"(fb1[2]));
+            auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb0[pb]),
+                                                               acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb1[pb]),
+                                                               acc1, 0, 0, 0);
+            };
+            mm(2, 0);
+            mm(0, 2);
+            mm(1, 1);
+            mm(1, 0);
+            mm(0, 1);
+            mm(0, 0);
+        }
+        stage ^= 1;
+    }
+    // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
+    // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
+    // L2 (measured: +116 us on the 262-us FFN1 of 32 k tokens) — so the wave's 32 x 64 tile goes through its share of the
+    // (now idle) LDS: bf16 triples written by column, read back by row as 16-B chunks, stored with full sectors.
+    asm volatile("s_barrier" ::: "memory");  // every wave has left the K loop: the images are free
+    float vv[2][16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int n = n0 + wn + 32 * half + (lane & 31);
+        const float bvv = bias[n];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm + row;
+            const float v = act_apply3((half ? acc1[reg] : acc0[reg]) + bvv, ACT);
+            vv[half][reg] = v;
+            if (Y && m < M) Y[(size_t)m * N + n] = v;
+        }
+    }
+    if (Yp) {
+        // staging: [plane][row 0..31][64 columns] bf16, row stride 136 B (68 halves): a column's rows land in different banks
+        constexpr int RS = G3B_STAGE_RS;
+        unsigned char* st = lds + wave * (3 * 32 * RS);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                uint32_t b1, b2, b3;
+                split3(vv[half][reg], b1, b2, b3);
+                uint16_t* q = reinterpret_cast<uint16_t*>(st + row * RS) + 32 * half + (lane & 31);
+                q[0] = (uint16_t)b1;
+                q[32 * RS / 2] = (uint16_t)b2;
+                q[2 * 32 * RS / 2] = (uint16_t)b3;
+            }
+        // (wave-private region: no barrier — the compiler's LDS ordering within a wave is enough)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // 32 rows x 8 chunks of 16 B per plane = 256 chunks: 4 per lane
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int ch = it * 64 + lane, row = ch >> 3, c = ch & 7;
+                const int m = m0 + wm + row;
+                const u32x4 w = *reinterpret_cast<const u32x4*>(st + p * 32 * RS + row * RS + c * 16);
+                if (m < M) *reinterpret_cast<u32x4*>(Yp + p * y_plane + (size_t)m * N + n0 + wn + c * 8) = w;
+            }
+    }
+}
+
+static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                          uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        attr = true;
+    }
+    const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
+    dim3 grid((n_tiles + 7) / 8 * 8), block(512);
+    const size_t lds = G3B_LDS;
+    if (act == 1) hipLaunchKernelGGL(gemm_bf16x3_big_kernel<1>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else if (act == 2) hipLaunchKernelGGL(gemm_bf16x3_big_kernel<2>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else hipLaunchKernelGGL(gemm_bf16x3_big_kernel<0>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+}
+
+int g_gemm3_big_min_m = 2048;  // rows from which the 128 x 128 kernel is used (tuning)
+int g_gemm3_stages = 2;  // tuning: ring depth of the bf16x3 kernel (2 .. 4)
+
+template <int STAGES>
+static void launch_g3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                      uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<0, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<1, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<2, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
+        attr = true;
+    }
+    const int n_tiles = (N / G3T) * ((M + G3T - 1) / G3T);
+    dim3 grid((n_tiles + 7) / 8 * 8), block(256);
+    const size_t lds = (size_t)STAGES * G3_BUF;
+    if (act == 1)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else if (act == 2)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<0, STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+}
+
+void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                        uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+    if (M <= 0) return;
+    if (M >= g_gemm3_big_min_m && N % G3B == 0) return launch_g3_big(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    if (g_gemm3_stages == 2) launch_g3<2>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    else if (g_gemm3_stages == 4) launch_g3<4>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    else launch_g3<3>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+}
+
+}  // namespace dawn

@@ -49,9 +49,11 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 
 // LayerNorm of one 384-wide row held as 6 values per lane (element d = lane + 64*i). model.rs:86-104:
 // mean = sum/H ; xc = x - mean ; var = sum(xc^2)/H (biased) ; xc / sqrt(var + eps) * gamma + beta
+// planes != NULL: the row is also written as three bf16 planes (embed_gemm3.hip: the dense layer that follows reads those)
 __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __restrict__ g,
                                                const float* __restrict__ b, float eps, int lane,
-                                               float* __restrict__ out) {
+                                               float* __restrict__ out, uint16_t* __restrict__ planes = nullptr,
+                                               size_t plane_stride = 0) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) s += v[i];
@@ -68,7 +70,21 @@ __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __res
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int d = lane + 64 * i;
-        out[d] = (v[i] / den) * g[d] + b[d];
+        const float y = (v[i] / den) * g[d] + b[d];
+        out[d] = y;
+        if (planes) {
+            const uint32_t u = __builtin_bit_cast(uint32_t, y);
+            const uint32_t b1 = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+            const float r1 = y - __builtin_bit_cast(float, b1 << 16);
+            const uint32_t u1 = __builtin_bit_cast(uint32_t, r1);
+            const uint32_t b2 = (u1 + 0x7FFFu + ((u1 >> 16) & 1u)) >> 16;
+            const float r2 = r1 - __builtin_bit_cast(float, b2 << 16);
+            const uint32_t u2 = __builtin_bit_cast(uint32_t, r2);
+            const uint32_t b3 = (u2 + 0x7FFFu + ((u2 >> 16) & 1u)) >> 16;
+            planes[d] = (uint16_t)b1;
+            planes[plane_stride + d] = (uint16_t)b2;
+            planes[2 * plane_stride + d] = (uint16_t)b3;
+        }
     }
 }
 
@@ -79,7 +95,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const uint32_t* __restric
                                                       const float* __restrict__ pos,
                                                       const float* __restrict__ type0,
                                                       const float* __restrict__ g, const float* __restrict__ b,
-                                                      float eps, float* __restrict__ x) {
+                                                      float eps, float* __restrict__ x, uint16_t* __restrict__ xp,
+                                                      size_t plane_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -91,13 +108,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const uint32_t* __restric
         const int d = lane + 64 * i;
         v[i] = (we[d] + type0[d]) + pe[d];  // model.rs:269-276 order
     }
-    row_layer_norm(v, g, b, eps, lane, x + (size_t)t * H);
+    row_layer_norm(v, g, b, eps, lane, x + (size_t)t * H, xp ? xp + (size_t)t * H : nullptr, plane_stride);
 }
 
 __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                     int T, const float* __restrict__ g,
                                                     const float* __restrict__ b, float eps,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, uint16_t* __restrict__ outp,
+                                                    size_t plane_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
         const int d = lane + 64 * i;
         v[i] = a[(size_t)t * H + d] + r[(size_t)t * H + d];
     }
-    row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H);
+    row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H, outp ? outp + (size_t)t * H : nullptr, plane_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,16 +677,17 @@ __global__ __launch_bounds__(384) void pool_norm_kernel(const float* __restrict_
 }
 
 void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
-                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s) {
+                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s,
+                     uint16_t* xp, size_t plane_stride) {
     if (T <= 0) return;
     hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, tok_pos, T, word, pos, type0, g, b,
-                       eps, x);
+                       eps, x, xp, plane_stride);
 }
 
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
-                   hipStream_t s) {
+                   hipStream_t s, uint16_t* outp, size_t plane_stride) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out);
+    hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride);
 }
 
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s) {

@@ -5,10 +5,12 @@
 
 namespace dawn {
 void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s);
+// xp / outp != NULL: the rows are also written as three bf16 planes [3][plane_stride] (embed_gemm3.hip)
 void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
-                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s);
+                     const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s,
+                     uint16_t* xp = nullptr, size_t plane_stride = 0);
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
-                   hipStream_t s);
+                   hipStream_t s, uint16_t* outp = nullptr, size_t plane_stride = 0);
 // Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
                     hipStream_t s);
@@ -16,8 +18,14 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 // not applicable to this shape
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s);
+// f32-accurate dense layer on the bf16 matrix cores (embed_gemm3.hip): operands as three bf16 planes each
+void launch_split_planes(const float* in, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t s);
+void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                        uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s);
 void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s);
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s);
 int attention_set_max_lds();
 extern int g_skinny_max_m;
+extern int g_gemm3_stages;
+extern int g_gemm3_big_min_m;
 }  // namespace dawn

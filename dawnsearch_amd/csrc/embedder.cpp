@@ -43,6 +43,8 @@ struct TensorRef {
 
 struct LayerW {
     float *qkv_w, *qkv_b, *ao_w, *ao_b, *ao_g, *ao_beta, *i_w, *i_b, *o_w, *o_b, *o_g, *o_beta;
+    // the four dense weights as three bf16 planes each (embed_gemm3.hip), split once at load time
+    uint16_t *qkv_p = nullptr, *ao_p = nullptr, *i_p = nullptr, *o_p = nullptr;
 };
 
 }  // namespace
@@ -57,6 +59,10 @@ struct dawn_embedder {
     // workspaces (grown on demand)
     int cap_T = 0, cap_B = 0;
     float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *tmp2 = nullptr, *attn = nullptr, *ff = nullptr;
+    // bf16x3 path (batches above the skinny limit): activations that feed a dense layer, as planes [3][cap_T][width]
+    uint16_t* d_wplanes = nullptr;
+    uint16_t *xp = nullptr, *ctxp = nullptr, *attnp = nullptr, *ffp = nullptr;
+    int use_bf16x3 = 1;  // option "gemm_bf16x3"
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
@@ -92,6 +98,12 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
                 (void)hipFree(*b);
                 *b = nullptr;
             }
+        uint16_t** pbufs[] = {&e->xp, &e->ctxp, &e->attnp, &e->ffp};
+        for (uint16_t** b : pbufs)
+            if (*b) {
+                (void)hipFree(*b);
+                *b = nullptr;
+            }
         if (e->d_ids) (void)hipFree(e->d_ids);
         if (e->d_pos) (void)hipFree(e->d_pos);
         e->d_ids = nullptr;
@@ -106,6 +118,12 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
         DAWN_HIP_TRY(hipMalloc((void**)&e->tmp2, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->attn, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ff, cap * I * 4));
+        if (cap > dawn::g_skinny_max_m) {  // planes are only used by the tile path
+            DAWN_HIP_TRY(hipMalloc((void**)&e->xp, (size_t)3 * cap * H * 2));
+            DAWN_HIP_TRY(hipMalloc((void**)&e->ctxp, (size_t)3 * cap * H * 2));
+            DAWN_HIP_TRY(hipMalloc((void**)&e->attnp, (size_t)3 * cap * H * 2));
+            DAWN_HIP_TRY(hipMalloc((void**)&e->ffp, (size_t)3 * cap * I * 2));
+        }
         DAWN_HIP_TRY(hipMalloc((void**)&e->d_ids, cap * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMalloc((void**)&e->d_pos, cap * sizeof(int)));
         e->cap_T = cap;
@@ -131,6 +149,25 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
     const int H = c.hidden_size, I = c.intermediate_size;
     const float eps = (float)c.layer_norm_eps;
     dawn::launch_tok_pos(d_off, B, e->d_pos, s);
+    if (e->use_bf16x3 && T > dawn::g_skinny_max_m && e->xp && e->d_wplanes) {
+        // Throughput form: the dense layers run f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way bf16 split,
+        // 6 products).  Whatever feeds a dense layer is produced as three bf16 planes by the kernel that computes it (the
+        // LayerNorms beside their f32 output — the residual —, FFN1's GELU epilogue instead of it); the attention context
+        // is split by one extra pass.
+        const size_t ps = (size_t)e->cap_T * H, psi = (size_t)e->cap_T * I;  // plane strides
+        dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, e->xp, ps);
+        for (const LayerW& L : e->layers) {
+            dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s);
+            dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s);
+            dawn::launch_split_planes(e->ctx, e->ctxp, (size_t)T * H, ps, s);
+            dawn::launch_gemm_bf16x3(e->ctxp, ps, L.ao_p, (size_t)H * H, L.ao_b, e->tmp, nullptr, 0, T, H, H, 0, s);
+            dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s, e->attnp, ps);
+            dawn::launch_gemm_bf16x3(e->attnp, ps, L.i_p, (size_t)I * H, L.i_b, nullptr, e->ffp, psi, T, I, H, c.act, s);
+            dawn::launch_gemm_bf16x3(e->ffp, psi, L.o_p, (size_t)H * I, L.o_b, e->tmp2, nullptr, 0, T, H, I, 0, s);
+            dawn::launch_add_ln(e->tmp2, e->attn, T, L.o_g, L.o_beta, eps, e->x, s, e->xp, ps);
+        }
+        return;
+    }
     dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s);
     // Latency form (few tokens: the reference's one text per call): the residual LayerNorms run as the prologue of the dense
     // layer that consumes them (launch_gemm_ln_nt) — `pending` = the output LayerNorm of the previous layer not applied
@@ -358,6 +395,32 @@ static int embedder_create_impl(const char* safetensors_path, const char* config
     for (int L = 0; L < NL; ++L)
         e->layers.push_back({W + lo[L].qw, W + lo[L].qb, W + lo[L].aow, W + lo[L].aob, W + lo[L].aog, W + lo[L].aobeta,
                              W + lo[L].iw, W + lo[L].ib, W + lo[L].ow, W + lo[L].ob, W + lo[L].og, W + lo[L].obeta});
+    // the dense weights once more as bf16 planes (6 B per weight: 64 MB for MiniLM-L6); without them the f32 path is used
+    {
+        const size_t per_layer = (size_t)3 * H * H + (size_t)H * H + (size_t)2 * I * H;
+        if (hipMalloc((void**)&e->d_wplanes, per_layer * NL * 3 * sizeof(uint16_t)) == hipSuccess) {
+            uint16_t* p = e->d_wplanes;
+            for (LayerW& Lw : e->layers) {
+                auto planes = [&](const float* w, size_t n) {
+                    uint16_t* at = p;
+                    dawn::launch_split_planes(w, at, n, n, e->stream);
+                    p += 3 * n;
+                    return at;
+                };
+                Lw.qkv_p = planes(Lw.qkv_w, (size_t)3 * H * H);
+                Lw.ao_p = planes(Lw.ao_w, (size_t)H * H);
+                Lw.i_p = planes(Lw.i_w, (size_t)I * H);
+                Lw.o_p = planes(Lw.o_w, (size_t)H * I);
+            }
+            if (hipStreamSynchronize(e->stream) != hipSuccess) {
+                (void)hipFree(e->d_wplanes);
+                e->d_wplanes = nullptr;
+            }
+        } else {
+            (void)hipGetLastError();
+            e->d_wplanes = nullptr;
+        }
+    }
     *out = e;
     return DAWN_OK;
 }
@@ -367,7 +430,8 @@ void dawn_embedder_destroy(dawn_embedder* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->drop_graphs();
-    void* ptrs[] = {e->d_weights, e->x, e->qkv, e->ctx, e->tmp, e->tmp2, e->attn, e->ff, e->d_ids, e->d_off, e->d_pos, e->d_out};
+    void* ptrs[] = {e->d_weights, e->d_wplanes, e->x, e->qkv, e->ctx, e->tmp, e->tmp2, e->attn, e->ff, e->xp, e->ctxp, e->attnp,
+                    e->ffp, e->d_ids, e->d_off, e->d_pos, e->d_out};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -379,6 +443,21 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
     if (std::string(name) == "skinny_max_rows") {  // token count up to which the GEMMs take the split-K skinny form
         if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "skinny_max_rows out of range");
         dawn::g_skinny_max_m = (int)value;
+        return DAWN_OK;
+    }
+    if (std::string(name) == "gemm_bf16x3") {  // 0: batches use the f32-MFMA tile kernel instead of the bf16x3 kernels
+        e->use_bf16x3 = value != 0;
+        e->drop_graphs();
+        return DAWN_OK;
+    }
+    if (std::string(name) == "gemm3_big_min_rows") {  // rows from which the 128 x 128 bf16x3 kernel is used (tuning)
+        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "gemm3_big_min_rows out of range");
+        dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (std::string(name) == "gemm3_stages") {  // ring depth of the bf16x3 kernel (tuning)
+        if (value < 2 || value > 4) return fail(DAWN_ERR_INVALID_ARG, "gemm3_stages must be 2..4");
+        dawn::g_gemm3_stages = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "graphs") {  // 0: never replay hipGraphs (every forward is ~45 plain launches)
@@ -471,7 +550,8 @@ int dawn_embedder_hidden_states(dawn_embedder* e, const uint32_t* token_ids, con
 int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, float* out) {
     if (!e || !in || !out || T <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
     const Config& c = e->cfg;
-    if (T > c.max_position_embeddings) return fail(DAWN_ERR_INVALID_ARG, "T exceeds max_position_embeddings");
+    if (op == 0 && T > c.max_position_embeddings) return fail(DAWN_ERR_INVALID_ARG, "T exceeds max_position_embeddings");
+    if (T > 65536) return fail(DAWN_ERR_INVALID_ARG, "T too large");
     DAWN_HIP_TRY(hipSetDevice(e->device));
     DAWN_TRY(ensure_ws(e, 2 * T, 1));
     hipStream_t s = e->stream;
@@ -496,12 +576,85 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
         dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s);
         dawn::g_skinny_max_m = keep;
         out_elems = (size_t)T * I;
+    } else if (op == 4 || op == 5) {
+        // 4: the same dense layer through the bf16x3 kernel (embed_gemm3.hip): planes made here from the f32 input / weights
+        // 5: ... its planes OUTPUT, re-assembled (p1 + p2 + p3) on the host side of this hook
+        uint16_t *ap = nullptr, *wp = nullptr, *yp = nullptr;
+        DAWN_HIP_TRY(hipMalloc((void**)&ap, (size_t)3 * T * H * 2));
+        DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * I * H * 2));
+        DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * I * 2));
+        DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
+        dawn::launch_split_planes(e->attn, ap, (size_t)T * H, (size_t)T * H, s);
+        dawn::launch_split_planes(L.i_w, wp, (size_t)I * H, (size_t)I * H, s);
+        dawn::launch_gemm_bf16x3(ap, (size_t)T * H, wp, (size_t)I * H, L.i_b, e->ff, yp, (size_t)T * I, T, (int)I, (int)H, c.act, s);
+        out_elems = (size_t)T * I;
+        if (op == 5) {
+            std::vector<uint16_t> hp((size_t)3 * T * I);
+            DAWN_HIP_TRY(hipMemcpyAsync(hp.data(), yp, hp.size() * 2, hipMemcpyDeviceToHost, s));
+            DAWN_HIP_TRY(hipStreamSynchronize(s));
+            for (size_t i = 0; i < out_elems; ++i) {
+                auto f = [&](size_t j) { uint32_t b = (uint32_t)hp[j] << 16; float v; std::memcpy(&v, &b, 4); return v; };
+                out[i] = (f(i) + f(out_elems + i)) + f(2 * out_elems + i);
+            }
+        }
+        DAWN_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(ap);
+        (void)hipFree(wp);
+        (void)hipFree(yp);
+        if (op == 5) return DAWN_OK;
     } else {
         return fail(DAWN_ERR_INVALID_ARG, "unknown op %d", op);
     }
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpyAsync(out, op >= 2 ? e->ff : e->x, out_elems * 4, hipMemcpyDeviceToHost, s));
     DAWN_HIP_TRY(hipStreamSynchronize(s));
+    return DAWN_OK;
+}
+
+// Timing hook: mean ms of one dense layer shape [T x K] . [N x K]^T over `iters` launches: variant 0 = f32 MFMA tile kernel,
+// 1 = bf16x3 kernel (planes prepared outside the timed region).  Layer-0 weights are reused for every shape (K, N) in
+// {(384, 1152), (384, 384), (384, 1536), (1536, 384)}.
+int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int variant, int iters, double* mean_ms) {
+    if (!e || !mean_ms || T <= 0 || iters <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
+    const Config& c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    const LayerW& L = e->layers[0];
+    const float *W = nullptr, *bias = nullptr;
+    if (K == H && N == 3 * H) W = L.qkv_w, bias = L.qkv_b;
+    else if (K == H && N == H) W = L.ao_w, bias = L.ao_b;
+    else if (K == H && N == I) W = L.i_w, bias = L.i_b;
+    else if (K == I && N == H) W = L.o_w, bias = L.o_b;
+    else return fail(DAWN_ERR_INVALID_ARG, "shape not in the model");
+    DAWN_HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    float *a = nullptr, *y = nullptr;
+    uint16_t *ap = nullptr, *wp = nullptr;
+    DAWN_HIP_TRY(hipMalloc((void**)&a, (size_t)T * K * 4));
+    DAWN_HIP_TRY(hipMalloc((void**)&y, (size_t)T * N * 4));
+    DAWN_HIP_TRY(hipMalloc((void**)&ap, (size_t)3 * T * K * 2));
+    DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * N * K * 2));
+    DAWN_HIP_TRY(hipMemsetAsync(a, 0, (size_t)T * K * 4, s));
+    dawn::launch_split_planes(a, ap, (size_t)T * K, (size_t)T * K, s);
+    dawn::launch_split_planes(W, wp, (size_t)N * K, (size_t)N * K, s);
+    const int keep = dawn::g_skinny_max_m;
+    dawn::g_skinny_max_m = 0;
+    hipEvent_t e0, e1;
+    DAWN_HIP_TRY(hipEventCreate(&e0));
+    DAWN_HIP_TRY(hipEventCreate(&e1));
+    for (int it = -2; it < iters; ++it) {
+        if (it == 0) DAWN_HIP_TRY(hipEventRecord(e0, s));
+        if (variant == 0) dawn::launch_gemm_nt(a, W, bias, y, T, N, K, 0, s);
+        else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s);
+    }
+    DAWN_HIP_TRY(hipEventRecord(e1, s));
+    DAWN_HIP_TRY(hipStreamSynchronize(s));
+    dawn::g_skinny_max_m = keep;
+    float ms = 0.f;
+    DAWN_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *mean_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (void* p : {(void*)a, (void*)y, (void*)ap, (void*)wp}) (void)hipFree(p);
     return DAWN_OK;
 }
 

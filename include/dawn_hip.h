@@ -233,8 +233,10 @@ int dawn_embedder_forward(dawn_embedder *e, const uint32_t *token_ids, const int
  * max_len are host-known launch geometry. */
 int dawn_embedder_forward_device(dawn_embedder *e, const uint32_t *d_token_ids, const int32_t *d_seq_offsets,
                                  int B, int total_tokens, int max_len, float *d_out, void *stream);
-/* Tuning knobs (defaults are the tuned values): "skinny_max_rows" = total tokens up to which the GEMMs use the
- * split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
+/* Tuning knobs (defaults are the tuned values): "gemm_bf16x3" 0 = batches above the latency form run their dense layers on
+ * the f32-MFMA tile kernel instead of the f32-accurate 3-way bf16 split on the bf16 matrix cores (default 1;
+ * "gemm3_big_min_rows" = rows from which its 128 x 128 form is used, "gemm3_stages" = ring depth of its 64 x 64 form);
+ * "skinny_max_rows" = total tokens up to which the GEMMs use the split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
  * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
 int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);
 /* BertModel::forward hidden states (model.rs:565-570) for tests: out [total_tokens][384]. */
@@ -243,8 +245,12 @@ int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, con
 /* Test hook: one kernel of the forward in isolation — op 0 BertEmbeddings (model.rs:266-281: in = T token ids of one
  * sequence, out [T][384]); 1 LayerNorm(a + r) with layer 0's attention-output LayerNorm (:86-104,378: in = a | r, each
  * [T][384]); 2 / 3 layer 0's intermediate dense + activation (:425-430, :28-37: in [T][384], out [T][1536]; 2 = the form
- * the forward would take for T rows, 3 = the 64x64 tile kernel). */
+ * the forward would take for T rows, 3 = the 64x64 f32-MFMA tile kernel); 4 / 5 the same layer through the bf16x3 kernel
+ * (4: its f32 output, 5: its three-plane output summed). */
 int dawn_embedder_debug_op(dawn_embedder *e, int op, const void *in, int T, float *out);
+/* Timing hook: mean ms of one dense-layer shape of the model ([T x K] . [N x K]^T) over `iters` launches; variant 0 = the
+ * f32-MFMA tile kernel, 1 = the bf16x3 kernel (f32-accurate 3-way bf16 split on the bf16 matrix cores). */
+int dawn_embedder_debug_gemm_time(dawn_embedder *e, int T, int N, int K, int variant, int iters, double *mean_ms);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host tokenizer — the `tokenizers` crate calls of EmbeddingProvider (embedding_service.rs:88,     */

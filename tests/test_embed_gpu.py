@@ -301,3 +301,40 @@ def test_create_rejects_hostile_config_before_allocating(dawn, tmp_path):
     (tmp_path / "config.json").write_text(json.dumps(synth.MINILM_CONFIG))
     h = C.c_void_p()
     assert _lib.lib.dawn_embedder_create(str(st).encode(), str(tmp_path / "config.json").encode(), 0, C.byref(h)) == _lib.ERR_IO
+
+
+def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider, oracle):
+    """Batches above the skinny limit run their dense layers f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way
+    bf16 split, 6 products; 64 x 64 tiles, 128 x 128 tiles from 2048 tokens): same 1e-5 bar against the oracle, and
+    rounding-level agreement with the f32-MFMA path (option "gemm_bf16x3" = 0) on the same batch."""
+    sb = oracle.SynthBert(3)
+    for n_seq, lo, hi in ((40, 20, 40), (30, 100, 128)):  # ~1200 tokens (64 x 64 tiles), ~3400 tokens (128 x 128 tiles)
+        seqs = synth.token_sequences(91 + n_seq, n_seq, lo, hi)
+        T = sum(len(s) for s in seqs)
+        assert T > 640 and (n_seq == 40 or T >= 2048)
+        emb = provider.calculate_embedding(seqs)
+        for i in (0, n_seq // 2, n_seq - 1):
+            assert np.abs(emb[i] - sb.embed(seqs[i])).max() < TOL_EMB
+        provider.set_option("gemm_bf16x3", 0)
+        try:
+            ref = provider.calculate_embedding(seqs)
+        finally:
+            provider.set_option("gemm_bf16x3", 1)
+        assert np.abs(emb - ref).max() < 2e-6
+        hs = provider.hidden_states(seqs[:2])
+        for s_, h in zip(seqs[:2], hs):
+            assert np.abs(h - sb.forward(s_)).max() < TOL_HID
+    # the dense layer alone, f32 and plane outputs, on 2500 rows (128 x 128 kernel incl. its LDS-staged plane epilogue)
+    w = synth.bert_weights(3)
+    rng = np.random.default_rng(9)
+    T = 2500
+    x = (rng.standard_normal((T, 384)) * np.linspace(0.05, 4, T)[:, None]).astype(np.float32)
+    z = x.astype(np.float64) @ w["encoder.layer.0.intermediate.dense.weight"].astype(np.float64).T \
+        + w["encoder.layer.0.intermediate.dense.bias"]
+    want = 0.5 * z * (1 + np.tanh(np.sqrt(2 / np.pi) * z * (1 + 0.044715 * z * z)))
+    for op in (3, 4, 5):
+        got = provider.debug_op(op, x, T, out_cols=1536)
+        assert np.abs(got - want).max() < 3e-6 * max(1.0, np.abs(want).max()), op
+    for T2 in (65, 700):  # the 64 x 64 bf16x3 kernel, ragged last tile
+        got = provider.debug_op(5, x[:T2], T2, out_cols=1536)
+        assert np.abs(got - want[:T2]).max() < 3e-6 * max(1.0, np.abs(want).max())
