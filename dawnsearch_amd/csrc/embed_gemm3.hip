@@ -174,23 +174,45 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
         if (++stage == STAGES) stage = 0;
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    asm volatile("s_barrier" ::: "memory");  // every wave has left the K loop: the images are free (plane staging below)
     const int n = n0 + wn + (lane & 31);
     const float bvv = bias[n];
+    float vv[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         const int m = m0 + wm + row;
-        if (m < M) {
-            const float v = act_apply3(acc[reg] + bvv, ACT);
-            if (Y) Y[(size_t)m * N + n] = v;
-            if (Yp) {
-                uint32_t b1, b2, b3;
-                split3(v, b1, b2, b3);
-                Yp[(size_t)m * N + n] = (uint16_t)b1;
-                Yp[y_plane + (size_t)m * N + n] = (uint16_t)b2;
-                Yp[2 * y_plane + (size_t)m * N + n] = (uint16_t)b3;
-            }
+        vv[reg] = act_apply3(acc[reg] + bvv, ACT);
+        if (Y && m < M) Y[(size_t)m * N + n] = vv[reg];
+    }
+    if (Yp) {
+        // plane output through the wave's share of the idle LDS (see gemm_bf16x3_big_kernel): [plane][32 rows][32 columns]
+        // bf16, row stride 72 B; read back by row as 16-B chunks: 32 rows x 4 chunks per plane = 2 per lane
+        constexpr int RS = 72;
+        unsigned char* st = lds + wave * (3 * 32 * RS);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            uint32_t b1, b2, b3;
+            split3(vv[reg], b1, b2, b3);
+            uint16_t* q = reinterpret_cast<uint16_t*>(st + row * RS) + (lane & 31);
+            q[0] = (uint16_t)b1;
+            q[32 * RS / 2] = (uint16_t)b2;
+            q[2 * 32 * RS / 2] = (uint16_t)b3;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int ch = it * 64 + lane, row = ch >> 2, c = ch & 3;
+                const int m = m0 + wm + row;
+                // (rows are 72 B apart: 8-B aligned chunks — two 8-B reads)
+                const uint2 w0 = *reinterpret_cast<const uint2*>(st + p * 32 * RS + row * RS + c * 16);
+                const uint2 w1 = *reinterpret_cast<const uint2*>(st + p * 32 * RS + row * RS + c * 16 + 8);
+                if (m < M)
+                    *reinterpret_cast<u32x4*>(Yp + p * y_plane + (size_t)m * N + n0 + wn + c * 8) = u32x4{w0.x, w0.y, w1.x, w1.y};
+            }
     }
 }
 
@@ -354,7 +376,10 @@ static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp
     else hipLaunchKernelGGL(gemm_bf16x3_big_kernel<0>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
 }
 
-int g_gemm3_big_min_m = 2048;  // rows from which the 128 x 128 kernel is used (tuning)
+// The 128 x 128 kernel is used when the GEMM has at least this many of its tiles (two per CU): below that the chip is better
+// filled by four times as many 64 x 64 tiles (4708 rows, 64 / 128 tiles: N = 384: 15.8 / 21.4 us, K = 1536: 44 / 68 us;
+// N = 1536: 51 / 46 us; 32768 rows: 857 / 761 us for the four shapes of a layer — tools/gemm3_probe.py).  0 = always.
+int g_gemm3_big_min_m = 512;
 int g_gemm3_stages = 2;  // tuning: ring depth of the bf16x3 kernel (2 .. 4)
 
 template <int STAGES>
@@ -384,7 +409,7 @@ static void launch_g3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, si
 void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
                         uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
     if (M <= 0) return;
-    if (M >= g_gemm3_big_min_m && N % G3B == 0) return launch_g3_big(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    if (N % G3B == 0 && (long long)((M + G3B - 1) / G3B) * (N / G3B) >= g_gemm3_big_min_m) return launch_g3_big(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
     if (g_gemm3_stages == 2) launch_g3<2>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
     else if (g_gemm3_stages == 4) launch_g3<4>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
     else launch_g3<3>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);

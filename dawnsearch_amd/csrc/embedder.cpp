@@ -450,8 +450,8 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
         e->drop_graphs();
         return DAWN_OK;
     }
-    if (std::string(name) == "gemm3_big_min_rows") {  // rows from which the 128 x 128 bf16x3 kernel is used (tuning)
-        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "gemm3_big_min_rows out of range");
+    if (std::string(name) == "gemm3_big_min_tiles") {  // 128 x 128 tiles from which that form of the bf16x3 kernel is used
+        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "gemm3_big_min_tiles out of range");
         dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }

@@ -235,7 +235,7 @@ int dawn_embedder_forward_device(dawn_embedder *e, const uint32_t *d_token_ids, 
                                  int B, int total_tokens, int max_len, float *d_out, void *stream);
 /* Tuning knobs (defaults are the tuned values): "gemm_bf16x3" 0 = batches above the latency form run their dense layers on
  * the f32-MFMA tile kernel instead of the f32-accurate 3-way bf16 split on the bf16 matrix cores (default 1;
- * "gemm3_big_min_rows" = rows from which its 128 x 128 form is used, "gemm3_stages" = ring depth of its 64 x 64 form);
+ * "gemm3_big_min_tiles" = number of 128 x 128 tiles from which that form is used, "gemm3_stages" = ring depth of its 64 x 64 form);
  * "skinny_max_rows" = total tokens up to which the GEMMs use the split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
  * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
 int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);

@@ -308,10 +308,11 @@ def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider,
     bf16 split, 6 products; 64 x 64 tiles, 128 x 128 tiles from 2048 tokens): same 1e-5 bar against the oracle, and
     rounding-level agreement with the f32-MFMA path (option "gemm_bf16x3" = 0) on the same batch."""
     sb = oracle.SynthBert(3)
-    for n_seq, lo, hi in ((40, 20, 40), (30, 100, 128)):  # ~1200 tokens (64 x 64 tiles), ~3400 tokens (128 x 128 tiles)
+    for n_seq, lo, hi, big in ((40, 20, 40, 512), (30, 100, 128, 0)):  # ~1200 tokens: 64 x 64 tiles; ~3400: 128 x 128 forced
         seqs = synth.token_sequences(91 + n_seq, n_seq, lo, hi)
         T = sum(len(s) for s in seqs)
-        assert T > 640 and (n_seq == 40 or T >= 2048)
+        assert T > 640
+        provider.set_option("gemm3_big_min_tiles", big)
         emb = provider.calculate_embedding(seqs)
         for i in (0, n_seq // 2, n_seq - 1):
             assert np.abs(emb[i] - sb.embed(seqs[i])).max() < TOL_EMB
@@ -324,6 +325,7 @@ def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider,
         hs = provider.hidden_states(seqs[:2])
         for s_, h in zip(seqs[:2], hs):
             assert np.abs(h - sb.forward(s_)).max() < TOL_HID
+    provider.set_option("gemm3_big_min_tiles", 0)
     # the dense layer alone, f32 and plane outputs, on 2500 rows (128 x 128 kernel incl. its LDS-staged plane epilogue)
     w = synth.bert_weights(3)
     rng = np.random.default_rng(9)
@@ -335,6 +337,7 @@ def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider,
     for op in (3, 4, 5):
         got = provider.debug_op(op, x, T, out_cols=1536)
         assert np.abs(got - want).max() < 3e-6 * max(1.0, np.abs(want).max()), op
+    provider.set_option("gemm3_big_min_tiles", 512)
     for T2 in (65, 700):  # the 64 x 64 bf16x3 kernel, ragged last tile
         got = provider.debug_op(5, x[:T2], T2, out_cols=1536)
         assert np.abs(got - want[:T2]).max() < 3e-6 * max(1.0, np.abs(want).max())

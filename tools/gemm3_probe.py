@@ -21,7 +21,7 @@ for T in (37, 200, 2500):
         print(f"T={T} op={op}: max abs err {err.max():.3e}  (|want| max {np.abs(want).max():.2f})  rel {np.max(err / (np.abs(want) + 1e-3)):.3e}", flush=True)
 ms = C.c_double(0)
 for big in (1 << 30, 0):
-  ep.set_option("gemm3_big_min_rows", big)
+  ep.set_option("gemm3_big_min_tiles", big)
   print("128x128 kernel from rows", big)
   for T in (4708, 8192, 32768):
     for (N, K) in ((1152, 384), (384, 384), (1536, 384), (384, 1536)):
