@@ -228,14 +228,15 @@ constexpr int G3B_PLANE = G3B * G3K * 2;  // 8192 B
 constexpr int G3B_BUF = 6 * G3B_PLANE;    // 48 KiB
 constexpr int G3B_STAGE_RS = 136;                        // epilogue staging: bytes per 64-column bf16 row (+ 8 B of padding)
 constexpr int G3B_STAGE = 8 * 3 * 32 * G3B_STAGE_RS;     // 8 waves x 3 planes x 32 rows
-constexpr int G3B_LDS = 2 * G3B_BUF > G3B_STAGE ? 2 * G3B_BUF : G3B_STAGE;  // 102 KiB
+constexpr int G3B_STAGES = 3;
+constexpr int G3B_LDS = G3B_STAGES * G3B_BUF > G3B_STAGE ? G3B_STAGES * G3B_BUF : G3B_STAGE;  // 144 KiB
 
-template <int ACT>
+template <int ACT, int STAGES>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __restrict__ Ap, size_t a_plane,
                                                              const uint16_t* __restrict__ Wp, size_t w_plane,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
                                                              uint16_t* __restrict__ Yp, size_t y_plane, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 x 48 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // STAGES x 48 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per_xcd = gridDim.x >> 3;
@@ -274,13 +275,24 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
 
+    // ring of STAGES images: a step is 24 MFMAs per wave (0.3 us of matrix time, two waves per SIMD) and an L2 round trip
+    // under load is ~1 us: with one image in flight the K loop runs at the DMA's latency (measured: 190 us for
+    // 32768 x 1152 x 384, whose MFMAs, LDS reads and L2 traffic each need ~70 us); two in flight cover it
     const int n_steps = K / G3K;
-    dma(0, 0);
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < n_steps) dma(st * G3K, st);
     int stage = 0;
     for (int i = 0; i < n_steps; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int younger = n_steps - 1 - i < STAGES - 2 ? n_steps - 1 - i : STAGES - 2;
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        if (i + 1 < n_steps) dma((i + 1) * G3K, stage ^ 1);
+        if (i + STAGES - 1 < n_steps) {
+            int ws = stage + STAGES - 1;
+            if (ws >= STAGES) ws -= STAGES;
+            dma((i + STAGES - 1) * G3K, ws);
+        }
         const uint32_t so = (uint32_t)(stage * G3B_BUF);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
             mm(0, 1);
             mm(0, 0);
         }
-        stage ^= 1;
+        if (++stage == STAGES) stage = 0;
     }
     // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
     // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
@@ -363,17 +375,17 @@ static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp
                           uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
         attr = true;
     }
     const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
     dim3 grid((n_tiles + 7) / 8 * 8), block(512);
     const size_t lds = G3B_LDS;
-    if (act == 1) hipLaunchKernelGGL(gemm_bf16x3_big_kernel<1>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
-    else if (act == 2) hipLaunchKernelGGL(gemm_bf16x3_big_kernel<2>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
-    else hipLaunchKernelGGL(gemm_bf16x3_big_kernel<0>, grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    if (act == 1) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<1, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else if (act == 2) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<2, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else hipLaunchKernelGGL((gemm_bf16x3_big_kernel<0, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
 }
 
 // The 128 x 128 kernel is used when the GEMM has at least this many of its tiles (two per CU): below that the chip is better
