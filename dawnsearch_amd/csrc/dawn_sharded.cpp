@@ -17,8 +17,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is loaded on first use (a single-GPU deployment never needs it)
 
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "index_internal.hpp"
 
@@ -54,6 +58,90 @@ Rccl g_rccl;  // process-wide handle of the library; communicators are per index
 
 constexpr int GATHER_AUTO = 0, GATHER_RCCL = 1, GATHER_PEER = 2;
 
+// One issuing thread per shard (shard 0: the caller's own).  A search is ~6 launches per device; issued one device after
+// the other the last of 8 shards starts ~0.2 ms after the first — a quarter of a 12.5 M-row shard scan.  The workers only
+// ISSUE (hipSetDevice is per thread; each touches its own shard and stream); ordering between devices stays with the
+// events.  run() returns when every shard's calls have been made.
+struct ShardWorkers {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<int(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+
+    void start(int G) {
+        rc.assign(G, DAWN_OK);
+        err.assign(G, std::string());
+        const uint64_t gen0 = gen;  // (a restart after "shard_threads" 0 -> 1 must not replay the last job)
+        for (int g = 1; g < G; ++g)
+            th.emplace_back([this, g, gen0] {
+                uint64_t seen = gen0;
+                for (;;) {
+                    std::function<int(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = job;
+                    }
+                    int r;
+                    try {
+                        r = f(g);
+                    } catch (...) {
+                        r = fail(DAWN_ERR_HIP, "exception in a shard worker");
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        rc[g] = r;
+                        if (r != DAWN_OK) err[g] = last_error();
+                        if (--pending == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    // f(g) for every shard: g = 0 on the calling thread, the others on their workers; the first failure is returned (its
+    // message becomes the caller's last error)
+    int run(int G, const std::function<int(int)>& f) {
+        if (th.empty()) {
+            for (int g = 0; g < G; ++g) DAWN_TRY(f(g));
+            return DAWN_OK;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f;
+            pending = G - 1;
+            ++gen;
+        }
+        cv_go.notify_all();
+        const int r0 = f(0);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        if (r0 != DAWN_OK) return r0;
+        for (int g = 1; g < G; ++g)
+            if (rc[g] != DAWN_OK) {
+                last_error() = err[g];
+                return rc[g];
+            }
+        return DAWN_OK;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+};
+
 }  // namespace
 
 struct ShardSet {
@@ -75,6 +163,7 @@ struct ShardSet {
     bool rccl_failed = false;
     std::string rccl_error;
     uint64_t n_searches = 0;
+    ShardWorkers workers;           // option "shard_threads" (default 1: one issuing thread per shard beyond the first)
 
     void locate(size_t p, int* s, size_t* local) const {
         const size_t c = p / chunk;
@@ -132,7 +221,10 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
     S.n_searches += nb;
     DAWN_HIP_TRY(hipSetDevice(root_dev(S)));
     DAWN_HIP_TRY(hipEventRecord(S.ev_q, cs));
-    for (int g = 0; g < S.G; ++g) {
+    const bool rccl = S.use_rccl() && init_rccl(S) == DAWN_OK;
+    // every shard's part, issued by its own thread: wait for the queries, fetch them over xGMI, the launch-only search, and
+    // (peer-copy gather) the copy of its blob into the root's buffer
+    DAWN_TRY(S.workers.run(S.G, [&](int g) -> int {
         dawn_index* sh = S.sh[g];
         DAWN_HIP_TRY(hipSetDevice(S.dev[g]));
         DAWN_HIP_TRY(hipStreamWaitEvent(sh->stream, S.ev_q, 0));  // (also: the previous merge has read d_gather[0])
@@ -144,9 +236,14 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
         char* blob = S.d_blob[g];
         DAWN_TRY(index_search_on_device(sh, q, nb, k, reinterpret_cast<uint64_t*>(blob), reinterpret_cast<float*>(blob + off_d),
                                         reinterpret_cast<uint32_t*>(blob + off_f), sh->stream));
-    }
+        if (!rccl) {
+            DAWN_HIP_TRY(hipMemcpyPeerAsync(S.d_gather[0] + (size_t)g * nbytes, root_dev(S), blob, S.dev[g], nbytes, sh->stream));
+            DAWN_HIP_TRY(hipEventRecord(S.ev_done[g], sh->stream));
+        }
+        return DAWN_OK;
+    }));
     bool gathered = false;
-    if (S.use_rccl() && init_rccl(S) == DAWN_OK) {
+    if (rccl) {
         // ONE collective: every device contributes its blob and receives all G (the root's copy feeds the merge)
         ncclResult_t r = g_rccl.GroupStart();
         for (int g = 0; g < S.G && r == ncclSuccess; ++g) {
@@ -162,13 +259,7 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
         gathered = true;
     }
     if (!gathered) {
-        // G peer copies over xGMI into the root's buffer, each behind its shard's search on that shard's stream
-        for (int g = 0; g < S.G; ++g) {
-            DAWN_HIP_TRY(hipSetDevice(S.dev[g]));
-            DAWN_HIP_TRY(hipMemcpyPeerAsync(S.d_gather[0] + (size_t)g * nbytes, root_dev(S), S.d_blob[g], S.dev[g], nbytes,
-                                            S.sh[g]->stream));
-            DAWN_HIP_TRY(hipEventRecord(S.ev_done[g], S.sh[g]->stream));
-        }
+        // (peer copies over xGMI into the root's buffer were issued behind each shard's search, on that shard's stream)
         DAWN_HIP_TRY(hipSetDevice(root_dev(S)));
         for (int g = 0; g < S.G; ++g) DAWN_HIP_TRY(hipStreamWaitEvent(cs, S.ev_done[g], 0));
     }
@@ -184,6 +275,7 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
 
 void sharded_destroy(dawn_index* idx) {
     ShardSet* S = idx->shards;
+    S->workers.shutdown();
     for (int g = 0; g < (int)S->sh.size(); ++g) {
         (void)hipSetDevice(S->dev[g]);
         (void)hipDeviceSynchronize();
@@ -395,6 +487,12 @@ int sharded_set_option(dawn_index* idx, const char* name, int64_t value) {
         S.chunk = (size_t)value;
         return DAWN_OK;
     }
+    if (n == "shard_threads") {  // 1: one issuing thread per shard beyond the first (default); 0: the caller issues everything
+        S.workers.shutdown();
+        S.workers.stop = false;
+        if (value && S.G > 1) S.workers.start(S.G);
+        return DAWN_OK;
+    }
     if (n == "shard_gather") {
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "shard_gather: 0 auto, 1 RCCL all-gather, 2 peer copies");
         if (value == GATHER_RCCL && !S.distinct)
@@ -521,6 +619,10 @@ int dawn_index_create_sharded(size_t dims, int dtype, int n_gpus, const int* dev
         }
         if (hipSetDevice(S->dev[0]) != hipSuccess || hipEventCreateWithFlags(&S->ev_q, hipEventDisableTiming) != hipSuccess)
             return bail(fail(DAWN_ERR_HIP, "creating the query event failed"));
+        // issuing threads pay off when the shards sit on different devices (per-device queues); logical shards on one
+        // device contend for the same queue: measured 0.302 -> 0.359 ms per search for 8 shards of 25 k rows
+        // (tools/shard_issue_time.py) — there the caller issues everything unless "shard_threads" = 1 asks otherwise
+        if (n_gpus > 1 && S->distinct) S->workers.start(n_gpus);
         *out = idx;
         return DAWN_OK;
     });

@@ -65,7 +65,8 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index **out);
  * files.  This is the multi-GPU counterpart of search_remote's fan-out + BestResults merge (search_service.rs:201-277)
  * for ONE process driving the GPUs of a node (the one-process-per-GPU form is dawn_index_search_device +
  * dawn_topk_merge_packed_device around the caller's own collective).  Extra options: "shard_chunk" (while empty),
- * "shard_gather" 0 auto / 1 RCCL / 2 peer copies. */
+ * "shard_gather" 0 auto / 1 RCCL / 2 peer copies, "shard_threads" 1 / 0: one issuing host thread per shard beyond the first
+ * (default when every shard has its own device) or the caller's thread alone. */
 int dawn_index_create_sharded(size_t dims, int dtype, int n_gpus, const int *devices, dawn_index **out);
 /* *n_shards (1 for a plain index); *gather: 1 RCCL all-gather in use, -1 RCCL selected and not initialised yet (first
  * search), 2 peer copies, 0 nothing to gather; shard_sizes[min(n_shards, cap)] rows per shard.  NULL = not wanted. */

@@ -27,9 +27,10 @@ def main():
     from dawnsearch_amd import synth
 
     devices = [0] * args.logical if args.logical else list(range(args.gpus))
-    modes = [(2, "peer_copies")]
+    # (gather mode, issuing threads, name)
+    modes = [(2, 1, "peer_copies"), (2, 0, "peer_copies_single_issuing_thread")]
     if not args.logical:
-        modes.append((1, "rccl_all_gather"))
+        modes.append((1, 1, "rccl_all_gather"))
     idx = dawn.VectorIndex(devices=devices)
     t0 = time.time()
     idx.fill_synthetic(1, 0, args.rows, 1)
@@ -37,11 +38,12 @@ def main():
     q1 = synth.planted_queries(1, [4242 % args.rows], 5)
     Q = synth.unit_rows(3, 0, 256)
     Q[0] = q1[0]
-    for mode, name in modes:
-        out = {"mode": name, "n_gpus": len(devices), "logical_shards_on_one_device": bool(args.logical),
+    for mode, threads, name in modes:
+        out = {"mode": name, "issuing_threads_per_shard": bool(threads), "n_gpus": len(devices), "logical_shards_on_one_device": bool(args.logical),
                "rows": args.rows, "k": args.k, "fill_seconds": fill_s}
         try:
             idx.set_option("shard_gather", mode)
+            idx.set_option("shard_threads", threads)
             for B, qs in ((1, q1), (256, Q)):
                 steps = args.steps if B == 1 else max(5, args.steps // 3)
                 for _ in range(3):
