@@ -23,25 +23,11 @@ namespace dawn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {  // finite inputs
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
-
 // f32 -> three bf16 planes (plane p at planes + p * plane_stride, element index unchanged)
-__device__ __forceinline__ void split3(float a, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
-    b1 = bf16_rne_bits(a);
-    const float r1 = a - bf16_bits_to_f32(b1);  // exact
-    b2 = bf16_rne_bits(r1);
-    const float r2 = r1 - bf16_bits_to_f32(b2);  // exact
-    b3 = bf16_rne_bits(r2);
-}
-
 __global__ void split_planes_kernel(const float* __restrict__ in, uint16_t* __restrict__ planes, size_t n, size_t plane_stride) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t b1, b2, b3;
-        split3(in[i], b1, b2, b3);
+        split3_bf16(in[i], b1, b2, b3);
         planes[i] = (uint16_t)b1;
         planes[plane_stride + i] = (uint16_t)b2;
         planes[2 * plane_stride + i] = (uint16_t)b3;
@@ -186,33 +172,42 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
         if (Y && m < M) Y[(size_t)m * N + n] = vv[reg];
     }
     if (Yp) {
-        // plane output through the wave's share of the idle LDS (see gemm_bf16x3_big_kernel): [plane][32 rows][32 columns]
-        // bf16, row stride 72 B; read back by row as 16-B chunks: 32 rows x 4 chunks per plane = 2 per lane
-        constexpr int RS = 72;
-        unsigned char* st = lds + wave * (3 * 32 * RS);
+        // plane output through the wave's share of the idle LDS (see gemm_bf16x3_big_kernel): the 32 x 32 tile in f32, 128 B per
+        // row; 16-B slot q of row r sits at (q + ((r >> 2) & 1)) & 7 (a ds_read_b128 lane group then covers all 16 slots of the
+        // 256-B bank row); read back as 8 consecutive floats per lane: 32 rows x 4 chunks = 2 per lane
+        float* st = reinterpret_cast<float*>(lds + wave * (32 * 128));
+        const int rot = 4 * (lane >> 5);  // ((row >> 2) & 1) in dwords: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            uint32_t b1, b2, b3;
-            split3(vv[reg], b1, b2, b3);
-            uint16_t* q = reinterpret_cast<uint16_t*>(st + row * RS) + (lane & 31);
-            q[0] = (uint16_t)b1;
-            q[32 * RS / 2] = (uint16_t)b2;
-            q[2 * 32 * RS / 2] = (uint16_t)b3;
+            st[row * 32 + (((lane & 31) + rot) & 31)] = vv[reg];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int it = 0; it < 2; ++it) {
+            const int ch = it * 64 + lane, row = ch >> 2, c = ch & 3;
+            const int m = m0 + wm + row;
+            const int r1 = (row >> 2) & 1;
+            const float4 f0 = *reinterpret_cast<const float4*>(st + row * 32 + (((2 * c + r1) & 7) << 2));
+            const float4 f1 = *reinterpret_cast<const float4*>(st + row * 32 + (((2 * c + 1 + r1) & 7) << 2));
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            uint32_t w[3][4];
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int ch = it * 64 + lane, row = ch >> 2, c = ch & 3;
-                const int m = m0 + wm + row;
-                // (rows are 72 B apart: 8-B aligned chunks — two 8-B reads)
-                const uint2 w0 = *reinterpret_cast<const uint2*>(st + p * 32 * RS + row * RS + c * 16);
-                const uint2 w1 = *reinterpret_cast<const uint2*>(st + p * 32 * RS + row * RS + c * 16 + 8);
-                if (m < M)
-                    *reinterpret_cast<u32x4*>(Yp + p * y_plane + (size_t)m * N + n0 + wn + c * 8) = u32x4{w0.x, w0.y, w1.x, w1.y};
+            for (int e = 0; e < 4; ++e) {
+                uint32_t a1, a2, a3, c1, c2, c3;
+                split3_bf16(f[2 * e], a1, a2, a3);
+                split3_bf16(f[2 * e + 1], c1, c2, c3);
+                w[0][e] = a1 | (c1 << 16);
+                w[1][e] = a2 | (c2 << 16);
+                w[2][e] = a3 | (c3 << 16);
             }
+            if (m < M) {
+                uint16_t* dst = Yp + (size_t)m * N + n0 + wn + c * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
+            }
+        }
     }
 }
 
@@ -226,8 +221,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
 constexpr int G3B = 128;
 constexpr int G3B_PLANE = G3B * G3K * 2;  // 8192 B
 constexpr int G3B_BUF = 6 * G3B_PLANE;    // 48 KiB
-constexpr int G3B_STAGE_RS = 136;                        // epilogue staging: bytes per 64-column bf16 row (+ 8 B of padding)
-constexpr int G3B_STAGE = 8 * 3 * 32 * G3B_STAGE_RS;     // 8 waves x 3 planes x 32 rows
+constexpr int G3B_STAGE = 8 * 32 * 256;                  // epilogue staging: 8 waves x 32 rows x 64 floats
 constexpr int G3B_STAGES = 3;
 constexpr int G3B_LDS = G3B_STAGES * G3B_BUF > G3B_STAGE ? G3B_STAGES * G3B_BUF : G3B_STAGE;  // 144 KiB
 
@@ -324,7 +318,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
     // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
     // L2 (measured: +116 us on the 262-us FFN1 of 32 k tokens) — so the wave's 32 x 64 tile goes through its share of the
-    // (now idle) LDS: bf16 triples written by column, read back by row as 16-B chunks, stored with full sectors.
+    // (now idle) LDS in f32, is read back by row, split there, and stored as 16-B chunks (full sectors).  (Splitting first
+    // and staging bf16 triples costs 96 two-byte LDS stores per lane instead of 32 dword stores: +5 % on the whole kernel.)
     asm volatile("s_barrier" ::: "memory");  // every wave has left the K loop: the images are free
     float vv[2][16];
 #pragma unroll
@@ -341,33 +336,45 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
         }
     }
     if (Yp) {
-        // staging: [plane][row 0..31][64 columns] bf16, row stride 136 B (68 halves): a column's rows land in different banks
-        constexpr int RS = G3B_STAGE_RS;
-        unsigned char* st = lds + wave * (3 * 32 * RS);
+        // staging in f32: the wave's 32 x 64 tile as [row][64 floats] (256 B per row, 8 KiB per wave), one 4-byte LDS
+        // store per value (a 32-lane group writes 32 consecutive banks); read back as 8 consecutive floats of a row per
+        // lane (two ds_read_b128), split there, and stored as one 16-B chunk per plane.  16-B slot q of row r sits at
+        // (q + ((r >> 1) & 1)) & 15: a b128 lane group (16 lanes = 4 rows x 4 even slots) then covers all 16 slots.
+        float* st = reinterpret_cast<float*>(lds + wave * (32 * 256));
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                uint32_t b1, b2, b3;
-                split3(vv[half][reg], b1, b2, b3);
-                uint16_t* q = reinterpret_cast<uint16_t*>(st + row * RS) + 32 * half + (lane & 31);
-                q[0] = (uint16_t)b1;
-                q[32 * RS / 2] = (uint16_t)b2;
-                q[2 * 32 * RS / 2] = (uint16_t)b3;
+                const int rot = 4 * ((reg >> 1) & 1);  // (row >> 1) & 1 in dwords
+                st[row * 64 + ((32 * half + (lane & 31) + rot) & 63)] = vv[half][reg];
             }
-        // (wave-private region: no barrier — the compiler's LDS ordering within a wave is enough)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // 32 rows x 8 chunks of 16 B per plane = 256 chunks: 4 per lane
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int it = 0; it < 4; ++it) {
+            const int ch = it * 64 + lane, row = ch >> 3, c = ch & 7;
+            const int m = m0 + wm + row;
+            const int r1 = (row >> 1) & 1;
+            const float4 f0 = *reinterpret_cast<const float4*>(st + row * 64 + (((2 * c + r1) & 15) << 2));
+            const float4 f1 = *reinterpret_cast<const float4*>(st + row * 64 + (((2 * c + 1 + r1) & 15) << 2));
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            uint32_t w[3][4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int ch = it * 64 + lane, row = ch >> 3, c = ch & 7;
-                const int m = m0 + wm + row;
-                const u32x4 w = *reinterpret_cast<const u32x4*>(st + p * 32 * RS + row * RS + c * 16);
-                if (m < M) *reinterpret_cast<u32x4*>(Yp + p * y_plane + (size_t)m * N + n0 + wn + c * 8) = w;
+            for (int e = 0; e < 4; ++e) {
+                uint32_t a1, a2, a3, c1, c2, c3;
+                split3_bf16(f[2 * e], a1, a2, a3);
+                split3_bf16(f[2 * e + 1], c1, c2, c3);
+                w[0][e] = a1 | (c1 << 16);
+                w[1][e] = a2 | (c2 << 16);
+                w[2][e] = a3 | (c3 << 16);
             }
+            if (m < M) {
+                uint16_t* dst = Yp + (size_t)m * N + n0 + wn + c * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
+            }
+        }
     }
 }
 

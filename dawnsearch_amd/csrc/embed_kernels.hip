@@ -73,14 +73,8 @@ __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __res
         const float y = (v[i] / den) * g[d] + b[d];
         out[d] = y;
         if (planes) {
-            const uint32_t u = __builtin_bit_cast(uint32_t, y);
-            const uint32_t b1 = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-            const float r1 = y - __builtin_bit_cast(float, b1 << 16);
-            const uint32_t u1 = __builtin_bit_cast(uint32_t, r1);
-            const uint32_t b2 = (u1 + 0x7FFFu + ((u1 >> 16) & 1u)) >> 16;
-            const float r2 = r1 - __builtin_bit_cast(float, b2 << 16);
-            const uint32_t u2 = __builtin_bit_cast(uint32_t, r2);
-            const uint32_t b3 = (u2 + 0x7FFFu + ((u2 >> 16) & 1u)) >> 16;
+            uint32_t b1, b2, b3;
+            split3_bf16(y, b1, b2, b3);
             planes[d] = (uint16_t)b1;
             planes[plane_stride + d] = (uint16_t)b2;
             planes[2 * plane_stride + d] = (uint16_t)b3;
@@ -490,52 +484,64 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // attention, sequences of 65..128 tokens (pages; the indexer embeds one page per call): one block (4 waves) per (head,
 // sequence), both contractions on v_mfma_f32_32x32x2_f32 (exact f32 FMAs).  Wave w owns query rows 32w..32w+31:
-//   scores: 4 key tiles x 16 MFMAs (A = Q rows, B = K rows, both read from LDS with row stride 33: conflict-free);
+//   scores: 4 key tiles x 16 MFMAs (A = Q rows, straight from global memory into registers; B = K rows from LDS, row
+//   stride 33: conflict-free);
 //   softmax in the accumulator layout (a lane holds one key column of 16 rows per tile: row max / row sum are a
 //   5-step xor butterfly over the 32 lanes of its half-wave);
-//   P is written to the wave's LDS strip and read back as the A operand of P.V (64 MFMAs, B = V rows).
-// 1 block per CU (117 KB of LDS); a thread per query row took 51 us per layer for one 128-token page.
+//   P.V one key tile at a time: the tile's 32 x 32 probabilities go through the wave's 4-KiB LDS strip and come back as the
+//   A operand (16 MFMAs per tile, B = V rows).
+// 50 KiB of LDS (K, V, four strips): three blocks per CU, so that one block's loads run under another's matrix work.
+// (With Q and the whole 32 x 128 P strip of every wave in LDS — 117 KiB, one block per CU — a layer of 256 pages took
+// 154 us; a thread per query row took 51 us per layer for ONE 128-token page.)
+// ctx (f32) and / or ctxp (three bf16 planes, embed_gemm3.hip) are written; either may be NULL.
 // ------------------------------------------------------------------------------------------------
 constexpr int ATM_S = 128;            // keys / query rows covered
-constexpr int ATM_LD = DH + 1;        // Q, K, V row stride
-constexpr int ATM_PLD = ATM_S + 1;    // P row stride
-constexpr int ATM_LDS_FLOATS = 3 * ATM_S * ATM_LD + 4 * 32 * ATM_PLD;
+constexpr int ATM_LD = DH + 1;        // K, V, P row stride
+constexpr int ATM_LDS_FLOATS = 2 * ATM_S * ATM_LD + 4 * 32 * ATM_LD;
 
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv /*[T][1152]*/,
                                                             const int* __restrict__ seq_offsets,
-                                                            float* __restrict__ ctx /*[T][384]*/) {
+                                                            float* __restrict__ ctx /*[T][384]*/,
+                                                            uint16_t* __restrict__ ctxp, size_t plane_stride) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm;
-    float* Ks = sm + ATM_S * ATM_LD;
-    float* Vs = sm + 2 * ATM_S * ATM_LD;
+    float* Ks = sm;
+    float* Vs = sm + ATM_S * ATM_LD;
     const int h = blockIdx.x, b = blockIdx.y;
     const int start = seq_offsets[b];
     const int S = seq_offsets[b + 1] - start;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* Ps = sm + 3 * ATM_S * ATM_LD + wave * (32 * ATM_PLD);
+    float* Ps = sm + 2 * ATM_S * ATM_LD + wave * (32 * ATM_LD);
+    const int r = lane & 31, kh = lane >> 5;
+    // this lane's Q fragment: Q[row 32w + r][2 kk + kh], kk = 0..15 (the two lanes of a row share its 128-B line)
+    float qa[16];
+    {
+        const int qrow = wave * 32 + r;
+        const float* q = qkv + (size_t)(start + (qrow < S ? qrow : 0)) * (3 * H) + h * DH;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(q + 4 * c);
+            if (qrow >= S) t = f32x4{0.f, 0.f, 0.f, 0.f};
+            qa[2 * c] = kh ? t[1] : t[0];
+            qa[2 * c + 1] = kh ? t[3] : t[2];
+        }
+    }
     for (int i = tid; i < ATM_S * (DH / 4); i += 256) {
         const int j = i >> 3, c = (i & 7) * 4;
-        f32x4 qq = {0.f, 0.f, 0.f, 0.f}, kk = qq, vv = qq;  // rows past the sequence: zeros (masked below)
+        f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;  // rows past the sequence: zeros (masked below)
         if (j < S) {
             const float* row = qkv + (size_t)(start + j) * (3 * H) + h * DH + c;
-            qq = *reinterpret_cast<const f32x4*>(row);
             kk = *reinterpret_cast<const f32x4*>(row + H);
             vv = *reinterpret_cast<const f32x4*>(row + 2 * H);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            Qs[j * ATM_LD + c + e] = qq[e];
             Ks[j * ATM_LD + c + e] = kk[e];
             Vs[j * ATM_LD + c + e] = vv[e];
         }
     }
     __syncthreads();
-    if (wave * 32 >= S) return;  // none of this wave's query rows exists (no barrier below)
-    const int r = lane & 31, kh = lane >> 5;
+    if (wave * 32 >= S) return;  // none of this wave's query rows exists (no block barrier below)
     // ---- scores: acc[jt][e] = S[row 32w + 8(e>>2) + (e&3) + 4kh][key 32jt + r]
-    float qa[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) qa[kk] = Qs[(wave * 32 + r) * ATM_LD + 2 * kk + kh];
     f32x16 acc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -567,13 +573,26 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         mx[e] = fmaxf(mx[e], lane_xor_f32<1>(mx[e], lane));
         sum[e] = 0.f;
     }
+    // ---- out = P.V, key tile by key tile: A = P[row r][key 2kk + kh] (this wave's strip), B = V[key][dim r].  The strip is
+    // private to the wave and LDS operations of one wave complete in order: no barrier between its writes and reads.
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    const int n_jt = (S + 31) >> 5;  // key tiles beyond S have P = 0 and V = 0: skipped
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
+        if (jt < n_jt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
-            sum[e] += p;
-            Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_PLD + jt * 32 + r] = p;
+            for (int e = 0; e < 16; ++e) {
+                const float p = expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
+                sum[e] += p;
+                Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_LD + r] = p;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_LD + 2 * kk + kh], Vs[(jt * 32 + 2 * kk + kh) * ATM_LD + r], o, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 #pragma unroll
@@ -584,17 +603,38 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         sum[e] += lane_xor_f32<2>(sum[e], lane);
         sum[e] += lane_xor_f32<1>(sum[e], lane);
     }
-    // ---- out = P.V: A = P[row r][key 2kk + kh] (this wave's strip), B = V[key 2kk + kh][dim r]
-    f32x16 o;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
-    const int n_kk = (S + 1) >> 1;  // keys beyond S have P = 0 and V = 0: skip them
-    for (int kk = 0; kk < n_kk; ++kk)
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_PLD + 2 * kk + kh], Vs[(2 * kk + kh) * ATM_LD + r], o, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int row = wave * 32 + 8 * (e >> 2) + (e & 3) + 4 * kh;
-        if (row < S) ctx[(size_t)(start + row) * H + h * DH + r] = o[e] / sum[e];
+        const int lrow = 8 * (e >> 2) + (e & 3) + 4 * kh;
+        const int row = wave * 32 + lrow;
+        const float v = o[e] / sum[e];
+        if (ctx && row < S) ctx[(size_t)(start + row) * H + h * DH + r] = v;
+        if (ctxp) Ps[lrow * ATM_LD + r] = v;
+    }
+    if (ctxp) {
+        // the 32 x 32 tile back by row: 8 consecutive dims per lane, split into the three bf16 planes, one 16-B store each
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int ch = it * 64 + lane, lrow = ch >> 2, c = ch & 3;
+            const int row = wave * 32 + lrow;
+            uint32_t w[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t a1, a2, a3, c1, c2, c3;
+                split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e], a1, a2, a3);
+                split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], c1, c2, c3);
+                w[0][e] = a1 | (c1 << 16);
+                w[1][e] = a2 | (c2 << 16);
+                w[2][e] = a3 | (c3 << 16);
+            }
+            if (row < S) {
+                uint16_t* dst = ctxp + (size_t)(start + row) * H + h * DH + c * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4*>(dst + p * plane_stride) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
+            }
+        }
     }
 }
 
@@ -690,20 +730,23 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
     hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride);
 }
 
-void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s) {
-    if (B <= 0) return;
+bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s, uint16_t* ctxp,
+                      size_t plane_stride) {
+    if (B <= 0) return false;
     if (max_len > 64 && max_len <= ATM_S) {
+        // (with planes asked for, only the planes are written: the dense layer that follows reads nothing else)
         hipLaunchKernelGGL(attention_mfma_kernel, dim3(NH, B), dim3(256), ATM_LDS_FLOATS * sizeof(float), s, qkv, seq_offsets,
-                           ctx);
-        return;
+                           ctxp ? nullptr : ctx, ctxp, plane_stride);
+        return ctxp != nullptr;
     }
     if (max_len > 64) {
         const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
         hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
-        return;
+        return false;
     }
     if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
+    return false;
 }
 
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s) {

@@ -18,11 +18,30 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 // not applicable to this shape
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s);
+#if defined(__HIPCC__)
+// f32 -> three bf16 values (bit patterns) with a = b1 + b2 + b3 up to 2^-24 |a|: b1 = bf16(a), b2 = bf16(a - b1),
+// b3 = bf16(a - b1 - b2), round to nearest even, the subtractions exact (finite inputs)
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3_bf16(float a, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    b1 = bf16_rne_bits(a);
+    const float r1 = a - __builtin_bit_cast(float, b1 << 16);
+    b2 = bf16_rne_bits(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, b2 << 16);
+    b3 = bf16_rne_bits(r2);
+}
+#endif
+
 // f32-accurate dense layer on the bf16 matrix cores (embed_gemm3.hip): operands as three bf16 planes each
 void launch_split_planes(const float* in, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t s);
 void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
                         uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s);
-void launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s);
+// ctxp != NULL asks for the context as three bf16 planes (embed_gemm3.hip): true = written (and ctx is NOT), false = this
+// sequence length has no plane-writing kernel: ctx was written, split it
+bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s,
+                      uint16_t* ctxp = nullptr, size_t plane_stride = 0);
 void launch_pool_norm(const float* x, const int* seq_offsets, int B, float* out, hipStream_t s);
 int attention_set_max_lds();
 extern int g_skinny_max_m;

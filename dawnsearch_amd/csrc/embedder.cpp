@@ -152,14 +152,14 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
     if (e->use_bf16x3 && T > dawn::g_skinny_max_m && e->xp && e->d_wplanes) {
         // Throughput form: the dense layers run f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way bf16 split,
         // 6 products).  Whatever feeds a dense layer is produced as three bf16 planes by the kernel that computes it (the
-        // LayerNorms beside their f32 output — the residual —, FFN1's GELU epilogue instead of it); the attention context
-        // is split by one extra pass.
+        // LayerNorms beside their f32 output — the residual —, FFN1's GELU epilogue and the page attention instead of it; the
+        // attention kernels of other sequence lengths write f32, split by one extra pass).
         const size_t ps = (size_t)e->cap_T * H, psi = (size_t)e->cap_T * I;  // plane strides
         dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, e->xp, ps);
         for (const LayerW& L : e->layers) {
             dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s);
-            dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s);
-            dawn::launch_split_planes(e->ctx, e->ctxp, (size_t)T * H, ps, s);
+            if (!dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, e->ctxp, ps))
+                dawn::launch_split_planes(e->ctx, e->ctxp, (size_t)T * H, ps, s);
             dawn::launch_gemm_bf16x3(e->ctxp, ps, L.ao_p, (size_t)H * H, L.ao_b, e->tmp, nullptr, 0, T, H, H, 0, s);
             dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s, e->attnp, ps);
             dawn::launch_gemm_bf16x3(e->attnp, ps, L.i_p, (size_t)I * H, L.i_b, nullptr, e->ffp, psi, T, I, H, c.act, s);
@@ -612,7 +612,7 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
 }
 
 // Timing hook: mean ms of one dense layer shape [T x K] . [N x K]^T over `iters` launches: variant 0 = f32 MFMA tile kernel,
-// 1 = bf16x3 kernel (planes prepared outside the timed region).  Layer-0 weights are reused for every shape (K, N) in
+// 1 = bf16x3 kernel (planes prepared outside the timed region), 2 = ... writing planes instead of f32, 3 = ... with GELU.  Layer-0 weights are reused for every shape (K, N) in
 // {(384, 1152), (384, 384), (384, 1536), (1536, 384)}.
 int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int variant, int iters, double* mean_ms) {
     if (!e || !mean_ms || T <= 0 || iters <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
@@ -633,7 +633,14 @@ int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int var
     DAWN_HIP_TRY(hipMalloc((void**)&y, (size_t)T * N * 4));
     DAWN_HIP_TRY(hipMalloc((void**)&ap, (size_t)3 * T * K * 2));
     DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * N * K * 2));
-    DAWN_HIP_TRY(hipMemsetAsync(a, 0, (size_t)T * K * 4, s));
+    // activations: the model's own (random) weights, repeated — zero operands would let the chip clock higher than real data
+    for (size_t off = 0, n = (size_t)T * K; off < n;) {
+        const size_t take = std::min(n - off, (size_t)3 * H * H);
+        DAWN_HIP_TRY(hipMemcpyAsync(a + off, L.qkv_w, take * 4, hipMemcpyDeviceToDevice, s));
+        off += take;
+    }
+    uint16_t* yp = nullptr;
+    if (variant >= 2) DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * N * 2));
     dawn::launch_split_planes(a, ap, (size_t)T * K, (size_t)T * K, s);
     dawn::launch_split_planes(W, wp, (size_t)N * K, (size_t)N * K, s);
     const int keep = dawn::g_skinny_max_m;
@@ -644,7 +651,8 @@ int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int var
     for (int it = -2; it < iters; ++it) {
         if (it == 0) DAWN_HIP_TRY(hipEventRecord(e0, s));
         if (variant == 0) dawn::launch_gemm_nt(a, W, bias, y, T, N, K, 0, s);
-        else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s);
+        else if (variant == 1) dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s);
+        else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, nullptr, yp, (size_t)T * N, T, N, K, variant == 3 ? 1 : 0, s);
     }
     DAWN_HIP_TRY(hipEventRecord(e1, s));
     DAWN_HIP_TRY(hipStreamSynchronize(s));
@@ -654,7 +662,7 @@ int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int var
     *mean_ms = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    for (void* p : {(void*)a, (void*)y, (void*)ap, (void*)wp}) (void)hipFree(p);
+    for (void* p : {(void*)a, (void*)y, (void*)ap, (void*)wp, (void*)yp}) (void)hipFree(p);
     return DAWN_OK;
 }
 
