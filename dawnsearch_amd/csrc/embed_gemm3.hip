@@ -9,12 +9,15 @@
 // for one 32x32 tile and 16 values of k.  The result differs from the f32-MFMA kernel (embed_kernels.hip) by the order of
 // the f32 additions and the three dropped product classes: ~1e-7 relative — the parity bar is 1e-5 on the unit embeddings.
 //
-// Operands travel as PLANES: three bf16 arrays [rows][K] per matrix (weights are split once at load time; activations are
+// Operands travel as PLANES: three bf16 arrays per matrix, K-blocked (plane_index in embed_kernels.hpp) (weights are split once at load time; activations are
 // written as planes by the kernel that produces them — a consumer tile would otherwise re-split every element N/64 times).
 // A 64x64 block tile, four waves of 32x32; per K-step of 32 each operand is three 4-KiB plane tiles that go HBM/L2 -> LDS by
 // LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; 6 instructions per wave and step) into a double
-// buffer; 16-B chunk c of row r sits at slot c ^ ((r >> 1) & 3) of its 64-B row, so that the ds_read_b128 of an MFMA
-// operand (32 rows x one chunk) touches every bank group once.
+// buffer; 16-B chunk c of row r sits at slot c ^ ((r >> 2) & 3) of its 64-B row, so that the ds_read_b128 of an MFMA
+// operand (32 rows x one chunk) is conflict-free: the instruction is served in four groups of 16 lanes — lanes {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} and the same + 32 — and the four rows of a group that share r & 3 (one 64-B quarter of the
+// 256-B bank row) differ in (r >> 2) & 3.  (With (r >> 1) & 3 every read was a 2-way conflict: SQ_LDS_BANK_CONFLICT was 12 %
+// of the kernel's cycles.)
 #include "embed_kernels.hpp"
 #include "wave_topk.hpp"
 
@@ -23,22 +26,25 @@ namespace dawn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// f32 -> three bf16 planes (plane p at planes + p * plane_stride, element index unchanged)
-__global__ void split_planes_kernel(const float* __restrict__ in, uint16_t* __restrict__ planes, size_t n, size_t plane_stride) {
+// f32 [rows][K] row-major -> three K-blocked bf16 planes (plane_index)
+__global__ void split_planes_kernel(const float* __restrict__ in, uint16_t* __restrict__ planes, int rows, int K, size_t rows_alloc) {
+    const size_t n = (size_t)rows * K, plane_stride = rows_alloc * K;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t b1, b2, b3;
         split3_bf16(in[i], b1, b2, b3);
-        planes[i] = (uint16_t)b1;
-        planes[plane_stride + i] = (uint16_t)b2;
-        planes[2 * plane_stride + i] = (uint16_t)b3;
+        const size_t o = plane_index(i / K, (int)(i % K), rows_alloc);
+        planes[o] = (uint16_t)b1;
+        planes[plane_stride + o] = (uint16_t)b2;
+        planes[2 * plane_stride + o] = (uint16_t)b3;
     }
 }
 
-void launch_split_planes(const float* in, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t s) {
+void launch_split_planes(const float* in, uint16_t* planes, int rows, int K, size_t rows_alloc, hipStream_t s) {
+    const size_t n = (size_t)rows * K;
     if (n == 0) return;
     size_t blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, planes, n, plane_stride);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, planes, rows, K, rows_alloc);
 }
 
 constexpr int G3T = 64;                 // block tile (rows of A, rows of W)
@@ -57,8 +63,8 @@ __device__ __forceinline__ float act_apply3(float v, int act) {
     return v;
 }
 
-// Y[M,N] (f32, may be NULL) and / or Yp (planes [3][y_rows][N], may be NULL) = act(A . W^T + bias)
-//   Ap: planes [3][a_rows][K] (a_plane = elements per plane), Wp: planes [3][N][K]
+// Y[M,N] (f32, may be NULL) and / or Yp (K-blocked planes of a [y_plane / N x N] operand, may be NULL) = act(A . W^T + bias)
+//   Ap: K-blocked planes of a [a_plane / K x K] operand (a_plane = elements per plane), Wp: of [N x K] (embed_kernels.hpp)
 // M arbitrary (rows past M are clamped on load and not stored), N % 64 == 0, K % 32 == 0.
 // A ring of STAGES K-step images: the DMA of step i + STAGES - 1 is issued at step i (after the barrier that says
 // everyone left step i - 1, whose image it overwrites), so a transfer has STAGES - 1 steps of matrix time to land — one
@@ -82,17 +88,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
 
     // DMA: this lane fills slot s = wave * 64 + lane of every plane tile: row s >> 2, physical chunk s & 3
     const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
-    const int s_c = s_cp ^ ((s_row >> 1) & 3);  // logical 16-B chunk (8 values of k) it has to fetch
+    const int s_c = s_cp ^ ((s_row >> 2) & 3);  // logical 16-B chunk (8 values of k) it has to fetch
     const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
-    const uint16_t* ga = Ap + (size_t)a_row * K + s_c * 8;
-    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * K + s_c * 8;
+    // K-blocked planes (plane_index): the 64 rows x 32 k of a step are 4 KiB contiguous; step k0 starts k0 * rows_alloc on
+    const size_t a_rows = a_plane / K, w_rows = w_plane / K, y_rows = Yp ? y_plane / N : 0;
+    const uint16_t* ga = Ap + (size_t)a_row * 32 + s_c * 8;
+    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * 32 + s_c * 8;
     auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
         unsigned char* base = lds + stage * G3_BUF + wave * 1024;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + (size_t)k0 * a_rows),
                                              (__attribute__((address_space(3))) void*)(base + p * G3_PLANE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + (size_t)k0 * w_rows),
                                              (__attribute__((address_space(3))) void*)(base + (3 + p) * G3_PLANE), 16, 0, 0);
         }
     };
@@ -102,8 +110,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
     uint32_t a_ad[2], b_ad[2];  // LDS byte offsets (stage 0) of this lane's chunk in k16 half j, plane 0
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 1) & 3)) << 4));
-        b_ad[j] = lds0 + (uint32_t)(3 * G3_PLANE + rb * 64 + (((2 * j + kh) ^ ((rb >> 1) & 3)) << 4));
+        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 2) & 3)) << 4));
+        b_ad[j] = lds0 + (uint32_t)(3 * G3_PLANE + rb * 64 + (((2 * j + kh) ^ ((rb >> 2) & 3)) << 4));
     }
 
     f32x16 acc;
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
                 w[1][e] = a2 | (c2 << 16);
                 w[2][e] = a3 | (c3 << 16);
             }
-            if (m < M) {
-                uint16_t* dst = Yp + (size_t)m * N + n0 + wn + c * 8;
+            if (m < M) {  // (the wave's 32 columns are one k-block of the next layer: 16 rows x 64 B contiguous per store)
+                uint16_t* dst = Yp + plane_index(m, n0 + wn + c * 8, y_rows);
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
@@ -225,7 +233,7 @@ constexpr int G3B_STAGE = 8 * 32 * 256;                  // epilogue staging: 8 
 constexpr int G3B_STAGES = 3;
 constexpr int G3B_LDS = G3B_STAGES * G3B_BUF > G3B_STAGE ? G3B_STAGES * G3B_BUF : G3B_STAGE;  // 144 KiB
 
-template <int ACT, int STAGES>
+template <int ACT, int STAGES, int PP>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __restrict__ Ap, size_t a_plane,
                                                              const uint16_t* __restrict__ Wp, size_t w_plane,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
@@ -242,17 +250,19 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
 
     // DMA: 512 lanes fill the 512 16-B slots of every 128-row plane tile: slot s = wave * 64 + lane: row s >> 2, chunk s & 3
     const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
-    const int s_c = s_cp ^ ((s_row >> 1) & 3);
+    const int s_c = s_cp ^ ((s_row >> 2) & 3);
     const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
-    const uint16_t* ga = Ap + (size_t)a_row * K + s_c * 8;
-    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * K + s_c * 8;
+    // K-blocked planes (plane_index): the 128 rows x 32 k of a step are 8 KiB contiguous — a wave's piece is 1 KiB of it
+    const size_t a_rows = a_plane / K, w_rows = w_plane / K, y_rows = Yp ? y_plane / N : 0;
+    const uint16_t* ga = Ap + (size_t)a_row * 32 + s_c * 8;
+    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * 32 + s_c * 8;
     auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
         unsigned char* base = lds + stage * G3B_BUF + wave * 1024;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + (size_t)k0 * a_rows),
                                              (__attribute__((address_space(3))) void*)(base + p * G3B_PLANE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + (size_t)k0 * w_rows),
                                              (__attribute__((address_space(3))) void*)(base + (3 + p) * G3B_PLANE), 16, 0, 0);
         }
     };
@@ -261,9 +271,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     uint32_t a_ad[2], b_ad[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 1) & 3)) << 4));
-        b_ad[0][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb0 * 64 + (((2 * j + kh) ^ ((rb0 >> 1) & 3)) << 4));
-        b_ad[1][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb1 * 64 + (((2 * j + kh) ^ ((rb1 >> 1) & 3)) << 4));
+        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 2) & 3)) << 4));
+        b_ad[0][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb0 * 64 + (((2 * j + kh) ^ ((rb0 >> 2) & 3)) << 4));
+        b_ad[1][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb1 * 64 + (((2 * j + kh) ^ ((rb1 >> 2) & 3)) << 4));
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -273,6 +283,78 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     // under load is ~1 us: with one image in flight the K loop runs at the DMA's latency (measured: 190 us for
     // 32768 x 1152 x 384, whose MFMAs, LDS reads and L2 traffic each need ~70 us); two in flight cover it
     const int n_steps = K / G3K;
+    if constexpr (PP != 0) {
+        // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  A wave's step is a memory phase M(i) — the
+        // 18 fragment reads of step i, its six DMA pieces of step i + STAGES - 1, the wait for its share of step i + 1 — and
+        // a matrix phase C(i) — the 24 MFMAs — with a block barrier after each; waves 4..7 start one barrier late, so that
+        // M(i) of one group runs under C(i) (or C(i - 1)) of the other: while a SIMD's matrix pipe works for one wave, the
+        // other wave's loads are being issued.  (In lockstep all eight waves issue DMA at the same time, ~100-180 cycles a
+        // piece, and nobody feeds the matrix pipe.  Measured on 32768 rows, lockstep / ping-pong: K = 1536: 229 / 214 us,
+        // the K = 384 shapes 1-2 %; with the K loop's parts removed (K = 1536): no DMA 154 us, no fragment reads 178 us,
+        // no MFMAs 125 us, the MFMAs alone would take 97 us.)
+        //   image i is read by group 0 in its M(i) and by group 1 one phase later; it is overwritten by the DMA of
+        //   M(i + 1), which both groups start after the barrier that ends group 1's M(i);
+        //   image i + 1 is complete when every wave has waited for its share: at the end of its M(i), in front of the
+        //   barrier that group 0's M(i + 1) follows.
+        const int grp = wave >> 2;
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < n_steps) dma(st * G3K, st);
+        if (n_steps - 1 >= STAGES - 2 && STAGES >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");  // image 0 is complete
+        if (grp == 1) asm volatile("s_barrier" ::: "memory");  // the stagger
+        int stage = 0;
+        for (int i = 0; i < n_steps; ++i) {
+            const uint32_t so = (uint32_t)(stage * G3B_BUF);
+            u32x4 fa[2][3], fb0[2][3], fb1[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j][p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[j][p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[j][p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
+                }
+            if (i + STAGES - 1 < n_steps) {
+                int ws = stage + STAGES - 1;
+                if (ws >= STAGES) ws -= STAGES;
+                dma((i + STAGES - 1) * G3K, ws);  // into the image of step i - 1
+            }
+            // my share of step i + 1: at most the younger steps' pieces may still be in flight
+            if (i + 1 < n_steps) {
+                const int younger = n_steps - 2 - i < STAGES - 2 ? n_steps - 2 - i : STAGES - 2;
+                if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fb0[0][0]), "+v"(fb0[0][1]), "+v"(fb0[0][2]),
+                           "+v"(fb1[0][0]), "+v"(fb1[0][1]), "+v"(fb1[0][2]));
+            asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fb0[1][2]),
+                         "+v"(fb1[1][0]), "+v"(fb1[1][1]), "+v"(fb1[1][2]));
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
+                                                                   __builtin_bit_cast(bf16x8, fb0[j][pb]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
+                                                                   __builtin_bit_cast(bf16x8, fb1[j][pb]), acc1, 0, 0, 0);
+                };
+                mm(2, 0);
+                mm(0, 2);
+                mm(1, 1);
+                mm(1, 0);
+                mm(0, 1);
+                mm(0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            if (++stage == STAGES) stage = 0;
+        }
+        if (grp == 0) asm volatile("s_barrier" ::: "memory");  // (as many barriers as group 1)
+    } else {
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
         if (st < n_steps) dma(st * G3K, st);
@@ -315,6 +397,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
         }
         if (++stage == STAGES) stage = 0;
     }
+    }
     // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
     // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
     // L2 (measured: +116 us on the 262-us FFN1 of 32 k tokens) — so the wave's 32 x 64 tile goes through its share of the
@@ -338,25 +421,29 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     if (Yp) {
         // staging in f32: the wave's 32 x 64 tile as [row][64 floats] (256 B per row, 8 KiB per wave), one 4-byte LDS
         // store per value (a 32-lane group writes 32 consecutive banks); read back as 8 consecutive floats of a row per
-        // lane (two ds_read_b128), split there, and stored as one 16-B chunk per plane.  16-B slot q of row r sits at
-        // (q + ((r >> 1) & 1)) & 15: a b128 lane group (16 lanes = 4 rows x 4 even slots) then covers all 16 slots.
+        // lane (two ds_read_b128), split there, and stored as one 16-B chunk per plane.  The tile's 64 columns are two
+        // k-blocks of the next layer's operand: lane q (+ 64 per round) takes chunk q & 3 of row (q >> 2) & 31 in k-block
+        // q >> 7, so that a store instruction writes 16 rows x 64 B = 1 KiB contiguous.  16-B slot s of row r sits at
+        // (s + (r & 1) + 8 ((r >> 1) & 1)) & 15: a b128 lane group (rows {0, 3, 5, 6} or {1, 2, 4, 7} + 8 n, four even or
+        // four odd slots each) then covers all 16 slots of the 256-B bank row.
         float* st = reinterpret_cast<float*>(lds + wave * (32 * 256));
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int rot = 4 * ((reg >> 1) & 1);  // (row >> 1) & 1 in dwords
+                const int rot = 4 * ((reg & 1) + 8 * ((reg >> 1) & 1));  // slot rotation of the row, in dwords
                 st[row * 64 + ((32 * half + (lane & 31) + rot) & 63)] = vv[half][reg];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int ch = it * 64 + lane, row = ch >> 3, c = ch & 7;
+            const int q = it * 64 + lane, c4 = q & 3, row = (q >> 2) & 31, kb = q >> 7;
             const int m = m0 + wm + row;
-            const int r1 = (row >> 1) & 1;
-            const float4 f0 = *reinterpret_cast<const float4*>(st + row * 64 + (((2 * c + r1) & 15) << 2));
-            const float4 f1 = *reinterpret_cast<const float4*>(st + row * 64 + (((2 * c + 1 + r1) & 15) << 2));
+            const int rot = (row & 1) + 8 * ((row >> 1) & 1);
+            const int s0 = 2 * (kb * 4 + c4);
+            const float4 f0 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + rot) & 15) << 2));
+            const float4 f1 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + 1 + rot) & 15) << 2));
             const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
             uint32_t w[3][4];
 #pragma unroll
@@ -369,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
                 w[2][e] = a3 | (c3 << 16);
             }
             if (m < M) {
-                uint16_t* dst = Yp + (size_t)m * N + n0 + wn + c * 8;
+                uint16_t* dst = Yp + plane_index(m, n0 + wn + kb * 32 + c4 * 8, y_rows);
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
@@ -378,21 +465,30 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     }
 }
 
-static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
-                          uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+int g_gemm3_pingpong = 1;  // tuning: 1 = the two waves of a SIMD run half a step apart (see the kernel)
+
+template <int PP>
+static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                            uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2, G3B_STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
         attr = true;
     }
     const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
     dim3 grid((n_tiles + 7) / 8 * 8), block(512);
     const size_t lds = G3B_LDS;
-    if (act == 1) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<1, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
-    else if (act == 2) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<2, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
-    else hipLaunchKernelGGL((gemm_bf16x3_big_kernel<0, G3B_STAGES>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    if (act == 1) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<1, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else if (act == 2) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<2, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+    else hipLaunchKernelGGL((gemm_bf16x3_big_kernel<0, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
+}
+
+static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
+                          uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+    if (g_gemm3_pingpong) return launch_g3_big_v<1>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    return launch_g3_big_v<0>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
 }
 
 // The 128 x 128 kernel is used when the GEMM has at least this many of its tiles (two per CU): below that the chip is better

@@ -49,11 +49,12 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 
 // LayerNorm of one 384-wide row held as 6 values per lane (element d = lane + 64*i). model.rs:86-104:
 // mean = sum/H ; xc = x - mean ; var = sum(xc^2)/H (biased) ; xc / sqrt(var + eps) * gamma + beta
-// planes != NULL: the row is also written as three bf16 planes (embed_gemm3.hip: the dense layer that follows reads those)
+// planes != NULL: row t is also written into three K-blocked bf16 planes (embed_gemm3.hip: the dense layer that follows
+// reads those; plane_stride = rows_alloc * H)
 __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __restrict__ g,
                                                const float* __restrict__ b, float eps, int lane,
                                                float* __restrict__ out, uint16_t* __restrict__ planes = nullptr,
-                                               size_t plane_stride = 0) {
+                                               size_t plane_stride = 0, size_t t = 0) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) s += v[i];
@@ -75,9 +76,10 @@ __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __res
         if (planes) {
             uint32_t b1, b2, b3;
             split3_bf16(y, b1, b2, b3);
-            planes[d] = (uint16_t)b1;
-            planes[plane_stride + d] = (uint16_t)b2;
-            planes[2 * plane_stride + d] = (uint16_t)b3;
+            const size_t o = plane_index(t, d, plane_stride / H);  // (32 lanes: 64 contiguous bytes)
+            planes[o] = (uint16_t)b1;
+            planes[plane_stride + o] = (uint16_t)b2;
+            planes[2 * plane_stride + o] = (uint16_t)b3;
         }
     }
 }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const uint32_t* __restric
         const int d = lane + 64 * i;
         v[i] = (we[d] + type0[d]) + pe[d];  // model.rs:269-276 order
     }
-    row_layer_norm(v, g, b, eps, lane, x + (size_t)t * H, xp ? xp + (size_t)t * H : nullptr, plane_stride);
+    row_layer_norm(v, g, b, eps, lane, x + (size_t)t * H, xp, plane_stride, (size_t)t);
 }
 
 __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a, const float* __restrict__ r,
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
         const int d = lane + 64 * i;
         v[i] = a[(size_t)t * H + d] + r[(size_t)t * H + d];
     }
-    row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H, outp ? outp + (size_t)t * H : nullptr, plane_stride);
+    row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H, outp, plane_stride, (size_t)t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,7 +501,7 @@ constexpr int ATM_S = 128;            // keys / query rows covered
 constexpr int ATM_LD = DH + 1;        // K, V, P row stride
 constexpr int ATM_LDS_FLOATS = 2 * ATM_S * ATM_LD + 4 * 32 * ATM_LD;
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+__global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const float* __restrict__ qkv /*[T][1152]*/,
                                                             const int* __restrict__ seq_offsets,
                                                             float* __restrict__ ctx /*[T][384]*/,
                                                             uint16_t* __restrict__ ctxp, size_t plane_stride) {
@@ -542,15 +544,17 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     __syncthreads();
     if (wave * 32 >= S) return;  // none of this wave's query rows exists (no block barrier below)
     // ---- scores: acc[jt][e] = S[row 32w + 8(e>>2) + (e&3) + 4kh][key 32jt + r]
+    // (kk outer, key tile inner: four independent accumulator chains — a dependent MFMA waits out its predecessor's 16 passes)
     f32x16 acc[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
             acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], Ks[(jt * 32 + r) * ATM_LD + 2 * kk + kh], acc[jt], 0, 0, 0);
-    }
     const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
     float mx[16], sum[16];
 #pragma unroll
@@ -575,9 +579,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     }
     // ---- out = P.V, key tile by key tile: A = P[row r][key 2kk + kh] (this wave's strip), B = V[key][dim r].  The strip is
     // private to the wave and LDS operations of one wave complete in order: no barrier between its writes and reads.
-    f32x16 o;
+    // (two accumulator chains: even and odd key pairs, added at the end)
+    f32x16 o, o1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    for (int e = 0; e < 16; ++e) o[e] = o1[e] = 0.f;
     const int n_jt = (S + 31) >> 5;  // key tiles beyond S have P = 0 and V = 0: skipped
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -590,11 +595,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
+            for (int kk = 0; kk < 16; kk += 2) {
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_LD + 2 * kk + kh], Vs[(jt * 32 + 2 * kk + kh) * ATM_LD + r], o, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_LD + 2 * kk + 2 + kh], Vs[(jt * 32 + 2 * kk + 2 + kh) * ATM_LD + r], o1, 0, 0, 0);
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] += o1[e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         sum[e] += lane_xor_f32<16>(sum[e], lane);
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                 w[2][e] = a3 | (c3 << 16);
             }
             if (row < S) {
-                uint16_t* dst = ctxp + (size_t)(start + row) * H + h * DH + c * 8;
+                uint16_t* dst = ctxp + plane_index((size_t)(start + row), h * DH + c * 8, plane_stride / H);  // head h = k-block h
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     *reinterpret_cast<u32x4*>(dst + p * plane_stride) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};

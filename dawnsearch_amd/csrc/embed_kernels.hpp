@@ -5,7 +5,7 @@
 
 namespace dawn {
 void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s);
-// xp / outp != NULL: the rows are also written as three bf16 planes [3][plane_stride] (embed_gemm3.hip)
+// xp / outp != NULL: the rows are also written as three bf16 planes (K-blocked, see plane_index; plane_stride = rows_alloc * 384)
 void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
                      const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s,
                      uint16_t* xp = nullptr, size_t plane_stride = 0);
@@ -18,7 +18,16 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 // not applicable to this shape
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s);
+// Planes (embed_gemm3.hip) are K-BLOCKED: element (row, k) of one plane of a [rows_alloc x width] operand sits at
+// ((k / 32) * rows_alloc + row) * 32 + k % 32 — the 32 values of k that one K-step of the dense kernels consumes are 64
+// contiguous bytes, and the rows of a tile follow each other: a tile's K-step slice of a plane is ONE contiguous run (8 KiB
+// for 128 rows), fetched in whole 128-B lines.  (Row-major planes gave 64-B pieces, every line requested twice: the
+// L2 -> LDS stream of the 128 x 128 kernel ran at 17 B/clk/CU and set its time.)  plane p of an operand starts at
+// p * rows_alloc * width.
 #if defined(__HIPCC__)
+__host__ __device__ __forceinline__ size_t plane_index(size_t row, int k, size_t rows_alloc) {
+    return ((size_t)(k >> 5) * rows_alloc + row) * 32 + (size_t)(k & 31);
+}
 // f32 -> three bf16 values (bit patterns) with a = b1 + b2 + b3 up to 2^-24 |a|: b1 = bf16(a), b2 = bf16(a - b1),
 // b3 = bf16(a - b1 - b2), round to nearest even, the subtractions exact (finite inputs)
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
@@ -35,7 +44,8 @@ __device__ __forceinline__ void split3_bf16(float a, uint32_t& b1, uint32_t& b2,
 #endif
 
 // f32-accurate dense layer on the bf16 matrix cores (embed_gemm3.hip): operands as three bf16 planes each
-void launch_split_planes(const float* in, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t s);
+// in: [rows][K] f32 row-major -> planes of a [rows_alloc x K] operand (K % 32 == 0, rows <= rows_alloc)
+void launch_split_planes(const float* in, uint16_t* planes, int rows, int K, size_t rows_alloc, hipStream_t s);
 void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
                         uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s);
 // ctxp != NULL asks for the context as three bf16 planes (embed_gemm3.hip): true = written (and ctx is NOT), false = this
@@ -47,4 +57,5 @@ int attention_set_max_lds();
 extern int g_skinny_max_m;
 extern int g_gemm3_stages;
 extern int g_gemm3_big_min_m;
+extern int g_gemm3_pingpong;
 }  // namespace dawn

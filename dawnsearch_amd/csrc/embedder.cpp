@@ -159,7 +159,7 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
         for (const LayerW& L : e->layers) {
             dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s);
             if (!dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, e->ctxp, ps))
-                dawn::launch_split_planes(e->ctx, e->ctxp, (size_t)T * H, ps, s);
+                dawn::launch_split_planes(e->ctx, e->ctxp, T, H, (size_t)e->cap_T, s);
             dawn::launch_gemm_bf16x3(e->ctxp, ps, L.ao_p, (size_t)H * H, L.ao_b, e->tmp, nullptr, 0, T, H, H, 0, s);
             dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s, e->attnp, ps);
             dawn::launch_gemm_bf16x3(e->attnp, ps, L.i_p, (size_t)I * H, L.i_b, nullptr, e->ffp, psi, T, I, H, c.act, s);
@@ -401,16 +401,17 @@ static int embedder_create_impl(const char* safetensors_path, const char* config
         if (hipMalloc((void**)&e->d_wplanes, per_layer * NL * 3 * sizeof(uint16_t)) == hipSuccess) {
             uint16_t* p = e->d_wplanes;
             for (LayerW& Lw : e->layers) {
-                auto planes = [&](const float* w, size_t n) {
+                auto planes = [&](const float* w, int rows, int K) {
+                    const size_t n = (size_t)rows * K;
                     uint16_t* at = p;
-                    dawn::launch_split_planes(w, at, n, n, e->stream);
+                    dawn::launch_split_planes(w, at, rows, K, (size_t)rows, e->stream);
                     p += 3 * n;
                     return at;
                 };
-                Lw.qkv_p = planes(Lw.qkv_w, (size_t)3 * H * H);
-                Lw.ao_p = planes(Lw.ao_w, (size_t)H * H);
-                Lw.i_p = planes(Lw.i_w, (size_t)I * H);
-                Lw.o_p = planes(Lw.o_w, (size_t)H * I);
+                Lw.qkv_p = planes(Lw.qkv_w, 3 * H, H);
+                Lw.ao_p = planes(Lw.ao_w, H, H);
+                Lw.i_p = planes(Lw.i_w, I, H);
+                Lw.o_p = planes(Lw.o_w, H, I);
             }
             if (hipStreamSynchronize(e->stream) != hipSuccess) {
                 (void)hipFree(e->d_wplanes);
@@ -453,6 +454,11 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
     if (std::string(name) == "gemm3_big_min_tiles") {  // 128 x 128 tiles from which that form of the bf16x3 kernel is used
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "gemm3_big_min_tiles out of range");
         dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (std::string(name) == "gemm3_pingpong") {  // 128 x 128 kernel: waves of a SIMD half a step apart (tuning; default 1)
+        if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "gemm3_pingpong must be 0 or 1");
+        dawn::g_gemm3_pingpong = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "gemm3_stages") {  // ring depth of the bf16x3 kernel (tuning)
@@ -584,8 +590,8 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
         DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * I * H * 2));
         DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * I * 2));
         DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
-        dawn::launch_split_planes(e->attn, ap, (size_t)T * H, (size_t)T * H, s);
-        dawn::launch_split_planes(L.i_w, wp, (size_t)I * H, (size_t)I * H, s);
+        dawn::launch_split_planes(e->attn, ap, T, (int)H, (size_t)T, s);
+        dawn::launch_split_planes(L.i_w, wp, (int)I, (int)H, (size_t)I, s);
         dawn::launch_gemm_bf16x3(ap, (size_t)T * H, wp, (size_t)I * H, L.i_b, e->ff, yp, (size_t)T * I, T, (int)I, (int)H, c.act, s);
         out_elems = (size_t)T * I;
         if (op == 5) {
@@ -594,7 +600,8 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
             DAWN_HIP_TRY(hipStreamSynchronize(s));
             for (size_t i = 0; i < out_elems; ++i) {
                 auto f = [&](size_t j) { uint32_t b = (uint32_t)hp[j] << 16; float v; std::memcpy(&v, &b, 4); return v; };
-                out[i] = (f(i) + f(out_elems + i)) + f(2 * out_elems + i);
+                const size_t o = dawn::plane_index(i / I, (int)(i % I), (size_t)T);  // K-blocked planes
+                out[i] = (f(o) + f(out_elems + o)) + f(2 * out_elems + o);
             }
         }
         DAWN_HIP_TRY(hipStreamSynchronize(s));
@@ -641,8 +648,8 @@ int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int var
     }
     uint16_t* yp = nullptr;
     if (variant >= 2) DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * N * 2));
-    dawn::launch_split_planes(a, ap, (size_t)T * K, (size_t)T * K, s);
-    dawn::launch_split_planes(W, wp, (size_t)N * K, (size_t)N * K, s);
+    dawn::launch_split_planes(a, ap, T, K, (size_t)T, s);
+    dawn::launch_split_planes(W, wp, N, K, (size_t)N, s);
     const int keep = dawn::g_skinny_max_m;
     dawn::g_skinny_max_m = 0;
     hipEvent_t e0, e1;

@@ -17,7 +17,7 @@ for r in c.execute("select * from pmc_events"):
     if dur < mind:
         continue
     m = re.search(r"(scan_\w+?kernel|\w+_kernel)", name)
-    key = (m.group(1) if m else name[:40], r["counter_name"])
+    key = ((m.group(1) if m else name[:40]) + (re.search(r"<[^>]*>", name).group(0) if "<" in name else ""), r["counter_name"])
     e = acc.setdefault(key, [0, 0.0, 0.0])
     e[0] += 1
     e[1] += r["counter_value"]
