@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const float* __r
         if (jt < n_jt) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
+                const float p = __expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
                 sum[e] += p;
                 Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_LD + r] = p;
             }
@@ -643,6 +643,148 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const float* __r
                 for (int p = 0; p < 3; ++p)
                     *reinterpret_cast<u32x4*>(dst + p * plane_stride) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention for BATCHES of short sequences (up to 32 NT tokens, NT = 1 or 2; the query batch of the search path): one WAVE
+// per (head, sequence, tile of 32 query rows), four of them per block, no block barrier.  Same contractions and
+// accumulator-layout softmax as attention_mfma_kernel, but every MFMA operand except P comes straight from global memory
+// into registers (Q, K: this lane's row, 8 x 16 B; V: 16 keys x one dim, 32 lanes = one 128-B line) — a sequence's rows are
+// read by this one wave (and its NT - 1 siblings), so there is nothing to share through LDS.  (The three-phase block
+// kernel above, built for ONE text per call, took 28 us per layer for 256 queries: 3072 blocks x four barrier phases.)
+// Single-tile scores and P.V run as two accumulator chains (even / odd k pairs), summed at the end.
+// Writes the context as K-blocked bf16 planes (embed_gemm3.hip).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void attention_wave_kernel(const float* __restrict__ qkv /*[T][1152]*/,
+                                                            const int* __restrict__ seq_offsets, int B,
+                                                            uint16_t* __restrict__ ctxp, size_t plane_stride) {
+    __shared__ float strips[4 * 32 * ATM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.y * 4 + wave;
+    const int b = item / NT, rt = item % NT;
+    if (b >= B) return;
+    const int h = blockIdx.x;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    if (rt * 32 >= S) return;
+    float* Ps = strips + wave * (32 * ATM_LD);
+    const int r = lane & 31, kh = lane >> 5;
+    const int n_jt = (S + 31) >> 5;
+    // fragment of row `row` of Q (which = 0) or K (which = 1): element 2 kk + kh, kk = 0..15; zeros past the sequence
+    auto row_frag = [&](int row, int which, float (&f)[16]) __attribute__((always_inline)) {
+        const float* q = qkv + (size_t)(start + (row < S ? row : 0)) * (3 * H) + which * H + h * DH;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(q + 4 * c);
+            if (row >= S) t = f32x4{0.f, 0.f, 0.f, 0.f};
+            f[2 * c] = kh ? t[1] : t[0];
+            f[2 * c + 1] = kh ? t[3] : t[2];
+        }
+    };
+    // every operand is requested up front, unconditionally (clamped addresses, zeros selected afterwards): one round trip
+    float qa[16], kb[NT][16], vb[NT][16];
+    row_frag(rt * 32 + r, 0, qa);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) row_frag(jt * 32 + r, 1, kb[jt]);
+    // V fragments: vb[jt][kk] = V[key 32 jt + 2 kk + kh][dim r]
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int key = jt * 32 + 2 * kk + kh;
+            const float v = qkv[(size_t)(start + (key < S ? key : 0)) * (3 * H) + 2 * H + h * DH + r];
+            vb[jt][kk] = key < S ? v : 0.f;
+        }
+    // ---- scores: acc[jt][e] = S[row 32 rt + 8(e>>2) + (e&3) + 4kh][key 32jt + r]
+    f32x16 acc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], kb[jt][kk], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk + 1], kb[jt][kk + 1], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[jt][e] = a0[e] + a1[e];
+    }
+    const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
+    float mx[16], sum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx[e] = -__builtin_inff();
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const bool key_ok = jt * 32 + r < S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc[jt][e] = key_ok ? acc[jt][e] * inv_scale : -__builtin_inff();
+            mx[e] = fmaxf(mx[e], acc[jt][e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        mx[e] = fmaxf(mx[e], lane_xor_f32<16>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<8>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<4>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<2>(mx[e], lane));
+        mx[e] = fmaxf(mx[e], lane_xor_f32<1>(mx[e], lane));
+        sum[e] = 0.f;
+    }
+    f32x16 o, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = o1[e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        if (jt < n_jt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __expf(acc[jt][e] - mx[e]);  // exp(-inf) = 0 for the masked keys
+                sum[e] += p;
+                Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_LD + r] = p;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 2) {
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_LD + 2 * kk + kh], vb[jt][kk], o, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[r * ATM_LD + 2 * kk + 2 + kh], vb[jt][kk + 1], o1, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        sum[e] += lane_xor_f32<16>(sum[e], lane);
+        sum[e] += lane_xor_f32<8>(sum[e], lane);
+        sum[e] += lane_xor_f32<4>(sum[e], lane);
+        sum[e] += lane_xor_f32<2>(sum[e], lane);
+        sum[e] += lane_xor_f32<1>(sum[e], lane);
+        Ps[(8 * (e >> 2) + (e & 3) + 4 * kh) * ATM_LD + r] = (o[e] + o1[e]) / sum[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ch = it * 64 + lane, lrow = ch >> 2, c = ch & 3;
+        const int row = rt * 32 + lrow;
+        uint32_t w[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t a1, a2, a3, c1, c2, c3;
+            split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e], a1, a2, a3);
+            split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], c1, c2, c3);
+            w[0][e] = a1 | (c1 << 16);
+            w[1][e] = a2 | (c2 << 16);
+            w[2][e] = a3 | (c3 << 16);
+        }
+        if (row < S) {
+            uint16_t* dst = ctxp + plane_index((size_t)(start + row), h * DH + c * 8, plane_stride / H);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<u32x4*>(dst + p * plane_stride) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
         }
     }
 }
@@ -752,6 +894,13 @@ bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_l
         const size_t lds = (size_t)max_len * DH * 2 * sizeof(float);
         hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
         return false;
+    }
+    if (ctxp) {  // the batch form (planes asked for: the throughput path)
+        if (max_len <= 32)
+            hipLaunchKernelGGL(attention_wave_kernel<1>, dim3(NH, (B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctxp, plane_stride);
+        else
+            hipLaunchKernelGGL(attention_wave_kernel<2>, dim3(NH, (2 * B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctxp, plane_stride);
+        return true;
     }
     if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);

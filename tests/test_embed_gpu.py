@@ -308,13 +308,15 @@ def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider,
     bf16 split, 6 products; 64 x 64 tiles, 128 x 128 tiles from 2048 tokens): same 1e-5 bar against the oracle, and
     rounding-level agreement with the f32-MFMA path (option "gemm_bf16x3" = 0) on the same batch."""
     sb = oracle.SynthBert(3)
-    for n_seq, lo, hi, big in ((40, 20, 40, 512), (30, 100, 128, 0)):  # ~1200 tokens: 64 x 64 tiles; ~3400: 128 x 128 forced
+    # ~1200 tokens: 64 x 64 tiles; ~3400: 128 x 128 forced; then the wave-per-sequence attention of short-sequence batches
+    # with one (<= 32 tokens, down to a single token) and two (33 .. 64) key tiles
+    for n_seq, lo, hi, big in ((40, 20, 40, 512), (30, 100, 128, 0), (80, 1, 32, 512), (40, 33, 64, 512)):
         seqs = synth.token_sequences(91 + n_seq, n_seq, lo, hi)
         T = sum(len(s) for s in seqs)
         assert T > 640
         provider.set_option("gemm3_big_min_tiles", big)
         emb = provider.calculate_embedding(seqs)
-        for i in (0, n_seq // 2, n_seq - 1):
+        for i in (range(n_seq) if hi <= 64 and lo != 20 else (0, n_seq // 2, n_seq - 1)):
             assert np.abs(emb[i] - sb.embed(seqs[i])).max() < TOL_EMB
         provider.set_option("gemm_bf16x3", 0)
         try:
