@@ -28,19 +28,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // f32 [rows][K] row-major -> three K-blocked bf16 planes (plane_index)
 __global__ void split_planes_kernel(const float* __restrict__ in, uint16_t* __restrict__ planes, int rows, int K, size_t rows_alloc) {
-    const size_t n = (size_t)rows * K, plane_stride = rows_alloc * K;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t b1, b2, b3;
-        split3_bf16(in[i], b1, b2, b3);
-        const size_t o = plane_index(i / K, (int)(i % K), rows_alloc);
-        planes[o] = (uint16_t)b1;
-        planes[plane_stride + o] = (uint16_t)b2;
-        planes[2 * plane_stride + o] = (uint16_t)b3;
+    const size_t n2 = (size_t)rows * K / 2, plane_stride = rows_alloc * K;  // K is even: a pair never straddles a row
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n2; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = 2 * j;
+        const float2 f = *reinterpret_cast<const float2*>(in + i);
+        uint32_t w[3];
+        split3_bf16_pair(f.x, f.y, w[0], w[1], w[2]);
+        const size_t o = plane_index(i / K, (int)(i % K), rows_alloc);  // (k even: the pair is adjacent in the plane too)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(planes + p * plane_stride + o) = w[p];
     }
 }
 
 void launch_split_planes(const float* in, uint16_t* planes, int rows, int K, size_t rows_alloc, hipStream_t s) {
-    const size_t n = (size_t)rows * K;
+    const size_t n = (size_t)rows * K / 2;
     if (n == 0) return;
     size_t blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -202,12 +203,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint16_t* __rest
             uint32_t w[3][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t a1, a2, a3, c1, c2, c3;
-                split3_bf16(f[2 * e], a1, a2, a3);
-                split3_bf16(f[2 * e + 1], c1, c2, c3);
-                w[0][e] = a1 | (c1 << 16);
-                w[1][e] = a2 | (c2 << 16);
-                w[2][e] = a3 | (c3 << 16);
+                split3_bf16_pair(f[2 * e], f[2 * e + 1], w[0][e], w[1][e], w[2][e]);
             }
             if (m < M) {  // (the wave's 32 columns are one k-block of the next layer: 16 rows x 64 B contiguous per store)
                 uint16_t* dst = Yp + plane_index(m, n0 + wn + c * 8, y_rows);
@@ -448,12 +444,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
             uint32_t w[3][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t a1, a2, a3, c1, c2, c3;
-                split3_bf16(f[2 * e], a1, a2, a3);
-                split3_bf16(f[2 * e + 1], c1, c2, c3);
-                w[0][e] = a1 | (c1 << 16);
-                w[1][e] = a2 | (c2 << 16);
-                w[2][e] = a3 | (c3 << 16);
+                split3_bf16_pair(f[2 * e], f[2 * e + 1], w[0][e], w[1][e], w[2][e]);
             }
             if (m < M) {
                 uint16_t* dst = Yp + plane_index(m, n0 + wn + kb * 32 + c4 * 8, y_rows);

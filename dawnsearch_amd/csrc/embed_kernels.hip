@@ -68,18 +68,25 @@ __device__ __forceinline__ void row_layer_norm(float (&v)[6], const float* __res
     }
     const float var = wave_allreduce_sum(q) * inv_h;
     const float den = sqrtf(var + eps);
+    float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int d = lane + 64 * i;
-        const float y = (v[i] / den) * g[d] + b[d];
-        out[d] = y;
-        if (planes) {
-            uint32_t b1, b2, b3;
-            split3_bf16(y, b1, b2, b3);
-            const size_t o = plane_index(t, d, plane_stride / H);  // (32 lanes: 64 contiguous bytes)
-            planes[o] = (uint16_t)b1;
-            planes[plane_stride + o] = (uint16_t)b2;
-            planes[2 * plane_stride + o] = (uint16_t)b3;
+        y[i] = (v[i] / den) * g[d] + b[d];
+        out[d] = y[i];
+    }
+    if (planes) {
+#pragma unroll
+        for (int i = 0; i < 6; i += 2) {
+            uint32_t w[3];
+            split3_bf16_pair(y[i], y[i + 1], w[0], w[1], w[2]);
+            const size_t o0 = plane_index(t, lane + 64 * i, plane_stride / H);  // (32 lanes: 64 contiguous bytes)
+            const size_t o1 = plane_index(t, lane + 64 * (i + 1), plane_stride / H);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                planes[p * plane_stride + o0] = (uint16_t)(w[p] & 0xFFFFu);
+                planes[p * plane_stride + o1] = (uint16_t)(w[p] >> 16);
+            }
         }
     }
 }
@@ -630,12 +637,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const float* __r
             uint32_t w[3][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t a1, a2, a3, c1, c2, c3;
-                split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e], a1, a2, a3);
-                split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], c1, c2, c3);
-                w[0][e] = a1 | (c1 << 16);
-                w[1][e] = a2 | (c2 << 16);
-                w[2][e] = a3 | (c3 << 16);
+                split3_bf16_pair(Ps[lrow * ATM_LD + c * 8 + 2 * e], Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], w[0][e], w[1][e], w[2][e]);
             }
             if (row < S) {
                 uint16_t* dst = ctxp + plane_index((size_t)(start + row), h * DH + c * 8, plane_stride / H);  // head h = k-block h
@@ -773,12 +775,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(const float* __rest
         uint32_t w[3][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            uint32_t a1, a2, a3, c1, c2, c3;
-            split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e], a1, a2, a3);
-            split3_bf16(Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], c1, c2, c3);
-            w[0][e] = a1 | (c1 << 16);
-            w[1][e] = a2 | (c2 << 16);
-            w[2][e] = a3 | (c3 << 16);
+            split3_bf16_pair(Ps[lrow * ATM_LD + c * 8 + 2 * e], Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], w[0][e], w[1][e], w[2][e]);
         }
         if (row < S) {
             uint16_t* dst = ctxp + plane_index((size_t)(start + row), h * DH + c * 8, plane_stride / H);

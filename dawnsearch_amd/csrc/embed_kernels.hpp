@@ -41,6 +41,21 @@ __device__ __forceinline__ void split3_bf16(float a, uint32_t& b1, uint32_t& b2,
     const float r2 = r1 - __builtin_bit_cast(float, b2 << 16);
     b3 = bf16_rne_bits(r2);
 }
+// the same for two values at once, on v_cvt_pk_bf16_f32 (round to nearest even in hardware; ~4.5 vector instructions per
+// value instead of ~18): dword p = (part p of a) | (part p of c) << 16 — the order two neighbours have in a plane
+typedef __bf16 dawn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dawn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack2(float a, float c) {
+    const dawn_f32x2 f = {a, c};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, dawn_bf16x2));
+}
+__device__ __forceinline__ void split3_bf16_pair(float a, float c, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    w1 = bf16_pack2(a, c);
+    const float ra = a - __builtin_bit_cast(float, w1 << 16), rc = c - __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+    w2 = bf16_pack2(ra, rc);
+    const float sa = ra - __builtin_bit_cast(float, w2 << 16), sc = rc - __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+    w3 = bf16_pack2(sa, sc);
+}
 #endif
 
 // f32-accurate dense layer on the bf16 matrix cores (embed_gemm3.hip): operands as three bf16 planes each
