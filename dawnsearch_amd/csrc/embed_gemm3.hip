@@ -237,106 +237,157 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // STAGES x 48 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_xcd = gridDim.x >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    // Tiles in XCD-aware order (see gemm_nt_kernel): the blocks of one XCD (blockIdx & 7) walk one eighth of the tile list,
+    // consecutive tiles — one strip of A — at the same time.  With fewer blocks than tiles (launch_g3_big: one per CU) a block
+    // loops: no block launch between two tiles, and a tile's plane stores drain under the next tile's first DMA.
     const int tiles_n = N / G3B;
-    if (tile >= tiles_n * ((M + G3B - 1) / G3B)) return;
-    const int m0 = (tile / tiles_n) * G3B, n0 = (tile % tiles_n) * G3B;
+    const int n_tiles = tiles_n * ((M + G3B - 1) / G3B);
+    const int per_xcd = (n_tiles + 7) >> 3, slots = gridDim.x >> 3;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;  // 4 x 2 waves
+    for (int local = (int)(blockIdx.x >> 3); local < per_xcd; local += slots) {
+        const int tile = (int)(blockIdx.x & 7) * per_xcd + local;
+        if (tile >= n_tiles) break;
+        const int m0 = (tile / tiles_n) * G3B, n0 = (tile % tiles_n) * G3B;
 
-    // DMA: 512 lanes fill the 512 16-B slots of every 128-row plane tile: slot s = wave * 64 + lane: row s >> 2, chunk s & 3
-    const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
-    const int s_c = s_cp ^ ((s_row >> 2) & 3);
-    const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
-    // K-blocked planes (plane_index): the 128 rows x 32 k of a step are 8 KiB contiguous — a wave's piece is 1 KiB of it
-    const size_t a_rows = a_plane / K, w_rows = w_plane / K, y_rows = Yp ? y_plane / N : 0;
-    const uint16_t* ga = Ap + (size_t)a_row * 32 + s_c * 8;
-    const uint16_t* gw = Wp + (size_t)(n0 + s_row) * 32 + s_c * 8;
-    auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
-        unsigned char* base = lds + stage * G3B_BUF + wave * 1024;
+        // DMA: 512 lanes fill the 512 16-B slots of every 128-row plane tile: slot s = wave * 64 + lane: row s >> 2, chunk s & 3
+        const int s_row = (wave * 64 + lane) >> 2, s_cp = lane & 3;
+        const int s_c = s_cp ^ ((s_row >> 2) & 3);
+        const int a_row = m0 + s_row < M ? m0 + s_row : M - 1;
+        // K-blocked planes (plane_index): the 128 rows x 32 k of a step are 8 KiB contiguous — a wave's piece is 1 KiB of it
+        const size_t a_rows = a_plane / K, w_rows = w_plane / K, y_rows = Yp ? y_plane / N : 0;
+        const uint16_t* ga = Ap + (size_t)a_row * 32 + s_c * 8;
+        const uint16_t* gw = Wp + (size_t)(n0 + s_row) * 32 + s_c * 8;
+        auto dma = [&](int k0, int stage) __attribute__((always_inline)) {
+            unsigned char* base = lds + stage * G3B_BUF + wave * 1024;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + (size_t)k0 * a_rows),
-                                             (__attribute__((address_space(3))) void*)(base + p * G3B_PLANE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + (size_t)k0 * w_rows),
-                                             (__attribute__((address_space(3))) void*)(base + (3 + p) * G3B_PLANE), 16, 0, 0);
+            for (int p = 0; p < 3; ++p) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * a_plane + (size_t)k0 * a_rows),
+                                                 (__attribute__((address_space(3))) void*)(base + p * G3B_PLANE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + p * w_plane + (size_t)k0 * w_rows),
+                                                 (__attribute__((address_space(3))) void*)(base + (3 + p) * G3B_PLANE), 16, 0, 0);
+            }
+        };
+        const int ra = wm + (lane & 31), rb0 = wn + (lane & 31), rb1 = rb0 + 32, kh = lane >> 5;
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        uint32_t a_ad[2], b_ad[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 2) & 3)) << 4));
+            b_ad[0][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb0 * 64 + (((2 * j + kh) ^ ((rb0 >> 2) & 3)) << 4));
+            b_ad[1][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb1 * 64 + (((2 * j + kh) ^ ((rb1 >> 2) & 3)) << 4));
         }
-    };
-    const int ra = wm + (lane & 31), rb0 = wn + (lane & 31), rb1 = rb0 + 32, kh = lane >> 5;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    uint32_t a_ad[2], b_ad[2][2];
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        a_ad[j] = lds0 + (uint32_t)(ra * 64 + (((2 * j + kh) ^ ((ra >> 2) & 3)) << 4));
-        b_ad[0][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb0 * 64 + (((2 * j + kh) ^ ((rb0 >> 2) & 3)) << 4));
-        b_ad[1][j] = lds0 + (uint32_t)(3 * G3B_PLANE + rb1 * 64 + (((2 * j + kh) ^ ((rb1 >> 2) & 3)) << 4));
-    }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
 
-    // ring of STAGES images: a step is 24 MFMAs per wave (0.3 us of matrix time, two waves per SIMD) and an L2 round trip
-    // under load is ~1 us: with one image in flight the K loop runs at the DMA's latency (measured: 190 us for
-    // 32768 x 1152 x 384, whose MFMAs, LDS reads and L2 traffic each need ~70 us); two in flight cover it
-    const int n_steps = K / G3K;
-    if constexpr (PP != 0) {
-        // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  A wave's step is a memory phase M(i) — the
-        // 18 fragment reads of step i, its six DMA pieces of step i + STAGES - 1, the wait for its share of step i + 1 — and
-        // a matrix phase C(i) — the 24 MFMAs — with a block barrier after each; waves 4..7 start one barrier late, so that
-        // M(i) of one group runs under C(i) (or C(i - 1)) of the other: while a SIMD's matrix pipe works for one wave, the
-        // other wave's loads are being issued.  (In lockstep all eight waves issue DMA at the same time, ~100-180 cycles a
-        // piece, and nobody feeds the matrix pipe.  Measured on 32768 rows, lockstep / ping-pong: K = 1536: 229 / 214 us,
-        // the K = 384 shapes 1-2 %; with the K loop's parts removed (K = 1536): no DMA 154 us, no fragment reads 178 us,
-        // no MFMAs 125 us, the MFMAs alone would take 97 us.)
-        //   image i is read by group 0 in its M(i) and by group 1 one phase later; it is overwritten by the DMA of
-        //   M(i + 1), which both groups start after the barrier that ends group 1's M(i);
-        //   image i + 1 is complete when every wave has waited for its share: at the end of its M(i), in front of the
-        //   barrier that group 0's M(i + 1) follows.
-        const int grp = wave >> 2;
+        // ring of STAGES images: a step is 24 MFMAs per wave (0.3 us of matrix time, two waves per SIMD) and an L2 round trip
+        // under load is ~1 us: with one image in flight the K loop runs at the DMA's latency (measured: 190 us for
+        // 32768 x 1152 x 384, whose MFMAs, LDS reads and L2 traffic each need ~70 us); two in flight cover it
+        const int n_steps = K / G3K;
+        if constexpr (PP != 0) {
+            // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  A wave's step is a memory phase M(i) — the
+            // 18 fragment reads of step i, its six DMA pieces of step i + STAGES - 1, the wait for its share of step i + 1 — and
+            // a matrix phase C(i) — the 24 MFMAs — with a block barrier after each; waves 4..7 start one barrier late, so that
+            // M(i) of one group runs under C(i) (or C(i - 1)) of the other: while a SIMD's matrix pipe works for one wave, the
+            // other wave's loads are being issued.  (In lockstep all eight waves issue DMA at the same time, ~100-180 cycles a
+            // piece, and nobody feeds the matrix pipe.  Measured on 32768 rows, lockstep / ping-pong: K = 1536: 229 / 214 us,
+            // the K = 384 shapes 1-2 %; with the K loop's parts removed (K = 1536): no DMA 154 us, no fragment reads 178 us,
+            // no MFMAs 125 us, the MFMAs alone would take 97 us.)
+            //   image i is read by group 0 in its M(i) and by group 1 one phase later; it is overwritten by the DMA of
+            //   M(i + 1), which both groups start after the barrier that ends group 1's M(i);
+            //   image i + 1 is complete when every wave has waited for its share: at the end of its M(i), in front of the
+            //   barrier that group 0's M(i + 1) follows.
+            const int grp = wave >> 2;
+#pragma unroll
+            for (int st = 0; st < STAGES - 1; ++st)
+                if (st < n_steps) dma(st * G3K, st);
+            if (n_steps - 1 >= STAGES - 2 && STAGES >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");  // image 0 is complete
+            if (grp == 1) asm volatile("s_barrier" ::: "memory");  // the stagger
+            int stage = 0;
+            for (int i = 0; i < n_steps; ++i) {
+                const uint32_t so = (uint32_t)(stage * G3B_BUF);
+                u32x4 fa[2][3], fb0[2][3], fb1[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j][p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[j][p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[j][p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
+                    }
+                if (i + STAGES - 1 < n_steps) {
+                    int ws = stage + STAGES - 1;
+                    if (ws >= STAGES) ws -= STAGES;
+                    dma((i + STAGES - 1) * G3K, ws);  // into the image of step i - 1
+                }
+                // my share of step i + 1: at most the younger steps' pieces may still be in flight
+                if (i + 1 < n_steps) {
+                    const int younger = n_steps - 2 - i < STAGES - 2 ? n_steps - 2 - i : STAGES - 2;
+                    if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fb0[0][0]), "+v"(fb0[0][1]), "+v"(fb0[0][2]),
+                               "+v"(fb1[0][0]), "+v"(fb1[0][1]), "+v"(fb1[0][2]));
+                asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fb0[1][2]),
+                             "+v"(fb1[1][0]), "+v"(fb1[1][1]), "+v"(fb1[1][2]));
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
+                                                                       __builtin_bit_cast(bf16x8, fb0[j][pb]), acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
+                                                                       __builtin_bit_cast(bf16x8, fb1[j][pb]), acc1, 0, 0, 0);
+                    };
+                    mm(2, 0);
+                    mm(0, 2);
+                    mm(1, 1);
+                    mm(1, 0);
+                    mm(0, 1);
+                    mm(0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                if (++stage == STAGES) stage = 0;
+            }
+            if (grp == 0) asm volatile("s_barrier" ::: "memory");  // (as many barriers as group 1)
+        } else {
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
             if (st < n_steps) dma(st * G3K, st);
-        if (n_steps - 1 >= STAGES - 2 && STAGES >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");  // image 0 is complete
-        if (grp == 1) asm volatile("s_barrier" ::: "memory");  // the stagger
         int stage = 0;
         for (int i = 0; i < n_steps; ++i) {
-            const uint32_t so = (uint32_t)(stage * G3B_BUF);
-            u32x4 fa[2][3], fb0[2][3], fb1[2][3];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j][p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[j][p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[j][p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
-                }
+            const int younger = n_steps - 1 - i < STAGES - 2 ? n_steps - 1 - i : STAGES - 2;
+            if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
             if (i + STAGES - 1 < n_steps) {
                 int ws = stage + STAGES - 1;
                 if (ws >= STAGES) ws -= STAGES;
-                dma((i + STAGES - 1) * G3K, ws);  // into the image of step i - 1
+                dma((i + STAGES - 1) * G3K, ws);
             }
-            // my share of step i + 1: at most the younger steps' pieces may still be in flight
-            if (i + 1 < n_steps) {
-                const int younger = n_steps - 2 - i < STAGES - 2 ? n_steps - 2 - i : STAGES - 2;
-                if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fb0[0][0]), "+v"(fb0[0][1]), "+v"(fb0[0][2]),
-                           "+v"(fb1[0][0]), "+v"(fb1[0][1]), "+v"(fb1[0][2]));
-            asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fb0[1][2]),
-                         "+v"(fb1[1][0]), "+v"(fb1[1][1]), "+v"(fb1[1][2]));
-            asm volatile("s_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t so = (uint32_t)(stage * G3B_BUF);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                u32x4 fa[3], fb0[3], fb1[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb1[0]),
+                               "+v"(fb1[1]), "+v"(fb1[2]));
                 auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
-                                                                   __builtin_bit_cast(bf16x8, fb0[j][pb]), acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j][pa]),
-                                                                   __builtin_bit_cast(bf16x8, fb1[j][pb]), acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb0[pb]),
+                                                                   acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb1[pb]),
+                                                                   acc1, 0, 0, 0);
                 };
                 mm(2, 0);
                 mm(0, 2);
@@ -345,117 +396,75 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
                 mm(0, 1);
                 mm(0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
             if (++stage == STAGES) stage = 0;
         }
-        if (grp == 0) asm volatile("s_barrier" ::: "memory");  // (as many barriers as group 1)
-    } else {
-#pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-        if (st < n_steps) dma(st * G3K, st);
-    int stage = 0;
-    for (int i = 0; i < n_steps; ++i) {
-        const int younger = n_steps - 1 - i < STAGES - 2 ? n_steps - 1 - i : STAGES - 2;
-        if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (i + STAGES - 1 < n_steps) {
-            int ws = stage + STAGES - 1;
-            if (ws >= STAGES) ws -= STAGES;
-            dma((i + STAGES - 1) * G3K, ws);
         }
-        const uint32_t so = (uint32_t)(stage * G3B_BUF);
+        // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
+        // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
+        // L2 (measured: +116 us on the 262-us FFN1 of 32 k tokens) — so the wave's 32 x 64 tile goes through its share of the
+        // (now idle) LDS in f32, is read back by row, split there, and stored as 16-B chunks (full sectors).  (Splitting first
+        // and staging bf16 triples costs 96 two-byte LDS stores per lane instead of 32 dword stores: +5 % on the whole kernel.)
+        asm volatile("s_barrier" ::: "memory");  // every wave has left the K loop: the images are free
+        float vv[2][16];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            u32x4 fa[3], fb0[3], fb1[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p]) : "v"(a_ad[j] + so), "n"(p * G3B_PLANE));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[p]) : "v"(b_ad[0][j] + so), "n"(p * G3B_PLANE));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb1[p]) : "v"(b_ad[1][j] + so), "n"(p * G3B_PLANE));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb1[0]),
-                           "+v"(fb1[1]), "+v"(fb1[2]));
-            auto mm = [&](int pa, int pb) __attribute__((always_inline)) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb0[pb]),
-                                                               acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa]), __builtin_bit_cast(bf16x8, fb1[pb]),
-                                                               acc1, 0, 0, 0);
-            };
-            mm(2, 0);
-            mm(0, 2);
-            mm(1, 1);
-            mm(1, 0);
-            mm(0, 1);
-            mm(0, 0);
-        }
-        if (++stage == STAGES) stage = 0;
-    }
-    }
-    // ---- epilogue.  f32 output: straight from the accumulators (a lane holds one column: 32 lanes = 128 contiguous bytes
-    // per row).  Plane output: a lane's values are 2 bytes each — 2-byte stores are read-modify-writes of 32-B sectors in
-    // L2 (measured: +116 us on the 262-us FFN1 of 32 k tokens) — so the wave's 32 x 64 tile goes through its share of the
-    // (now idle) LDS in f32, is read back by row, split there, and stored as 16-B chunks (full sectors).  (Splitting first
-    // and staging bf16 triples costs 96 two-byte LDS stores per lane instead of 32 dword stores: +5 % on the whole kernel.)
-    asm volatile("s_barrier" ::: "memory");  // every wave has left the K loop: the images are free
-    float vv[2][16];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int n = n0 + wn + 32 * half + (lane & 31);
-        const float bvv = bias[n];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            const int m = m0 + wm + row;
-            const float v = act_apply3((half ? acc1[reg] : acc0[reg]) + bvv, ACT);
-            vv[half][reg] = v;
-            if (Y && m < M) Y[(size_t)m * N + n] = v;
-        }
-    }
-    if (Yp) {
-        // staging in f32: the wave's 32 x 64 tile as [row][64 floats] (256 B per row, 8 KiB per wave), one 4-byte LDS
-        // store per value (a 32-lane group writes 32 consecutive banks); read back as 8 consecutive floats of a row per
-        // lane (two ds_read_b128), split there, and stored as one 16-B chunk per plane.  The tile's 64 columns are two
-        // k-blocks of the next layer's operand: lane q (+ 64 per round) takes chunk q & 3 of row (q >> 2) & 31 in k-block
-        // q >> 7, so that a store instruction writes 16 rows x 64 B = 1 KiB contiguous.  16-B slot s of row r sits at
-        // (s + (r & 1) + 8 ((r >> 1) & 1)) & 15: a b128 lane group (rows {0, 3, 5, 6} or {1, 2, 4, 7} + 8 n, four even or
-        // four odd slots each) then covers all 16 slots of the 256-B bank row.
-        float* st = reinterpret_cast<float*>(lds + wave * (32 * 256));
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < 2; ++half) {
+            const int n = n0 + wn + 32 * half + (lane & 31);
+            const float bvv = bias[n];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int rot = 4 * ((reg & 1) + 8 * ((reg >> 1) & 1));  // slot rotation of the row, in dwords
-                st[row * 64 + ((32 * half + (lane & 31) + rot) & 63)] = vv[half][reg];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q = it * 64 + lane, c4 = q & 3, row = (q >> 2) & 31, kb = q >> 7;
-            const int m = m0 + wm + row;
-            const int rot = (row & 1) + 8 * ((row >> 1) & 1);
-            const int s0 = 2 * (kb * 4 + c4);
-            const float4 f0 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + rot) & 15) << 2));
-            const float4 f1 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + 1 + rot) & 15) << 2));
-            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-            uint32_t w[3][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                split3_bf16_pair(f[2 * e], f[2 * e + 1], w[0][e], w[1][e], w[2][e]);
-            }
-            if (m < M) {
-                uint16_t* dst = Yp + plane_index(m, n0 + wn + kb * 32 + c4 * 8, y_rows);
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
+                const int m = m0 + wm + row;
+                const float v = act_apply3((half ? acc1[reg] : acc0[reg]) + bvv, ACT);
+                vv[half][reg] = v;
+                if (Y && m < M) Y[(size_t)m * N + n] = v;
             }
         }
+        if (Yp) {
+            // staging in f32: the wave's 32 x 64 tile as [row][64 floats] (256 B per row, 8 KiB per wave), one 4-byte LDS
+            // store per value (a 32-lane group writes 32 consecutive banks); read back as 8 consecutive floats of a row per
+            // lane (two ds_read_b128), split there, and stored as one 16-B chunk per plane.  The tile's 64 columns are two
+            // k-blocks of the next layer's operand: lane q (+ 64 per round) takes chunk q & 3 of row (q >> 2) & 31 in k-block
+            // q >> 7, so that a store instruction writes 16 rows x 64 B = 1 KiB contiguous.  16-B slot s of row r sits at
+            // (s + (r & 1) + 8 ((r >> 1) & 1)) & 15: a b128 lane group (rows {0, 3, 5, 6} or {1, 2, 4, 7} + 8 n, four even or
+            // four odd slots each) then covers all 16 slots of the 256-B bank row.
+            float* st = reinterpret_cast<float*>(lds + wave * (32 * 256));
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const int rot = 4 * ((reg & 1) + 8 * ((reg >> 1) & 1));  // slot rotation of the row, in dwords
+                    st[row * 64 + ((32 * half + (lane & 31) + rot) & 63)] = vv[half][reg];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + lane, c4 = q & 3, row = (q >> 2) & 31, kb = q >> 7;
+                const int m = m0 + wm + row;
+                const int rot = (row & 1) + 8 * ((row >> 1) & 1);
+                const int s0 = 2 * (kb * 4 + c4);
+                const float4 f0 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + rot) & 15) << 2));
+                const float4 f1 = *reinterpret_cast<const float4*>(st + row * 64 + (((s0 + 1 + rot) & 15) << 2));
+                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                uint32_t w[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    split3_bf16_pair(f[2 * e], f[2 * e + 1], w[0][e], w[1][e], w[2][e]);
+                }
+                if (m < M) {
+                    uint16_t* dst = Yp + plane_index(m, n0 + wn + kb * 32 + c4 * 8, y_rows);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<u32x4*>(dst + p * y_plane) = u32x4{w[p][0], w[p][1], w[p][2], w[p][3]};
+                }
+            }
+        }
+        // (the staging reads are done — their data is in registers — before the next tile's DMA lands on the same LDS)
+        if (local + slots < per_xcd) asm volatile("s_barrier" ::: "memory");
     }
 }
 
+int g_gemm3_persistent = 256;  // tuning: blocks of the 128 x 128 kernel (a multiple of 8; 0 = one per tile)
 int g_gemm3_pingpong = 1;  // tuning: 1 = the two waves of a SIMD run half a step apart (see the kernel)
 
 template <int PP>
@@ -469,7 +478,9 @@ static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* 
         attr = true;
     }
     const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
-    dim3 grid((n_tiles + 7) / 8 * 8), block(512);
+    int blocks = (n_tiles + 7) / 8 * 8;
+    if (g_gemm3_persistent > 0 && blocks > g_gemm3_persistent) blocks = g_gemm3_persistent;  // one block per CU walks the tiles
+    dim3 grid(blocks), block(512);
     const size_t lds = G3B_LDS;
     if (act == 1) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<1, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
     else if (act == 2) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<2, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);

@@ -73,4 +73,5 @@ extern int g_skinny_max_m;
 extern int g_gemm3_stages;
 extern int g_gemm3_big_min_m;
 extern int g_gemm3_pingpong;
+extern int g_gemm3_persistent;
 }  // namespace dawn

@@ -456,6 +456,11 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
         dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }
+    if (std::string(name) == "gemm3_persistent") {  // 128 x 128 kernel: blocks that walk the tile list (0 = a block per tile)
+        if (value < 0 || value > 4096 || value % 8) return fail(DAWN_ERR_INVALID_ARG, "gemm3_persistent must be a multiple of 8 in 0..4096");
+        dawn::g_gemm3_persistent = (int)value;
+        return DAWN_OK;
+    }
     if (std::string(name) == "gemm3_pingpong") {  // 128 x 128 kernel: waves of a SIMD half a step apart (tuning; default 1)
         if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "gemm3_pingpong must be 0 or 1");
         dawn::g_gemm3_pingpong = (int)value;

@@ -21,10 +21,11 @@ for T in (37, 200, 2500):
         print(f"T={T} op={op}: max abs err {err.max():.3e}  (|want| max {np.abs(want).max():.2f})  rel {np.max(err / (np.abs(want) + 1e-3)):.3e}", flush=True)
 ms = C.c_double(0)
 names = {0: "f32 MFMA", 1: "bf16x3 -> f32", 2: "bf16x3 -> planes", 3: "bf16x3 -> gelu planes"}
-for big, var in ((1 << 30, 0), (0, 0), (0, 1)):
+for big, var, pers in ((1 << 30, 0, 0), (0, 0, 0), (0, 1, 0), (0, 1, 256)):
     ep.set_option("gemm3_big_min_tiles", big)
     ep.set_option("gemm3_pingpong", var)
-    print(f"128x128 kernel from tiles {big}, ping-pong {var}")
+    ep.set_option("gemm3_persistent", pers)
+    print(f"128x128 kernel from tiles {big}, ping-pong {var}, persistent blocks {pers}")
     if big == 0 and var < 2:
         for T in (200, 2500):  # (accuracy of this form; 2500 rows: a ragged last tile)
             x = (rng.standard_normal((T, 384)) * np.linspace(0.05, 4, T)[:, None]).astype(np.float32)
