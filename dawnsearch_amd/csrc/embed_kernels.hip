@@ -99,12 +99,20 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const uint32_t* __restric
                                                       const float* __restrict__ type0,
                                                       const float* __restrict__ g, const float* __restrict__ b,
                                                       float eps, float* __restrict__ x, uint16_t* __restrict__ xp,
-                                                      size_t plane_stride) {
+                                                      size_t plane_stride, const int* __restrict__ seq_offsets, int B) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
+    int p;
+    if (tok_pos) {
+        p = tok_pos[t];
+    } else {  // a few sequences (one text per call): find this token's sequence here instead of in a launch of its own
+        int b = 0;
+        while (b + 1 < B && seq_offsets[b + 1] <= t) ++b;
+        p = t - seq_offsets[b];
+    }
     const float* we = word + (size_t)ids[t] * H;
-    const float* pe = pos + (size_t)tok_pos[t] * H;
+    const float* pe = pos + (size_t)p * H;
     float v[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -662,6 +670,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const float* __r
 template <int NT>
 __global__ __launch_bounds__(256) void attention_wave_kernel(const float* __restrict__ qkv /*[T][1152]*/,
                                                             const int* __restrict__ seq_offsets, int B,
+                                                            float* __restrict__ ctx /*[T][384], used when ctxp == NULL*/,
                                                             uint16_t* __restrict__ ctxp, size_t plane_stride) {
     __shared__ float strips[4 * 32 * ATM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -777,7 +786,17 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) {
             split3_bf16_pair(Ps[lrow * ATM_LD + c * 8 + 2 * e], Ps[lrow * ATM_LD + c * 8 + 2 * e + 1], w[0][e], w[1][e], w[2][e]);
         }
-        if (row < S) {
+        if (row < S && !ctxp) {  // f32 context (the latency path): the same 8 values as two 16-B stores
+            float* dst = ctx + (size_t)(start + row) * H + h * DH + c * 8;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = Ps[lrow * ATM_LD + c * 8 + e];
+                v1[e] = Ps[lrow * ATM_LD + c * 8 + 4 + e];
+            }
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 4) = v1;
+        } else if (row < S) {
             uint16_t* dst = ctxp + plane_index((size_t)(start + row), h * DH + c * 8, plane_stride / H);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -864,12 +883,56 @@ __global__ __launch_bounds__(384) void pool_norm_kernel(const float* __restrict_
     out[(size_t)b * H + d] = m / sqrtf(tot);
 }
 
+// The last LayerNorm of the encoder and the pooling in one launch (the latency form: one text per call): one block of 16 waves
+// per sequence; a wave per token normalises a + r into x (the hidden states), then — after the block's barrier — thread d
+// sums column d over the tokens in order, exactly as pool_norm_kernel does.
+__global__ __launch_bounds__(1024) void add_ln_pool_norm_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                                const int* __restrict__ seq_offsets, const float* __restrict__ g,
+                                                                const float* __restrict__ bta, float eps, float* __restrict__ x,
+                                                                float* __restrict__ out) {
+    __shared__ float red[6];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;
+    for (int i = wave; i < S; i += 16) {
+        const size_t t = (size_t)(start + i);
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int d = lane + 64 * j;
+            v[j] = a[t * H + d] + r[t * H + d];
+        }
+        row_layer_norm(v, g, bta, eps, lane, x + t * H);
+    }
+    __syncthreads();  // (a workgroup's global writes are visible to it after its barrier)
+    const int d = tid;
+    float sq = 0.f, m = 0.f;
+    if (d < H) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += x[(size_t)(start + t) * H + d];
+        m = s * (float)(1.0 / (double)S);
+        sq = wave_allreduce_sum(m * m);
+        if ((d & 63) == 0) red[d >> 6] = sq;
+    }
+    __syncthreads();
+    if (d < H) {
+        const float tot = ((red[0] + red[1]) + (red[2] + red[3])) + (red[4] + red[5]);
+        out[(size_t)b * H + d] = m / sqrtf(tot);
+    }
+}
+
 void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
                      const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s,
-                     uint16_t* xp, size_t plane_stride) {
+                     uint16_t* xp, size_t plane_stride, const int* seq_offsets, int B) {
     if (T <= 0) return;
     hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, tok_pos, T, word, pos, type0, g, b,
-                       eps, x, xp, plane_stride);
+                       eps, x, xp, plane_stride, seq_offsets, B);
+}
+
+void launch_add_ln_pool_norm(const float* a, const float* r, const int* seq_offsets, int B, const float* g, const float* b,
+                             float eps, float* x, float* out, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(add_ln_pool_norm_kernel, dim3(B), dim3(1024), 0, s, a, r, seq_offsets, g, b, eps, x, out);
 }
 
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
@@ -877,6 +940,9 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
     if (T <= 0) return;
     hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride);
 }
+
+int g_attn_wave = 0;  // tuning: 1 = sequences of up to 64 tokens always take attention_wave_kernel (0: only with planes — for ONE
+                      // text the block kernel is as fast: 12 tokens 0.160 vs 0.173 ms per forward, 27 tokens 0.184 vs 0.181)
 
 bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s, uint16_t* ctxp,
                       size_t plane_stride) {
@@ -892,12 +958,12 @@ bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_l
         hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
         return false;
     }
-    if (ctxp) {  // the batch form (planes asked for: the throughput path)
+    if (ctxp || g_attn_wave) {  // the wave-per-sequence form (planes asked for: the throughput path)
         if (max_len <= 32)
-            hipLaunchKernelGGL(attention_wave_kernel<1>, dim3(NH, (B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctxp, plane_stride);
+            hipLaunchKernelGGL(attention_wave_kernel<1>, dim3(NH, (B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctx, ctxp, plane_stride);
         else
-            hipLaunchKernelGGL(attention_wave_kernel<2>, dim3(NH, (2 * B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctxp, plane_stride);
-        return true;
+            hipLaunchKernelGGL(attention_wave_kernel<2>, dim3(NH, (2 * B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctx, ctxp, plane_stride);
+        return ctxp != nullptr;
     }
     if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);

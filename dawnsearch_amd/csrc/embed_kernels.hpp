@@ -8,7 +8,11 @@ void launch_tok_pos(const int* seq_offsets, int B, int* tok_pos, hipStream_t s);
 // xp / outp != NULL: the rows are also written as three bf16 planes (K-blocked, see plane_index; plane_stride = rows_alloc * 384)
 void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float* word, const float* pos,
                      const float* type0, const float* g, const float* b, float eps, float* x, hipStream_t s,
-                     uint16_t* xp = nullptr, size_t plane_stride = 0);
+                     uint16_t* xp = nullptr, size_t plane_stride = 0, const int* seq_offsets = nullptr, int B = 0);
+// x = LayerNorm(a + r) and out[b] = normalise(mean over the tokens of sequence b of x) in one launch (a block per sequence)
+void launch_add_ln_pool_norm(const float* a, const float* r, const int* seq_offsets, int B, const float* g, const float* b,
+                             float eps, float* x, float* out, hipStream_t s);
+extern int g_attn_wave;
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
                    hipStream_t s, uint16_t* outp = nullptr, size_t plane_stride = 0);
 // Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.

@@ -143,19 +143,26 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
 }
 
 // BertModel::forward on packed tokens already on the device; result (last hidden states) in e->x.
-void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, int B, int T, int max_len,
-                     hipStream_t s) {
+// d_pool_out != NULL: the caller wants the pooled unit vectors too; true = this call produced them (the latency form fuses
+// the pooling into its last LayerNorm launch), false = launch_pool_norm on e->x is still to be done.
+bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, int B, int T, int max_len,
+                     hipStream_t s, float* d_pool_out = nullptr) {
     const Config& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size;
     const float eps = (float)c.layer_norm_eps;
-    dawn::launch_tok_pos(d_off, B, e->d_pos, s);
+    // token positions: a launch of their own for batches; found inside embed_ln for a few sequences (one text per call)
+    const int* d_pos = nullptr;
+    if (B > 16) {
+        dawn::launch_tok_pos(d_off, B, e->d_pos, s);
+        d_pos = e->d_pos;
+    }
     if (e->use_bf16x3 && T > dawn::g_skinny_max_m && e->xp && e->d_wplanes) {
         // Throughput form: the dense layers run f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way bf16 split,
         // 6 products).  Whatever feeds a dense layer is produced as three bf16 planes by the kernel that computes it (the
         // LayerNorms beside their f32 output — the residual —, FFN1's GELU epilogue and the page attention instead of it; the
         // attention kernels of other sequence lengths write f32, split by one extra pass).
         const size_t ps = (size_t)e->cap_T * H, psi = (size_t)e->cap_T * I;  // plane strides
-        dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, e->xp, ps);
+        dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, e->xp, ps, d_off, B);
         for (const LayerW& L : e->layers) {
             dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s);
             if (!dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, e->ctxp, ps))
@@ -166,9 +173,9 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
             dawn::launch_gemm_bf16x3(e->ffp, psi, L.o_p, (size_t)H * I, L.o_b, e->tmp2, nullptr, 0, T, H, I, 0, s);
             dawn::launch_add_ln(e->tmp2, e->attn, T, L.o_g, L.o_beta, eps, e->x, s, e->xp, ps);
         }
-        return;
+        return false;
     }
-    dawn::launch_embed_ln(d_ids, e->d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s);
+    dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, nullptr, 0, d_off, B);
     // Latency form (few tokens: the reference's one text per call): the residual LayerNorms run as the prologue of the dense
     // layer that consumes them (launch_gemm_ln_nt) — `pending` = the output LayerNorm of the previous layer not applied
     // yet: x = LN(tmp2 + attn) is produced by this layer's Q|K|V launch.
@@ -190,7 +197,12 @@ void encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
         dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s);                 // :460
         pending = &L;                                                                      // :462 LayerNorm(dense + attn)
     }
+    if (pending && d_pool_out && B <= 64) {  // (a block per sequence: few sequences only)
+        dawn::launch_add_ln_pool_norm(e->tmp2, e->attn, d_off, B, pending->o_g, pending->o_beta, eps, e->x, d_pool_out, s);
+        return true;
+    }
     if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
+    return false;
 }
 
 int check_sequences(const dawn_embedder* e, const uint32_t* ids, const int32_t* off, int B, int* T_out, int* max_len) {
@@ -456,6 +468,11 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
         dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }
+    if (std::string(name) == "attention_wave") {  // sequences of up to 64 tokens: 1 = always the wave-per-sequence kernel (tuning)
+        if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "attention_wave must be 0 or 1");
+        dawn::g_attn_wave = (int)value;
+        return DAWN_OK;
+    }
     if (std::string(name) == "gemm3_persistent") {  // 128 x 128 kernel: blocks that walk the tile list (0 = a block per tile)
         if (value < 0 || value > 4096 || value % 8) return fail(DAWN_ERR_INVALID_ARG, "gemm3_persistent must be a multiple of 8 in 0..4096");
         dawn::g_gemm3_persistent = (int)value;
@@ -504,8 +521,8 @@ int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, 
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s);
-                dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);
+                if (!encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s, d_out))
+                    dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);
                 const hipError_t ce = hipStreamEndCapture(s, &g);
                 if (ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
                     (void)hipGraphDestroy(g);
@@ -519,8 +536,8 @@ int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, 
             e->use_graphs = 0;  // capture is not available here: plain launches from now on
         }
     }
-    encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s);
-    dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);  // embedding_service.rs:126-136
+    if (!encoder_forward(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, s, d_out))
+        dawn::launch_pool_norm(e->x, d_seq_offsets, B, d_out, s);  // embedding_service.rs:126-136
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }

@@ -303,6 +303,26 @@ def test_create_rejects_hostile_config_before_allocating(dawn, tmp_path):
     assert _lib.lib.dawn_embedder_create(str(st).encode(), str(tmp_path / "config.json").encode(), 0, C.byref(h)) == _lib.ERR_IO
 
 
+def test_wave_attention_f32_output_and_fused_pooling(provider, oracle):
+    """The latency form of a call (<= 640 tokens): positions found inside embed_ln, last LayerNorm fused with the pooling
+    (<= 64 sequences), and — option "attention_wave" — the wave-per-sequence attention writing f32: all within the bar, for
+    one text and for a few, one and two key tiles."""
+    sb = oracle.SynthBert(3)
+    for wave in (1, 0):
+        provider.set_option("attention_wave", wave)
+        try:
+            for seqs in (synth.token_sequences(11, 1, 27, 27), synth.token_sequences(12, 9, 2, 32), synth.token_sequences(13, 6, 33, 64),
+                         synth.token_sequences(14, 70, 2, 8)):  # (70 sequences: the separate pooling launch)
+                emb = provider.calculate_embedding(seqs)
+                for i, s_ in enumerate(seqs):
+                    assert np.abs(emb[i] - sb.embed(s_)).max() < TOL_EMB
+                hs = provider.hidden_states(seqs[:2])
+                for s_, h in zip(seqs[:2], hs):
+                    assert np.abs(h - sb.forward(s_)).max() < TOL_HID
+        finally:
+            provider.set_option("attention_wave", 0)
+
+
 def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider, oracle):
     """Batches above the skinny limit run their dense layers f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way
     bf16 split, 6 products; 64 x 64 tiles, 128 x 128 tiles from 2048 tokens): same 1e-5 bar against the oracle, and

@@ -16,8 +16,9 @@ for L in (12, 27, 128):
     d_ids = torch.from_numpy(np.concatenate(seqs).astype(np.int32)).to(dev)
     d_off = torch.from_numpy(np.array([0, L], dtype=np.int32)).to(dev)
     d_out = torch.zeros((1, 384), dtype=torch.float32, device=dev)
-    for graphs in (1, 0):
+    for graphs, wave in ((1, 1), (1, 0), (0, 1)):
         ep.set_option("graphs", graphs)
+        ep.set_option("attention_wave", wave)
         for _ in range(5):
             ep.calculate_embedding(seqs)
         t0 = time.perf_counter()
@@ -32,4 +33,4 @@ for L in (12, 27, 128):
             ep.forward_device(d_ids.data_ptr(), d_off.data_ptr(), 1, L, L, d_out.data_ptr(), stream)
         torch.cuda.synchronize()
         devl = (time.perf_counter() - t0) / 200 * 1e3
-        print(f"len {L:4d} graphs={graphs}: host API {host:.3f} ms/call   device loop {devl:.3f} ms/forward", flush=True)
+        print(f"len {L:4d} graphs={graphs} attention_wave={wave}: host API {host:.3f} ms/call   device loop {devl:.3f} ms/forward", flush=True)
