@@ -925,6 +925,400 @@ __global__ __launch_bounds__(256) void scan_i8_pipe_kernel(const unsigned char* 
     if (!DENSE) flush_wave();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pipeline on v_mfma_i32_16x16x64_i8.  With every CU busy the chip holds a higher clock on the small shape:
+// operands in registers, pseudo-random data, 256 CUs: 32x32x32 3.38 Pop/s, 16x16x64 3.98 Pop/s (+18 %; on 32 CUs, no power
+// limit, both run at the 4.97 Pop/s peak — tools/probes/mfma_i8_shapes.hip).  Same images, same DMA, same barriers, same
+// fragment ring; what changes:
+//   a wave's 64 queries are FOUR groups of 16 (B operand: lane (query n = lane & 15, q4 = lane >> 4) holds the 16 bytes
+//   k = 64 s + 16 q4 ..+15 of k-step s = 0..5 — chunk 4 s + q4 of the query's image);
+//   a fragment step f = (sub16 = f / 6, s = f % 6) is FOUR MFMAs (one per group) on 16 rows x 64 k.  The A operand — lane
+//   (row r16 = lane & 15, q4) wants k = 64 s + 16 q4 ..+15 of row 16 sub16 + r16 — is read from the unchanged image (built
+//   for the 32x32x32 operand: 1-KiB fragment (sub, s32) = lane (r, h) -> 16 bytes k = 32 s32 + 16 h of row 32 sub + r) at
+//   byte ((sub16 / 2) * 12 + 2 s) * 1024 + 256 (sub16 & 1) + 512 q4 + 16 r16: per lane group still 16 distinct 16-B slots;
+//   the accumulators of a (16-row, 16-query) tile are 4 registers per lane (rows 4 q4 ..+3 of the lane's query): a lane's
+//   test is a max over 4 values, a staged hit entry is 4 accumulators + 5 words (48 B, one entry per lane at the flush).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t I16_ECAP = 64;  // staged hit entries per wave (the flush gives an entry to a lane) ...
+constexpr uint32_t I16_EDW = 12;   // ... of 12 dwords: 4 accumulators, query, first row, threshold, s s_q, E + K2, 3 unused
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char* __restrict__ xs, const float2* __restrict__ meta,
+                                                            uint32_t n_rows, uint32_t first_tile, uint32_t tile_stride,
+                                                            uint32_t n_tiles, const i32x4_t* __restrict__ qi,
+                                                            const float2* __restrict__ qmeta, int n_q,
+                                                            const float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                            uint2* __restrict__ cand, float* __restrict__ dense) {
+    constexpr int NW = 4, PD = 8, DPW = 48 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char img[3 * I8_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[NW * I16_ECAP * I16_EDW];  // 12 KiB beside the 144-KiB ring
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r16 = lane & 15, q4 = lane >> 4;
+    // group g of this wave: queries 32 wave + 16 g ..+15 (g = 0, 1) and 128 + 32 wave + 16 (g - 2) ..+15 (g = 2, 3): a query
+    // belongs to the same wave as in scan_i8_pipe_kernel
+    auto group_first = [&](int g) { return (g < 2 ? wave * 32 + 16 * g : (wave + NW) * 32 + 16 * (g - 2)); };
+    const bool live0 = wave * 32 < n_q, live1 = (wave + NW) * 32 < n_q;  // wave-uniform: groups {0, 1} / {2, 3}
+
+    i32x4_t qf[4][6];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) qf[g][s] = qi[(size_t)(group_first(g) + (int)r16) * 24 + 4 * s + q4];
+    float sq_l[4], k2_l[4], c1[4], c2[4];  // (as in scan_i8_pipe_kernel)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int qi_ = group_first(g) + (int)r16;
+        const float2 qm = qmeta[qi_];
+        sq_l[g] = qm.x;
+        k2_l[g] = qm.y;
+        c1[g] = 3.0e38f;  // padding column: threshold +2e9
+        c2[g] = 0.f;
+        if (!(DENSE || qi_ >= n_q)) {
+            const float tk = tau[qi_] - qm.y;
+            const float rsq = 1.0f / qm.x;
+            c1[g] = (tk - fabsf(tk) * 1e-6f) * rsq;  // (tau = -inf: -inf, every row is a candidate)
+            c2[g] = 1.000001f * rsq;
+        }
+    }
+
+    const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t G = gridDim.x;
+    const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
+    const uint32_t last = n_units - 1;
+    auto unit_tile = [&](uint32_t t) { return first_tile + (blockIdx.x + t * G) * tile_stride; };
+    auto unit_row0 = [&](uint32_t t) { return unit_tile(t) * I8_TILE_ROWS; };
+    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * I8_TILE_ROWS; };
+    constexpr int NGP = DPW / 4;
+    auto dma = [&](uint32_t t, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
+        unsigned char* dst = img + image * I8_TILE_BYTES + wave * (DPW * 1024);
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)gp[j];
+            __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 4096);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 2 /* nt */);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 2);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 2);
+        }
+    };
+    auto dma_setup = [&](uint32_t t, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
+    };
+    auto dma_one = [&](auto i_c, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_c)::value, J = I / 4, O = (I % 4) * 1024;
+        unsigned char* dst = img + image * I8_TILE_BYTES + wave * (DPW * 1024) + J * 4096;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[J],
+                                         (__attribute__((address_space(3))) void*)dst, 16, O, 2 /* nt */);
+    };
+    auto keep = [&](const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) asm volatile("" ::"v"(gp[j]));
+    };
+
+    // ---- candidate staging, private to the wave, lane-parallel (see scan_i8_pipe_kernel): entry = 4 accumulators + {query,
+    // first row, threshold, s s_q, E + K2}
+    uint32_t wpos = 0;  // wave-uniform fill of this wave's region
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores below
+        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;
+        if ((uint32_t)lane < wpos) {
+            const uint32_t* en = stage + (wave * I16_ECAP + lane) * I16_EDW;
+            const uint32_t qidx = en[4], row0 = en[5];
+            const int th = (int)en[6];
+            const float gl = __builtin_bit_cast(float, en[7]), ek = __builtin_bit_cast(float, en[8]);
+            uint32_t hits = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hits |= ((int)en[i] > th && row0 + (uint32_t)i < n_rows) ? (1u << i) : 0u;
+            uint32_t slot = hits ? atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], (uint32_t)__popc(hits)) : 0u;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                if (hits & (1u << i)) {
+                    if (slot < I8_SEG_CAP)
+                        cand[(size_t)qidx * BATCH_CAP + seg * I8_SEG_CAP + slot] =
+                            make_uint2(__builtin_bit_cast(uint32_t, __builtin_fmaf((float)(int)en[i], gl, ek)), row0 + (uint32_t)i);
+                    ++slot;
+                }
+            }
+        }
+        wpos = 0;
+    };
+    const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
+    // slow path of one query group: mxl = the lane's maximum over its 4 accumulators, thr_lane its integer threshold,
+    // gl / ek its s * s_q and E + K2; row_base: first row of the 16-row tile, q_first: query of lane 0
+    auto stage_hits = [&](const i32x4_t& acc, int mxl, uint32_t row_base, uint32_t q_first, int thr_lane, float gl, float ek)
+        __attribute__((always_inline)) {
+        const bool hitl = mxl > thr_lane;
+        const unsigned long long hm = __ballot(hitl);
+        const uint32_t n = (uint32_t)__popcll(hm);
+        if (wpos + n > I16_ECAP) {
+            flush_wave();
+            asm volatile("" ::: "memory");  // the flush's reads of the stage stay in front of the stores below
+        }
+        if (hitl) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            const uint32_t pa = stage_base + (wave * I16_ECAP + wpos + rank) * (I16_EDW * 4u);
+            asm volatile(
+                "ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16\n\tds_write_b32 %0, %3 offset:20\n\t"
+                "ds_write_b32 %0, %4 offset:24\n\tds_write_b32 %0, %5 offset:28\n\tds_write_b32 %0, %6 offset:32"
+                :
+                : "v"(pa), "v"(acc), "v"(q_first + r16), "v"(row_base + 4 * q4), "v"(thr_lane), "v"(gl), "v"(ek));
+        }
+        wpos += n;  // (n <= 64 = I16_ECAP: after a flush the entries always fit)
+    };
+    i32x4_t acc[2][4];
+    int mx[4] = {0, 0, 0, 0}, thr[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[1][g][e] = 0;
+    // {s, E} of the four 32-row sub-tiles: mu = the tile whose sub-tiles are under test, ml = the next one
+    f32x4 mu0, mu1, ml0, ml1;
+    auto sub_meta = [&](int j, float& rs_, float& e_) __attribute__((always_inline)) {  // {1 / s, E} of 32-row sub-tile j
+        rs_ = j == 0 ? mu0.x : j == 1 ? mu0.z : j == 2 ? mu1.x : mu1.z;
+        e_ = j == 0 ? mu0.y : j == 1 ? mu0.w : j == 2 ? mu1.y : mu1.w;
+    };
+    // dense store of one finished 16-row tile (accumulator set SET, 16-row tile J16 of the tile in mu)
+    auto tail_dense = [&](auto set_c, auto nl_c, int J16, uint32_t row_base, uint32_t slot_base) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
+        const uint32_t row0 = row_base + 4 * q4;
+        float rs_, e_;
+        sub_meta(J16 >> 1, rs_, e_);
+        const float s_ = __builtin_amdgcn_rcpf(rs_);
+#pragma unroll
+        for (int g = 0; g < 2 * NL; ++g) {
+            const int qidx = group_first(g) + (int)r16;
+            const float gl = s_ * sq_l[g], ek = e_ + k2_l[g];
+            if (qidx < n_q) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (row0 + e) < n_rows ? __builtin_fmaf((float)acc[SET][g][e], gl, ek) : NEG_INF;
+                *reinterpret_cast<f32x4*>(dense + (size_t)qidx * BATCH_CAP + slot_base + 4 * q4) = o;
+            }
+        }
+    };
+    // integer thresholds of 32-row sub-tile J for the live groups (see scan_i8_pipe_kernel::set_thr), two groups per packed fma
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    auto set_thr = [&](auto nl_c, int J) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        float rs_, e_;
+        sub_meta(J, rs_, e_);
+#pragma unroll
+        for (int p = 0; p < NL; ++p) {
+            const f32x2_t u = __builtin_elementwise_fma(f32x2_t{-e_, -e_}, f32x2_t{c2[2 * p], c2[2 * p + 1]}, f32x2_t{c1[2 * p], c1[2 * p + 1]});
+            const f32x2_t t2 = __builtin_elementwise_fma(u, f32x2_t{rs_, rs_}, f32x2_t{-2.0f, -2.0f});
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float tf = __builtin_amdgcn_fmed3f(i == 0 ? t2.x : t2.y, -2.0e9f, 2.0e9f);
+                int ti;
+                asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(ti) : "v"(tf));
+                thr[2 * p + i] = ti;
+            }
+        }
+    };
+    auto slow = [&](auto set_c, auto nl_c, int J16, uint32_t row_base) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, NL = decltype(nl_c)::value;
+        float rs_, e_;
+        sub_meta(J16 >> 1, rs_, e_);
+        const float s_ = __builtin_amdgcn_rcpf(rs_);
+#pragma unroll
+        for (int g = 0; g < 2 * NL; ++g)
+            if (__any(mx[g] > thr[g]))
+                stage_hits(acc[SET][g], mx[g], row_base, (uint32_t)group_first(g), thr[g], s_ * sq_l[g], e_ + k2_l[g]);
+    };
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) asm volatile("" ::"v"(qf[g][s]));
+        asm volatile("" ::"v"(c1[g]), "v"(sq_l[g]), "v"(k2_l[g]), "v"(c2[g]));
+    }
+    const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
+    const f32x4* meta4 = reinterpret_cast<const f32x4*>(meta);  // 2 per tile
+
+    ml0 = meta4[(size_t)unit_tile(0) * 2];
+    ml1 = meta4[(size_t)unit_tile(0) * 2 + 1];
+    asm volatile("" : "+v"(ml0), "+v"(ml1));
+    mu0 = ml0;
+    mu1 = ml1;
+    const unsigned char* gp0[NGP];
+    const unsigned char* gp1[NGP];
+    dma(0, 0, gp0);
+    dma(last < 1u ? last : 1u, 1, gp1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
+    keep(gp0);
+    keep(gp1);
+    // byte offset of this lane's 16 bytes of fragment step f within a tile image
+    const uint32_t lane_off = q4 * 512u + r16 * 16u;
+#define DAWN_I16_FOFF(F) ((((F) / 12) * 12 + 2 * ((F) % 6)) * 1024 + 256 * (((F) / 6) & 1))
+    i32x4_t a[PD];
+    {
+        const uint32_t ad = o0 + lane_off;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[0]) : "v"(ad), "n"(DAWN_I16_FOFF(0)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[1]) : "v"(ad), "n"(DAWN_I16_FOFF(1)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[2]) : "v"(ad), "n"(DAWN_I16_FOFF(2)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[3]) : "v"(ad), "n"(DAWN_I16_FOFF(3)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[4]) : "v"(ad), "n"(DAWN_I16_FOFF(4)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[5]) : "v"(ad), "n"(DAWN_I16_FOFF(5)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[6]) : "v"(ad), "n"(DAWN_I16_FOFF(6)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[7]) : "v"(ad), "n"(DAWN_I16_FOFF(7)));
+    }
+
+    uint32_t t = 0;
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    auto step = [&](auto nl_c, uint32_t rd, uint32_t nx, uint32_t wr) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;  // live group PAIRS
+        const uint32_t ad = o0 + rd * I8_TILE_BYTES + lane_off;
+        const uint32_t adn = o0 + nx * I8_TILE_BYTES + lane_off;
+        const unsigned char* gp[NGP];
+#pragma unroll
+        for (int f = 0; f < 48; ++f) {
+            const int sub16 = f / 6, s = f % 6, set = sub16 & 1;
+            // the 16-row tile whose test runs during this one: (t, sub16 - 1), or (t - 1, 7) while sub16 == 0
+            const int J16 = sub16 == 0 ? 7 : sub16 - 1;
+            if (NL > 0) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));  // fragment f has landed
+                __builtin_amdgcn_sched_barrier(0);
+                // asm MFMAs (see scan_i8_pipe_kernel): accumulators and the query fragments of groups 0, 1 in VGPRs, those of
+                // groups 2, 3 in AGPRs read directly as SrcB
+#define DAWN_I16_ZERO(D, A, B, CB) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(D) : "v"(A), CB(B))
+#define DAWN_I16_ACC(D, A, B, CB) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(D) : "v"(A), CB(B))
+                if (s == 0) {
+                    DAWN_I16_ZERO(acc[set][0], a[f % PD], qf[0][0], "v");
+                    DAWN_I16_ZERO(acc[set][1], a[f % PD], qf[1][0], "v");
+                    if (NL > 1) {
+                        DAWN_I16_ZERO(acc[set][2], a[f % PD], qf[2][0], "a");
+                        DAWN_I16_ZERO(acc[set][3], a[f % PD], qf[3][0], "a");
+                    }
+                } else {
+                    DAWN_I16_ACC(acc[set][0], a[f % PD], qf[0][s], "v");
+                    DAWN_I16_ACC(acc[set][1], a[f % PD], qf[1][s], "v");
+                    if (NL > 1) {
+                        DAWN_I16_ACC(acc[set][2], a[f % PD], qf[2][s], "a");
+                        DAWN_I16_ACC(acc[set][3], a[f % PD], qf[3][s], "a");
+                    }
+                }
+#undef DAWN_I16_ZERO
+#undef DAWN_I16_ACC
+                __builtin_amdgcn_sched_barrier(0);
+                const bool have_prev = sub16 > 0 || t > 0;  // (sub16 is a constant: folds to `t > 0` or true)
+                if (!DENSE) {
+                    // thresholds belong to a 32-row sub-tile: computed for its first 16-row tile, kept for the second.  (No s_nop in
+                    // front of the slices below: the accumulators they read were last written eight MFMAs ago.)
+                    if (s == 0 && (J16 & 1) == 0) set_thr(nl_c, J16 >> 1);
+                    if (s == 1 || s == 2) {
+#pragma unroll
+                        for (int g = 2 * (s - 1); g < 2 * (s - 1) + 2; ++g) {
+                            if (g < 2 * NL) {
+                                mx[g] = max(max(acc[1 - set][g][0], acc[1 - set][g][1]), max(acc[1 - set][g][2], acc[1 - set][g][3]));
+                                asm volatile("" : "+v"(mx[g]));
+                            }
+                        }
+                    }
+                    if (s == 3 && have_prev) {
+                        bool hit = mx[0] > thr[0] || mx[1] > thr[1];
+                        if (NL > 1) hit = hit || mx[2] > thr[2] || mx[3] > thr[3];
+                        if (__builtin_expect(__any(hit), 0)) {  // (unlikely: keeps the slow paths out of the hot instruction stream)
+                            const uint32_t rb = sub16 == 0 ? unit_row0(t - 1) + 112 : unit_row0(t) + 16 * (sub16 - 1);
+                            if (set == 0) slow(C1(), nl_c, J16, rb);
+                            else slow(C0(), nl_c, J16, rb);
+                        }
+                    }
+                }
+                if (DENSE && s == 1 && have_prev) {
+                    asm volatile("s_nop 7");
+                    const uint32_t rb = sub16 == 0 ? unit_row0(t - 1) + 112 : unit_row0(t) + 16 * (sub16 - 1);
+                    const uint32_t sb = sub16 == 0 ? unit_slot0(t - 1) + 112 : unit_slot0(t) + 16 * (sub16 - 1);
+                    if (set == 0) tail_dense(C1(), nl_c, J16, rb, sb);
+                    else tail_dense(C0(), nl_c, J16, rb, sb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f == 5) {  // the last test of tile t-1 is done: its {s, E} make room for tile t's (landed since P2 of t-1)
+                mu0 = ml0;
+                mu1 = ml1;
+                asm volatile("" : "+v"(mu0), "+v"(mu1));
+            }
+            if (f == 12) {  // P1: every wave has left tile t-1, its image may be overwritten
+                asm volatile("s_barrier");
+                __builtin_amdgcn_sched_barrier(0);
+                // {s, E} of tile t+1, IN FRONT of the DMA of tile t+2: P2's vmcnt(DPW) covers them
+                const f32x4* mp = meta4 + (size_t)unit_tile(t + 1 < n_units ? t + 1 : last) * 2;
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                             : "=&v"(ml0), "=&v"(ml1)
+                             : "v"(mp));
+                dma_setup(t + 2 < n_units ? t + 2 : last, gp);
+            }
+            if (f == 13) dma_one(std::integral_constant<int, 0>(), wr, gp);
+            if (f == 14) dma_one(std::integral_constant<int, 1>(), wr, gp);
+            if (f == 15) dma_one(std::integral_constant<int, 2>(), wr, gp);
+            if (f == 16) dma_one(std::integral_constant<int, 3>(), wr, gp);
+            if (f == 17) dma_one(std::integral_constant<int, 4>(), wr, gp);
+            if (f == 18) dma_one(std::integral_constant<int, 5>(), wr, gp);
+            if (f == 19) dma_one(std::integral_constant<int, 6>(), wr, gp);
+            if (f == 20) dma_one(std::integral_constant<int, 7>(), wr, gp);
+            if (f == 21) dma_one(std::integral_constant<int, 8>(), wr, gp);
+            if (f == 22) dma_one(std::integral_constant<int, 9>(), wr, gp);
+            if (f == 23) dma_one(std::integral_constant<int, 10>(), wr, gp);
+            if (f == 24) dma_one(std::integral_constant<int, 11>(), wr, gp);
+            if (f == 39) {  // P2: tile t+1 and the {s, E} loads in front of tile t+2's DMA have landed
+                __builtin_amdgcn_sched_barrier(0);
+                if (DENSE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier");  // (dense stores share vmcnt)
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPW));
+                asm volatile("" : "+v"(ml0), "+v"(ml1));
+            }
+            if (NL > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (f + PD < 48)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[f % PD]) : "v"(ad), "n"(DAWN_I16_FOFF(f + PD)));
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[f % PD]) : "v"(adn), "n"(DAWN_I16_FOFF(f + PD < 48 ? 0 : f + PD - 48)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        keep(gp);
+        ++t;
+    };
+    auto run = [&](auto nl_c) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_c)::value;
+        uint32_t rd = 0, nx = 1, wr = 2;
+        while (t < n_units) {
+            step(nl_c, rd, nx, wr);
+            const uint32_t o = rd;
+            rd = nx;
+            nx = wr;
+            wr = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15");  // the ring's look-ahead reads; the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (NL > 0) {  // the last 16-row tile (t = last, sub16 7, accumulator set 1); mu holds tile `last` since its f == 5
+            const uint32_t rb = unit_row0(last) + 112, sb = unit_slot0(last) + 112;
+            if (DENSE) {
+                tail_dense(C1(), nl_c, 7, rb, sb);
+            } else {
+                set_thr(nl_c, 3);
+#pragma unroll
+                for (int g = 0; g < 2 * NL; ++g) mx[g] = max(max(acc[1][g][0], acc[1][g][1]), max(acc[1][g][2], acc[1][g][3]));
+                slow(C1(), nl_c, 7, rb);
+            }
+        }
+    };
+    if (live1) run(C2());
+    else if (live0) run(C1());
+    else run(C0());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
+    if (!DENSE) flush_wave();
+#undef DAWN_I16_FOFF
+}
+
 // append pass; mfma_sched 41 / 42 / 44 / 47: timing experiments with parts switched off (results are wrong)
 static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t n_rows, uint32_t stride, uint32_t n_tiles,
                              const i32x4_t* qi, const float2* qm, int B, const BatchWorkspace& ws, uint32_t blocks,
@@ -942,9 +1336,25 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 49: DAWN_I8_PIPE(16); break;
         case 50: DAWN_I8_PIPE(32); break;
 #endif
-        default: DAWN_I8_PIPE(0); break;
+        case 32: DAWN_I8_PIPE(0); break;  // the 32x32x32 form (option "mfma_sched" = 32)
+        default:
+            hipLaunchKernelGGL(scan_i8_pipe16_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
+                               qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+            break;
     }
 #undef DAWN_I8_PIPE
+}
+
+// dense pass (every score of the tiles it visits)
+static void launch_i8_dense(const unsigned char* xs, const float2* mt, uint32_t n_rows, uint32_t stride, uint32_t n_tiles,
+                            const i32x4_t* qi, const float2* qm, int B, const BatchWorkspace& ws, uint32_t blocks,
+                            hipStream_t stream) {
+    if (ws.sched == 32)
+        hipLaunchKernelGGL(scan_i8_pipe_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, qi, qm,
+                           B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+    else
+        hipLaunchKernelGGL(scan_i8_pipe16_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, qi,
+                           qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
 }
 
 // Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
@@ -972,10 +1382,8 @@ void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32
     const uint32_t n = n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP;
     const uint32_t n_tiles = (n + I8_TILE_ROWS - 1) / I8_TILE_ROWS;
     if (n_tiles == 0) return;
-    hipLaunchKernelGGL(scan_i8_pipe_kernel<true>, dim3(n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid), dim3(256), 0, stream,
-                       reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 0u, 1u,
-                       n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
-                       reinterpret_cast<float*>(ws.cand));
+    launch_i8_dense(reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 1u, n_tiles,
+                    reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid, stream);
 }
 
 void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids,
@@ -992,9 +1400,7 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
         if (n_tiles == 0) return;
         const uint32_t blocks = n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid;
         if (dense_pass)
-            hipLaunchKernelGGL(scan_i8_pipe_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
-                               reinterpret_cast<const i32x4_t*>(qi), qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand),
-                               reinterpret_cast<float*>(ws.cand));
+            launch_i8_dense(xs, mt, n_rows, stride, n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream);
         else
             launch_i8_append(xs, mt, n_rows, stride, n_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream);
     };

@@ -377,6 +377,28 @@ def test_batched_two_sample_plan_3m(dawn, oracle, shadow):
     assert idx.stats()["fallbacks"] == 0
 
 
+def test_int8_filter_mfma_shapes_agree(dawn, oracle):
+    """The int8 batched filter runs on v_mfma_i32_16x16x64_i8 (default) or, option "mfma_sched" = 32, on
+    v_mfma_i32_32x32x32_i8 — same images, same thresholds: identical results (the filter only has to be an upper bound, the
+    rescoring is exact), both equal to the oracle; ragged sizes, 1..256 queries, with and without the sampled thresholds."""
+    for n, B, k in ((8200, 40, 10), (100_003, 1 + 32, 20), (300_001, 256, 10), (70_000, 17, 64)):
+        idx = _mk_index(dawn, n)
+        x = oracle.unit_rows(1, 0, n)
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        Q = synth.unit_rows(2, 0, B)
+        Q[B // 2] = x[n - 1]
+        res = {}
+        for sched in (32, 4):
+            idx.set_option("mfma_sched", sched)
+            res[sched] = idx.search_batch(Q, k)
+        assert all(np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+                   for a, b in zip(res[32], res[4]))
+        for b in (0, B // 2, B - 1):
+            olab, odist = oracle.scan_topk(x, ids, Q[b], k, threads=8)
+            _assert_same(res[4][0][b][:k], res[4][1][b][:k], olab, odist)
+        assert idx.stats()["fallbacks"] == 0
+
+
 def test_batched_filter_error_within_bound(dawn):
     """The certificate assumes |f16 filter score - exact dot| <= FILTER_EPS_F16 = 1.25e-3 (kernels.hpp); measure it
     against float64 on random unit rows, on planted near-duplicates (large scores) and on sparse rows with tiny
