@@ -141,6 +141,8 @@ def test_pipelined_kernels_keep_their_accumulators_out_of_agpr_spills(tmp_path):
     assert len(i8) == 2 and len(f16) == 1, (i8, f16)
     assert set(i8.values()) == {48}, i8
     assert set(f16.values()) == {96}, f16
+    i16 = {k: v for k, v in seen.items() if "scan_i8_pipe16_kernel" in k}  # the 16x16x64 form: groups 2, 3 = 48 AGPRs
+    assert len(i16) == 2 and set(i16.values()) == {48}, i16
 
 
 def test_release_library_holds_no_experiment_kernels(tmp_path):
