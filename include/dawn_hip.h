@@ -180,7 +180,8 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 2)
  *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
  *   "mfma_sched"       4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave kernel only,
- *                      0 = lockstep converting kernel on the f32 rows.  (The timing experiments 2 / 41..55 — parts of the
+ *                      0 = lockstep converting kernel on the f32 rows, 32 = the int8 filter on v_mfma_i32_32x32x32_i8 (default:
+ *                      16x16x64, the shape the chip clocks higher under load; same results).  (The timing experiments 2 / 41..55 — parts of the
  *                      pipelined kernels switched off, wrong results by design — only exist in `make EXPERIMENTS=1`
  *                      builds; the release library rejects them.)
  *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (1024; twice that for count > 32)
@@ -236,7 +237,10 @@ int dawn_embedder_forward_device(dawn_embedder *e, const uint32_t *d_token_ids, 
                                  int B, int total_tokens, int max_len, float *d_out, void *stream);
 /* Tuning knobs (defaults are the tuned values): "gemm_bf16x3" 0 = batches above the latency form run their dense layers on
  * the f32-MFMA tile kernel instead of the f32-accurate 3-way bf16 split on the bf16 matrix cores (default 1;
- * "gemm3_big_min_tiles" = number of 128 x 128 tiles from which that form is used, "gemm3_stages" = ring depth of its 64 x 64 form);
+ * "gemm3_big_min_tiles" = number of 128 x 128 tiles from which that form is used, "gemm3_stages" = ring depth of its 64 x 64 form,
+ * "gemm3_pingpong" 0 = the 128 x 128 form's waves in lockstep, "gemm3_persistent" = its workgroups (default 256, one per CU, walking
+ * the tile list; 0 = one per tile)); "attention_wave" 1 = sequences of up to 64 tokens always take the wave-per-sequence
+ * attention kernel (default 0: only where the dense layers read planes);
  * "skinny_max_rows" = total tokens up to which the GEMMs use the split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
  * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
 int dawn_embedder_set_option(dawn_embedder *e, const char *name, int64_t value);
