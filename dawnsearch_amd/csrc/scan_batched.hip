@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
+    const float q_val = threadIdx.x < EM ? q[(size_t)b * EM + threadIdx.x] : 0.f;  // (used after the selection: block_exact_dots)
     // candidates of this query: DENSE every row; else the segments' counts (a segment past its capacity dropped
     // candidates: the query goes to the exact pass)
     uint32_t count = n_rows;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     float bs;
     uint32_t bp;
     bool heavy;
-    const uint32_t flag = certify_rounds<RT>(select, base, !overflow, n_rows, found, eps, force_fallback, q + (size_t)b * EM, x,
+    const uint32_t flag = certify_rounds<RT>(select, base, !overflow, n_rows, found, eps, force_fallback, q_val, x,
                                              rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
     if (wave == 0) {
         if ((uint32_t)lane < found && bp != NO_POS) {

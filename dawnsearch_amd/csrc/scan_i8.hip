@@ -236,10 +236,6 @@ void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta
 // ------------------------------------------------------------------------------------------------
 // streaming filter
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pack4_i8(int a, int b, int c, int d) {
-    return (a & 255) | ((b & 255) << 8) | ((c & 255) << 16) | (int)((uint32_t)(d & 255) << 24);
-}
-
 // Lists hold ub (see the header) as the score.  q: the n_q <= QB <= 8 queries, f32 [n_q][384].
 template <bool NT>
 __device__ __forceinline__ u32x4 row_load(const u32x4* p) {
@@ -264,53 +260,48 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const uint32_t n_sub = (n_rows + 31u) >> 5;
     const uint32_t c = lane & 31, h = lane >> 5;
 
-    // B operand: column c < 8 = H of query c, column 8 + c = L; lane (h, c) holds k = 32f + 16h .. +15 of k-step f
-    i32x4_t qf[12];
-#pragma unroll
-    for (int f = 0; f < 12; ++f) qf[f] = i32x4_t{0, 0, 0, 0};
-    const int qcol = (int)(c & 7u);
-    const bool lo_part = c >= 8;
-    float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;  // this lane's query: s_q / 254, K2, 254 / s_q
-    // the queries in the shadow's basis: wave w rotates queries w, w + nwaves, ... into LDS
-    __shared__ __attribute__((aligned(16))) float sh_q[QB * EM];
-    for (int b = wave; b < n_q; b += nwaves) {
+    // B operand: column c < 8 = H of query c, column 8 + c = L; lane (h, c) holds k = 32f + 16h .. +15 of k-step f.
+    // The two int8 images of a query are built ONCE per workgroup, by the wave that rotates it (lane l holds elements
+    // l + 64 j: wave maximum -> s_q, six H and six L bytes per lane into LDS), and every wave reads its twelve fragments
+    // back as 16-B chunks.  (Each lane of columns 0 / 8 quantising all 384 elements itself — 192 divisions and a 96-step
+    // maximum per lane, in every wave — made the kernel take 30 us on an index of 4096 rows.)
+    __shared__ __attribute__((aligned(16))) signed char sh_img[2][QB][EM];  // [H | L][query][k]
+    __shared__ float sh_sq[QB];
+    for (int b = wave; b < QB; b += nwaves) {
         float v[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) v[j] = q[(size_t)b * EM + lane + 64 * j];
-        rotate384_wave(v, lane);
+        for (int j = 0; j < 6; ++j) v[j] = b < n_q ? q[(size_t)b * EM + lane + 64 * j] : 0.f;
+        rotate384_wave(v, lane);  // the shadow's basis (header of this file)
+        float amax = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) sh_q[b * EM + lane + 64 * j] = v[j];
+        for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float t = v[j] / sq;
+            const float H = fminf(fmaxf(rintf(t), -127.f), 127.f);
+            const float L = fminf(fmaxf(rintf((t - H) * 254.0f), -127.f), 127.f);
+            sh_img[0][b][lane + 64 * j] = b < n_q ? (signed char)(int)H : (signed char)0;
+            sh_img[1][b][lane + 64 * j] = b < n_q ? (signed char)(int)L : (signed char)0;
+        }
+        if (lane == 0) sh_sq[b] = sq;
     }
     __syncthreads();
-    if (qcol < n_q && c < 16) {
-        const f32x4* qc = reinterpret_cast<const f32x4*>(sh_q + (size_t)qcol * EM);
-        float amax = 0.f;
-        for (int i = 0; i < ROW_F4; ++i) {
-            const f32x4 v = qc[i];
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        }
-        const float sq = fmaxf(amax, 1e-20f) / 127.0f;
-        sq254_l = sq / 254.0f;
-        rsq254_l = 254.0f / sq;
-        k2_l = I8_K2_PER_SQ * sq;
+    i32x4_t qf[12];
+    const int qcol = (int)(c & 7u);
+    float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;  // this lane's query: s_q / 254, K2, 254 / s_q
+    {
+        const bool col_live = qcol < n_q && qcol < QB && c < 16;
+        const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&sh_img[c >= 8 ? 1 : 0][col_live ? qcol : 0][0]);
 #pragma unroll
-        for (int f = 0; f < 12; ++f) {
-            int w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 v = qc[8 * f + 4 * h + j];
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                int b4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = vv[i] / sq;
-                    const float H = fminf(fmaxf(rintf(t), -127.f), 127.f);
-                    const float L = fminf(fmaxf(rintf((t - H) * 254.0f), -127.f), 127.f);
-                    b4[i] = (int)(lo_part ? L : H);
-                }
-                w[j] = pack4_i8(b4[0], b4[1], b4[2], b4[3]);
-            }
-            qf[f] = i32x4_t{w[0], w[1], w[2], w[3]};
+        for (int f = 0; f < 12; ++f) qf[f] = col_live ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
+        if (col_live) {
+            const float sq = sh_sq[qcol];
+            sq254_l = sq / 254.0f;
+            rsq254_l = 254.0f / sq;
+            k2_l = I8_K2_PER_SQ * sq;
         }
     }
     float ls[QB], tau[QB], sq254[QB], k2[QB];

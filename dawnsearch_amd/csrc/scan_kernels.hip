@@ -419,10 +419,16 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const float* cs = cand_s + (size_t)b * n_lists * LIST;
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
     __shared__ uint32_t sh_ctl[4];
+    __shared__ float sh_t[16];
+    const float q_val = threadIdx.x < EM ? q[(size_t)b * EM + threadIdx.x] : 0.f;  // (used after the selection: see block_exact_dots)
+    // rows in no list scored <= T = the largest 64th entry of any list (round 1: the merged 64th entry is >= T anyway); found
+    // by the first selection from the entries it loads anyway (lane 0 of a reversed list holds its 64th entry)
+    float T = NEG_INF;
     // the next 64 candidates by filter score among the per-workgroup lists
     auto select = [&](bool first, float ex_s, uint32_t ex_p, float& s, uint32_t& p) {
         s = NEG_INF;
         p = NO_POS;
+        float t0 = NEG_INF;
         constexpr int INF = 16;  // lists in flight per wave: the usual 256 lists are ONE round of loads
         for (int l0 = wave; l0 < n_lists; l0 += INF * nwaves) {
             float os[INF];
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
 #pragma unroll
             for (int j = 0; j < INF; ++j) {
                 if (l0 + j * nwaves >= n_lists) continue;  // wave-uniform
+                if (first) t0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, os[j]))));
                 if (!first) {
                     // entries down to the last one already rescored drop out: they are a prefix of the (descending) list,
                     // so the survivors are sorted again with the fillers moved behind them
@@ -452,23 +459,16 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
                 merge64(s, p, os[j], op[j], lane);
             }
         }
+        if (first && lane == 0) sh_t[wave] = t0;  // (visible after block_merge's barriers)
         block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+        if (first)
+            for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_t[w]);
     };
-    // rows in no list scored <= T = the largest 64th entry of any list (round 1: the merged 64th entry is >= T anyway)
-    float tmax = NEG_INF;
-    for (int l = threadIdx.x; l < n_lists; l += blockDim.x) tmax = fmaxf(tmax, cs[(size_t)l * LIST + 63]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-    __shared__ float sh_t[16];
-    if (lane == 0) sh_t[wave] = tmax;
-    __syncthreads();
-    float T = NEG_INF;
-    for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_t[w]);
     const uint32_t found = n_rows < k ? n_rows : k;
     float bs;
     uint32_t bp;
     bool heavy;
-    const uint32_t flag = certify_rounds<RT>(select, T, true, n_rows, found, eps, force_fallback, q + (size_t)b * EM, x,
+    const uint32_t flag = certify_rounds<RT>(select, T, true, n_rows, found, eps, force_fallback, q_val, x,
                                              rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
     if (wave == 0) {
         if ((uint32_t)lane < found && bp != NO_POS) {

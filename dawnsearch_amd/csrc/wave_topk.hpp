@@ -217,12 +217,14 @@ struct RescoreStage {
 };
 
 template <int RT>
-__device__ __forceinline__ float block_exact_dots(const float* __restrict__ qv, const void* __restrict__ x, uint32_t p,
+// q_val: element threadIdx.x of the query (threads < 384), loaded by the caller at the START of its kernel — a load issued
+// here would be one more exposed round trip in front of the row gather
+__device__ __forceinline__ float block_exact_dots(float q_val, const void* __restrict__ x, uint32_t p,
                                                   unsigned char* stage, uint32_t* sh_rows, int wave, int lane) {
     typedef RescoreStage<RT> S;
     float* sh_q = reinterpret_cast<float*>(stage + S::ROWS_BYTES);  // the query too: 96 dependent global reads otherwise
     if (wave == 0) sh_rows[lane] = p;
-    if (threadIdx.x < EM) sh_q[threadIdx.x] = qv[threadIdx.x];
+    if (threadIdx.x < EM) sh_q[threadIdx.x] = q_val;
     __syncthreads();
     const u32x4* xr = reinterpret_cast<const u32x4*>(x);
     for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
@@ -311,6 +313,8 @@ __device__ __forceinline__ float round_up_f32(double t) {
 // entry of round r excluded), rescores them the same cooperative way (block_exact_dots: ~4 us), merges the exact results
 // and tries the certificate with the bound 64 ranks further down — up to CERT_ROUNDS x 64 rows.  Same mathematics as
 // round 1, each round ~10 us.
+//   base: read AFTER the first select() — the caller may compute it there (merge_rescore_kernel does);
+//   q_val: element threadIdx.x of the query (see block_exact_dots);
 //   select(first, ex_s, ex_p, s, p): called by every thread; leaves in wave 0 the (up to) 64 best candidates by filter
 //   score (descending, ties -> lower row; fillers (-inf, NO_POS) last) among those strictly worse than (ex_s, ex_p)
 //   (first: among all).
@@ -320,8 +324,8 @@ __device__ __forceinline__ float round_up_f32(double t) {
 constexpr int CERT_ROUNDS = 4;
 
 template <int RT, class SelectFn>
-__device__ __forceinline__ uint32_t certify_rounds(SelectFn select, float base, bool complete, uint32_t n_rows, uint32_t found,
-                                                   float eps, int force_fallback, const float* __restrict__ qv,
+__device__ __forceinline__ uint32_t certify_rounds(SelectFn select, const float& base, bool complete, uint32_t n_rows, uint32_t found,
+                                                   float eps, int force_fallback, float q_val,
                                                    const void* __restrict__ x, unsigned char* rescore_stage, uint32_t* sh_rows,
                                                    uint32_t* sh_ctl, int wave, int lane, float& bs, uint32_t& bp, bool& heavy) {
     float s;
@@ -332,7 +336,7 @@ __device__ __forceinline__ uint32_t certify_rounds(SelectFn select, float base, 
     uint32_t flag = FLAG_OK;
     heavy = false;
     for (int r = 0;; ++r) {
-        const float dot = block_exact_dots<RT>(qv, x, p, rescore_stage, sh_rows, wave, lane);
+        const float dot = block_exact_dots<RT>(q_val, x, p, rescore_stage, sh_rows, wave, lane);
         if (wave == 0) {
             const uint32_t have_r = __popcll(__ballot(p != NO_POS));
             const float s_last = read_lane63(s);
