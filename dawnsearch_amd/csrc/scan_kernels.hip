@@ -20,6 +20,14 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf, and
 // the exact paths use separate multiply and add as the reference (Rust) does.
 #include "kernels.hpp"
+#ifdef DAWN_EXPERIMENTS
+// timestamp probes (100-MHz counter) of workgroup 0, thread 0: merge_rescore_kernel's phases (dawn_debug_read_ts)
+static __device__ unsigned long long dawn_ts[16];
+#define DAWN_TS(i)                                                                       \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x == 0) dawn_ts[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#endif
 #include "wave_topk.hpp"
 
 namespace dawn {
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
     __shared__ uint32_t sh_ctl[4];
     __shared__ float sh_t[16];
+    DAWN_TS(0);
     const float q_val = threadIdx.x < EM ? q[(size_t)b * EM + threadIdx.x] : 0.f;  // (used after the selection: see block_exact_dots)
     // rows in no list scored <= T = the largest 64th entry of any list (round 1: the merged 64th entry is >= T anyway); found
     // by the first selection from the entries it loads anyway (lane 0 of a reversed list holds its 64th entry)
@@ -460,7 +469,9 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
             }
         }
         if (first && lane == 0) sh_t[wave] = t0;  // (visible after block_merge's barriers)
+        DAWN_TS(1);
         block_merge(s, p, sh_s, sh_p, wave, lane, nwaves);
+        DAWN_TS(2);
         if (first)
             for (int w = 0; w < nwaves; ++w) T = fmaxf(T, sh_t[w]);
     };
@@ -480,6 +491,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
             out_flags[b] = flag;
         }
     }
+    DAWN_TS(7);
     if (!heavy) return;
 
     // ---- second chance (wave_topk.hpp): the union of the workgroup lists holds every row whose filter score exceeds T;
@@ -887,3 +899,12 @@ void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t st
 }
 
 }  // namespace dawn
+
+#ifdef DAWN_EXPERIMENTS
+extern "C" int dawn_debug_read_ts(unsigned long long* out, int n) {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];
+    return 0;
+}
+#endif

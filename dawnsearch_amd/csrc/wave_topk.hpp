@@ -3,6 +3,11 @@
 #pragma once
 #include "kernels.hpp"
 
+// Timestamp probes of the experiments build (scan_kernels.hip defines DAWN_TS before including this file); nothing otherwise.
+#ifndef DAWN_TS
+#define DAWN_TS(i)
+#endif
+
 namespace dawn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -118,6 +123,9 @@ __device__ __forceinline__ void merge64(float& s, uint32_t& p, float os_rev, uin
 }
 
 // Block-level tree merge of per-wave lists through LDS; result in wave 0.  nwaves is a power of two.
+// (A flat form — four leader waves merge three lists each, wave 0 merges the leaders': three barrier pairs instead of four —
+// measured the same: in merge_rescore_kernel the ~6 us up to the end of this merge are the sixteen waves' own 256 bitonic
+// merges sharing one CU's vector ALUs, not the barriers: tools/merge_ts.py.)
 __device__ __forceinline__ void block_merge(float& s, uint32_t& p, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST],
                                             int wave, int lane, int nwaves) {
     for (int stride = nwaves >> 1; stride >= 1; stride >>= 1) {
@@ -226,6 +234,7 @@ __device__ __forceinline__ float block_exact_dots(float q_val, const void* __res
     if (wave == 0) sh_rows[lane] = p;
     if (threadIdx.x < EM) sh_q[threadIdx.x] = q_val;
     __syncthreads();
+    DAWN_TS(3);
     const u32x4* xr = reinterpret_cast<const u32x4*>(x);
     for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
         const int r = i / S::CH, c = i % S::CH;
@@ -235,11 +244,13 @@ __device__ __forceinline__ float block_exact_dots(float q_val, const void* __res
                 RT == 1 ? xr[frag_chunk(row, c)] : xr[(size_t)row * S::CH + c];
     }
     __syncthreads();
+    DAWN_TS(4);
     float dot = 0.0f;
     if (wave == 0 && p != NO_POS) {
         if (RT == 1) dot = exact_dot_seq_bf16<8>(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
         else dot = exact_dot_seq<16>(sh_q, reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
     }
+    DAWN_TS(5);
     return dot;
 }
 
@@ -387,6 +398,7 @@ __device__ __forceinline__ uint32_t certify_rounds(SelectFn select, const float&
                 sh_ctl[3] = flag;
             }
         }
+        DAWN_TS(6);
         __syncthreads();
         const uint32_t next = sh_ctl[0];
         const float ex_s = __builtin_bit_cast(float, sh_ctl[1]);
