@@ -323,6 +323,25 @@ def test_wave_attention_f32_output_and_fused_pooling(provider, oracle):
             provider.set_option("attention_wave", 0)
 
 
+def test_dense_kernel_forms_are_bit_identical(provider):
+    """The 128 x 128 form of the bf16x3 dense kernel has tuning options that change only its schedule — waves of a SIMD in
+    lockstep or half a step apart ("gemm3_pingpong"), one workgroup per tile or 256 walking the tile list
+    ("gemm3_persistent") — never the arithmetic: a page batch (ragged last tile included) embeds to the same bits."""
+    seqs = synth.token_sequences(123, 37, 90, 128)  # ~4000 tokens
+    provider.set_option("gemm3_big_min_tiles", 0)
+    try:
+        ref = provider.calculate_embedding(seqs)
+        for pp, pers in ((0, 0), (0, 256), (1, 0), (1, 64)):
+            provider.set_option("gemm3_pingpong", pp)
+            provider.set_option("gemm3_persistent", pers)
+            got = provider.calculate_embedding(seqs)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (pp, pers)
+    finally:
+        provider.set_option("gemm3_pingpong", 1)
+        provider.set_option("gemm3_persistent", 256)
+        provider.set_option("gemm3_big_min_tiles", 512)
+
+
 def test_large_batches_take_the_bf16x3_kernels_and_stay_within_the_bar(provider, oracle):
     """Batches above the skinny limit run their dense layers f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way
     bf16 split, 6 products; 64 x 64 tiles, 128 x 128 tiles from 2048 tokens): same 1e-5 bar against the oracle, and
