@@ -102,6 +102,7 @@ _SIGS = {
     "dawn_best_get": (_i32, [_vp, _sz, C.POINTER(_sz), C.POINTER(C.c_float)]),
     "dawn_embedder_create": (_i32, [C.c_char_p, C.c_char_p, _i32, _pp]),
     "dawn_embedder_destroy": (None, [_vp]),
+    "dawn_embedder_check_files": (_i32, [C.c_char_p, C.c_char_p]),
     "dawn_embedder_forward": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "dawn_embedder_forward_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "dawn_embedder_set_option": (_i32, [_vp, C.c_char_p, _i64]),

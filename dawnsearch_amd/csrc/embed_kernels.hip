@@ -419,9 +419,9 @@ static void launch_skinny16(const float* A, const float* W, const float* bias, f
 }
 
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                    hipStream_t s) {
+                    hipStream_t s, bool tile_only) {
     if (M <= 0) return;
-    if (M <= g_skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
+    if (!tile_only && M <= g_skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
         if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
         if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
     }

@@ -15,9 +15,10 @@ void launch_add_ln_pool_norm(const float* a, const float* r, const int* seq_offs
 extern int g_attn_wave;
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
                    hipStream_t s, uint16_t* outp = nullptr, size_t plane_stride = 0);
-// Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.
+// Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.  tile_only: never the
+// split-K latency form (test / timing hooks ask for the 64x64 tile kernel whatever M is)
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                    hipStream_t s);
+                    hipStream_t s, bool tile_only = false);
 // Y = act(LN(a + r) . W^T + bias) and x_out = LN(a + r) in ONE launch (latency form: M <= skinny limit, K = 384); false =
 // not applicable to this shape
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,

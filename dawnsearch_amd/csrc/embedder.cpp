@@ -19,32 +19,33 @@
 
 #include "common.hpp"
 #include "embed_kernels.hpp"
-#include "mini_json.hpp"
+#include "model_files.hpp"
 
 using dawn::fail;
-using dawn::JParser;
-using dawn::JVal;
-using dawn::read_file;
 
 namespace {
 
-struct Config {  // model.rs:115-133 ; defaults = Config::_all_mini_lm_l6_v2 (:160-180)
-    int vocab_size = 30522, hidden_size = 384, num_hidden_layers = 6, num_attention_heads = 12;
-    int intermediate_size = 1536, max_position_embeddings = 512, type_vocab_size = 2;
-    int act = 1;  // 1 = gelu (tanh form), 2 = relu
-    double layer_norm_eps = 1e-12;
-    std::string model_type = "bert";
-};
-
-struct TensorRef {
-    std::vector<int64_t> shape;
-    size_t begin = 0, end = 0;
-};
+using Config = dawn::BertConfig;
 
 struct LayerW {
     float *qkv_w, *qkv_b, *ao_w, *ao_b, *ao_g, *ao_beta, *i_w, *i_b, *o_w, *o_b, *o_g, *o_beta;
     // the four dense weights as three bf16 planes each (embed_gemm3.hip), split once at load time
     uint16_t *qkv_p = nullptr, *ao_p = nullptr, *i_p = nullptr, *o_p = nullptr;
+};
+
+struct DevBuf {  // scratch device memory of the test / timing hooks
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+struct DevEvent {
+    hipEvent_t e = nullptr;
+    hipError_t create() { return hipEventCreate(&e); }
+    ~DevEvent() {
+        if (e) (void)hipEventDestroy(e);
+    }
 };
 
 }  // namespace
@@ -257,136 +258,14 @@ static int embedder_create_impl(const char* safetensors_path, const char* config
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
 
-    Config cfg;
-    if (config_json_path) {
-        std::vector<char> txt;
-        if (!read_file(config_json_path, txt)) return fail(DAWN_ERR_IO, "cannot read %s", config_json_path);
-        JParser jp{txt.data(), txt.data() + txt.size()};
-        JVal j = jp.parse();
-        if (!jp.ok || j.kind != JVal::Obj) return fail(DAWN_ERR_IO, "%s: invalid JSON", config_json_path);
-        auto geti = [&](const char* k, int& dst) {
-            if (const JVal* v = j.get(k))
-                if (v->kind == JVal::Num) dst = (int)v->num;
-        };
-        geti("vocab_size", cfg.vocab_size);
-        geti("hidden_size", cfg.hidden_size);
-        geti("num_hidden_layers", cfg.num_hidden_layers);
-        geti("num_attention_heads", cfg.num_attention_heads);
-        geti("intermediate_size", cfg.intermediate_size);
-        geti("max_position_embeddings", cfg.max_position_embeddings);
-        geti("type_vocab_size", cfg.type_vocab_size);
-        if (const JVal* v = j.get("layer_norm_eps"))
-            if (v->kind == JVal::Num) cfg.layer_norm_eps = v->num;
-        if (const JVal* v = j.get("model_type"))
-            if (v->kind == JVal::Str) cfg.model_type = v->str;
-        if (const JVal* v = j.get("hidden_act")) {  // enum HiddenAct { Gelu, Relu } model.rs:10-15
-            if (v->kind == JVal::Str && v->str == "gelu") cfg.act = 1;
-            else if (v->kind == JVal::Str && v->str == "relu") cfg.act = 2;
-            else return fail(DAWN_ERR_UNSUPPORTED, "hidden_act must be \"gelu\" or \"relu\"");
-        }
-    }
-    if (cfg.hidden_size != 384 || cfg.num_attention_heads != 12 || cfg.intermediate_size % 64 != 0 ||
-        cfg.num_hidden_layers < 1 || cfg.num_hidden_layers > 48 || cfg.max_position_embeddings > 512)
-        return fail(DAWN_ERR_UNSUPPORTED,
-                    "kernels are built for hidden 384 / 12 heads / intermediate %%64 / <=512 positions (all-MiniLM-L6-v2)");
-    // every size below comes from a file: bound it before it sizes an allocation (a C ABI must not throw / terminate)
-    if (cfg.vocab_size < 1 || cfg.vocab_size > (1 << 22) || cfg.type_vocab_size < 1 || cfg.type_vocab_size > 1024 ||
-        cfg.intermediate_size < 64 || cfg.intermediate_size > 65536 || cfg.max_position_embeddings < 1 ||
-        !(cfg.layer_norm_eps >= 0.0) || cfg.layer_norm_eps > 1.0)
-        return fail(DAWN_ERR_UNSUPPORTED, "config.json: vocab_size / type_vocab_size / intermediate_size / "
-                                          "max_position_embeddings / layer_norm_eps out of range");
-
-    std::vector<char> file;
-    if (!read_file(safetensors_path, file) || file.size() < 8) return fail(DAWN_ERR_IO, "cannot read %s", safetensors_path);
-    uint64_t hlen = 0;
-    std::memcpy(&hlen, file.data(), 8);
-    if (hlen > file.size() - 8) return fail(DAWN_ERR_IO, "%s: bad safetensors header length", safetensors_path);
-    JParser jp{file.data() + 8, file.data() + 8 + hlen};
-    JVal hdr = jp.parse();
-    if (!jp.ok || hdr.kind != JVal::Obj) return fail(DAWN_ERR_IO, "%s: invalid safetensors header", safetensors_path);
-    const char* data = file.data() + 8 + hlen;
-    const size_t data_len = file.size() - 8 - hlen;
-    std::map<std::string, TensorRef> tensors;
-    for (auto& kv : hdr.obj) {
-        if (kv.first == "__metadata__") continue;
-        const JVal* dt = kv.second.get("dtype");
-        const JVal* sh = kv.second.get("shape");
-        const JVal* off = kv.second.get("data_offsets");
-        if (!dt || !sh || !off || off->arr.size() != 2) return fail(DAWN_ERR_IO, "tensor %s: malformed entry", kv.first.c_str());
-        if (dt->str != "F32") continue;  // DTYPE = F32 (model.rs:8); other dtypes are not used by this model
-        TensorRef t;
-        for (auto& d : sh->arr) t.shape.push_back((int64_t)d.num);
-        t.begin = (size_t)off->arr[0].num;
-        t.end = (size_t)off->arr[1].num;
-        if (t.end > data_len || t.begin > t.end) return fail(DAWN_ERR_IO, "tensor %s: data out of range", kv.first.c_str());
-        tensors[kv.first] = t;
-    }
-
-    // name resolution: plain, then "{model_type}." prefix (model.rs:538-556)
-    std::string prefix;
-    auto has = [&](const std::string& n) { return tensors.count(n) != 0; };
-    if (!has("embeddings.word_embeddings.weight")) {
-        prefix = cfg.model_type + ".";
-        if (!has(prefix + "embeddings.word_embeddings.weight"))
-            return fail(DAWN_ERR_IO, "cannot find tensor embeddings.word_embeddings.weight (also tried prefix %s)", prefix.c_str());
-    }
+    dawn::ModelHost m;
+    DAWN_TRY(dawn::load_model_files(safetensors_path, config_json_path, m));
+    const Config& cfg = m.cfg;
     const int H = cfg.hidden_size, I = cfg.intermediate_size, NL = cfg.num_hidden_layers;
-    size_t total = (size_t)cfg.vocab_size * H + (size_t)cfg.max_position_embeddings * H + (size_t)cfg.type_vocab_size * H + 2 * H;
-    total += (size_t)NL * ((size_t)3 * H * H + 3 * H + (size_t)H * H + H + 2 * H + (size_t)I * H + I + (size_t)H * I + H + 2 * H);
-    std::vector<float> host(total);
-    size_t cur = 0;
-    std::string err;
-    auto take = [&](const std::string& name, std::vector<int64_t> shape, const std::string& alt = "") -> size_t {
-        std::string full = prefix + name;
-        auto it = tensors.find(full);
-        if (it == tensors.end() && !alt.empty()) it = tensors.find(prefix + alt);
-        size_t n = 1;
-        for (auto d : shape) n *= (size_t)d;
-        const size_t at = cur;
-        cur += n;
-        if (it == tensors.end()) {
-            if (err.empty()) err = "cannot find tensor " + full;
-            return at;
-        }
-        if (it->second.shape != shape || it->second.end - it->second.begin != n * 4) {
-            if (err.empty()) err = "shape mismatch for tensor " + full;
-            return at;
-        }
-        std::memcpy(host.data() + at, data + it->second.begin, n * 4);
-        return at;
-    };
-    auto ln = [&](const std::string& base, size_t& g, size_t& b) {  // weight/bias, fallback gamma/beta (:210-222)
-        g = take(base + ".weight", {H}, base + ".gamma");
-        b = take(base + ".bias", {H}, base + ".beta");
-    };
-    struct LOff {
-        size_t qw, kw, vw, qb, kb, vb, aow, aob, aog, aobeta, iw, ib, ow, ob, og, obeta;
-    };
-    size_t o_word = take("embeddings.word_embeddings.weight", {cfg.vocab_size, H});
-    size_t o_pos = take("embeddings.position_embeddings.weight", {cfg.max_position_embeddings, H});
-    size_t o_type = take("embeddings.token_type_embeddings.weight", {cfg.type_vocab_size, H});
-    size_t o_eg, o_eb;
-    ln("embeddings.LayerNorm", o_eg, o_eb);
-    std::vector<LOff> lo(NL);
-    for (int L = 0; L < NL; ++L) {
-        const std::string p = "encoder.layer." + std::to_string(L) + ".";
-        // Q|K|V weights and biases are laid out back to back so one GEMM produces [T][1152]
-        lo[L].qw = take(p + "attention.self.query.weight", {H, H});
-        lo[L].kw = take(p + "attention.self.key.weight", {H, H});
-        lo[L].vw = take(p + "attention.self.value.weight", {H, H});
-        lo[L].qb = take(p + "attention.self.query.bias", {H});
-        lo[L].kb = take(p + "attention.self.key.bias", {H});
-        lo[L].vb = take(p + "attention.self.value.bias", {H});
-        lo[L].aow = take(p + "attention.output.dense.weight", {H, H});
-        lo[L].aob = take(p + "attention.output.dense.bias", {H});
-        ln(p + "attention.output.LayerNorm", lo[L].aog, lo[L].aobeta);
-        lo[L].iw = take(p + "intermediate.dense.weight", {I, H});
-        lo[L].ib = take(p + "intermediate.dense.bias", {I});
-        lo[L].ow = take(p + "output.dense.weight", {H, I});
-        lo[L].ob = take(p + "output.dense.bias", {H});
-        ln(p + "output.LayerNorm", lo[L].og, lo[L].obeta);
-    }
-    if (!err.empty()) return fail(DAWN_ERR_IO, "%s: %s", safetensors_path, err.c_str());
+    const size_t total = m.weights.size();
+    const std::vector<float>& host = m.weights;
+    const std::vector<dawn::LayerOffsets>& lo = m.layers;
+    const size_t o_word = m.o_word, o_pos = m.o_pos, o_type = m.o_type, o_eg = m.o_eg, o_eb = m.o_eb;
 
     auto* e = new dawn_embedder();
     e->device = device;
@@ -451,7 +330,11 @@ void dawn_embedder_destroy(dawn_embedder* e) {
     delete e;
 }
 
+static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t value);
 int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) {
+    return dawn::guarded([&] { return embedder_set_option_impl(e, name, value); });
+}
+static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t value) {
     if (!e || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (std::string(name) == "skinny_max_rows") {  // token count up to which the GEMMs take the split-K skinny form
         if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "skinny_max_rows out of range");
@@ -501,7 +384,13 @@ int dawn_embedder_set_option(dawn_embedder* e, const char* name, int64_t value) 
     return fail(DAWN_ERR_INVALID_ARG, "unknown option %s", name);
 }
 
+static int embedder_forward_device_impl(dawn_embedder* e, const uint32_t* d_token_ids, const int32_t* d_seq_offsets, int B,
+                                 int total_tokens, int max_len, float* d_out, void* stream);
 int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, const int32_t* d_seq_offsets, int B,
+                                 int total_tokens, int max_len, float* d_out, void* stream) {
+    return dawn::guarded([&] { return embedder_forward_device_impl(e, d_token_ids, d_seq_offsets, B, total_tokens, max_len, d_out, stream); });
+}
+static int embedder_forward_device_impl(dawn_embedder* e, const uint32_t* d_token_ids, const int32_t* d_seq_offsets, int B,
                                  int total_tokens, int max_len, float* d_out, void* stream) {
     if (!e || !d_token_ids || !d_seq_offsets || !d_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (B <= 0 || total_tokens <= 0) return DAWN_OK;
@@ -542,7 +431,11 @@ int dawn_embedder_forward_device(dawn_embedder* e, const uint32_t* d_token_ids, 
     return DAWN_OK;
 }
 
+static int embedder_forward_impl(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B, float* out);
 int dawn_embedder_forward(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B, float* out) {
+    return dawn::guarded([&] { return embedder_forward_impl(e, token_ids, seq_offsets, B, out); });
+}
+static int embedder_forward_impl(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B, float* out) {
     if (!e || !token_ids || !seq_offsets || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (B <= 0) return DAWN_OK;
     int T = 0, max_len = 0;
@@ -555,7 +448,13 @@ int dawn_embedder_forward(dawn_embedder* e, const uint32_t* token_ids, const int
     return DAWN_OK;
 }
 
+static int embedder_hidden_states_impl(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B,
+                                float* out);
 int dawn_embedder_hidden_states(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B,
+                                float* out) {
+    return dawn::guarded([&] { return embedder_hidden_states_impl(e, token_ids, seq_offsets, B, out); });
+}
+static int embedder_hidden_states_impl(dawn_embedder* e, const uint32_t* token_ids, const int32_t* seq_offsets, int B,
                                 float* out) {
     if (!e || !token_ids || !seq_offsets || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (B <= 0) return DAWN_OK;
@@ -575,7 +474,11 @@ int dawn_embedder_hidden_states(dawn_embedder* e, const uint32_t* token_ids, con
 //   op 1  LayerNorm(a + r) with layer 0's attention-output LayerNorm (model.rs:86-104,378): in = a [T][384] | r [T][384]
 //   op 2  layer 0's intermediate dense + activation (model.rs:425-430, HiddenActLayer :28-37): in [T][384] -> [T][1536]
 //   op 3  the same GEMM through the 64x64 tile kernel regardless of T (op 2 takes the skinny form for T <= 640)
+static int debug_op_impl(dawn_embedder* e, int op, const void* in, int T, float* out);
 int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, float* out) {
+    return dawn::guarded([&] { return debug_op_impl(e, op, in, T, out); });
+}
+static int debug_op_impl(dawn_embedder* e, int op, const void* in, int T, float* out) {
     if (!e || !in || !out || T <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
     const Config& c = e->cfg;
     if (op == 0 && T > c.max_position_embeddings) return fail(DAWN_ERR_INVALID_ARG, "T exceeds max_position_embeddings");
@@ -599,18 +502,16 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
         dawn::launch_add_ln(e->tmp, e->attn, T, L.ao_g, L.ao_beta, eps, e->x, s);
     } else if (op == 2 || op == 3) {
         DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
-        const int keep = dawn::g_skinny_max_m;
-        if (op == 3) dawn::g_skinny_max_m = 0;
-        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s);
-        dawn::g_skinny_max_m = keep;
+        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s, op == 3);
         out_elems = (size_t)T * I;
     } else if (op == 4 || op == 5) {
         // 4: the same dense layer through the bf16x3 kernel (embed_gemm3.hip): planes made here from the f32 input / weights
         // 5: ... its planes OUTPUT, re-assembled (p1 + p2 + p3) on the host side of this hook
-        uint16_t *ap = nullptr, *wp = nullptr, *yp = nullptr;
-        DAWN_HIP_TRY(hipMalloc((void**)&ap, (size_t)3 * T * H * 2));
-        DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * I * H * 2));
-        DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * I * 2));
+        DevBuf b_ap, b_wp, b_yp;  // (freed on every return path)
+        DAWN_HIP_TRY(b_ap.alloc((size_t)3 * T * H * 2));
+        DAWN_HIP_TRY(b_wp.alloc((size_t)3 * I * H * 2));
+        DAWN_HIP_TRY(b_yp.alloc((size_t)3 * T * I * 2));
+        uint16_t *ap = (uint16_t*)b_ap.p, *wp = (uint16_t*)b_wp.p, *yp = (uint16_t*)b_yp.p;
         DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
         dawn::launch_split_planes(e->attn, ap, T, (int)H, (size_t)T, s);
         dawn::launch_split_planes(L.i_w, wp, (int)I, (int)H, (size_t)I, s);
@@ -627,10 +528,9 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
             }
         }
         DAWN_HIP_TRY(hipStreamSynchronize(s));
-        (void)hipFree(ap);
-        (void)hipFree(wp);
-        (void)hipFree(yp);
         if (op == 5) return DAWN_OK;
+        DAWN_HIP_TRY(hipMemcpy(out, e->ff, out_elems * 4, hipMemcpyDeviceToHost));
+        return DAWN_OK;
     } else {
         return fail(DAWN_ERR_INVALID_ARG, "unknown op %d", op);
     }
@@ -643,8 +543,12 @@ int dawn_embedder_debug_op(dawn_embedder* e, int op, const void* in, int T, floa
 // Timing hook: mean ms of one dense layer shape [T x K] . [N x K]^T over `iters` launches: variant 0 = f32 MFMA tile kernel,
 // 1 = bf16x3 kernel (planes prepared outside the timed region), 2 = ... writing planes instead of f32, 3 = ... with GELU.  Layer-0 weights are reused for every shape (K, N) in
 // {(384, 1152), (384, 384), (384, 1536), (1536, 384)}.
+static int debug_gemm_time_impl(dawn_embedder* e, int T, int N, int K, int variant, int iters, double* mean_ms);
 int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int variant, int iters, double* mean_ms) {
-    if (!e || !mean_ms || T <= 0 || iters <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
+    return dawn::guarded([&] { return debug_gemm_time_impl(e, T, N, K, variant, iters, mean_ms); });
+}
+static int debug_gemm_time_impl(dawn_embedder* e, int T, int N, int K, int variant, int iters, double* mean_ms) {
+    if (!e || !mean_ms || T <= 0 || T > (1 << 20) || iters <= 0) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
     const Config& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size;
     const LayerW& L = e->layers[0];
@@ -656,42 +560,38 @@ int dawn_embedder_debug_gemm_time(dawn_embedder* e, int T, int N, int K, int var
     else return fail(DAWN_ERR_INVALID_ARG, "shape not in the model");
     DAWN_HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = e->stream;
-    float *a = nullptr, *y = nullptr;
-    uint16_t *ap = nullptr, *wp = nullptr;
-    DAWN_HIP_TRY(hipMalloc((void**)&a, (size_t)T * K * 4));
-    DAWN_HIP_TRY(hipMalloc((void**)&y, (size_t)T * N * 4));
-    DAWN_HIP_TRY(hipMalloc((void**)&ap, (size_t)3 * T * K * 2));
-    DAWN_HIP_TRY(hipMalloc((void**)&wp, (size_t)3 * N * K * 2));
+    DevBuf b_a, b_y, b_ap, b_wp, b_yp;  // (freed on every return path)
+    DAWN_HIP_TRY(b_a.alloc((size_t)T * K * 4));
+    DAWN_HIP_TRY(b_y.alloc((size_t)T * N * 4));
+    DAWN_HIP_TRY(b_ap.alloc((size_t)3 * T * K * 2));
+    DAWN_HIP_TRY(b_wp.alloc((size_t)3 * N * K * 2));
+    float *a = (float*)b_a.p, *y = (float*)b_y.p;
+    uint16_t *ap = (uint16_t*)b_ap.p, *wp = (uint16_t*)b_wp.p;
     // activations: the model's own (random) weights, repeated — zero operands would let the chip clock higher than real data
     for (size_t off = 0, n = (size_t)T * K; off < n;) {
         const size_t take = std::min(n - off, (size_t)3 * H * H);
         DAWN_HIP_TRY(hipMemcpyAsync(a + off, L.qkv_w, take * 4, hipMemcpyDeviceToDevice, s));
         off += take;
     }
-    uint16_t* yp = nullptr;
-    if (variant >= 2) DAWN_HIP_TRY(hipMalloc((void**)&yp, (size_t)3 * T * N * 2));
+    if (variant >= 2) DAWN_HIP_TRY(b_yp.alloc((size_t)3 * T * N * 2));
+    uint16_t* yp = (uint16_t*)b_yp.p;
     dawn::launch_split_planes(a, ap, T, K, (size_t)T, s);
     dawn::launch_split_planes(W, wp, N, K, (size_t)N, s);
-    const int keep = dawn::g_skinny_max_m;
-    dawn::g_skinny_max_m = 0;
-    hipEvent_t e0, e1;
-    DAWN_HIP_TRY(hipEventCreate(&e0));
-    DAWN_HIP_TRY(hipEventCreate(&e1));
+    DevEvent ev0, ev1;
+    DAWN_HIP_TRY(ev0.create());
+    DAWN_HIP_TRY(ev1.create());
+    const hipEvent_t e0 = ev0.e, e1 = ev1.e;
     for (int it = -2; it < iters; ++it) {
         if (it == 0) DAWN_HIP_TRY(hipEventRecord(e0, s));
-        if (variant == 0) dawn::launch_gemm_nt(a, W, bias, y, T, N, K, 0, s);
+        if (variant == 0) dawn::launch_gemm_nt(a, W, bias, y, T, N, K, 0, s, true);
         else if (variant == 1) dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s);
         else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, nullptr, yp, (size_t)T * N, T, N, K, variant == 3 ? 1 : 0, s);
     }
     DAWN_HIP_TRY(hipEventRecord(e1, s));
     DAWN_HIP_TRY(hipStreamSynchronize(s));
-    dawn::g_skinny_max_m = keep;
     float ms = 0.f;
     DAWN_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *mean_ms = ms / iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    for (void* p : {(void*)a, (void*)y, (void*)ap, (void*)wp, (void*)yp}) (void)hipFree(p);
     return DAWN_OK;
 }
 

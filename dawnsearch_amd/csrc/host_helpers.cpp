@@ -1,4 +1,4 @@
-// host_helpers.cpp — host-side pieces of the C ABI: error text, device probing, and the
+// host_helpers.cpp — pure-host pieces of the C ABI (no HIP header: also part of the CPU sanitizer build of tests/native): error text and the
 // bit-compatible restatements of src/search/vector.rs and src/search/best_results.rs that the
 // reference's callers use right next to the index (normalisation gate, i24 wire codec, local+remote
 // result merge).  Compiled with -ffp-contract=off: Rust never fuses a*b+c.
@@ -9,23 +9,13 @@
 #include <cstring>
 #include <vector>
 
-#include "common.hpp"
+#include "host_common.hpp"
 
 namespace dawn {
 
 std::string& last_error() {
     static thread_local std::string e;
     return e;
-}
-
-int require_device(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return fail(DAWN_ERR_NO_DEVICE, "no usable HIP device (%s); libdawn_hip has no CPU fallback",
-                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
-    if (device < 0 || device >= n) return fail(DAWN_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-    return DAWN_OK;
 }
 
 // vector.rs:181-192
@@ -43,6 +33,7 @@ bool host_is_normalized(const float* v) {
 }  // namespace dawn
 
 using dawn::fail;
+using dawn::guarded;
 
 extern "C" {
 
@@ -50,24 +41,13 @@ const char* dawn_last_error(void) { return dawn::last_error().c_str(); }
 
 int dawn_version(void) { return 100; }  // 0.1.0
 
-int dawn_device_count(int* count) {
-    if (!count) return fail(DAWN_ERR_INVALID_ARG, "count is NULL");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) {
-        *count = 0;
-        return fail(DAWN_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
-    }
-    *count = n;
-    return DAWN_OK;
-}
-
 // ---- src/search/vector.rs --------------------------------------------------------------------
 
 int dawn_vec_is_normalized(const float* v) { return (v && dawn::host_is_normalized(v)) ? 1 : 0; }
 
 // vector.rs:194-197
 void dawn_vec_normalize(float* v, size_t n) {
+    if (!v) return;
     float s = 0.0f;
     for (size_t i = 0; i < n; ++i) s += v[i] * v[i];
     const float len = std::sqrt(s);
@@ -76,6 +56,7 @@ void dawn_vec_normalize(float* v, size_t n) {
 
 // vector.rs:74-86: (((x as f64 + 1.0) / 2.0) * I24_MAX as f64) as i32 -> 3 little-endian bytes
 void dawn_vec_to24(const float* v, uint8_t* out) {
+    if (!v || !out) return;
     for (int i = 0; i < DAWN_EM_LEN; ++i) {
         const double t = (((double)v[i] + 1.0) / 2.0) * (double)0x7FFFFF;
         int32_t iv;
@@ -91,6 +72,7 @@ void dawn_vec_to24(const float* v, uint8_t* out) {
 
 // vector.rs:57-72 (the `v |= 0xFF` "sign extend" of the low byte is reproduced as written)
 int dawn_vec_from24(const uint8_t* in, float* out) {
+    if (!in || !out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     for (int i = 0; i < DAWN_EM_LEN; ++i) {
         int32_t v = 0;
         v |= (int32_t)in[i * 3];
@@ -108,6 +90,8 @@ int dawn_topk_merge_host(size_t G, size_t B, size_t count, const uint64_t* in_la
                          const uint32_t* in_found, uint64_t* labels, float* distances, uint32_t* found) {
     if (!in_labels || !in_distances || !in_found || !labels || !distances || !found)
         return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (G > 65536) return fail(DAWN_ERR_INVALID_ARG, "%zu shards", G);
+    return guarded([&] {
     std::vector<size_t> cur(G);
     for (size_t b = 0; b < B; ++b) {
         std::fill(cur.begin(), cur.end(), 0);
@@ -132,6 +116,7 @@ int dawn_topk_merge_host(size_t G, size_t B, size_t count, const uint64_t* in_la
         found[b] = (uint32_t)n;
     }
     return DAWN_OK;
+    });
 }
 
 // ---- src/search/best_results.rs ----------------------------------------------------------------
@@ -165,33 +150,41 @@ struct dawn_best_results {
 
 int dawn_best_new(size_t size, dawn_best_results** out) {
     if (!out) return fail(DAWN_ERR_INVALID_ARG, "out is NULL");
-    auto* b = new dawn_best_results();
-    b->size = size;
-    b->results.reserve(size);
-    *out = b;
-    return DAWN_OK;
+    *out = nullptr;
+    return guarded([&] {
+        auto* b = new dawn_best_results();
+        b->size = size;
+        b->results.reserve(std::min<size_t>(size, 4096));  // (Vec::with_capacity(size) :37; a huge size must not throw here)
+        *out = b;
+        return DAWN_OK;
+    });
 }
 
 void dawn_best_free(dawn_best_results* b) { delete b; }
 
+// 1 inserted / 0 not / negative error code.  (size 0: the reference would index an empty Vec and panic, :58; here nothing
+// is ever inserted.)
 int dawn_best_insert(dawn_best_results* b, size_t id, float distance) {  // :44-65
-    if (b->results.size() < b->size) {
-        if (b->contains_id(id)) return 0;
-        b->results.push_back({id, distance});
-        if (b->results.size() == b->size) b->update_worst();
-        return 1;
-    }
-    if (distance < b->worst_distance) {
-        if (b->contains_id(id)) return 0;
-        b->results[b->worst_result_index] = {id, distance};
-        b->update_worst();
-        return 1;
-    }
-    return 0;
+    if (!b) return fail(DAWN_ERR_INVALID_ARG, "best_results is NULL");
+    return guarded([&] {
+        if (b->results.size() < b->size) {
+            if (b->contains_id(id)) return 0;
+            b->results.push_back({id, distance});
+            if (b->results.size() == b->size) b->update_worst();
+            return 1;
+        }
+        if (b->size != 0 && distance < b->worst_distance) {
+            if (b->contains_id(id)) return 0;
+            b->results[b->worst_result_index] = {id, distance};
+            b->update_worst();
+            return 1;
+        }
+        return 0;
+    });
 }
 
 void dawn_best_sort(dawn_best_results* b) {  // :71-79, stable like Vec::sort_by
-    if (b->results.empty()) return;
+    if (!b || b->results.empty()) return;
     for (size_t i = 1; i < b->results.size(); ++i) {
         auto t = b->results[i];
         size_t j = i;
@@ -205,10 +198,11 @@ void dawn_best_sort(dawn_best_results* b) {  // :71-79, stable like Vec::sort_by
     b->worst_distance = b->results.back().distance;
 }
 
-float dawn_best_worst_distance(const dawn_best_results* b) { return b->worst_distance; }
-size_t dawn_best_len(const dawn_best_results* b) { return b->results.size(); }
+float dawn_best_worst_distance(const dawn_best_results* b) { return b ? b->worst_distance : 0.0f; }
+size_t dawn_best_len(const dawn_best_results* b) { return b ? b->results.size() : 0; }
 
 int dawn_best_get(const dawn_best_results* b, size_t i, size_t* id, float* distance) {
+    if (!b) return fail(DAWN_ERR_INVALID_ARG, "best_results is NULL");
     if (i >= b->results.size()) return fail(DAWN_ERR_INVALID_ARG, "index %zu out of range", i);
     if (id) *id = b->results[i].id;
     if (distance) *distance = b->results[i].distance;

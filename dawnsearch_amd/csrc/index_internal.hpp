@@ -121,21 +121,6 @@ struct dawn_index {
 
 namespace dawn {
 
-// A C ABI must not let C++ exceptions through (the callers are Rust / C): every entry point that can allocate runs
-// inside guarded().
-template <class F>
-int guarded(F&& f) noexcept {
-    try {
-        return f();
-    } catch (const std::bad_alloc&) {
-        return fail(DAWN_ERR_OOM, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(DAWN_ERR_INVALID_ARG, "%s", e.what());
-    } catch (...) {
-        return fail(DAWN_ERR_HIP, "unexpected exception");
-    }
-}
-
 // ---- single-device pieces used by the sharded router -------------------------------------------------------------
 int index_create_single(int dtype, int device, dawn_index** out);
 void index_destroy_single(dawn_index* idx);

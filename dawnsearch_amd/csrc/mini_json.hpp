@@ -1,5 +1,8 @@
 // mini_json.hpp — a small JSON reader (objects / arrays / strings / numbers / literals): enough for safetensors
-// headers, HF config.json and tokenizer.json.
+// headers, HF config.json and tokenizer.json.  The input is an untrusted file: nesting is bounded (kMaxDepth — parse()
+// recurses once per level, and so does ~JVal), the number of values is bounded (kMaxNodes — a JVal is ~100 B, so a file
+// of "0,0,0,..." would otherwise cost 50 x its size in host memory), numbers are scanned inside [p, end) only (the
+// buffer is not NUL-terminated), and any violation just clears `ok`.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -44,9 +47,13 @@ struct JVal {
 };
 
 struct JParser {
+    static constexpr int kMaxDepth = 64;
+    static constexpr size_t kMaxNodes = (size_t)4 << 20;
     const char* p;
     const char* end;
     bool ok = true;
+    int depth = 0;
+    size_t nodes = 0;
     void ws() {
         while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
     }
@@ -116,8 +123,50 @@ struct JParser {
         else ++p;
         return out;
     }
+    // JSON number grammar only (-? digits [. digits] [e[+-] digits]), at most 63 characters, converted from a local
+    // NUL-terminated copy
+    bool parse_number(double& out) {
+        char buf[64];
+        size_t n = 0;
+        const char* q = p;
+        auto take = [&](bool cond) {
+            if (!cond || n + 1 >= sizeof(buf)) return false;
+            buf[n++] = *q++;
+            return true;
+        };
+        auto digits = [&]() {
+            size_t k = 0;
+            while (q < end && *q >= '0' && *q <= '9' && take(true)) ++k;
+            return k;
+        };
+        if (q < end && *q == '-') take(true);
+        if (!digits()) return false;
+        if (q < end && *q == '.') {
+            take(true);
+            if (!digits()) return false;
+        }
+        if (q < end && (*q == 'e' || *q == 'E')) {
+            take(true);
+            if (q < end && (*q == '+' || *q == '-')) take(true);
+            if (!digits()) return false;
+        }
+        if (q < end && ((*q >= '0' && *q <= '9') || *q == '.')) return false;  // longer than the local buffer
+        buf[n] = 0;
+        out = std::strtod(buf, nullptr);
+        p = q;
+        return true;
+    }
     JVal parse() {
         JVal v;
+        if (++nodes > kMaxNodes || depth >= kMaxDepth) {
+            ok = false;
+            return v;
+        }
+        struct Level {
+            int& d;
+            explicit Level(int& x) : d(x) { ++d; }
+            ~Level() { --d; }
+        } level(depth);
         ws();
         if (p >= end) {
             ok = false;
@@ -184,24 +233,33 @@ struct JParser {
         } else if (lit("null")) {
             v.kind = JVal::Null;
         } else {
-            char* e = nullptr;
             v.kind = JVal::Num;
-            v.num = std::strtod(p, &e);
-            if (e == p || e > end) ok = false;
-            else p = e;
+            if (!parse_number(v.num)) ok = false;
         }
         return v;
     }
 };
 
 
-inline bool read_file(const char* path, std::vector<char>& out) {
+// A JSON number as an integer in [lo, hi]: false for anything else (strings, fractions, NaN, out of range) — a
+// double -> integer cast of an unchecked value is undefined behaviour.
+inline bool jint(const JVal* v, int64_t lo, int64_t hi, int64_t& out) {
+    if (!v || v->kind != JVal::Num) return false;
+    const double d = v->num;
+    if (!(d >= (double)lo && d <= (double)hi)) return false;
+    const int64_t i = (int64_t)d;
+    if ((double)i != d) return false;
+    out = i;
+    return true;
+}
+
+inline bool read_file(const char* path, std::vector<char>& out, size_t max_bytes = (size_t)-1) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return false;
     std::fseek(f, 0, SEEK_END);
     long n = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    if (n < 0) {
+    if (n < 0 || (size_t)n > max_bytes) {  // (a directory reports LONG_MAX or -1)
         std::fclose(f);
         return false;
     }

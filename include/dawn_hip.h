@@ -208,7 +208,7 @@ int dawn_vec_from24(const uint8_t *in, float *out);         /* vector.rs:57-72; 
 typedef struct dawn_best_results dawn_best_results;          /* best_results.rs:28-33 */
 int dawn_best_new(size_t size, dawn_best_results **out);     /* :36-43 */
 void dawn_best_free(dawn_best_results *b);
-int dawn_best_insert(dawn_best_results *b, size_t id, float distance); /* :44-65 -> 1 inserted / 0 */
+int dawn_best_insert(dawn_best_results *b, size_t id, float distance); /* :44-65 -> 1 inserted / 0 not / < 0 error */
 void dawn_best_sort(dawn_best_results *b);                   /* :71-79 */
 float dawn_best_worst_distance(const dawn_best_results *b);  /* :93-95 (0 until full) */
 size_t dawn_best_len(const dawn_best_results *b);            /* :85-87 */
@@ -226,6 +226,10 @@ typedef struct dawn_embedder dawn_embedder;
 int dawn_embedder_create(const char *safetensors_path, const char *config_json_path, int device,
                          dawn_embedder **out);
 void dawn_embedder_destroy(dawn_embedder *e);
+/* Host-only check of the files dawn_embedder_create would load (same parsing, same tensor-name resolution, same errors:
+ * DAWN_ERR_IO / DAWN_ERR_UNSUPPORTED) — needs no device, so a deployment can validate model.safetensors / config.json
+ * before it claims a GPU.  The files are untrusted input: whatever they hold, the call returns a code. */
+int dawn_embedder_check_files(const char *safetensors_path, const char *config_json_path);
 /* calculate_embedding (:97-139) for B token sequences packed back to back: token_ids[seq_offsets[B]],
  * sequence b = token_ids[seq_offsets[b] .. seq_offsets[b+1]).  Every sequence gets its batch-1
  * result (no padding tokens exist).  out [B][384] unit vectors. */
