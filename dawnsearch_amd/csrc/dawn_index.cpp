@@ -926,7 +926,8 @@ int dawn_topk_merge_device(int device, size_t G, size_t B, size_t count, const u
                            float* d_distances, uint32_t* d_found, void* stream) {
     if (!d_in_labels || !d_in_distances || !d_in_found || !d_labels || !d_distances || !d_found)
         return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    if (G == 0 || count == 0 || G * count > 512) return fail(DAWN_ERR_UNSUPPORTED, "G*count must be 1..512");
+    if (G == 0 || count == 0 || count > DAWN_MAX_K || G > dawn::kMaxMergeCands / DAWN_MAX_K)
+        return fail(DAWN_ERR_UNSUPPORTED, "G must be 1..64 and count 1..%d", DAWN_MAX_K);
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
     if (B == 0) return DAWN_OK;
@@ -941,7 +942,8 @@ size_t dawn_result_blob_bytes(size_t B, size_t count) { return (B * count * 12 +
 int dawn_topk_merge_packed_device(int device, size_t G, size_t B, size_t count, const void* d_blobs,
                                   uint64_t* d_labels, float* d_distances, uint32_t* d_found, void* stream) {
     if (!d_blobs || !d_labels || !d_distances || !d_found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    if (G == 0 || count == 0 || G * count > 512) return fail(DAWN_ERR_UNSUPPORTED, "G*count must be 1..512");
+    if (G == 0 || count == 0 || count > DAWN_MAX_K || G > dawn::kMaxMergeCands / DAWN_MAX_K)
+        return fail(DAWN_ERR_UNSUPPORTED, "G must be 1..64 and count 1..%d", DAWN_MAX_K);
     DAWN_TRY(dawn::require_device(device));
     DAWN_HIP_TRY(hipSetDevice(device));
     if (B == 0) return DAWN_OK;
@@ -1027,8 +1029,16 @@ int dawn_index_load(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     return dawn::guarded([&] {
         DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        // EVERY failure below leaves the index empty (usearch's load resets the index before it reads): the reference's
+        // `if !load(path).is_ok() { fill_index_from_db() }` (search_provider.rs:115-117) must never append to old rows
+        auto failed_empty = [&](int rc) {
+            const std::string msg = dawn::last_error();
+            (void)dawn::index_clear(idx);
+            dawn::last_error() = msg;
+            return rc;
+        };
         const int fd = ::open(path, O_RDONLY);
-        if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s", path);
+        if (fd < 0) return failed_empty(fail(DAWN_ERR_IO, "cannot open %s", path));
         struct stat stt;
         char header[24];
         uint32_t dims = 0, dtype = 0;
@@ -1046,21 +1056,20 @@ int dawn_index_load(dawn_index* idx, const char* path) {
                 rc = fail(DAWN_ERR_IO, "%s: truncated (header promises %llu rows, the file holds %llu bytes)", path,
                           (unsigned long long)n, (unsigned long long)stt.st_size);
         }
-        if (rc == DAWN_OK) rc = dawn::index_clear(idx);  // load replaces the contents (usearch load semantics)
+        if (rc != DAWN_OK) {
+            ::close(fd);
+            return failed_empty(rc);
+        }
+        rc = dawn::index_clear(idx);  // load replaces the contents (usearch load semantics)
         if (rc == DAWN_OK && n) {
             rc = dawn_index_reserve(idx, n);
             if (rc == DAWN_OK)
                 rc = ingest_file_rows(idx, fd, dawn::RowSrc::HostRows, n, 24 + (off_t)(n * 8), 24, 0, path);
             if (rc == DAWN_OK) rc = dawn::index_append_commit(idx);
             else dawn::index_append_abort(idx);
-            if (rc != DAWN_OK) {
-                const std::string msg = dawn::last_error();
-                (void)dawn::index_clear(idx);
-                dawn::last_error() = msg;
-            }
         }
         ::close(fd);
-        return rc;
+        return rc == DAWN_OK ? rc : failed_empty(rc);
     });
 }
 

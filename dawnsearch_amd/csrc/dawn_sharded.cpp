@@ -12,7 +12,7 @@
 //     k = 20: latency-bound) together — ONE grouped ncclAllGather over RCCL, or G peer copies into the root's buffer
 //     (option "shard_gather") —, and merges them on the root device: ties go to the lower insertion position, exactly
 //     the single index's order, and the winners are translated to labels.  The answer equals the single-device answer
-//     bit for bit (tests/test_sharded_gpu.py).
+//     bit for bit (tests/test_sharded_capi_gpu.py).
 // One host thread issues everything (the reference drives its index from one thread); the devices run concurrently.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is loaded on first use (a single-GPU deployment never needs it)
@@ -56,7 +56,7 @@ struct Rccl {
 };
 Rccl g_rccl;  // process-wide handle of the library; communicators are per index
 
-constexpr int GATHER_AUTO = 0, GATHER_RCCL = 1, GATHER_PEER = 2;
+constexpr int GATHER_AUTO = 0, GATHER_RCCL = 1;  // (2 = peer copies: whatever is not RCCL)
 
 // One issuing thread per shard (shard 0: the caller's own).  A search is ~6 launches per device; issued one device after
 // the other the last of 8 shards starts ~0.2 ms after the first — a quarter of a 12.5 M-row shard scan.  The workers only
@@ -157,6 +157,8 @@ struct ShardSet {
     std::vector<char*> d_gather;    // per shard device: the G blobs back to back ([0]: what the root merges)
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_q = nullptr;      // root: the queries of the search in flight are ready
+    hipEvent_t ev_merged = nullptr; // root: the previous search's merge has read d_gather[0] (whatever stream it ran on)
+    bool merged_valid = false;
     int gather = GATHER_AUTO;       // option "shard_gather"
     bool distinct = true;           // no device holds two shards (RCCL needs that)
     std::vector<ncclComm_t> comms;  // RCCL communicators (created at the first search that uses them)
@@ -227,7 +229,9 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
     DAWN_TRY(S.workers.run(S.G, [&](int g) -> int {
         dawn_index* sh = S.sh[g];
         DAWN_HIP_TRY(hipSetDevice(S.dev[g]));
-        DAWN_HIP_TRY(hipStreamWaitEvent(sh->stream, S.ev_q, 0));  // (also: the previous merge has read d_gather[0])
+        DAWN_HIP_TRY(hipStreamWaitEvent(sh->stream, S.ev_q, 0));
+        // the previous search's merge may sit on ANOTHER caller stream: its blobs / gather buffer are reused from here on
+        if (S.merged_valid) DAWN_HIP_TRY(hipStreamWaitEvent(sh->stream, S.ev_merged, 0));
         const float* q = d_q;
         if (S.dev[g] != root_dev(S)) {
             DAWN_HIP_TRY(hipMemcpyPeerAsync(sh->d_q, S.dev[g], d_q, root_dev(S), nb * EM * sizeof(float), sh->stream));
@@ -268,6 +272,8 @@ int search_chunk(ShardSet& S, const float* d_q, size_t nb, size_t k, uint64_t* d
                        reinterpret_cast<const uint32_t*>(base + off_f), nbytes / 8, nbytes / 4, nbytes / 4, S.d_gids, d_labels,
                        d_dist, d_found, cs);
     DAWN_HIP_TRY(hipGetLastError());
+    DAWN_HIP_TRY(hipEventRecord(S.ev_merged, cs));
+    S.merged_valid = true;
     return DAWN_OK;
 }
 
@@ -292,6 +298,7 @@ void sharded_destroy(dawn_index* idx) {
     if (!S->dev.empty()) (void)hipSetDevice(S->dev[0]);
     if (S->d_gids) (void)hipFree(S->d_gids);
     if (S->ev_q) (void)hipEventDestroy(S->ev_q);
+    if (S->ev_merged) (void)hipEventDestroy(S->ev_merged);
     delete S;
     delete idx;
 }
@@ -617,7 +624,8 @@ int dawn_index_create_sharded(size_t dims, int dtype, int n_gpus, const int* dev
                 (void)hipGetLastError();  // (already enabled / not supported: the copies still work, staged)
             }
         }
-        if (hipSetDevice(S->dev[0]) != hipSuccess || hipEventCreateWithFlags(&S->ev_q, hipEventDisableTiming) != hipSuccess)
+        if (hipSetDevice(S->dev[0]) != hipSuccess || hipEventCreateWithFlags(&S->ev_q, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S->ev_merged, hipEventDisableTiming) != hipSuccess)
             return bail(fail(DAWN_ERR_HIP, "creating the query event failed"));
         // issuing threads pay off when the shards sit on different devices (per-device queues); logical shards on one
         // device contend for the same queue: measured 0.302 -> 0.359 ms per search for 8 shards of 25 k rows

@@ -147,6 +147,7 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.
+constexpr size_t kMaxMergeCands = 64 * 64;  // G * k a merge launch accepts (48 KiB of LDS at most)
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
                         const uint32_t* in_found, size_t sl, size_t sd, size_t sf, const uint64_t* pos_to_label,
                         uint64_t* out_labels, float* out_dist, uint32_t* out_found, hipStream_t stream);

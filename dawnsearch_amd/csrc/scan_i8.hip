@@ -19,7 +19,8 @@
 //     (|dq_i| <= s_q (0.5/254 + 127 * 2^-23) < 2.0e-3 s_q; ||sX||_2 <= ||x||_2 + ||dx||_2 < 1.01 + 0.09).
 //     ub = fma(float(C), s * s_q/254, E + K2) therefore bounds the real dot product from above up to the rounding of
 //     this expression (< 1e-6: the product s * s_q comes from a stored 1 / s through v_rcp_f32, 1 ulp each) and the
-//     reference's own sequential-sum error gamma_384 * 1.0201 = 2.34e-5: FILTER_EPS_I8 = 2.6e-5 on top of ub.
+//     reference's own sequential-sum error gamma_384 * 1.0201 = 2.34e-5; with the f32 rounding of the rotation below on both
+//     operands (2 x 1.1e-6 x 1.0201) the budget is 2.67e-5: FILTER_EPS_I8 = 2.9e-5 (kernels.hpp) on top of ub.
 //   * a bf16 index gets the same shadow of its (bf16-rounded) rows: ||x||_2 <= 1.01 (1 + 2^-8) keeps ||sX||_2 < 1.1, and
 //     the exact side's gamma_384 * 1.0201 * 1.004 = 2.35e-5 stays inside FILTER_EPS_I8.
 //   * the hot loop never leaves the integers: the lane's list threshold tau is turned into an integer threshold once

@@ -644,6 +644,8 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 // Ties: lower shard, then shard-local order (contiguous row shards: that IS insertion order).  POS = true (the
 // single-process sharded index of dawn_sharded.cpp, whose rows are dealt to the shards chunk by chunk): the "labels" coming
 // in are global insertion positions, ties go to the lower position, and pos_to_label[] turns the winners into labels.
+// Any G * k fits: a thread owns candidates t, t + 512, ... (one each up to G * k = 512, the usual case — 8 GPUs x k <= 64);
+// LDS is sized by the launch (G * k * 4 B of distances, + G * k * 8 B of positions when POS).
 template <bool POS>
 __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B, uint32_t k,
                                                          const uint64_t* __restrict__ in_labels,
@@ -653,31 +655,28 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
                                                          uint64_t* __restrict__ out_labels,
                                                          float* __restrict__ out_dist,
                                                          uint32_t* __restrict__ out_found) {
-    __shared__ float sh_d[512];
-    __shared__ uint64_t sh_l[POS ? 512 : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_lds[];
+    const uint32_t total = G * k;
+    uint64_t* sh_l = reinterpret_cast<uint64_t*>(merge_lds);                      // [POS ? total : 0]
+    float* sh_d = reinterpret_cast<float*>(merge_lds + (POS ? (size_t)total * 8 : 0));  // [total]
     const uint32_t b = blockIdx.x;
-    const uint32_t t = threadIdx.x;
-    const uint32_t total = G * k;  // <= 512
-    uint32_t g = t / k, i = t % k;
-    float d = POS_INF;
-    uint64_t label = 0;
-    bool valid = false;
-    if (t < total) {
-        valid = i < in_found[g * sf + b];
-        if (valid) {
-            d = in_dist[g * sd + (size_t)b * k + i];
-            label = in_labels[g * sl + (size_t)b * k + i];
-        }
+    for (uint32_t c = threadIdx.x; c < total; c += blockDim.x) {
+        const uint32_t g = c / k, i = c % k;
+        const bool valid = i < in_found[g * sf + b];
+        sh_d[c] = valid ? in_dist[g * sd + (size_t)b * k + i] : POS_INF;
+        if (POS) sh_l[c] = valid ? in_labels[g * sl + (size_t)b * k + i] : ~0ull;
     }
-    sh_d[t] = d;
-    if (POS) sh_l[t] = valid ? label : ~0ull;
     __syncthreads();
-    if (valid) {
-        // rank = number of candidates ordered before (d, g, i); t = g*k+i is that lexicographic index
+    for (uint32_t c = threadIdx.x; c < total; c += blockDim.x) {
+        const uint32_t g = c / k, i = c % k;
+        if (i >= in_found[g * sf + b]) continue;
+        const float d = sh_d[c];
+        const uint64_t label = POS ? sh_l[c] : in_labels[g * sl + (size_t)b * k + i];
+        // rank = number of candidates ordered before (d, g, i); c = g*k+i is that lexicographic index
         uint32_t rank = 0;
         for (uint32_t o = 0; o < total; ++o) {
             const float od = sh_d[o];
-            const bool before = POS ? sh_l[o] < label : o < t;
+            const bool before = POS ? sh_l[o] < label : o < c;
             rank += (od < d || (od == d && before)) ? 1u : 0u;
         }
         if (rank < k) {
@@ -685,7 +684,7 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
             out_dist[(size_t)b * k + rank] = d;
         }
     }
-    if (t == 0) {
+    if (threadIdx.x == 0) {
         uint32_t sum = 0;
         for (uint32_t gg = 0; gg < G; ++gg) sum += in_found[gg * sf + b];
         out_found[b] = sum < k ? sum : k;
@@ -695,11 +694,12 @@ __global__ __launch_bounds__(512) void shard_merge_kernel(uint32_t G, uint32_t B
 void launch_shard_merge(size_t G, size_t B, size_t k, const uint64_t* in_labels, const float* in_dist,
                         const uint32_t* in_found, size_t sl, size_t sd, size_t sf, const uint64_t* pos_to_label,
                         uint64_t* out_labels, float* out_dist, uint32_t* out_found, hipStream_t stream) {
+    const size_t total = G * k;  // callers bound it: <= kMaxMergeCands (64 shards x DAWN_MAX_K)
     if (pos_to_label)
-        hipLaunchKernelGGL(shard_merge_kernel<true>, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
+        hipLaunchKernelGGL(shard_merge_kernel<true>, dim3((unsigned)B), dim3(512), total * 12, stream, (uint32_t)G, (uint32_t)B,
                            (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, pos_to_label, out_labels, out_dist, out_found);
     else
-        hipLaunchKernelGGL(shard_merge_kernel<false>, dim3((unsigned)B), dim3(512), 0, stream, (uint32_t)G, (uint32_t)B,
+        hipLaunchKernelGGL(shard_merge_kernel<false>, dim3((unsigned)B), dim3(512), total * 4, stream, (uint32_t)G, (uint32_t)B,
                            (uint32_t)k, in_labels, in_dist, in_found, sl, sd, sf, pos_to_label, out_labels, out_dist, out_found);
 }
 

@@ -103,8 +103,9 @@ int dawn_index_search_batch(dawn_index *idx, const float *queries, size_t B, siz
 
 /* index.save(path) :117,178.  Atomic: written to `path`.tmp, fsync'ed, renamed — an interrupted save leaves the old file. */
 int dawn_index_save(dawn_index *idx, const char *path);
-/* index.load(path) :115.  Replaces the contents; all or nothing: a truncated / corrupt file or a row failing the
- * is_normalized gate leaves the index EMPTY (never partially filled), so the reference's
+/* index.load(path) :115.  Replaces the contents; all or nothing: ANY failure — a missing file, a bad header, a truncated /
+ * corrupt file, a row failing the is_normalized gate — leaves the index EMPTY (never partially filled, never its old
+ * rows), so the reference's
  * `if !load(path).is_ok() { fill_index_from_db() }` (:115-117) rebuilds onto a clean index.  The file streams through
  * pinned host staging, reads overlapped with the DMA into HBM. */
 int dawn_index_load(dawn_index *idx, const char *path);

@@ -210,8 +210,15 @@ def test_load_is_all_or_nothing(dawn, oracle, tmp_path):
         idx2.fill_synthetic(3, 0, 100, 1)
         with pytest.raises(dawn.DawnError):
             idx2.load(t)
-        assert idx2.size() == 100  # the header is checked against the file size before the index is touched
-        assert len(idx2.search(q, 10)[0]) == min(10, idx2.size())
+        # EVERY failure empties the index (usearch resets before it reads): the old rows must not survive into the rebuild
+        assert idx2.size() == 0 and len(idx2.search(q, 10)[0]) == 0
+    idx2 = dawn.VectorIndex(0)
+    idx2.fill_synthetic(3, 0, 100, 1)
+    with pytest.raises(dawn.DawnError):
+        idx2.load(str(tmp_path / "no_such_file.dawn"))
+    assert idx2.size() == 0
+    idx2.fill_synthetic(3, 0, 100, 1)  # ... and it fills again (what fill_index_from_db does next)
+    assert idx2.size() == 100 and len(idx2.search(q, 10)[0]) == 10
     # a bad row far into the file: the rows in front of it were already on the device
     bad = bytearray(data)
     off = 24 + n * 8 + 50_000 * 1536

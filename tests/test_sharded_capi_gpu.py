@@ -168,3 +168,130 @@ def test_rccl_all_gather_path_on_one_device(dawn, oracle):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
     with pytest.raises(dawn.DawnError):  # two shards on one device cannot form an RCCL communicator
         dawn.VectorIndex(devices=[0, 0]).set_option("shard_gather", 1)
+
+
+@pytest.mark.parametrize("G,k", [(16, 64), (32, 20), (64, 64)])
+def test_many_shards_merge_beyond_512_candidates(dawn, oracle, G, k):
+    """G * k > 512 (more merge candidates than the merge kernel has threads): every shard's list must still be ranked.
+    (Round 2 ranked the first 512 only and silently dropped the shards behind them.)"""
+    n = 64 * G * 3 + 17
+    rows = synth.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    sh = dawn.VectorIndex(devices=[0] * G)
+    sh.set_option("shard_chunk", 64)
+    sh.add_batch(ids, rows)
+    assert min(sh.shard_info()["sizes"]) > 0
+    # queries planted on rows of the LAST shards, and plain ones
+    Q = np.concatenate([synth.planted_queries(1, [64 * (G - 1) + 5, 64 * (2 * G - 2) + 9, n - 1], 3), synth.unit_rows(2, 0, 5)])
+    got = sh.search_batch(Q, k)
+    for b, q in enumerate(Q):
+        ol, od = oracle.scan_topk(rows, ids, q, k)
+        assert got[2][b] == k
+        assert np.array_equal(got[0][b], ol) and np.array_equal(got[1][b].view(np.uint32), od.view(np.uint32))
+    assert got[0][0][0] == 64 * (G - 1) + 5 + 1
+
+
+def test_packed_merge_accepts_many_shards(dawn):
+    """dawn_topk_merge_packed_device with G * count > 512: the one-process-per-GPU form's merge, e.g. 16 ranks x k = 64."""
+    import torch
+    from dawnsearch_amd import _lib
+    G, B, k = 16, 3, 64
+    rng = np.random.default_rng(5)
+    nbytes = _lib.lib.dawn_result_blob_bytes(B, k)
+    blobs = np.zeros((G, nbytes), dtype=np.uint8)
+    all_d, all_l = [], []
+    for g in range(G):
+        d = np.sort(rng.random((B, k), dtype=np.float32), axis=1)
+        d[:, ::7] = np.float32(0.5)  # ties across shards
+        d = np.sort(d, axis=1)
+        lab = (np.arange(B * k, dtype=np.uint64).reshape(B, k) + np.uint64(g * 10_000))
+        blobs[g, :B * k * 8] = lab.view(np.uint8).reshape(-1)
+        blobs[g, B * k * 8:B * k * 12] = d.view(np.uint8).reshape(-1)
+        blobs[g, B * k * 12:B * k * 12 + B * 4] = np.full(B, k, dtype=np.uint32).view(np.uint8)
+        all_d.append(d)
+        all_l.append(lab)
+    dev = torch.device("cuda", 0)
+    db = torch.from_numpy(blobs).to(dev)
+    lab = torch.zeros((B, k), dtype=torch.int64, device=dev)
+    dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    fnd = torch.zeros((B,), dtype=torch.int32, device=dev)
+    rc = _lib.lib.dawn_topk_merge_packed_device(0, G, B, k, db.data_ptr(), lab.data_ptr(), dist.data_ptr(), fnd.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, dawn.last_error()
+    torch.cuda.synchronize()
+    D = np.stack(all_d)  # [G][B][k]
+    L = np.stack(all_l)
+    for b in range(B):
+        flat_d, flat_l = D[:, b, :].reshape(-1), L[:, b, :].reshape(-1)
+        order = np.argsort(flat_d, kind="stable")[:k]  # stable: ties -> lower shard, then shard-local order
+        assert np.array_equal(dist[b].cpu().numpy(), flat_d[order])
+        assert np.array_equal(lab[b].cpu().numpy().view(np.uint64), flat_l[order])
+    assert fnd.cpu().tolist() == [k] * B
+
+
+def test_sharded_searches_from_two_caller_streams(dawn):
+    """Back-to-back device-resident searches issued on DIFFERENT caller streams: the second search's shard work reuses the
+    per-shard blobs and the gather buffer, so it has to wait for the first search's merge, which sits on the other stream."""
+    import torch
+    n, B, k = 200_000, 200, 20
+    sh = dawn.VectorIndex(devices=[0, 0, 0, 0])
+    sh.fill_synthetic(1, 0, n, 1)
+    single = dawn.VectorIndex(0)
+    single.fill_synthetic(1, 0, n, 1)
+    dev = torch.device("cuda", 0)
+    Qa, Qb = synth.unit_rows(2, 0, B), synth.unit_rows(2, 1000, B)
+    want_a, want_b = single.search_batch(Qa, k), single.search_batch(Qb, k)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    qa, qb = torch.from_numpy(Qa).to(dev), torch.from_numpy(Qb).to(dev)
+    outs = []
+    for _ in range(2):
+        outs.append((torch.zeros((B, k), dtype=torch.int64, device=dev), torch.zeros((B, k), dtype=torch.float32, device=dev),
+                     torch.zeros((B,), dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for (q, st, o) in ((qa, s1, outs[0]), (qb, s2, outs[1])):
+            sh.search_device(q.data_ptr(), B, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    for o, want in ((outs[0], want_a), (outs[1], want_b)):
+        assert np.array_equal(o[0].cpu().numpy().view(np.uint64), want[0])
+        assert np.array_equal(o[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+
+
+def test_distinct_devices_rccl_and_peer_gathers(dawn, oracle):
+    """Runs wherever the box shows at least two GPUs (skips on the 1-GPU test box): one shard per DEVICE — per-shard issuing
+    threads on, queries copied to the other devices over xGMI, blobs gathered by the grouped ncclAllGather (gather 1) and by
+    peer copies (gather 2) — bit-equal to the single-device index and to the oracle.  The first multi-GPU box that runs the
+    suite covers dawn_sharded.cpp's G > 1 paths (ncclCommInitAll over G devices, hipMemcpyPeerAsync, ShardWorkers)."""
+    G = min(dawn.device_count(), 8)
+    if G < 2:
+        pytest.skip("needs at least two visible GPUs")
+    n = 300_000
+    single = dawn.VectorIndex(0)
+    single.fill_synthetic(1, 0, n, 1)
+    rows, ids = single.get_rows(0, n)
+    Q = np.concatenate([synth.unit_rows(2, 0, 30), synth.planted_queries(1, [0, 4096, n - 1], 3)])
+    for gather in (1, 2):
+        sh = dawn.VectorIndex(devices=list(range(G)))
+        sh.set_option("shard_gather", gather)
+        sh.fill_synthetic(1, 0, n, 1)
+        info = sh.shard_info()
+        assert info["n_shards"] == G and sum(info["sizes"]) == n
+        for k in (10, 20, 64):
+            a, b = sh.search_batch(Q, k), single.search_batch(Q, k)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        for b in (0, 31):
+            ol, od = oracle.scan_topk(rows, ids, Q[b], 20, threads=8)
+            l, d = sh.search(Q[b], 20)
+            assert np.array_equal(l, ol) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+        assert sh.shard_info()["gather"] == (1 if gather == 1 else 2)
+        # mutations across devices: one-by-one adds, then a bad row rolls the whole batch back on every device
+        extra = synth.unit_rows(9, 0, 300)
+        for i in range(40):
+            sh.add(10_000_000 + i, extra[i])
+        bad = extra[40:300].copy()
+        bad[200] *= 2
+        with pytest.raises(dawn.NotNormalizedError):
+            sh.add_batch(np.arange(260, dtype=np.uint64) + 20_000_000, bad)
+        assert sh.size() == n + 40
+        l, d = sh.search(extra[7], 5)
+        assert l[0] == 10_000_007
