@@ -270,6 +270,76 @@ size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const flo
     return flen;
 }
 
+/* The same exact scan over SYNTHETIC rows that are never materialised as a whole: rows [first_row, first_row + n) of
+ * stream `seed` (orc_synth_unit_row; bf16 != 0: each row rounded to nearest-even bf16, what a DAWN_DTYPE_BF16 index
+ * stores) are generated chunk by chunk in thread-local buffers and scored with orc_distance_cosine for nq queries at
+ * once; per-thread (distance, position)-ordered lists are merged at the end, so the answer is the single-threaded
+ * orc_scan_topk answer over the whole range whatever the thread count.  label = first_id + (row - first_row).  This is
+ * what lets the tests check the 100 M-row headline index against the oracle itself (153.6 GB of rows would not fit the
+ * host): out_labels / out_distances are [nq][k]; returns min(k, n). */
+size_t orc_scan_topk_synth(uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, int bf16, const float *q,
+                           size_t nq, size_t k, uint64_t *out_labels, float *out_distances, int threads) {
+    if (k == 0 || nq == 0) return 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+    const size_t CH = 1024;
+    const size_t n_chunks = (n + CH - 1) / CH;
+    cand_t *lists = (cand_t *)malloc(sizeof(cand_t) * k * nq * (size_t)threads);
+    size_t *lens = (size_t *)calloc((size_t)threads * nq, sizeof(size_t));
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        float *buf = (float *)malloc(sizeof(float) * CH * EM);
+        cand_t *mine = lists + (size_t)t * nq * k;
+        size_t *mylen = lens + (size_t)t * nq;
+#pragma omp for schedule(dynamic, 16)
+        for (size_t c = 0; c < n_chunks; c++) {
+            const size_t lo = c * CH, m = (lo + CH <= n) ? CH : n - lo;
+            for (size_t r = 0; r < m; r++) {
+                float *row = buf + r * EM;
+                orc_synth_unit_row(seed, first_row + lo + r, row);
+                if (bf16)
+                    for (int i = 0; i < EM; i++) { /* round to nearest even, as dawnsearch_amd/synth.py round_bf16 */
+                        uint32_t u;
+                        memcpy(&u, &row[i], 4);
+                        u = ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16) << 16;
+                        memcpy(&row[i], &u, 4);
+                    }
+            }
+            for (size_t b = 0; b < nq; b++)
+                for (size_t r = 0; r < m; r++) {
+                    float d = orc_distance_cosine(q + b * EM, buf + r * EM);
+                    topk_push(mine + b * k, &mylen[b], k, d, lo + r);
+                }
+        }
+        free(buf);
+    }
+    cand_t *fin = (cand_t *)malloc(sizeof(cand_t) * k);
+    size_t flen = 0;
+    for (size_t b = 0; b < nq; b++) {
+        flen = 0;
+        for (int t = 0; t < threads; t++) {
+            const cand_t *l = lists + ((size_t)t * nq + b) * k;
+            for (size_t i = 0; i < lens[(size_t)t * nq + b]; i++) topk_push(fin, &flen, k, l[i].d, l[i].pos);
+        }
+        for (size_t i = 0; i < flen; i++) {
+            out_labels[b * k + i] = first_id + (uint64_t)fin[i].pos;
+            out_distances[b * k + i] = fin[i].d;
+        }
+    }
+    free(fin);
+    free(lists);
+    free(lens);
+    return flen;
+}
+
 /* examples_old/search.rs:49-72 over PageEntry records (src/index/warc.rs:35-43). */
 size_t orc_scan_examples_old(const uint8_t *page_entries, size_t n_entries, const float *q,
                              size_t *out_entry, float *out_score) {

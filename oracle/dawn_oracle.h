@@ -73,6 +73,9 @@ size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const flo
 /* Literal restatement of examples_old/search.rs:49-72 (L2^2 score, top-10, the un-sorted-first-10
  * quirk included) over a packed PageEntry file image (src/index/warc.rs:35-43: 1568-B records,
  * vector at byte offset 16).  Returns number of results (<= 10). */
+/* exact scan over rows generated on the fly (never materialised): see dawn_oracle.c */
+size_t orc_scan_topk_synth(uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, int bf16, const float *q,
+                           size_t nq, size_t k, uint64_t *out_labels, float *out_distances, int threads);
 size_t orc_scan_examples_old(const uint8_t *page_entries, size_t n_entries, const float *q,
                              size_t *out_entry, float *out_score);
 

@@ -72,6 +72,9 @@ def lib():
     L.orc_scan_topk.restype = C.c_size_t
     L.orc_scan_topk_mt.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_size_t, _u64p, _f32p, C.c_int]
     L.orc_scan_topk_mt.restype = C.c_size_t
+    L.orc_scan_topk_synth.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint64, C.c_int, _f32p, C.c_size_t, C.c_size_t,
+                                      _u64p, _f32p, C.c_int]
+    L.orc_scan_topk_synth.restype = C.c_size_t
     L.orc_scan_examples_old.argtypes = [_u8p, C.c_size_t, _f32p, np.ctypeslib.ndpointer(dtype=np.uintp), _f32p]
     L.orc_scan_examples_old.restype = C.c_size_t
     L.orc_splitmix64.argtypes = [C.c_uint64]
@@ -117,6 +120,18 @@ def scan_topk(x: np.ndarray, ids, q: np.ndarray, k: int, threads: int = 1):
     else:
         found = lib().orc_scan_topk_mt(x, idp, n, q, k, labels, dist, threads)
     return labels[:found].copy(), dist[:found].copy()
+
+
+def scan_topk_synth(seed: int, first_row: int, n: int, first_id: int, Q: np.ndarray, k: int, bf16: bool = False,
+                    threads: int = 0):
+    """Exact top-k of every query of Q over the synthetic rows [first_row, first_row + n) of stream `seed`, generated chunk
+    by chunk on all host cores (the rows are never materialised): (labels u64 [nq][found], distances f32 [nq][found])."""
+    Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float32)
+    nq = Q.shape[0]
+    labels = np.zeros((nq, k), dtype=np.uint64)
+    dist = np.zeros((nq, k), dtype=np.float32)
+    found = lib().orc_scan_topk_synth(seed, first_row, n, first_id, int(bf16), Q, nq, k, labels, dist, threads)
+    return labels[:, :found].copy(), dist[:, :found].copy()
 
 
 class BestResults:

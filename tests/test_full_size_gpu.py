@@ -1,5 +1,6 @@
-"""BASELINE.json's full single-GPU size — 100 M x 384 f32 rows resident in HBM — checked through properties that do not
-need the CPU oracle to scan 153.6 GB: independent GPU paths must agree bit for bit (f16-shadow MFMA stream, f32-row
+"""BASELINE.json's full single-GPU size — 100 M x 384 f32 rows resident in HBM — checked against the oracle's own scan of
+all 100 M rows (generated chunk by chunk on the host: test_100m_default_path_equals_the_oracle_scan_of_all_rows) and
+through properties that do not need the CPU at all: independent GPU paths must agree bit for bit (f16-shadow MFMA stream, f32-row
 stream, matrix-core batched pass, forced exact pass: four different kernels over the same rows), planted rows must
 come back first with the distance the oracle computes for that ONE row, results are ascending, in range, idempotent,
 and equal to the merge of two half-index searches (the sharded identity).  The card must hold the index: on a GPU with
@@ -139,6 +140,30 @@ def test_100m_batch256_all_paths_agree(dawn, big):
     assert after["second_chances"] - before["second_chances"] == after["deepened"] - before["deepened"]
 
 
+def test_100m_default_path_equals_the_oracle_scan_of_all_rows(dawn, oracle, big):
+    """Parity at BASELINE's metric size against the oracle ITSELF: the C oracle scans all 100 M synthetic rows (generated
+    chunk by chunk on the host cores — orc_scan_topk_synth — since 153.6 GB do not fit host memory) for six queries, k = 20;
+    the default int8 path must return exactly that — labels and distance bits — at batch 1 (k = 10 and k = 20) and for the
+    same queries inside a 256-batch (k = 10 and k = 20)."""
+    idx = big
+    Qp, planted = _queries()
+    Q6 = np.concatenate([Qp[:3], Qp[[6, 10, 15]]])  # three plain queries; planted on rows 0, 12 345 678 and N - 1
+    ol, od = oracle.scan_topk_synth(1, 0, N, 1, Q6, 20)
+    assert ol.shape == (6, 20) and list(ol[3:, 0]) == [1, 12_345_679, N]
+    for b in range(6):
+        for k in (10, 20):
+            lab, dist = idx.search(Q6[b], k)
+            assert np.array_equal(lab, ol[b, :k]) and np.array_equal(dist.view(np.uint32), od[b, :k].view(np.uint32)), (b, k)
+    Q = synth.unit_rows(3, 0, 256)
+    slots = [0, 41, 127, 128, 200, 255]
+    Q[slots] = Q6
+    for k in (10, 20):
+        labels, dist, found = idx.search_batch(Q, k)
+        assert np.all(found == k)
+        assert np.array_equal(labels[slots], ol[:, :k]) and np.array_equal(dist[slots].view(np.uint32), od[:, :k].view(np.uint32)), k
+    assert idx.stats()["fallbacks"] == 0
+
+
 def test_100m_k_edge_and_sharded_identity(dawn, big):
     """k = 1 and k = 64 (no certificate margin: exact pass) agree on the common prefix with k = 10; the top-k of the
     whole index equals the stable merge of the top-k of its two halves (what the multi-GPU path computes)."""
@@ -215,4 +240,15 @@ def test_125m_bf16_shard_paths_agree(dawn, oracle):
     finally:
         idx.set_option("force_fallback", 0)
     assert np.array_equal(lab, labels[2]) and np.array_equal(dd.view(np.uint32), dist[2].view(np.uint32))
+    # configs[4] as configured: batch 256 on this shard (k = 20), and the oracle's scan of the same 125 M bf16-rounded rows
+    # for four of the queries (two planted, two plain)
+    Q256 = synth.unit_rows(3, 0, 256)
+    slots = [0, 99, 128, 255]
+    Q256[slots] = Q[[0, 5, 8, 11]]
+    l256, d256, f256 = idx.search_batch(Q256, 20)
+    assert np.all(f256 == 20) and np.all(np.diff(d256, axis=1) >= 0)
+    ol, od = oracle.scan_topk_synth(1, 0, n, 1, Q256[slots], 20, bf16=True)
+    assert np.array_equal(l256[slots], ol) and np.array_equal(d256[slots].view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(l256[slots][:, :K], labels[[0, 5, 8, 11]])
+    assert idx.stats()["fallbacks"] == 0
     idx.close()

@@ -185,7 +185,7 @@ def test_add_reserve_growth_and_save_load(dawn, oracle, tmp_path):
     _assert_same(*idx2.search(q, 20), *want)
     with pytest.raises(dawn.DawnError):
         idx2.load(str(tmp_path / "missing.dawn"))
-    assert idx2.size() == 3000  # a file that cannot be opened leaves the index alone
+    assert idx2.size() == 0  # every load failure empties the index (usearch resets before it reads; dawn_hip.h)
     import os
     assert not os.path.exists(p + ".tmp")  # save writes path.tmp, fsyncs and renames
 

@@ -1,0 +1,256 @@
+// Microbenchmark (dev tool): what can this chip READ?  The bare form of the headline kernel's stream
+// (scan_filter_i8s_kernel, csrc/scan_i8.hip): the same grid (one workgroup per CU), the same 16 B/lane loads in 1-KiB
+// wave-instructions, the same ring of twelve fragments (12 KiB) in flight per wave, whole 12-KiB sub-tiles per wave —
+// and nothing else: no MFMA, no lists, no meta loads; every loaded dword is xor-ed into one register so that nothing is
+// dead.  Sweeps what the round-2 verdict asked for:
+//   cache policy   plain / nt / sc0 / sc1 / sc0 sc1 / nt sc1 / nt sc0 sc1   (buffer loads, aux bits; + the product's own
+//                  __builtin_nontemporal_load global loads)
+//   address map    0 chip-wide moving window (the product: wave w reads sub-tiles w, w + W, w + 2W, ...)
+//                  1 per-XCD contiguous ranges (workgroup b runs on XCD b % 8; each XCD's waves sweep their own eighth)
+//                  2 per-wave contiguous ranges
+//                  3 per-workgroup contiguous ranges
+//                  4 2-MiB groups: a workgroup takes whole 2-MiB-aligned regions, one region per step of the window
+//   waves per CU   2 / 4 / 8 / 16
+// build: hipcc --offload-arch=gfx950 -O3 -o hbm_read hbm_read.hip ; run: ./hbm_read [GB=38.4] [reps=5]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t SUB_BYTES = 12 * 1024;  // one sub-tile of the int8 shadow: 32 rows x 384 B
+
+#define CHECK(x)                                                                                  \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                          \
+            std::exit(1);                                                                         \
+        }                                                                                         \
+    } while (0)
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    // raw buffer: stride 0, 2 GiB window from p, gfx9 data format word
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+
+// POL < 0: global loads (-1 plain, -2 __builtin_nontemporal_load — the product's); POL >= 0: buffer loads with aux = POL
+template <int POL>
+__device__ __forceinline__ u32x4 load16(const char* sub_base, rsrc_t rs, uint32_t off) {
+    if constexpr (POL == -1) return *reinterpret_cast<const u32x4*>(sub_base + off);
+    else if constexpr (POL == -2) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sub_base + off));
+    else return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, POL));
+}
+
+// sub-tile index of step i for this wave under map MAP (n_sub sub-tiles in all); returns false past the end
+template <int MAP>
+__device__ __forceinline__ bool sub_of(uint32_t i, uint32_t n_sub, uint32_t wave, uint32_t nwaves, uint32_t* t) {
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    if constexpr (MAP == 0) {
+        const uint64_t v = (uint64_t)i * nb * nwaves + b * nwaves + wave;
+        *t = (uint32_t)v;
+        return v < n_sub;
+    } else if constexpr (MAP == 1) {
+        const uint32_t xcd = b & 7u, j = b >> 3, per_xcd_blocks = (nb + 7u) >> 3;
+        const uint32_t lo = (uint32_t)((uint64_t)n_sub * xcd / 8), hi = (uint32_t)((uint64_t)n_sub * (xcd + 1) / 8);
+        const uint64_t v = (uint64_t)lo + (uint64_t)i * per_xcd_blocks * nwaves + j * nwaves + wave;
+        *t = (uint32_t)v;
+        return v < hi;
+    } else if constexpr (MAP == 2) {
+        const uint32_t gw = b * nwaves + wave, tw = nb * nwaves;
+        const uint32_t lo = (uint32_t)((uint64_t)n_sub * gw / tw), hi = (uint32_t)((uint64_t)n_sub * (gw + 1) / tw);
+        *t = lo + i;
+        return lo + i < hi;
+    } else if constexpr (MAP == 3) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_sub * b / nb), hi = (uint32_t)((uint64_t)n_sub * (b + 1) / nb);
+        const uint64_t v = (uint64_t)lo + (uint64_t)i * nwaves + wave;
+        *t = (uint32_t)v;
+        return v < hi;
+    } else {  // 2-MiB groups: 2 MiB = 170.67 sub-tiles -> use groups of 512 sub-tiles = 6 MiB = three whole 2-MiB pages
+        constexpr uint32_t GRP = 512;
+        const uint32_t per = (GRP + nwaves - 1) / nwaves;     // steps per group
+        const uint32_t gi = i / per, k = i % per;
+        const uint64_t grp = (uint64_t)gi * nb + b;
+        const uint64_t v = grp * GRP + (uint64_t)k * nwaves + wave;
+        *t = (uint32_t)v;
+        if ((uint64_t)k * nwaves + wave >= GRP) {  // (a hole: this wave idles one step)
+            *t = 0xFFFFFFFFu;
+            return grp * GRP < n_sub;
+        }
+        return v < n_sub;
+    }
+}
+
+template <int POL, int MAP, int RING = 12>
+__global__ __launch_bounds__(1024) void read_kernel(const char* __restrict__ x, uint32_t n_sub, uint32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
+    u32x4 acc = {0, 0, 0, 0};
+    uint32_t t;
+    uint32_t i = 0;
+    bool live = sub_of<MAP>(0, n_sub, wave, nwaves, &t);
+    while (live && t == 0xFFFFFFFFu) live = sub_of<MAP>(++i, n_sub, wave, nwaves, &t);
+    if (live) {
+        const char* p = x + (size_t)t * SUB_BYTES;
+        rsrc_t rs = make_rsrc(p);
+        // RING <= 12: RING fragments of the sub-tile in flight; RING = 24: the whole NEXT sub-tile too
+        u32x4 a[RING];
+        if constexpr (RING <= 12) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) a[d] = load16<POL>(p, rs, lane * 16 + d * 1024);
+        }
+        for (;;) {
+            uint32_t tn;
+            bool more = sub_of<MAP>(++i, n_sub, wave, nwaves, &tn);
+            while (more && tn == 0xFFFFFFFFu) more = sub_of<MAP>(++i, n_sub, wave, nwaves, &tn);
+            const char* pn = more ? x + (size_t)tn * SUB_BYTES : p;  // (the last sub-tile re-reads itself: no branch)
+            const rsrc_t rsn = make_rsrc(pn);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) {
+                acc ^= a[f % RING];
+                if (f + RING < 12) a[f % RING] = load16<POL>(p, rs, lane * 16 + (f + RING) * 1024);
+                else a[f % RING] = load16<POL>(pn, rsn, lane * 16 + (f + RING - 12) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rs = rsn;
+            if (!more) break;
+            p = pn;
+        }
+    }
+    const uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (r == 0x12345678u) out[0] = r;  // (practically never true, never dead)
+}
+
+// pseudo-random bytes (all-equal data lets the memory system and the fabric toggle less than real rows do)
+__global__ void fill_kernel(uint32_t* x, size_t n_words) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v = (uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32);
+        v ^= v >> 16;
+        v *= 0x7feb352du;
+        v ^= v >> 15;
+        x[i] = v;
+    }
+}
+
+struct Result {
+    double best_ms, med_ms;
+};
+
+template <int POL, int MAP, int RING = 12>
+Result run(const char* x, uint32_t n_sub, uint32_t* out, int blocks, int threads, int reps) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int r = -1; r < reps; ++r) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((read_kernel<POL, MAP, RING>), dim3(blocks), dim3(threads), 0, 0, x, n_sub, out);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t = 0;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 0) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+    return {ms.front(), ms[ms.size() / 2]};
+}
+
+static const char* pol_name(int p) {
+    switch (p) {
+        case -2: return "global nt (product)";
+        case -1: return "global plain";
+        case 0: return "buffer plain";
+        case 1: return "buffer sc0";
+        case 2: return "buffer nt";
+        case 16: return "buffer sc1";
+        case 17: return "buffer sc0 sc1";
+        case 18: return "buffer nt sc1";
+        case 19: return "buffer nt sc0 sc1";
+    }
+    return "?";
+}
+static const char* map_name(int m) {
+    static const char* n[] = {"chip-wide window", "per-XCD ranges", "per-wave ranges", "per-workgroup ranges", "6-MiB groups"};
+    return n[m];
+}
+
+template <int POL, int MAP, int RING = 12>
+void row(const char* x, uint32_t n_sub, uint32_t* out, int blocks, int threads, int reps, double* best_gbps) {
+    const Result r = run<POL, MAP, RING>(x, n_sub, out, blocks, threads, reps);
+    const double bytes = (double)n_sub * SUB_BYTES;
+    const double g = bytes / (r.best_ms * 1e-3) / 1e9;
+    std::printf("%-22s %-22s %4d x %4d ring %2d (%3d KiB/CU)  best %8.3f ms  median %8.3f ms   %7.1f GB/s  (%.3f of 8 TB/s)\n", pol_name(POL),
+                map_name(MAP), blocks, threads, RING,
+                RING * (threads / 64) * (blocks / 256), r.best_ms, r.med_ms, g, g / 8000.0);
+    std::fflush(stdout);
+    if (g > *best_gbps) *best_gbps = g;
+}
+
+template <int POL>
+void all_maps(const char* x, uint32_t n_sub, uint32_t* out, int reps, double* best) {
+    row<POL, 0>(x, n_sub, out, 256, 256, reps, best);
+    row<POL, 1>(x, n_sub, out, 256, 256, reps, best);
+    row<POL, 2>(x, n_sub, out, 256, 256, reps, best);
+    row<POL, 3>(x, n_sub, out, 256, 256, reps, best);
+    row<POL, 4>(x, n_sub, out, 256, 256, reps, best);
+}
+
+int main(int argc, char** argv) {
+    const double gb = argc > 1 ? std::atof(argv[1]) : 38.4;
+    const int reps = argc > 2 ? std::atoi(argv[2]) : 5;
+    const uint32_t n_sub = (uint32_t)(gb * 1e9 / SUB_BYTES);
+    const size_t bytes = (size_t)n_sub * SUB_BYTES;
+    char* x = nullptr;
+    uint32_t* out = nullptr;
+    CHECK(hipMalloc((void**)&x, bytes + SUB_BYTES));
+    CHECK(hipMalloc((void**)&out, 64));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(x), (bytes + SUB_BYTES) / 4);
+    CHECK(hipMemset(out, 0, 64));
+    CHECK(hipDeviceSynchronize());
+    hipDeviceProp_t pr;
+    CHECK(hipGetDeviceProperties(&pr, 0));
+    std::printf("# %s, %d CUs; buffer %.3f GB = %u sub-tiles of 12 KiB; %d timed launches per line after 1 warm-up\n", pr.name,
+                pr.multiProcessorCount, bytes / 1e9, n_sub, reps);
+    double best = 0;
+    std::printf("# --- cache policy x address map, 4 waves per CU (the product's geometry at 100 M rows)\n");
+    all_maps<-2>(x, n_sub, out, reps, &best);
+    all_maps<-1>(x, n_sub, out, reps, &best);
+    all_maps<2>(x, n_sub, out, reps, &best);
+    all_maps<0>(x, n_sub, out, reps, &best);
+    all_maps<1>(x, n_sub, out, reps, &best);
+    all_maps<16>(x, n_sub, out, reps, &best);
+    all_maps<17>(x, n_sub, out, reps, &best);
+    all_maps<18>(x, n_sub, out, reps, &best);
+    all_maps<19>(x, n_sub, out, reps, &best);
+    std::printf("# --- waves per CU (global nt, chip-wide window / per-XCD ranges)\n");
+    for (int threads : {128, 256, 512, 1024}) {
+        row<-2, 0>(x, n_sub, out, 256, threads, reps, &best);
+        row<-2, 1>(x, n_sub, out, 256, threads, reps, &best);
+    }
+    std::printf("# --- KiB in flight per CU = waves x ring (global nt, per-XCD ranges)\n");
+    row<-2, 1, 12>(x, n_sub, out, 256, 64, reps, &best);
+    row<-2, 1, 6>(x, n_sub, out, 256, 128, reps, &best);
+    row<-2, 1, 4>(x, n_sub, out, 256, 192, reps, &best);
+    row<-2, 1, 6>(x, n_sub, out, 256, 192, reps, &best);
+    row<-2, 1, 12>(x, n_sub, out, 256, 192, reps, &best);
+    row<-2, 1, 3>(x, n_sub, out, 256, 256, reps, &best);
+    row<-2, 1, 4>(x, n_sub, out, 256, 256, reps, &best);
+    row<-2, 1, 6>(x, n_sub, out, 256, 256, reps, &best);
+    row<-2, 1, 3>(x, n_sub, out, 256, 512, reps, &best);
+    row<-2, 1, 2>(x, n_sub, out, 256, 1024, reps, &best);
+    std::printf("# --- two workgroups per CU (global nt)\n");
+    row<-2, 0>(x, n_sub, out, 512, 128, reps, &best);
+    row<-2, 0>(x, n_sub, out, 512, 256, reps, &best);
+    std::printf("# best of all lines: %.1f GB/s = %.3f of the 8 TB/s spec\n", best, best / 8000.0);
+    std::printf("{\"hbm_read_ceiling_GBps\": %.1f}\n", best);
+    return 0;
+}
