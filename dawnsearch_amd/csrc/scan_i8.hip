@@ -412,6 +412,226 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     }
 }
 
+// ---- the same filter, software-pipelined (round 3; the default) ------------------------------------------------------
+// The kernel above tests a sub-tile right after its twelve MFMAs: ~60 VALU instructions during which the wave issues no
+// load, every sub-tile — a 150-clock hole in the wave's request stream per 770 clocks of matrix work.  The bare-read
+// probe (tools/probes/hbm_read.hip, profiles/r03/hbm_read_probe.log) shows what that costs on this chip: with loads
+// re-issued the moment a fragment lands, TWO waves per CU x 12 KiB in flight read 7.18-7.23 TB/s (0.90 of the 8 TB/s
+// spec), four waves 7.03-7.08 — fewer bytes in flight are faster, provided the stream of requests never pauses.
+// Here the test of sub-tile t - 1 is cut into slices that sit in the shadow of sub-tile t's MFMAs (a 32x32x32 int8 MFMA
+// keeps the matrix pipe busy for 64 clocks; the slices are <= 6 VALU instructions each), two accumulator sets, so loads
+// are re-issued at the steady cadence of the MFMAs and nothing else is on the wave's critical path.  Results are
+// identical to the kernel above by construction (same scores, same tests in the same order).
+// XCD: workgroup b runs on XCD b % 8 (round-robin dispatch); each XCD's workgroups sweep their own contiguous eighth of
+// the shadow instead of the chip-wide window (probe: +0.6 % at two waves per CU).
+template <int QB, bool XCD>
+__global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+                                                                    uint32_t n_rows, const float* __restrict__ q, int n_q,
+                                                                    float* __restrict__ out_s, uint32_t* __restrict__ out_p,
+                                                                    uint32_t q_stride_lists) {
+    __shared__ float sh_s[16][LIST];
+    __shared__ uint32_t sh_p[16][LIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t n_sub = (n_rows + 31u) >> 5;
+    const uint32_t c = lane & 31, h = lane >> 5;
+    // this wave's sub-tiles: first, first + stride, ... < end
+    uint32_t t, t_stride, t_end;
+    if (XCD) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (gridDim.x + 7u) >> 3;
+        const uint32_t lo = (uint32_t)((uint64_t)n_sub * xcd / 8), hi = (uint32_t)((uint64_t)n_sub * (xcd + 1) / 8);
+        t = lo + j * nwaves + wave;
+        t_stride = per * nwaves;
+        t_end = hi;
+    } else {
+        t = blockIdx.x * nwaves + wave;
+        t_stride = gridDim.x * nwaves;
+        t_end = n_sub;
+    }
+
+    // query images: as in scan_filter_i8s_kernel
+    __shared__ __attribute__((aligned(16))) signed char sh_img[2][QB][EM];
+    __shared__ float sh_sq[QB];
+    for (int b = wave; b < QB; b += nwaves) {
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = b < n_q ? q[(size_t)b * EM + lane + 64 * j] : 0.f;
+        rotate384_wave(v, lane);
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float tt = v[j] / sq;
+            const float H = fminf(fmaxf(rintf(tt), -127.f), 127.f);
+            const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
+            sh_img[0][b][lane + 64 * j] = b < n_q ? (signed char)(int)H : (signed char)0;
+            sh_img[1][b][lane + 64 * j] = b < n_q ? (signed char)(int)L : (signed char)0;
+        }
+        if (lane == 0) sh_sq[b] = sq;
+    }
+    __syncthreads();
+    i32x4_t qf[12];
+    const int qcol = (int)(c & 7u);
+    float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;
+    {
+        const bool col_live = qcol < n_q && qcol < QB && c < 16;
+        const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&sh_img[c >= 8 ? 1 : 0][col_live ? qcol : 0][0]);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) qf[f] = col_live ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
+        if (col_live) {
+            const float sq = sh_sq[qcol];
+            sq254_l = sq / 254.0f;
+            rsq254_l = 254.0f / sq;
+            k2_l = I8_K2_PER_SQ * sq;
+        }
+    }
+    float ls[QB], tau[QB], sq254[QB], k2[QB];
+    uint32_t lp[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        ls[b] = NEG_INF;
+        lp[b] = NO_POS;
+        tau[b] = NEG_INF;
+        sq254[b] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq254_l), b));
+        k2[b] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k2_l), b));
+    }
+    const bool tested = (int)c < n_q && c < 8;
+    float tau_m = tested ? NEG_INF : __builtin_inff();
+
+    if (t < t_end) {
+        const u32x4* p = x + (size_t)t * (12 * 64) + lane;
+        u32x4 a[12];
+#pragma unroll
+        for (int d = 0; d < 12; ++d) a[d] = row_load<true>(p + d * 64);
+        float2 mt = meta[t];
+        // state of the sub-tile under test (the previous one)
+        i32x16_t accs[2];  // ping-pong: one being accumulated, the other under test (no copies)
+        float2 pmt = mt;
+        uint32_t prow = 0;
+        int C[16];
+        int thr = 0, mx = 0;
+
+        // the slow path of a tested sub-tile: exactly the kernel above's
+        auto slow_path = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+                unsigned long long m = __ballot(C[e] > thr && prow + roff + 4u * h < n_rows);
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float cf = (float)__builtin_amdgcn_readlane(C[e], l);
+                    const int qb = l & 31;
+                    const uint32_t row = prow + roff + 4u * (uint32_t)(l >> 5);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) {
+                        if (b == qb) {
+                            const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254[b], pmt.y + k2[b]);
+                            if (sc > tau[b]) {
+                                wave_insert(ls[b], lp[b], sc, row, lane);
+                                tau[b] = read_lane63(ls[b]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+                if ((int)c == b && tested) {
+                    const float tk = tau[b] - k2[b];
+                    tau_m = tk - fabsf(tk) * 1e-6f;
+                }
+        };
+        // slice s (0..11) of the test of the previous sub-tile; slices 1..8 turn two accumulators each into C and fold them
+        // into the maximum, slice 0 makes the integer threshold
+        auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
+            if (s == 0) {
+                const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l, -2.0f);
+                thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
+                if (!tested) thr_f = 2.0e9f;
+                thr = (int)floorf(thr_f);
+            } else if (s <= 8) {
+#pragma unroll
+                for (int e = 2 * (s - 1); e < 2 * s; ++e) {
+                    const int ae = pacc[e];
+                    C[e] = __mul24(ae, 254) + __builtin_amdgcn_update_dpp(0, ae, 0x108, 0xf, 0xf, true);
+                    mx = e == 0 ? C[0] : max(mx, C[e]);
+                }
+            }
+        };
+
+        // one round: the twelve MFMAs of sub-tile t (its fragments are in the ring), the ring refilled from the wave's next
+        // sub-tile, and — TEST — the slices of the previous sub-tile's test in the MFMAs' shadow.  The first round has no
+        // previous sub-tile and is a copy of its own without the slices (a flag tested in the loop would let the compiler
+        // sink the slices behind the MFMAs, into the branch that uses them).
+        bool more;
+        auto round = [&](auto with_test, auto parity) __attribute__((always_inline)) {
+            constexpr int P = decltype(parity)::value;
+            i32x16_t& acc = accs[P];
+            const uint32_t tn = t + t_stride;
+            more = tn < t_end;
+            // (the last sub-tile re-reads its own first fragments: no branch in the stream)
+            const u32x4* pn = more ? x + (size_t)tn * (12 * 64) + lane : p;
+            const float2 mtn = meta[more ? tn : t];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0;
+#pragma unroll
+            for (int f = 0; f < 12; ++f) {
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f]), qf[f], acc, 0, 0, 0);
+                a[f] = row_load<true>(pn + f * 64);
+                if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (decltype(with_test)::value)
+                if (__any(mx > thr)) slow_path();
+            // this sub-tile is the next round's test
+            pmt = mt;
+            prow = t * 32u;
+            t = tn;
+            p = pn;
+            mt = mtn;
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        round(std::false_type{}, P0{});
+        int last = 0;
+        while (more) {
+            round(std::true_type{}, P1{});
+            last = 1;
+            if (!more) break;
+            round(std::true_type{}, P0{});
+            last = 0;
+        }
+        // the last sub-tile's test, unpipelined
+        if (last) {
+#pragma unroll
+            for (int s = 0; s < 12; ++s) test_slice(s, accs[1]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 12; ++s) test_slice(s, accs[0]);
+        }
+        if (__any(mx > thr)) slow_path();
+    }
+
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        if (b < n_q) {
+            block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+            if (wave == 0) {
+                const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
+                out_s[o] = ls[b];
+                out_p[o] = lp[b];
+            }
+        }
+    }
+}
+
 template <int QB>
 static void launch_filter_i8s_qb(const void* d_shadow, const void* d_meta, uint32_t n_rows, const float* q8, int n_q,
                                  float* cand_s, uint32_t* cand_p, const ScanGeom& g, hipStream_t stream) {
@@ -425,6 +645,14 @@ static void launch_filter_i8s_qb(const void* d_shadow, const void* d_meta, uint3
         case 1: DAWN_I8S_LAUNCH(3); break;
         case 2: DAWN_I8S_LAUNCH(4); break;
         case 4: DAWN_I8S_LAUNCH(6); break;
+        case 6:  // software-pipelined test (two accumulator sets), chip-wide window
+            hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, false>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
+        case 7:  // ... and per-XCD contiguous ranges
+            hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, true>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
         case 5:  // 12 fragments, plain (temporal) loads
             hipLaunchKernelGGL((scan_filter_i8s_kernel<QB, 12, false>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
                                q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);

@@ -107,6 +107,30 @@ class SearchProvider:
             self.index.reserve(self.index.size() + 1024)
         self.index.add(id_, q)
 
+    def insert_batch(self, pages: List[ExtractedPage], embeddings: np.ndarray) -> None:
+        """`insert` for many pages in one call (what a batching indexer binds: one dawn_index_add_batch instead of one
+        dawn_index_add per page).  Same gates, same rowids; a page whose URL is already stored is skipped (:259-263); a
+        non-normalised embedding fails the whole call before anything is stored."""
+        emb = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if emb.ndim != 2 or emb.shape != (len(pages), EM_LEN):
+            raise ValueError("embeddings must be [len(pages), 384]")
+        keep = [i for i, p in enumerate(pages) if p.url not in self._by_url]
+        if self.page_count() + len(keep) > MAX_LOCAL_PAGES:
+            raise DawnError(-1, "No space available")
+        for i in keep:
+            if not is_normalized(emb[i]):
+                raise NotNormalizedError(-2, "Insert embedding is not normalized")
+        if not keep:
+            return
+        ids = np.arange(self._next_rowid, self._next_rowid + len(keep), dtype=np.uint64)
+        if self.index.size() + len(keep) > self.index.capacity():
+            self.index.reserve(self.index.size() + max(len(keep), 1024))
+        self.index.add_batch(ids, emb[keep])
+        for id_, i in zip(ids.tolist(), keep):
+            self._pages[id_] = (pages[i].url, pages[i].title, pages[i].text, emb[i].copy())
+            self._by_url[pages[i].url] = id_
+        self._next_rowid += len(keep)
+
     # -- :127-153 ---------------------------------------------------------------------------------
     def fill_index_from_db(self) -> None:
         count = self.page_count()

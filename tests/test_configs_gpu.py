@@ -34,7 +34,7 @@ def provider(dawn, tmp_path_factory):
 
 def _vocab_file(tmp_path, n_words=3000):
     """A synthetic WordPiece vocabulary with [CLS] / [SEP] at BERT's ids 101 / 102 and `n_words` whole words + suffixes."""
-    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"unused{i}" for i in range(95)] + ["x101", "x102"]
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"unused{i}" for i in range(96)] + ["x101", "x102"]
     words[2], words[101] = words[101], "[CLS]"
     words[3], words[102] = words[102], "[SEP]"
     syll = ["ka", "lo", "mi", "ne", "su", "ta", "ri", "vo", "de", "pu", "sha", "qui", "zor", "bel", "fen", "gar"]
