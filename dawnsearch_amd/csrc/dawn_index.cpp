@@ -672,7 +672,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
                 return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_threads must be 64/128/256/512");
             idx->geom_h.threads = (int)value;
         } else {
-            if (value < 1 || value > 8) return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_unroll must be 1..8");
+            if (value < 1 || value > 10) return fail(DAWN_ERR_INVALID_ARG, "shadow_scan_unroll must be 1..10");
             idx->geom_h.unroll = (int)value;
         }
         idx->geom_h_pinned = true;
@@ -800,6 +800,34 @@ int ingest_file_rows(dawn_index* idx, int fd, dawn::RowSrc kind, size_t n_rows, 
     return rc;
 }
 
+int add_batch_now(dawn_index* idx, size_t n, const uint64_t* ids, const float* v);
+}  // namespace
+
+int dawn::index_flush_adds(dawn_index* idx) {
+    if (idx->staged == 0) return DAWN_OK;
+    const size_t n = idx->staged;
+    idx->staged = 0;  // (whatever happens: the rows are either in or dropped with the error)
+    return add_batch_now(idx, n, idx->h_add_ids, idx->h_add_rows);
+}
+
+namespace {
+int add_batch_now(dawn_index* idx, size_t n, const uint64_t* ids, const float* v) {
+    // (pageable caller buffers: the runtime stages them; every call ends synchronised in commit)
+    for (size_t o = 0; o < n; o += dawn::kStageChunk) {
+        const size_t m = std::min(dawn::kStageChunk, n - o);
+        int rc = dawn::index_append_async(idx, dawn::RowSrc::HostRows, v + o * dawn::EM, ids + o, 0, m, -1);
+        if (rc != DAWN_OK) {
+            dawn::index_append_abort(idx);
+            return rc;
+        }
+    }
+    return dawn::index_append_commit(idx);
+}
+
+// The staged single-row adds join the index (index_internal.hpp: h_add_rows).  Called in front of everything that looks at
+// the rows; an error (growth failed: out of HBM) belongs to the adds and is reported by the call that flushes them.
+int flush_adds(dawn_index* idx) { return dawn::index_flush_adds(idx); }
+
 int root_device(const dawn_index* idx) { return idx->shards ? dawn::sharded_root_device(idx) : idx->device; }
 int index_dtype(const dawn_index* idx) { return idx->shards ? dawn::sharded_dtype(idx) : idx->dtype; }
 
@@ -818,16 +846,23 @@ int dawn_index_create(size_t dims, int dtype, int device, dawn_index** out) {
 
 void dawn_index_destroy(dawn_index* idx) {
     if (!idx) return;
+    if (idx->h_add_rows) (void)hipHostFree(idx->h_add_rows);  // (staged adds that were never looked at go with the index)
+    idx->h_add_rows = nullptr;
     if (idx->shards) return dawn::sharded_destroy(idx);
     dawn::index_destroy_single(idx);
 }
 
 int dawn_index_reserve(dawn_index* idx, size_t capacity) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    return dawn::guarded([&] { return idx->shards ? dawn::sharded_reserve(idx, capacity) : dawn::index_reserve_single(idx, capacity); });
+    return dawn::guarded([&] {
+        DAWN_TRY(flush_adds(idx));
+        return idx->shards ? dawn::sharded_reserve(idx, capacity) : dawn::index_reserve_single(idx, capacity);
+    });
 }
 
-size_t dawn_index_size(const dawn_index* idx) { return !idx ? 0 : idx->shards ? dawn::sharded_size(idx) : idx->size; }
+size_t dawn_index_size(const dawn_index* idx) {
+    return !idx ? 0 : (idx->shards ? dawn::sharded_size(idx) : idx->size) + idx->staged;
+}
 size_t dawn_index_capacity(const dawn_index* idx) {
     return !idx ? 0 : idx->shards ? dawn::sharded_capacity(idx) : idx->cap_reported;
 }
@@ -836,23 +871,30 @@ int dawn_index_add_batch(dawn_index* idx, size_t n, const uint64_t* ids, const f
     if (!idx || (!ids && n) || (!v && n)) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (n == 0) return DAWN_OK;
     return dawn::guarded([&] {
-        // (the caller's buffers are pageable: the runtime stages them; every call ends synchronised in commit)
-        for (size_t o = 0; o < n; o += dawn::kStageChunk) {
-            const size_t m = std::min(dawn::kStageChunk, n - o);
-            int rc = dawn::index_append_async(idx, dawn::RowSrc::HostRows, v + o * dawn::EM, ids + o, 0, m, -1);
-            if (rc != DAWN_OK) {
-                dawn::index_append_abort(idx);
-                return rc;
-            }
-        }
-        return dawn::index_append_commit(idx);
+        DAWN_TRY(flush_adds(idx));  // (insertion order)
+        return add_batch_now(idx, n, ids, v);
     });
 }
 
+// One row: gated on the host (vector.rs:185-192, as the reference does right before index.add, search_provider.rs:265-267),
+// then staged; see index_internal.hpp.  ~0.3 us per call instead of a transfer + two synchronisations.
 int dawn_index_add(dawn_index* idx, uint64_t id, const float* v) {
     if (!idx || !v) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (!dawn::host_is_normalized(v)) return fail(DAWN_ERR_NOT_NORMALIZED, "Insert embedding is not normalized");
-    return dawn_index_add_batch(idx, 1, &id, v);
+    return dawn::guarded([&] {
+        if (!idx->h_add_rows) {
+            DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+            void* hp = nullptr;
+            DAWN_HIP_TRY(hipHostMalloc(&hp, dawn::kAddStageRows * (dawn::EM * sizeof(float) + sizeof(uint64_t)), hipHostMallocDefault));
+            idx->h_add_rows = reinterpret_cast<float*>(hp);
+            idx->h_add_ids = reinterpret_cast<uint64_t*>(idx->h_add_rows + dawn::kAddStageRows * dawn::EM);
+        }
+        if (idx->staged == dawn::kAddStageRows) DAWN_TRY(flush_adds(idx));
+        std::memcpy(idx->h_add_rows + idx->staged * dawn::EM, v, dawn::EM * sizeof(float));
+        idx->h_add_ids[idx->staged] = id;
+        ++idx->staged;
+        return DAWN_OK;
+    });
 }
 
 int dawn_index_search_device(dawn_index* idx, const float* d_queries, size_t B, size_t count, uint64_t* d_labels,
@@ -860,6 +902,10 @@ int dawn_index_search_device(dawn_index* idx, const float* d_queries, size_t B, 
     if (!idx || !d_queries || !d_labels || !d_distances || !d_found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (count == 0 || count > DAWN_MAX_K) return fail(DAWN_ERR_UNSUPPORTED, "count must be 1..%d", DAWN_MAX_K);
     if (B == 0) return DAWN_OK;
+    if (idx->staged) {  // (rows added one by one since the last call: they join the index now — this one search synchronises)
+        const int rc = dawn::guarded([&] { return flush_adds(idx); });
+        if (rc != DAWN_OK) return rc;
+    }
     if (idx->shards)
         return dawn::guarded(
             [&] { return dawn::sharded_search_device(idx, d_queries, B, count, d_labels, d_distances, d_found, (hipStream_t)stream); });
@@ -875,6 +921,10 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
     for (size_t b = 0; b < B; ++b)  // search_provider.rs:206-208
         if (!dawn::host_is_normalized(queries + b * dawn::EM))
             return fail(DAWN_ERR_NOT_NORMALIZED, "Search vector is not normalized");
+    if (idx->staged) {
+        const int rc = dawn::guarded([&] { return flush_adds(idx); });
+        if (rc != DAWN_OK) return rc;
+    }
     if (idx->shards)
         return dawn::guarded([&] { return dawn::sharded_search_batch(idx, queries, B, count, labels, distances, found); });
     DAWN_TRY(set_device(idx));
@@ -960,6 +1010,7 @@ int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (n == 0) return DAWN_OK;
     return dawn::guarded([&] {
+        DAWN_TRY(flush_adds(idx));
         if (idx->shards) return dawn::sharded_fill_synthetic(idx, seed, first_row, n, first_id);
         int rc = dawn::index_fill_async(idx, seed, first_row, n, first_id, false, 0);
         if (rc != DAWN_OK) {
@@ -973,6 +1024,7 @@ int dawn_index_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row
 int dawn_index_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     return dawn::guarded([&] {
+        DAWN_TRY(flush_adds(idx));
         return idx->shards ? dawn::sharded_get_rows(idx, first, n, out_rows, out_ids)
                            : dawn::index_get_rows_single(idx, first, n, out_rows, out_ids);
     });
@@ -987,6 +1039,7 @@ int dawn_index_save(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     return dawn::guarded([&] {
         DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        DAWN_TRY(flush_adds(idx));
         const std::string tmp = std::string(path) + ".tmp";
         const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s for writing", tmp.c_str());
@@ -1029,6 +1082,7 @@ int dawn_index_load(dawn_index* idx, const char* path) {
     if (!idx || !path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     return dawn::guarded([&] {
         DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        idx->staged = 0;  // (load replaces the contents, staged single-row adds included)
         // EVERY failure below leaves the index empty (usearch's load resets the index before it reads): the reference's
         // `if !load(path).is_ok() { fill_index_from_db() }` (search_provider.rs:115-117) must never append to old rows
         auto failed_empty = [&](int rc) {
@@ -1081,6 +1135,7 @@ int dawn_index_load_page_entries(dawn_index* idx, const char* emb_path, uint64_t
     if (!idx || !emb_path) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     return dawn::guarded([&] {
         DAWN_HIP_TRY(hipSetDevice(root_device(idx)));
+        DAWN_TRY(flush_adds(idx));
         const int fd = ::open(emb_path, O_RDONLY);
         if (fd < 0) return fail(DAWN_ERR_IO, "cannot open %s", emb_path);
         struct stat stt;
@@ -1136,8 +1191,10 @@ int dawn_index_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_by
 
 int dawn_index_set_option(dawn_index* idx, const char* name, int64_t value) {
     if (!idx || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
-    return dawn::guarded(
-        [&] { return idx->shards ? dawn::sharded_set_option(idx, name, value) : dawn::index_set_option_single(idx, name, value); });
+    return dawn::guarded([&] {
+        DAWN_TRY(flush_adds(idx));
+        return idx->shards ? dawn::sharded_set_option(idx, name, value) : dawn::index_set_option_single(idx, name, value);
+    });
 }
 
 // ---- test / timing hooks (single-device indexes only) ------------------------------------------------------------------
@@ -1146,6 +1203,7 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     if (!idx || !queries || !out || !n_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
     if (B == 0 || B > (size_t)dawn::BATCH_QT) return fail(DAWN_ERR_INVALID_ARG, "B must be 1..%d", dawn::BATCH_QT);
+    DAWN_TRY(flush_adds(idx));
     DAWN_TRY(set_device(idx));
     const size_t n = std::min<size_t>(idx->size, dawn::BATCH_CAP);
     *n_out = n;
@@ -1172,6 +1230,7 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
                                   size_t cap_blocks, size_t* n_blocks) {
     if (!idx || !query || !out_scores || !out_rows || !n_blocks) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
+    DAWN_TRY(flush_adds(idx));
     DAWN_TRY(set_device(idx));
     hipStream_t stream = idx->stream;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -1207,6 +1266,7 @@ int dawn_index_debug_time_full_pass(dawn_index* idx, size_t B, int iters, double
     if (!idx || !mean_ms || iters < 1) return fail(DAWN_ERR_INVALID_ARG, "bad argument");
     if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
     if (B == 0 || B > (size_t)dawn::BATCH_QT || !idx->bws.cand) return fail(DAWN_ERR_INVALID_ARG, "run a batched search first");
+    DAWN_TRY(flush_adds(idx));
     DAWN_TRY(set_device(idx));
     hipEvent_t e0, e1;
     DAWN_HIP_TRY(hipEventCreate(&e0));

@@ -638,6 +638,10 @@ int dawn_index_create_sharded(size_t dims, int dtype, int n_gpus, const int* dev
 
 int dawn_index_shard_info(dawn_index* idx, int* n_shards, int* gather, size_t* shard_sizes, size_t cap) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    {
+        const int rc = dawn::guarded([&] { return dawn::index_flush_adds(idx); });
+        if (rc != DAWN_OK) return rc;
+    }
     if (!idx->shards) {
         if (n_shards) *n_shards = 1;
         if (gather) *gather = 0;

@@ -18,6 +18,7 @@ constexpr size_t kMaxBatch = 256;        // queries per internal pass of the hos
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
 constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
 constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
+constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host before they travel together
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
 }  // namespace dawn
 
@@ -114,12 +115,24 @@ struct dawn_index {
     hipEvent_t ev_slot[2] = {nullptr, nullptr};
     bool ev_slot_used[2] = {false, false};
 
+    // Single-row adds (dawn_index_add — the reference's insert path and its rebuild loop call index.add once per row,
+    // search_provider.rs:149,284) are STAGED in pinned host memory: the row has passed the is_normalized gate on the host, so
+    // nothing on the device can reject it; it joins the index with the next flush — when the stage is full, or in front of
+    // whatever call looks at the rows next (search, save, get_rows, add_batch, ...): one transfer, one validation kernel, one
+    // shadow update and one synchronisation per kAddStageRows rows instead of per row.  size() counts staged rows.
+    float* h_add_rows = nullptr;     // [kAddStageRows][384], pinned (allocated at the first add)
+    uint64_t* h_add_ids = nullptr;   // [kAddStageRows]
+    size_t staged = 0;
+
     // one process, several devices (dawn_index_create_sharded): this handle owns no rows itself and routes every call
     dawn::ShardSet* shards = nullptr;
     bool pos_ids = false;  // this index is a shard of such a handle: d_ids hold global insertion positions
 };
 
 namespace dawn {
+
+// Staged single-row adds (dawn_index::h_add_rows) join the index: called in front of everything that looks at the rows.
+int index_flush_adds(dawn_index* idx);
 
 // ---- single-device pieces used by the sharded router -------------------------------------------------------------
 int index_create_single(int dtype, int device, dawn_index** out);

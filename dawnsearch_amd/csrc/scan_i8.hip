@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
 // identical to the kernel above by construction (same scores, same tests in the same order).
 // XCD: workgroup b runs on XCD b % 8 (round-robin dispatch); each XCD's workgroups sweep their own contiguous eighth of
 // the shadow instead of the chip-wide window (probe: +0.6 % at two waves per CU).
-template <int QB, bool XCD>
+template <int QB, bool XCD, int PD = 12>
 __global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
                                                                     uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                                     float* __restrict__ out_s, uint32_t* __restrict__ out_p,
@@ -505,9 +505,10 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* 
 
     if (t < t_end) {
         const u32x4* p = x + (size_t)t * (12 * 64) + lane;
-        u32x4 a[12];
+        static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+        u32x4 a[PD];
 #pragma unroll
-        for (int d = 0; d < 12; ++d) a[d] = row_load<true>(p + d * 64);
+        for (int d = 0; d < PD; ++d) a[d] = row_load<true>(p + d * 64);
         float2 mt = meta[t];
         // state of the sub-tile under test (the previous one)
         i32x16_t accs[2];  // ping-pong: one being accumulated, the other under test (no copies)
@@ -583,8 +584,9 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* 
             for (int e = 0; e < 16; ++e) acc[e] = 0;
 #pragma unroll
             for (int f = 0; f < 12; ++f) {
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f]), qf[f], acc, 0, 0, 0);
-                a[f] = row_load<true>(pn + f * 64);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
+                if (f + PD < 12) a[f % PD] = row_load<true>(p + (f + PD) * 64);
+                else a[f % PD] = row_load<true>(pn + (f + PD - 12) * 64);
                 if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -647,6 +649,18 @@ static void launch_filter_i8s_qb(const void* d_shadow, const void* d_meta, uint3
         case 4: DAWN_I8S_LAUNCH(6); break;
         case 6:  // software-pipelined test (two accumulator sets), chip-wide window
             hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, false>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
+        case 8:  // ... with a ring of 6 fragments
+            hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, false, 6>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
+        case 9:  // ... of 4
+            hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, false, 4>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
+                               q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
+            break;
+        case 10:  // ... of 3
+            hipLaunchKernelGGL((scan_filter_i8s_pipe_kernel<QB, false, 3>), dim3(g.blocks), dim3(g.threads), 0, stream, x8, mt, n_rows,
                                q8, n_q, cand_s, cand_p, (uint32_t)g.blocks);
             break;
         case 7:  // ... and per-XCD contiguous ranges

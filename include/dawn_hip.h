@@ -79,7 +79,11 @@ size_t dawn_index_capacity(const dawn_index *idx);             /* index.capacity
 
 /* index.add(id, &q) :149,284.  v = 384 f32, must pass is_normalized (vector.rs:185-192) — the
  * reference checks this right before every add (:147 bytes_to_embedding, :265-267). Grows like
- * usearch after an explicit reserve; also grows on its own when full. */
+ * usearch after an explicit reserve; also grows on its own when full.  The row is gated on the host and STAGED in pinned
+ * host memory; up to 1024 staged rows travel to the GPU together (one transfer, one shadow update, one synchronisation)
+ * when the stage is full or in front of the next call that looks at the rows (search, save, get_rows, add_batch, ...):
+ * the reference's one-row-per-call insert and rebuild loops (:127-153, :280-284) cost well under a microsecond per row.
+ * dawn_index_size counts staged rows; a growth failure (out of HBM) is reported by the call that flushes. */
 int dawn_index_add(dawn_index *idx, uint64_t id, const float *v);
 /* Bulk form of fill_index_from_db's loop (:135-150): n rows in one transfer + one validation kernel.
  * On a non-normalised row nothing is added and DAWN_ERR_NOT_NORMALIZED is returned. */

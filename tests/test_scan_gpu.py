@@ -780,3 +780,53 @@ def test_heavy_tailed_golden_fixture_all_paths(dawn, oracle):
     f = idx.debug_filter_scores(Q)
     slack = f.astype(np.float64) - Q.astype(np.float64) @ X[:f.shape[1]].astype(np.float64).T
     assert slack.min() > -4e-6 and slack.max() < 0.03, (slack.min(), slack.max())
+
+
+def test_single_row_adds_are_staged_and_flushed_in_order(dawn, oracle, tmp_path):
+    """dawn_index_add stages rows on the host (1024 at a time) and flushes them in front of whatever looks at the rows next:
+    the reference's one-row-per-call loops (search_provider.rs:127-153,280-284) see exactly the old semantics — size() counts
+    every added row at once, a search right after an add finds it, order is insertion order, a bad row is refused on the spot
+    and nothing else is lost, load() replaces staged rows too."""
+    rows = synth.unit_rows(8, 0, 2600)
+    ids = np.arange(7000, 7000 + 2600, dtype=np.uint64)
+    for devices in (None, [0, 0, 0]):
+        idx = dawn.VectorIndex(0) if devices is None else dawn.VectorIndex(devices=devices)
+        if devices is not None:
+            idx.set_option("shard_chunk", 64)
+        for i in range(2600):
+            if idx.size() == idx.capacity():
+                idx.reserve(idx.size() + 1024)
+            idx.add(int(ids[i]), rows[i])
+            assert idx.size() == i + 1
+            if i in (0, 5, 1023, 1024, 1500, 2599):  # a search right behind an add sees the row
+                lab, dist = idx.search(rows[i], 3)
+                assert lab[0] == ids[i] and dist[0] < 1e-6
+            if i == 700:
+                with pytest.raises(dawn.NotNormalizedError):
+                    idx.add(1, rows[0] * np.float32(1.5))
+                assert idx.size() == 701
+        q = synth.unit_rows(2, 5, 1)[0]
+        want = oracle.scan_topk(rows, ids, q, 20)
+        _assert_same(*idx.search(q, 20), *want)
+        got, gids = idx.get_rows(0, 2600)
+        assert np.array_equal(got, rows) and np.array_equal(gids, ids)
+        # staged rows (not flushed yet) are part of a save, and are replaced by a load
+        extra = synth.unit_rows(9, 0, 10)
+        for j in range(10):
+            idx.add(9000 + j, extra[j])
+        p = str(tmp_path / f"staged_{0 if devices is None else 1}.dawn")
+        idx.save(p)
+        other = dawn.VectorIndex(0)
+        other.load(p)
+        assert other.size() == 2610 and other.search(extra[9], 1)[0][0] == 9009
+        for j in range(5):
+            other.add(1 + j, rows[j])  # staged ...
+        assert other.size() == 2615
+        other.load(p)  # ... and dropped: load replaces the contents
+        assert other.size() == 2610
+        # batches and single adds interleave in insertion order (ties -> earlier-added row)
+        dup = dawn.VectorIndex(0)
+        dup.add(5, rows[3])
+        dup.add_batch(np.array([4, 3], dtype=np.uint64), np.stack([rows[3], rows[3]]))
+        dup.add(2, rows[3])
+        assert dup.search(rows[3], 4)[0].tolist() == [5, 4, 3, 2]
