@@ -48,9 +48,13 @@ struct dawn_index {
     const dawn::ScanGeom& shadow_geom() const {
         return (!geom_h_pinned && size < dawn::kShadowSmallRows) ? geom_h_small : geom_h;
     }
-    // int8 shadow stream: 4 waves per CU, whole sub-tiles (12 KiB) in flight per wave (tools/scan_sweep_shadow.py, 80M
-    // rows: 7.01 TB/s against 6.97 with 2 waves; everything with >= 24 KiB in flight per CU lands within 2 %)
-    dawn::ScanGeom geom_i8{256, 256, 3};
+    // int8 shadow stream: the software-pipelined kernel (scan_filter_i8s_pipe_kernel), 4 waves per CU x a ring of 6
+    // fragments = 24 KiB in flight per CU (unroll code 8).  tools/stream_pipe_ab.py, 100 M rows, interleaved rounds
+    // (profiles/r03/stream_pipe_ab_100M*.log): 5.40 ms = 7.12 TB/s = 0.890 of spec; 2 waves x 12: 5.44-5.45 (0.883); the round-2
+    // kernel (code 3, 4 waves x 12 KiB): 5.48-5.55 (0.865-0.876); 8 waves x 6: 5.49-5.52; rings of 3 / 4: 5.54-5.58.  The bare read
+    // of the same stream (tools/probes/hbm_read.hip) tops out at 7.17-7.23 TB/s: fewer bytes in flight are FASTER on this
+    // chip as long as the request stream never pauses.
+    dawn::ScanGeom geom_i8{256, 256, 8};
     // ... and 8 waves per CU below 16 M rows (12.5 M rows — one shard of 100 M on 8 GPUs —: 723 vs 731 us; 25 M: a tie)
     const dawn::ScanGeom& i8_geom() const {
         return geom_h_pinned ? geom_h : size < ((size_t)16 << 20) ? geom_h_small : geom_i8;

@@ -196,7 +196,10 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow
  *   "scan_blocks" / "scan_threads" / "scan_unroll"                  geometry of the f32-row stream
- *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the shadow fragment streams
+ *   "shadow_scan_blocks" / "shadow_scan_threads" / "shadow_scan_unroll"   geometry of the shadow fragment streams; the int8
+ *                      stream's unroll code picks the kernel: 1-4 the round-2 kernel with rings of 3 / 4 / 12 / 6 fragments, 5 the
+ *                      same with plain loads, 6 / 8 / 9 / 10 the software-pipelined kernel with rings of 12 / 6 / 4 / 3 (8 = default
+ *                      at 4 waves per CU), 7 pipelined + per-XCD address ranges; same results whatever the code
  *   "force_fallback"   1: every query also takes the exact pass (tests)
  *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
  *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails */

@@ -431,9 +431,13 @@ void orc_synth_scaled_normal(uint64_t seed, size_t n, float scale, float offset,
 
 /* model.rs:53-64  y = x·Wᵀ + b, W stored [out,in] (:188-192) */
 static void linear(const float *x, int T, int in, int out, const float *w, const float *b, float *y) {
+    /* every output element is its own sequential sum: threads split the (t, o) pairs, results do not depend on the
+     * thread count (bench.py's "all_cores" CPU embedder baseline; omp_set_num_threads(1) gives the reference's
+     * single embedding thread) */
+#pragma omp parallel for collapse(2) schedule(static) if ((size_t)T * (size_t)out * (size_t)in > 100000)
     for (int t = 0; t < T; t++) {
-        const float *xr = x + (size_t)t * in;
         for (int o = 0; o < out; o++) {
+            const float *xr = x + (size_t)t * in;
             const float *wr = w + (size_t)o * in;
             float s = 0.0f;
             for (int i = 0; i < in; i++) s += xr[i] * wr[i];

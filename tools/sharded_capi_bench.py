@@ -59,6 +59,7 @@ def main():
                 out[f"batch{B}"] = {"queries_per_s": steps * B / el, "ms_per_call_mean": el / steps * 1e3,
                                     "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
                                     "planted_top1_ok": bool(lab[0][0] == 1 + (4242 % args.rows)), "steps": steps,
+                                    "planted_labels": [int(v) for v in lab[0]],
                                     "timing": "host API (H2D queries, N shard searches, gather, merge, D2H results, sync)"}
             out["shard_info"] = idx.shard_info()
             out["stats"] = idx.stats()

@@ -16,7 +16,7 @@ idx = dawn.VectorIndex(0)
 idx.fill_synthetic(1, 0, rows, 1)
 Q = np.concatenate([synth.unit_rows(2, 0, 3), synth.planted_queries(1, [rows // 3], 4)])
 want = [idx.search(q, 20) for q in Q]
-cfgs = [(3, 256), (6, 128), (8, 256), (8, 512), (9, 256), (9, 512), (10, 512)]
+cfgs = [(3, 256), (3, 512), (6, 128), (8, 256), (8, 512)]
 acc = {c: [] for c in cfgs}
 iters = 8 if rows > 10_000_000 else 100
 for r in range(rounds):
