@@ -134,7 +134,8 @@ void f16_shadow_sync(dawn_index* idx) {
     if (idx->shadow_cap < idx->cap_phys) {
         char* ns = nullptr;
         const size_t prow = padded_rows(idx->cap_phys);
-        if (!enough_free(prow * dawn::EM * 2) || hipMalloc((void**)&ns, prow * dawn::EM * 2) != hipSuccess) {
+        if ((idx->debug_fail_alloc & 2) || !enough_free(prow * dawn::EM * 2) ||
+            hipMalloc((void**)&ns, prow * dawn::EM * 2) != hipSuccess) {
             (void)hipGetLastError();
             idx->shadow_failed = true;
             return;
@@ -171,7 +172,7 @@ bool i8_shadow_sync(dawn_index* idx) {
         idx->i8_rows = 0;
         char* ns = nullptr;
         float* nm = nullptr;
-        if (!enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
+        if ((idx->debug_fail_alloc & 1) || !enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
             hipMalloc((void**)&nm, mbytes) != hipSuccess) {
             (void)hipGetLastError();
             if (ns) (void)hipFree(ns);
@@ -657,6 +658,23 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     }
     if (n == "i8_batched") {
         idx->i8_batched = value != 0;
+        return reprepare();
+    }
+    if (n == "debug_fail_alloc") {
+        // test hook for the out-of-memory order (int8 shadow -> f16 shadow -> the f32 rows themselves): bit 0 makes the
+        // next int8-shadow allocation fail, bit 1 the next f16-shadow allocation; the shadows held now are dropped so that
+        // the allocation is attempted again.  0 restores normal behaviour (and retries).
+        if (value < 0 || value > 3) return fail(DAWN_ERR_INVALID_ARG, "debug_fail_alloc is a 2-bit mask");
+        DAWN_HIP_TRY(hipDeviceSynchronize());
+        void* drop[] = {idx->d_i8, idx->d_i8meta, idx->d_shadow};
+        for (void* p : drop)
+            if (p) (void)hipFree(p);
+        idx->d_i8 = nullptr;
+        idx->d_i8meta = nullptr;
+        idx->d_shadow = nullptr;
+        idx->i8_cap = idx->i8_rows = idx->shadow_cap = idx->shadow_rows = 0;
+        idx->i8_failed = idx->shadow_failed = false;
+        idx->debug_fail_alloc = (int)value;
         return reprepare();
     }
     if (n == "f16_shadow_b1") {

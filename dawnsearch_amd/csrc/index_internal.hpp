@@ -55,9 +55,11 @@ struct dawn_index {
     // of the same stream (tools/probes/hbm_read.hip) tops out at 7.17-7.23 TB/s: fewer bytes in flight are FASTER on this
     // chip as long as the request stream never pauses.
     dawn::ScanGeom geom_i8{256, 256, 8};
-    // ... and 8 waves per CU below 16 M rows (12.5 M rows — one shard of 100 M on 8 GPUs —: 723 vs 731 us; 25 M: a tie)
+    // ... and the round-2 kernel at 8 waves per CU x 12 KiB below 6 M rows (a few dozen sub-tiles per wave: start-up and
+    // balance count; 1 M rows: 75 us against 82 for the pipelined form at 4 waves).  12.5 M rows — one shard of 100 M on 8
+    // GPUs —: pipelined 4 x 6 694 us, round-2 8 x 12 702 us (profiles/r03/stream_pipe_ab_12p5M.log)
     const dawn::ScanGeom& i8_geom() const {
-        return geom_h_pinned ? geom_h : size < ((size_t)16 << 20) ? geom_h_small : geom_i8;
+        return geom_h_pinned ? geom_h : size < dawn::kShadowSmallRows ? geom_h_small : geom_i8;
     }
     bool shadow_failed = false;  // allocation failed once: do not retry until the index is re-created
     // int8 shadow of the index rows (ROW_I8S, scan_i8.hip: 384 B/row + 8 B per 32 rows; f32 and bf16 indexes alike) read by
@@ -71,6 +73,7 @@ struct dawn_index {
     int use_i8 = 1;              // option "i8_shadow"
     int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
     bool i8_failed = false;
+    int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 = the int8 / f16 shadow allocation fails
     float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records
     size_t stage_bytes = 0;
     size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }

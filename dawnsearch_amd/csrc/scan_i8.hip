@@ -260,6 +260,17 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const uint32_t total_waves = gridDim.x * nwaves;
     const uint32_t n_sub = (n_rows + 31u) >> 5;
     const uint32_t c = lane & 31, h = lane >> 5;
+    // the wave's first fragments are requested before anything else: they fly while the query images are made (~3 us of
+    // dependent work at the head of a kernel that lasts 75 us on 1 M rows)
+    uint32_t t = gwave;
+    const u32x4* p = x + (size_t)(t < n_sub ? t : 0) * (12 * 64) + lane;
+    u32x4 a[PD];
+    float2 mt = {0.f, 0.f};
+    if (t < n_sub) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) a[d] = row_load<NT>(p + d * 64);
+        mt = meta[t];
+    }
 
     // B operand: column c < 8 = H of query c, column 8 + c = L; lane (h, c) holds k = 32f + 16h .. +15 of k-step f.
     // The two int8 images of a query are built ONCE per workgroup, by the wave that rotates it (lane l holds elements
@@ -321,13 +332,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const bool tested = (int)c < n_q && c < 8;
     float tau_m = tested ? NEG_INF : __builtin_inff();
 
-    uint32_t t = gwave;
     if (t < n_sub) {
-        const u32x4* p = x + (size_t)t * (12 * 64) + lane;
-        u32x4 a[PD];
-#pragma unroll
-        for (int d = 0; d < PD; ++d) a[d] = row_load<NT>(p + d * 64);
-        float2 mt = meta[t];
         for (;;) {
             const uint32_t tn = t + total_waves;
             const bool more = tn < n_sub;
@@ -449,6 +454,16 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* 
         t_stride = gridDim.x * nwaves;
         t_end = n_sub;
     }
+    // the first fragments fly while the query images are made (see scan_filter_i8s_kernel)
+    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    const u32x4* p = x + (size_t)(t < t_end ? t : 0) * (12 * 64) + lane;
+    u32x4 a[PD];
+    float2 mt = {0.f, 0.f};
+    if (t < t_end) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) a[d] = row_load<true>(p + d * 64);
+        mt = meta[t];
+    }
 
     // query images: as in scan_filter_i8s_kernel
     __shared__ __attribute__((aligned(16))) signed char sh_img[2][QB][EM];
@@ -504,12 +519,6 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_pipe_kernel(const u32x4* 
     float tau_m = tested ? NEG_INF : __builtin_inff();
 
     if (t < t_end) {
-        const u32x4* p = x + (size_t)t * (12 * 64) + lane;
-        static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
-        u32x4 a[PD];
-#pragma unroll
-        for (int d = 0; d < PD; ++d) a[d] = row_load<true>(p + d * 64);
-        float2 mt = meta[t];
         // state of the sub-tile under test (the previous one)
         i32x16_t accs[2];  // ping-pong: one being accumulated, the other under test (no copies)
         float2 pmt = mt;

@@ -830,3 +830,40 @@ def test_single_row_adds_are_staged_and_flushed_in_order(dawn, oracle, tmp_path)
         dup.add_batch(np.array([4, 3], dtype=np.uint64), np.stack([rows[3], rows[3]]))
         dup.add(2, rows[3])
         assert dup.search(rows[3], 4)[0].tolist() == [5, 4, 3, 2]
+
+
+def test_out_of_memory_order_of_the_filter_sources(dawn, oracle):
+    """When HBM runs out the filters fall back int8 shadow -> f16 shadow -> the f32 rows themselves (a 100 M-row f32 index with
+    both shadows needs 230 GB).  "debug_fail_alloc" makes the allocations fail as a full card would: every stage of the order
+    must still answer bit-identically to the oracle, for single queries and for batches, and report what it holds."""
+    n = 150_000
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 11), synth.planted_queries(1, [31_337], 4)])
+    want = [oracle.scan_topk(x, ids, q, 20, threads=4) for q in Q]
+    seen = []
+    for mask in (0, 1, 3, 2, 0):  # normal; int8 fails -> f16; both fail -> rows; f16 fails alone (int8 carries everything); normal
+        idx.set_option("debug_fail_alloc", mask)
+        seen.append(idx.memory()["shadows"])
+        lab, dist, found = idx.search_batch(Q, 20)
+        for b in range(len(Q)):
+            assert np.array_equal(lab[b], want[b][0]) and np.array_equal(dist[b].view(np.uint32), want[b][1].view(np.uint32)), (mask, b)
+        for b in (0, 11):
+            _assert_same(*idx.search(Q[b], 20), *want[b])
+        # rows added while a shadow is missing keep every path exact
+        extra = synth.unit_rows(9, mask * 10, 3)
+        for j in range(3):
+            idx.add(10_000_000 + mask * 10 + j, extra[j])
+        l1, d1 = idx.search(extra[1], 1)
+        assert l1[0] == 10_000_000 + mask * 10 + 1
+        x = np.concatenate([x, extra])
+        ids = np.concatenate([ids, np.arange(10_000_000 + mask * 10, 10_000_000 + mask * 10 + 3, dtype=np.uint64)])
+        want = [oracle.scan_topk(x, ids, q, 20, threads=4) for q in Q]
+    i8_bytes, f16_bytes = n * 384, n * 768
+    assert seen[0] >= i8_bytes and seen[0] < f16_bytes          # int8 shadow only
+    assert seen[1] >= f16_bytes and seen[1] < 2 * f16_bytes          # f16 shadow only
+    assert seen[2] == 0                                          # nothing: the filters stream the f32 rows
+    assert seen[3] >= i8_bytes and seen[3] < f16_bytes and seen[4] >= i8_bytes
+    assert idx.stats()["fallbacks"] == 0
