@@ -1006,27 +1006,88 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
                                                          const uint2* __restrict__ cand,
                                                          uint32_t* __restrict__ cnt, uint32_t dense_count,
                                                          uint32_t m, float* __restrict__ tau) {
-    __shared__ float sh_s[16][LIST];
-    __shared__ uint32_t sh_p[16][LIST];
+    // The m-th largest of a query's <= 8192 sample scores by radix selection on the order-preserving key (three digits of
+    // 11 + 11 + 10 bits, LDS histograms, one block scan per digit): every thread keeps its <= 8 values in registers and
+    // touches memory once.  (Round 2 kept a sorted 64-entry list per wave — a bitonic sort, up to eight insert rounds and
+    // a four-level block merge, ~1200 instructions per wave, sixteen waves per CU: 15-20 us; this is the same value.)
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t misc[32];  // [0] crossing digit [1] entries above it; [16..31] scan scratch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tid = threadIdx.x;
     const int b = blockIdx.x;
-    uint32_t count = DENSE ? dense_count : 0u;
-    if (count > (uint32_t)BATCH_CAP) count = BATCH_CAP;
-    float s;
-    uint32_t p;
-    block_top64<DENSE>(dense + (size_t)b * BATCH_CAP, cand + (size_t)b * BATCH_CAP, cnt + (size_t)b * BATCH_CAND_SEGS, count,
-                       s, p, sh_s, sh_p, wave, lane, 16, m);
-    if (wave != 0) return;
-    const uint32_t have = __popcll(__ballot(p != NO_POS));
-    float t = NEG_INF;
-    if (have > 0) {
-        const uint32_t pick = (m <= have ? m : have) - 1u;
-        t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)pick));
+    constexpr int PER = BATCH_CAP / 1024;  // 8
+    uint32_t key[PER];
+    uint32_t have = 0;
+    if (DENSE) {
+        const uint32_t count = dense_count < (uint32_t)BATCH_CAP ? dense_count : (uint32_t)BATCH_CAP;
+        const float* dq = dense + (size_t)b * BATCH_CAP;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t e = tid + 1024u * j;
+            const float v = e < count ? dq[e] : NEG_INF;
+            key[j] = v > NEG_INF ? order_key(v) : 0u;  // 0 = no entry (order_key of a score is never 0: that is -NaN)
+        }
+    } else {
+        const uint2* cq = cand + (size_t)b * BATCH_CAP;
+        const uint32_t* cn = cnt + (size_t)b * BATCH_CAND_SEGS;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t e = tid + 1024u * j, sg = e / SEG_CAP, jj = e % SEG_CAP;
+            uint32_t c = cn[sg];
+            if (c > SEG_CAP) c = SEG_CAP;
+            key[j] = jj < c ? order_key(__builtin_bit_cast(float, cq[e].x)) : 0u;
+        }
     }
-    if (lane == 0) tau[b] = t;
-    // (every wave read its segment's count before the first barrier of block_top64's merge)
-    if (lane < BATCH_CAND_SEGS) cnt[(size_t)b * BATCH_CAND_SEGS + lane] = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) have += key[j] != 0u;
+    // total number of entries (block sum)
+    const uint32_t incl_have = block_incl_scan_u32(have, misc + 16, wave, lane);
+    if (tid == 1023) misc[2] = incl_have;
+    __syncthreads();
+    const uint32_t total = misc[2];
+    __syncthreads();
+    float t = NEG_INF;
+    if (total > 0) {
+        uint32_t rank = m <= total ? m : total;  // 1-based from the top
+        uint32_t prefix = 0;                      // the digits fixed so far, right-aligned
+        // digit p covers key bits [shift, shift + bits)
+        const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int sh = shifts[p];
+            const uint32_t mask = (1u << nbits[p]) - 1u;
+            hist[2 * tid] = 0;
+            hist[2 * tid + 1] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t kk = key[j];
+                const bool in = kk != 0u && (p == 0 || (kk >> (sh + nbits[p])) == prefix);
+                if (in) atomicAdd(&hist[(kk >> sh) & mask], 1u);
+            }
+            __syncthreads();
+            // digits in descending order: thread t owns digits 2047 - 2t and 2046 - 2t (zero counts beyond the digit's range)
+            const uint32_t c0 = hist[2047 - 2 * tid], c1 = hist[2046 - 2 * tid];
+            const uint32_t incl = block_incl_scan_u32(c0 + c1, misc + 16, wave, lane);
+            const uint32_t excl = incl - (c0 + c1);
+            if (excl < rank && excl + c0 >= rank) {
+                misc[0] = 2047 - 2 * tid;
+                misc[1] = excl;
+            } else if (excl + c0 < rank && incl >= rank) {
+                misc[0] = 2046 - 2 * tid;
+                misc[1] = excl + c0;
+            }
+            __syncthreads();
+            prefix = (prefix << nbits[p]) | misc[0];
+            rank -= misc[1];
+            __syncthreads();
+        }
+        t = key_to_float(prefix);
+    }
+    if (tid == 0) tau[b] = t;
+    // (every thread read its segments' counts at the top)
+    if (tid < BATCH_CAND_SEGS) cnt[(size_t)b * BATCH_CAND_SEGS + tid] = 0u;
 }
 
 // Final: shortlist = top-64 candidates by filter score; exact rescore in the reference order; certificate.

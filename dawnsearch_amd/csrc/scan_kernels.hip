@@ -541,6 +541,7 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
 // The last workgroup to finish a query merges the per-workgroup lists and writes the result (done[b]: arrival counter,
 // zero between searches): the exact pass is ONE launch, and when no flag is set — every search on ordinary data — it
 // costs one empty kernel instead of two.
+constexpr int kMaxFlags = 256;
 template <int RT>
 __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict__ x, const uint64_t* __restrict__ ids,
                                                         uint32_t n_rows, const float* __restrict__ q, int n_q,
@@ -557,9 +558,15 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
     const int nwaves = blockDim.x >> 6;
     const uint32_t gwave = blockIdx.x * nwaves + wave;
     const uint32_t total_waves = gridDim.x * nwaves;
+    // all flags of the batch in one round trip (n_q <= kMaxFlags: the search paths pass at most 256 queries per launch): a
+    // slot's 16 flags read one after the other in the loop below were 16 dependent loads — 8 of the 12 us this launch
+    // took behind a 256-query search in which no flag was set
+    __shared__ uint32_t sh_flags[kMaxFlags];
+    for (int i = threadIdx.x; i < n_q && i < kMaxFlags; i += blockDim.x) sh_flags[i] = flags[i];
+    __syncthreads();
     // grid.y <= 16 query slots: the common launch (no flag set) costs a few thousand workgroups less than one per query
     for (int b = blockIdx.y; b < n_q; b += gridDim.y) {
-        const uint32_t flag = flags[b];
+        const uint32_t flag = b < kMaxFlags ? sh_flags[b] : flags[b];
         // certificate statistics of the index (dawn_index_stats*): this kernel closes every search and sees every
         // query's final flag, so the counters also cover searches issued through dawn_index_search_device
         if (stats && flag != FLAG_OK && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[flag], 1u);
