@@ -698,11 +698,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     }
     if (n == "mfma_sched") {
 #ifdef DAWN_EXPERIMENTS
-        const bool ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 5 || value == 6 || value == 32 || (value >= 41 && value <= 55);
+        const bool ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 5 || value == 32 || (value >= 41 && value <= 55);
 #else
-        const bool ok = value == 0 || value == 1 || value == 4 || value == 5 || value == 6 || value == 32;
+        const bool ok = value == 0 || value == 1 || value == 4 || value == 5 || value == 32;
 #endif
-        if (!ok) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 4, 5, 6 or 32");
+        if (!ok) return fail(DAWN_ERR_INVALID_ARG, "mfma_sched must be 0, 1, 4, 5 or 32");
 #ifdef DAWN_EXPERIMENTS
         if (value == 2 && !idx->bws.diag) {
             DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.diag, 4096 * 8 * 8 * sizeof(unsigned long long)));

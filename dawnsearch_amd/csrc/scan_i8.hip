@@ -1562,236 +1562,6 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
 #undef DAWN_I16_FOFF
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 3: the append pass with the QUERIES in registers and the rows straight from global memory (no LDS image, no
-// LDS-DMA, no block barrier) — the batch form of the single-query stream above.
-//
-// A CDNA4 wave running alone on its SIMD owns 512 registers per lane.  The int8 images of 128 queries are 8 groups x 6
-// k-steps x 16 B per lane = 192 registers: they live in AGPRs for the whole kernel and enter v_mfma_i32_16x16x64_i8
-// directly as SrcB.  A wave then needs nothing but the rows: one 16-B global load per lane is the A operand of EIGHT MFMAs
-// (16 rows x 64 k against 8 x 16 queries), the ring holds two 32-row sub-tiles (24 loads = 24 KiB in flight per wave).
-// Two waves of a workgroup share a row stream — wave qh takes queries 128 qh ..+127, the second wave's loads of the same
-// lines hit L1/L2 — so a workgroup walks two streams (four when the batch has <= 128 queries).  The pass of
-// scan_i8_pipe16_kernel moves every row tile HBM -> LDS by DMA and then reads it from LDS four times (once per wave) under
-// two barriers per tile; its MFMAs + fragment reads alone ran at the power-limited clock for 0.67-0.73 of the pass and the DMA
-// cost another 0.19.  Here the LDS does nothing but hold the hit stage.
-// A operand from the unchanged shadow (built for the 32x32x32 operand): lane (r16 = lane & 15, q4 = lane >> 4) wants
-// k = 64 s + 16 q4 ..+15 of row 16 th + r16 of the sub-tile: byte (2 s + (q4 >> 1)) * 1024 + ((q4 & 1) * 32 + 16 th + r16) * 16
-// — a wave-load touches four whole 256-B segments.  Thresholds, hit staging, flush: as in scan_i8_pipe16_kernel (same
-// candidates, same results).
-// ------------------------------------------------------------------------------------------------
-template <int HALVES>  // 2: up to 256 queries, a pair of waves per row stream; 1: up to 128 queries, every wave its own stream
-__global__ __launch_bounds__(256) void scan_i8_regq_kernel(const unsigned char* __restrict__ xs, const float2* __restrict__ meta,
-                                                           uint32_t n_rows, const i32x4_t* __restrict__ qi,
-                                                           const float2* __restrict__ qmeta, int n_q,
-                                                           const float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                           uint2* __restrict__ cand) {
-    constexpr int NW = 4, NG = 8, STREAMS = NW / HALVES;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[NW * I16_ECAP * I16_EDW];
-    __shared__ float2 sh_qm[BATCH_QT];  // {s_q, K2} for the slow path (a global load there would drain the ring: vmcnt is in order)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t r16 = lane & 15, q4 = lane >> 4;
-    const int qh = wave % HALVES, rs = wave / HALVES;
-    const int q_base = qh * 128;  // first query of this wave
-    const uint32_t n_sub = (n_rows + 31u) >> 5;
-    const uint32_t ts = gridDim.x * STREAMS;
-    uint32_t t = blockIdx.x * STREAMS + rs;  // this wave's sub-tiles: t, t + ts, ...
-
-    // the rows first: two sub-tiles in flight while the query images are fetched
-    const uint32_t lane_off = (q4 >> 1) * 1024u + (q4 & 1u) * 512u + r16 * 16u;
-    auto sub_ptr = [&](uint32_t tt) { return xs + (size_t)tt * (12 * 1024) + lane_off; };
-    i32x4_t a[2][12];  // [slot][th * 6 + s]
-    const bool any_rows = t < n_sub;
-    {
-        const unsigned char* p0 = sub_ptr(any_rows ? t : 0);
-        const unsigned char* p1 = sub_ptr(t + ts < n_sub ? t + ts : (any_rows ? t : 0));
-#pragma unroll
-        for (int f = 0; f < 12; ++f) {
-            a[0][f] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(p0 + (f / 6) * 256 + (f % 6) * 2048));
-            a[1][f] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(p1 + (f / 6) * 256 + (f % 6) * 2048));
-        }
-    }
-    i32x4_t qf[NG][6];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) qf[g][s6] = qi[(size_t)(q_base + 16 * g + (int)r16) * 24 + 4 * s6 + q4];
-    float c1[NG], c2[NG];  // (as in scan_i8_pipe_kernel: threshold = floor((c1 - E c2) / s - 2))
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int qi_ = q_base + 16 * g + (int)r16;
-        const float2 qm = qmeta[qi_];
-        c1[g] = 3.0e38f;  // padding column: threshold +2e9
-        c2[g] = 0.f;
-        if (qi_ < n_q) {
-            const float tk = tau[qi_] - qm.y;
-            const float rsq = 1.0f / qm.x;
-            c1[g] = (tk - fabsf(tk) * 1e-6f) * rsq;
-            c2[g] = 1.000001f * rsq;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) asm volatile("" ::"a"(qf[g][s6]));
-        asm volatile("" ::"v"(c1[g]), "v"(c2[g]));
-    }
-    sh_qm[tid] = qmeta[tid];  // (256 threads, BATCH_QT = 256 entries)
-    __syncthreads();
-    if (!any_rows) return;
-
-    // ---- candidate staging: scan_i8_pipe16_kernel's, a private region per wave
-    uint32_t wpos = 0;
-    auto flush_wave = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t seg = blockIdx.x % BATCH_CAND_SEGS;
-        if ((uint32_t)lane < wpos) {
-            const uint32_t* en = stage + (wave * I16_ECAP + lane) * I16_EDW;
-            const uint32_t qidx = en[4], row0 = en[5];
-            const int th_ = (int)en[6];
-            const float gl = __builtin_bit_cast(float, en[7]), ek = __builtin_bit_cast(float, en[8]);
-            uint32_t hits = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hits |= ((int)en[i] > th_ && row0 + (uint32_t)i < n_rows) ? (1u << i) : 0u;
-            uint32_t slot = hits ? atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], (uint32_t)__popc(hits)) : 0u;
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                if (hits & (1u << i)) {
-                    if (slot < I8_SEG_CAP)
-                        cand[(size_t)qidx * BATCH_CAP + seg * I8_SEG_CAP + slot] =
-                            make_uint2(__builtin_bit_cast(uint32_t, __builtin_fmaf((float)(int)en[i], gl, ek)), row0 + (uint32_t)i);
-                    ++slot;
-                }
-            }
-        }
-        wpos = 0;
-    };
-    const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
-    auto stage_hits = [&](const i32x4_t& acc_, int mxl, uint32_t row_base, uint32_t q_first, int thr_lane, float gl, float ek)
-        __attribute__((always_inline)) {
-        const bool hitl = mxl > thr_lane;
-        const unsigned long long hm = __ballot(hitl);
-        const uint32_t n = (uint32_t)__popcll(hm);
-        if (wpos + n > I16_ECAP) {
-            flush_wave();
-            asm volatile("" ::: "memory");
-        }
-        if (hitl) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-            const uint32_t pa = stage_base + (wave * I16_ECAP + wpos + rank) * (I16_EDW * 4u);
-            asm volatile(
-                "ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16\n\tds_write_b32 %0, %3 offset:20\n\t"
-                "ds_write_b32 %0, %4 offset:24\n\tds_write_b32 %0, %5 offset:28\n\tds_write_b32 %0, %6 offset:32"
-                :
-                : "v"(pa), "v"(acc_), "v"(q_first + r16), "v"(row_base + 4 * q4), "v"(thr_lane), "v"(gl), "v"(ek));
-        }
-        wpos += n;
-    };
-
-    i32x4_t acc[2][NG];  // [tile parity][group]
-    int mx[NG], thr[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        mx[g] = 0;
-        thr[g] = 0x7fffffff;
-    }
-    float2 mt_cur = meta[t];        // {1 / s, E} of the sub-tile whose MFMAs run
-    float2 mt_test = mt_cur;        // ... of the sub-tile whose tiles are under test
-    uint32_t row_test = 0;          // first row of the 16-row tile under test
-    bool have_prev = false;
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    // integer thresholds of the sub-tile in mt_test for groups 2 p, 2 p + 1 (one packed fma pair)
-    auto set_thr2 = [&](int p) __attribute__((always_inline)) {
-        const float rs_ = mt_test.x, e_ = mt_test.y;
-        const f32x2_t u = __builtin_elementwise_fma(f32x2_t{-e_, -e_}, f32x2_t{c2[2 * p], c2[2 * p + 1]}, f32x2_t{c1[2 * p], c1[2 * p + 1]});
-        const f32x2_t t2 = __builtin_elementwise_fma(u, f32x2_t{rs_, rs_}, f32x2_t{-2.0f, -2.0f});
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float tf = __builtin_amdgcn_fmed3f(i == 0 ? t2.x : t2.y, -2.0e9f, 2.0e9f);
-            int ti;
-            asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(ti) : "v"(tf));
-            thr[2 * p + i] = ti;
-        }
-    };
-    auto slow = [&](int set) __attribute__((always_inline)) {
-        const float s_ = __builtin_amdgcn_rcpf(mt_test.x), e_ = mt_test.y;
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            if (__any(mx[g] > thr[g])) {
-                const float2 qm = sh_qm[q_base + 16 * g + (int)r16];
-                stage_hits(set ? acc[1][g] : acc[0][g], mx[g], row_test, (uint32_t)(q_base + 16 * g), thr[g], s_ * qm.x, e_ + qm.y);
-            }
-    };
-#define DAWN_RQ_ZERO(D, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(D) : "v"(A), "a"(B))
-#define DAWN_RQ_ACC(D, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
-    // one 16-row tile: 48 MFMAs on accumulator set TH; in their shadow the test of the previous tile (set 1 - TH) and the
-    // refill of the ring slot from the wave's sub-tile two steps ahead
-    auto tile = [&](auto slot_c, auto th_c, const unsigned char* pn) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_c)::value, TH = decltype(th_c)::value;
-#pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) {
-            __builtin_amdgcn_sched_barrier(0);  // (the compiler counts vmcnt for the ring: 23 younger loads stay in flight)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (s6 == 0) DAWN_RQ_ZERO(acc[TH][g], a[SLOT][TH * 6 + s6], qf[g][0]);
-                else DAWN_RQ_ACC(acc[TH][g], a[SLOT][TH * 6 + s6], qf[g][s6]);
-                // slices of the previous tile's test, one after each MFMA
-                if (s6 == 0 && TH == 1 && (g & 1) == 0) set_thr2(g >> 1);  // this sub-tile's thresholds (tile 0's test comes below)
-                if (s6 == 1) {
-                    mx[g] = max(max(acc[1 - TH][g][0], acc[1 - TH][g][1]), max(acc[1 - TH][g][2], acc[1 - TH][g][3]));
-                    asm volatile("" : "+v"(mx[g]));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the consumed fragment's register takes the same fragment of the sub-tile two steps ahead
-            a[SLOT][TH * 6 + s6] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(pn + TH * 256 + s6 * 2048));
-            __builtin_amdgcn_sched_barrier(0);
-            if (s6 == 2 && have_prev) {
-                bool hit = false;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) hit = hit || mx[g] > thr[g];
-                if (__builtin_expect(__any(hit), 0)) slow(1 - TH);
-            }
-        }
-    };
-    typedef std::integral_constant<int, 0> C0;
-    typedef std::integral_constant<int, 1> C1;
-    // one sub-tile in ring slot SLOT.  Tile 0's shadow tests tile 1 of the PREVIOUS sub-tile (its thresholds are still in
-    // thr); tile 1's shadow computes this sub-tile's thresholds, then tests tile 0.
-    auto sub = [&](auto slot_c) __attribute__((always_inline)) {
-        const uint32_t t2 = t + 2 * ts;
-        const unsigned char* pn = sub_ptr(t2 < n_sub ? t2 : t);  // (past the end: re-read this sub-tile, no branch in the stream)
-        const uint32_t tn = t + ts;
-        const float2 mt_next = meta[tn < n_sub ? tn : t];
-        tile(slot_c, C0(), pn);
-        // tile 0's MFMAs are issued: from here on the tests belong to THIS sub-tile
-        mt_test = mt_cur;
-        row_test = t * 32u;
-        have_prev = true;
-        tile(slot_c, C1(), pn);
-        row_test = t * 32u + 16u;
-        mt_cur = mt_next;
-        t = tn;
-    };
-    // (the test of tile 0 reads thr computed in tile 1's first k-step: set_thr2 runs at s6 == 0, the test at s6 == 2)
-    for (;;) {
-        sub(C0());
-        if (t >= n_sub) break;
-        sub(C1());
-        if (t >= n_sub) break;
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the ring's look-ahead loads; the last MFMAs
-    // the last tile (tile 1 of the last sub-tile: accumulator set 1, thresholds in thr, row_test set)
-#pragma unroll
-    for (int g = 0; g < NG; ++g) mx[g] = max(max(acc[1][g][0], acc[1][g][1]), max(acc[1][g][2], acc[1][g][3]));
-    slow(1);
-    flush_wave();
-#undef DAWN_RQ_ZERO
-#undef DAWN_RQ_ACC
-}
-
 // append pass; mfma_sched 41 / 42 / 44 / 47: timing experiments with parts switched off (results are wrong)
 static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t n_rows, uint32_t stride, uint32_t n_tiles,
                              const i32x4_t* qi, const float2* qm, int B, const BatchWorkspace& ws, uint32_t blocks,
@@ -1810,17 +1580,6 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 50: DAWN_I8_PIPE(32); break;
 #endif
         case 32: DAWN_I8_PIPE(0); break;  // the 32x32x32 form (option "mfma_sched" = 32)
-        case 6:  // queries in registers, rows straight from global memory (full passes only)
-            if (stride == 1) {
-                if (B > 128)
-                    hipLaunchKernelGGL(scan_i8_regq_kernel<2>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, qi, qm, B, ws.tau, ws.cnt,
-                                       reinterpret_cast<uint2*>(ws.cand));
-                else
-                    hipLaunchKernelGGL(scan_i8_regq_kernel<1>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, qi, qm, B, ws.tau, ws.cnt,
-                                       reinterpret_cast<uint2*>(ws.cand));
-                break;
-            }
-            [[fallthrough]];
         default:
             hipLaunchKernelGGL(scan_i8_pipe16_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
                                qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
