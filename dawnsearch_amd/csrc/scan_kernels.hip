@@ -564,8 +564,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
     __shared__ uint32_t sh_flags[kMaxFlags];
     for (int i = threadIdx.x; i < n_q && i < kMaxFlags; i += blockDim.x) sh_flags[i] = flags[i];
     __syncthreads();
-    // grid.y <= 16 query slots: the common launch (no flag set) costs a few thousand workgroups less than one per query
-    for (int b = blockIdx.y; b < n_q; b += gridDim.y) {
+    for (int b = blockIdx.y; b < n_q; b += gridDim.y) {  // (gridDim.y == 1)
         const uint32_t flag = b < kMaxFlags ? sh_flags[b] : flags[b];
         // certificate statistics of the index (dawn_index_stats*): this kernel closes every search and sees every
         // query's final flag, so the counters also cover searches issued through dawn_index_search_device
@@ -634,7 +633,10 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                        const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
                        int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
-    const dim3 grid(n_lists, B < 16 ? B : 16);
+    // one workgroup per list; it walks the batch's flags (LDS, one round trip) and scans for the flagged queries one after the
+    // other.  (Round 2 launched 16 query slots side by side: 4096 workgroups whose launch alone took 12 us behind every 256-query
+    // search, flags set or not; a flagged query's scan is HBM-bound with 256 workgroups, so the slots bought nothing.)
+    const dim3 grid(n_lists, 1);
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, d_stats,
                            cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
