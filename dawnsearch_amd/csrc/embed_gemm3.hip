@@ -493,10 +493,15 @@ static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp
     return launch_g3_big_v<0>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
 }
 
-// The 128 x 128 kernel is used when the GEMM has at least this many of its tiles (two per CU): below that the chip is better
-// filled by four times as many 64 x 64 tiles (4708 rows, 64 / 128 tiles: N = 384: 15.8 / 21.4 us, K = 1536: 44 / 68 us;
-// N = 1536: 51 / 46 us; 32768 rows: 857 / 761 us for the four shapes of a layer — tools/gemm3_probe.py).  0 = always.
-int g_gemm3_big_min_m = 512;
+// The 128 x 128 kernel is used when the GEMM has at least this many of its tiles: below that the chip is better filled by four
+// times as many 64 x 64 tiles (4708 rows, 64 / 128 tiles: N = 384 — 111 tiles —: 15.8 / 21.4 us, K = 1536: 44 / 68 us;
+// N = 1536 — 444 tiles —: 51 / 46 us; 32768 rows: 857 / 761 us for the four shapes of a layer — tools/gemm3_probe.py).
+// Round 3, whole forwards (tools/embed_tile_sweep.py, profiles/r03/embed_tile_sweep.log; results are bit-identical whatever the
+// form): the round-2 threshold of 512 tiles (two per CU) kept every GEMM of a 4708-token batch and the N = 384 GEMMs of a 9174-token
+// batch on the small form; from ~190 tiles (three quarters of the CUs busy with one persistent workgroup each) the big form
+// wins: 256 queries / 4708 tokens 0.965 -> 0.90 ms, 512 queries / 9174 tokens 1.71 -> 1.50 ms, 64 pages 1.44 -> 1.40 ms;
+// at 111 tiles it loses (1.00 ms).  0 = always.
+int g_gemm3_big_min_m = 190;
 int g_gemm3_stages = 2;  // tuning: ring depth of the bf16x3 kernel (2 .. 4)
 
 template <int STAGES>

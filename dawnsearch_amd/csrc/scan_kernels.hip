@@ -558,18 +558,25 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
     const int nwaves = blockDim.x >> 6;
     const uint32_t gwave = blockIdx.x * nwaves + wave;
     const uint32_t total_waves = gridDim.x * nwaves;
-    // all flags of the batch in one round trip (n_q <= kMaxFlags: the search paths pass at most 256 queries per launch): a
-    // slot's 16 flags read one after the other in the loop below were 16 dependent loads — 8 of the 12 us this launch
-    // took behind a 256-query search in which no flag was set
-    __shared__ uint32_t sh_flags[kMaxFlags];
-    for (int i = threadIdx.x; i < n_q && i < kMaxFlags; i += blockDim.x) sh_flags[i] = flags[i];
+    // The batch's flags, one per thread, in ONE round trip (n_q <= kMaxFlags = blockDim: the search paths pass at most 256
+    // queries per launch); the flagged queries come out of wave ballots as bit masks and only those are visited.  (Round 2
+    // read a slot's flags one after the other — 16 dependent loads per workgroup, 4096 workgroups: 12.8 us behind every
+    // 256-query search; a serial walk over 256 LDS flags was worse, 44 us.)
+    __shared__ unsigned long long sh_mask[kMaxFlags / 64];
+    {
+        const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
+        // certificate statistics of the index (dawn_index_stats*): this kernel closes every search and sees every query's
+        // final flag, so the counters also cover searches issued through dawn_index_search_device
+        if (stats && blockIdx.x == 0 && myflag != FLAG_OK) atomicAdd(&stats[myflag], 1u);
+        const unsigned long long m = __ballot(myflag == FLAG_FALLBACK);
+        if (lane == 0) sh_mask[wave] = m;
+    }
     __syncthreads();
-    for (int b = blockIdx.y; b < n_q; b += gridDim.y) {  // (gridDim.y == 1)
-        const uint32_t flag = b < kMaxFlags ? sh_flags[b] : flags[b];
-        // certificate statistics of the index (dawn_index_stats*): this kernel closes every search and sees every
-        // query's final flag, so the counters also cover searches issued through dawn_index_search_device
-        if (stats && flag != FLAG_OK && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[flag], 1u);
-        if (flag != FLAG_FALLBACK) continue;  // block-uniform
+    for (int w = 0; w < kMaxFlags / 64; ++w) {
+      unsigned long long todo = sh_mask[w];  // block-uniform
+      while (todo) {
+        const int b = w * 64 + __builtin_ctzll(todo);
+        todo &= todo - 1;
         const float* qv = q + (size_t)b * EM;
 
         float ls = NEG_INF, tau = NEG_INF;
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
             }
         }
         __syncthreads();  // sh_s / sh_p / sh_last are reused by the next query
+      }
     }
 }
 
