@@ -43,6 +43,19 @@
 #include "kernels.hpp"
 #include "wave_topk.hpp"
 
+#ifdef DAWN_EXPERIMENTS
+// timestamp probes (100-MHz counter) of scan_filter_i8s_kernel: workgroups 0 / 85 / 170 / 255, first and last wave, 8 points
+// (dawn_debug_read_ts_i8; tools/stream_ts.py)
+static __device__ unsigned long long dawn_ts_i8[4 * 2 * 8];
+#define DAWN_TSI(i)                                                                                            \
+    do {                                                                                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x % 85 == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == (blockDim.x >> 6) - 1)) \
+            dawn_ts_i8[((blockIdx.x / 85) * 2 + ((threadIdx.x >> 6) != 0)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();               \
+    } while (0)
+#else
+#define DAWN_TSI(i)
+#endif
+
 namespace dawn {
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
+    __shared__ float sh_strip[16][32];  // (QB == 1) a sub-tile's 32 upper bounds, one strip per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const uint32_t total_waves = gridDim.x * nwaves;
     const uint32_t n_sub = (n_rows + 31u) >> 5;
     const uint32_t c = lane & 31, h = lane >> 5;
+    DAWN_TSI(0);
     // the wave's first fragments are requested before anything else: they fly while the query images are made (~3 us of
     // dependent work at the head of a kernel that lasts 75 us on 1 M rows)
     uint32_t t = gwave;
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
         if (lane == 0) sh_sq[b] = sq;
     }
     __syncthreads();
+    DAWN_TSI(1);
     i32x4_t qf[12];
     const int qcol = (int)(c & 7u);
     float sq254_l = 0.f, k2_l = 0.f, rsq254_l = 0.f;  // this lane's query: s_q / 254, K2, 254 / s_q
@@ -332,8 +348,13 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
     const bool tested = (int)c < n_q && c < 8;
     float tau_m = tested ? NEG_INF : __builtin_inff();
 
+    DAWN_TSI(2);
+    [[maybe_unused]] int ts_iter = 0;
     if (t < n_sub) {
         for (;;) {
+            if (ts_iter == 1) DAWN_TSI(3);
+            if (ts_iter == 2) DAWN_TSI(4);
+            ++ts_iter;
             const uint32_t tn = t + total_waves;
             const bool more = tn < n_sub;
             // the ring runs into the wave's next sub-tile (the last one re-reads its own first fragments: no branch)
@@ -367,6 +388,49 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
             for (int e = 1; e < 16; ++e) mx = max(mx, C[e]);
             if (__any(mx > thr)) {
                 const uint32_t row_base = t * 32u;
+                bool merged = false;
+                if constexpr (QB == 1) {
+                    // Many hits in one sub-tile — the first sub-tiles of every wave, while its list fills: a wave's first 64
+                    // rows all enter, the j-th sub-tile still contributes 64 / (j + 1) — are merged as ONE sorted batch instead
+                    // of one ballot-and-shift insertion each: the 32 upper bounds, held by the two lanes of column 0, go through
+                    // a 128-B strip of LDS to one per lane, a bitonic sort and one merge64.  Same list afterwards (rows arrive in
+                    // ascending order: a later row never displaces an equal score).
+                    int nh = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        nh += (C[e] > thr && row_base + (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h < n_rows) ? 1 : 0;
+                    const int total = __builtin_amdgcn_readlane(nh, 0) + __builtin_amdgcn_readlane(nh, 32);
+                    if (total > 6) {
+                        float* strip = &sh_strip[wave][0];
+                        if (c == 0) {  // lanes 0 (h = 0) and 32 (h = 1)
+                            const float g1 = __builtin_amdgcn_rcpf(mt.x) * sq254[0], g0 = mt.y + k2[0];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
+                                const bool ok = C[e] > thr && row_base + roff < n_rows;
+                                strip[roff] = ok ? __builtin_fmaf((float)C[e], g1, g0) : NEG_INF;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private strip: LDS operations of a wave are in order)
+                        float d = POS_INF;
+                        uint32_t row = NO_POS;
+                        if (lane < 32) {
+                            const float sc = strip[lane];
+                            if (sc > tau[0]) {
+                                d = -sc;
+                                row = row_base + (uint32_t)lane;
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        sort64_asc(d, row, lane);
+                        const float os = -__shfl(d, 63 - lane);
+                        const uint32_t op = __shfl(row, 63 - lane);
+                        merge64(ls[0], lp[0], os, op, lane);
+                        tau[0] = read_lane63(ls[0]);
+                        merged = true;
+                    }
+                }
+                if (!merged) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
@@ -390,6 +454,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
                         }
                     }
                 }
+                }
 #pragma unroll
                 for (int b = 0; b < QB; ++b)
                     if ((int)c == b && tested) {
@@ -404,10 +469,12 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
         }
     }
 
+    DAWN_TSI(5);
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         if (b < n_q) {  // uniform
             block_merge(ls[b], lp[b], sh_s, sh_p, wave, lane, nwaves);
+            DAWN_TSI(6);
             if (wave == 0) {
                 const size_t o = ((size_t)b * q_stride_lists + blockIdx.x) * LIST + lane;
                 out_s[o] = ls[b];
@@ -415,6 +482,7 @@ __global__ __launch_bounds__(512) void scan_filter_i8s_kernel(const u32x4* __res
             }
         }
     }
+    DAWN_TSI(7);
 }
 
 // ---- the same filter, software-pipelined (round 3; the default) ------------------------------------------------------
@@ -1669,3 +1737,12 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
 }
 
 }  // namespace dawn
+
+#ifdef DAWN_EXPERIMENTS
+extern "C" int dawn_debug_read_ts_i8(unsigned long long* out, int n) {
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_i8), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 64; ++i) out[i] = h[i];
+    return 0;
+}
+#endif
