@@ -660,6 +660,13 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->i8_batched = value != 0;
         return reprepare();
     }
+    if (n == "debug_i8_levels") {  // experiment hook: quantise the int8 shadow to +-value levels (127 = normal); process-wide
+        if (value < 3 || value > 127) return fail(DAWN_ERR_INVALID_ARG, "debug_i8_levels must be 3..127");
+        DAWN_HIP_TRY(hipDeviceSynchronize());
+        dawn::g_i8_levels = (float)value;
+        idx->i8_rows = 0;  // re-quantise everything
+        return reprepare();
+    }
     if (n == "debug_fail_alloc") {
         // test hook for the out-of-memory order (int8 shadow -> f16 shadow -> the f32 rows themselves): bit 0 makes the
         // next int8-shadow allocation fail, bit 1 the next f16-shadow allocation; the shadows held now are dropped so that

@@ -96,6 +96,7 @@ void launch_scan_filter_f16s(const void* d_rows, int rt, uint32_t n_rows, const 
 // int8 shadow (scan_i8.hip): d_meta = float2 {scale, error bound} per 32-row sub-tile
 void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                             uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+extern float g_i8_levels;  // quantiser levels of the int8 shadow (127; "debug_i8_levels": fewer, experiments on coarser shadows)
 void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);

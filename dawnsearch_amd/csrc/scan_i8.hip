@@ -164,7 +164,7 @@ constexpr float I8_K2_PER_SQ = 1.1f * 19.6f * I8_QRES;  // K2 = I8_K2_PER_SQ * s
 template <int RT>
 __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict__ xv, uint32_t* __restrict__ out,
                                                            float2* __restrict__ meta, uint32_t first_sub,
-                                                           uint32_t n_valid) {
+                                                           uint32_t n_valid, float levels) {
     __shared__ float sh[4];
     const uint32_t sub = first_sub + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict
     __syncthreads();
     amax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     __syncthreads();
-    const float s = fmaxf(amax, 1e-20f) / 127.0f;
+    const float s = fmaxf(amax, 1e-20f) / levels;  // levels = 127 (option "debug_i8_levels": fewer, to study coarser shadows)
     float e2 = 0.f;
     uint32_t* o = out + (size_t)sub * (12 * 256);  // 12 KiB per sub-tile, in dwords
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float t = rintf(vv[i] / s);
-            t = fminf(fmaxf(t, -127.f), 127.f);
+            t = fminf(fmaxf(t, -levels), levels);
             X[i] = (int)t;
             const float dx = vv[i] - s * t;
             e2 = __builtin_fmaf(dx, dx, e2);
@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict
     }
 }
 
+float g_i8_levels = 127.0f;  // option "debug_i8_levels"
+
 // rt: ROW_F32 (f32 rows) or ROW_BF16 (fragment-ordered bf16 rows)
 void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream) {
@@ -241,10 +243,10 @@ void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta
     if (end_sub <= first_sub) return;
     if (rt == ROW_BF16)
         hipLaunchKernelGGL(rows_to_i8s_kernel<1>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, g_i8_levels);
     else
         hipLaunchKernelGGL(rows_to_i8s_kernel<0>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, g_i8_levels);
 }
 
 // ------------------------------------------------------------------------------------------------

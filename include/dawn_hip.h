@@ -201,6 +201,8 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *                      same with plain loads, 6 / 8 / 9 / 10 the software-pipelined kernel with rings of 12 / 6 / 4 / 3 (8 = default
  *                      at 4 waves per CU), 7 pipelined + per-XCD address ranges; same results whatever the code
  *   "force_fallback"   1: every query also takes the exact pass (tests)
+ *   "debug_i8_levels"  experiment hook (process-wide): quantise the int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
+ *                      what a coarser shadow would cost the certificates (tools/coarse_shadow_probe.py); results stay exact
  *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (int8 shadow -> f16 shadow -> the rows themselves):
  *                      bit 0 / bit 1 make the int8 / f16 shadow allocation fail as if the card were full; 0 = normal
  *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
