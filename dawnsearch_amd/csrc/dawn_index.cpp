@@ -82,7 +82,7 @@ int ensure_room(dawn_index* idx, size_t extra) {
 }
 
 size_t ws_lists_needed(const dawn_index* idx) {
-    return (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks});
+    return (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks, idx->geom_i6.blocks});
 }
 
 // Search workspaces for batches of up to B queries (creation: kMaxBatch; a search_device call with more queries in one
@@ -108,11 +108,17 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     if (idx->d_cand_s) (void)hipFree(idx->d_cand_s);
     if (idx->d_cand_p) (void)hipFree(idx->d_cand_p);
     if (idx->d_flags) (void)hipFree(idx->d_flags);
+    if (idx->d_cand_es) (void)hipFree(idx->d_cand_es);
+    if (idx->d_cand_ep) (void)hipFree(idx->d_cand_ep);
     idx->d_cand_s = nullptr;
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
+    idx->d_cand_es = nullptr;
+    idx->d_cand_ep = nullptr;
     idx->ws_B = 0;
     const size_t n = B * lists * dawn::LIST;
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_es, lists * dawn::LIST * sizeof(float)));  // (6-bit stream: one query)
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_ep, lists * dawn::LIST * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, 2 * B * sizeof(uint32_t)));  // flags[B] | arrival counters of the exact pass[B]
@@ -192,6 +198,46 @@ bool i8_shadow_sync(dawn_index* idx) {
     return true;
 }
 
+// Bring the 6-bit shadow up to date (indexes of at least i6_min_rows rows); false when it is not wanted or does not fit.
+bool i6_shadow_sync(dawn_index* idx) {
+    hipStream_t stream = idx->stream;
+    if (!idx->use_i6 || idx->i6_failed || idx->size < idx->i6_min_rows || idx->size == 0) return false;
+    if (idx->i6_cap < idx->cap_phys) {
+        const size_t prow = padded_rows(idx->cap_phys) + 128;
+        const size_t bytes = prow * 288, mbytes = (prow / 32 + 1) * 8;
+        (void)hipDeviceSynchronize();  // nothing reads the old buffers any more
+        if (idx->d_i6) (void)hipFree(idx->d_i6);
+        if (idx->d_i6meta) (void)hipFree(idx->d_i6meta);
+        idx->d_i6 = nullptr;
+        idx->d_i6meta = nullptr;
+        idx->i6_cap = 0;
+        idx->i6_rows = 0;
+        char* ns = nullptr;
+        float* nm = nullptr;
+        if ((idx->debug_fail_alloc & 4) || !enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
+            hipMalloc((void**)&nm, mbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ns) (void)hipFree(ns);
+            idx->i6_failed = true;
+            return false;
+        }
+        (void)hipMemsetAsync(ns, 0, bytes, stream);
+        (void)hipMemsetAsync(nm, 0, mbytes, stream);
+        idx->d_i6 = ns;
+        idx->d_i6meta = nm;
+        idx->i6_cap = idx->cap_phys;
+    }
+    if (idx->i6_rows < idx->size) {
+        dawn::launch_rows_to_i6s(idx->d_x, idx->dtype, idx->d_i6, idx->d_i6meta, idx->i6_rows, idx->size, stream);
+        idx->i6_rows = idx->size;
+    }
+    return true;
+}
+
+bool i6_live(const dawn_index* idx) {
+    return idx->use_i6 && !idx->i6_failed && idx->d_i6 && idx->size >= idx->i6_min_rows && idx->i6_rows == idx->size &&
+           idx->shadow_small_batches;
+}
 bool i8_live(const dawn_index* idx) {
     return idx->use_i8 && !idx->i8_failed && idx->i8_rows == idx->size && (idx->d_i8 || idx->size == 0);
 }
@@ -222,6 +268,7 @@ int index_prepare_search(dawn_index* idx) {
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
     if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
+    if (idx->shadow_small_batches) (void)i6_shadow_sync(idx);  // single queries of a large index stream the 6-bit shadow
     if (idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed) {
         const bool batched_needs = !(i8_ok && idx->i8_batched);
         const bool small_needs = idx->shadow_small_batches && !i8_ok;
@@ -267,6 +314,12 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                                 idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0, idx->d_flags + b0,
                                 idx->force_fallback, stream, b0 == 0 ? e0 : nullptr, b0 == 0 ? e1 : nullptr);
         }
+    } else if (B == 1 && i6_live(idx)) {
+        // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
+        // stream's epilogue, one merge + certificate (scan_i6.hip)
+        launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_cand_s, idx->d_cand_p,
+                       idx->d_cand_es, idx->d_cand_ep, idx->geom_i6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                       idx->force_fallback, true, stream, e0, e1);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
         const ScanGeom& gh = idx->i8_geom();
@@ -303,12 +356,15 @@ int index_create_single(int dtype, int device, dawn_index** out) {
     idx->device = device;
     idx->dtype = dtype;
     if (const char* e = getenv("DAWN_I8_SHADOW")) idx->use_i8 = atoi(e) != 0;  // default of the "i8_shadow" option
+    if (const char* e = getenv("DAWN_I6_SHADOW")) idx->use_i6 = atoi(e) != 0;  // default of the "i6_shadow" option
+    if (const char* e = getenv("DAWN_I6_MIN_ROWS")) idx->i6_min_rows = (size_t)std::max(0ll, atoll(e));
     hipDeviceProp_t prop{};
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
         idx->geom_h.blocks = prop.multiProcessorCount;
         idx->geom_h_small.blocks = prop.multiProcessorCount;
         idx->geom_i8.blocks = prop.multiProcessorCount;
+        idx->geom_i6.blocks = prop.multiProcessorCount;
         idx->mfma_blocks = prop.multiProcessorCount;
     }
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -349,7 +405,7 @@ void index_destroy_single(dawn_index* idx) {
     }
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
                     idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
@@ -484,6 +540,7 @@ int index_clear(dawn_index* idx) {
     idx->pending = 0;
     idx->shadow_rows = 0;
     idx->i8_rows = 0;
+    idx->i6_rows = 0;
     return DAWN_OK;
 }
 
@@ -599,6 +656,10 @@ int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_
         const uint64_t prow = padded_rows(idx->i8_cap) + 128;
         shadows += prow * EM + (prow / 32 + 1) * 8;
     }
+    if (idx->d_i6) {
+        const uint64_t prow = padded_rows(idx->i6_cap) + 128;
+        shadows += prow * 288 + (prow / 32 + 1) * 8;
+    }
     uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
     if (idx->d_cand_s) other += (uint64_t)idx->ws_B * idx->ws_lists * LIST * 8 + 2 * idx->ws_B * 4 + 16;
     if (idx->bws.cand) other += (uint64_t)BATCH_QT * (EM * 2 + 4 + BATCH_CAND_SEGS * 4 + (uint64_t)BATCH_CAP * 8);
@@ -656,6 +717,37 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         if (value) idx->i8_failed = false;
         return reprepare();
     }
+    if (n == "i6_shadow") {  // single queries of a large index stream the 6-bit shadow (scan_i6.hip); 0: the int8 shadow
+        idx->use_i6 = value != 0;
+        if (value) idx->i6_failed = false;
+        if (!value && idx->d_i6) {  // give the memory back (28.8 GB per 100 M rows)
+            DAWN_HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(idx->d_i6);
+            (void)hipFree(idx->d_i6meta);
+            idx->d_i6 = nullptr;
+            idx->d_i6meta = nullptr;
+            idx->i6_cap = idx->i6_rows = 0;
+        }
+        return reprepare();
+    }
+    if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 6 Mi; tests: 0)
+        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "i6_min_rows must be >= 0");
+        idx->i6_min_rows = (size_t)value;
+        return reprepare();
+    }
+    if (n == "i6_scan_threads" || n == "i6_scan_ring" || n == "i6_scan_blocks") {
+        if (n == "i6_scan_threads") {
+            if (value < 64 || value > 512 || value % 64) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_threads must be 64..512, a multiple of 64");
+            idx->geom_i6.threads = (int)value;
+        } else if (n == "i6_scan_ring") {
+            if (value != 12 && value != 6 && value != 4 && value != 3 && value != 2) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_ring must be 12, 6, 4, 3 or 2");
+            idx->geom_i6.unroll = (int)value;
+        } else {
+            if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_blocks out of range");
+            idx->geom_i6.blocks = (int)value;
+        }
+        return reprepare();
+    }
     if (n == "i8_batched") {
         idx->i8_batched = value != 0;
         return reprepare();
@@ -671,16 +763,18 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         // test hook for the out-of-memory order (int8 shadow -> f16 shadow -> the f32 rows themselves): bit 0 makes the
         // next int8-shadow allocation fail, bit 1 the next f16-shadow allocation; the shadows held now are dropped so that
         // the allocation is attempted again.  0 restores normal behaviour (and retries).
-        if (value < 0 || value > 3) return fail(DAWN_ERR_INVALID_ARG, "debug_fail_alloc is a 2-bit mask");
+        if (value < 0 || value > 7) return fail(DAWN_ERR_INVALID_ARG, "debug_fail_alloc is a 3-bit mask");
         DAWN_HIP_TRY(hipDeviceSynchronize());
-        void* drop[] = {idx->d_i8, idx->d_i8meta, idx->d_shadow};
+        void* drop[] = {idx->d_i8, idx->d_i8meta, idx->d_shadow, idx->d_i6, idx->d_i6meta};
         for (void* p : drop)
             if (p) (void)hipFree(p);
         idx->d_i8 = nullptr;
         idx->d_i8meta = nullptr;
         idx->d_shadow = nullptr;
-        idx->i8_cap = idx->i8_rows = idx->shadow_cap = idx->shadow_rows = 0;
-        idx->i8_failed = idx->shadow_failed = false;
+        idx->d_i6 = nullptr;
+        idx->d_i6meta = nullptr;
+        idx->i8_cap = idx->i8_rows = idx->shadow_cap = idx->shadow_rows = idx->i6_cap = idx->i6_rows = 0;
+        idx->i8_failed = idx->shadow_failed = idx->i6_failed = false;
         idx->debug_fail_alloc = (int)value;
         return reprepare();
     }
@@ -1260,7 +1354,12 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     hipStream_t stream = idx->stream;
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
     size_t blocks;
-    if (idx->shadow_small_batches && i8_live(idx)) {
+    if (i6_live(idx)) {
+        blocks = idx->geom_i6.blocks;
+        dawn::launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->d_x, idx->dtype, idx->d_ids, (uint32_t)idx->size, idx->d_q, idx->d_cand_s,
+                             idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->geom_i6, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                             false, stream, nullptr, nullptr);
+    } else if (idx->shadow_small_batches && i8_live(idx)) {
         const dawn::ScanGeom& gh = idx->i8_geom();
         blocks = gh.blocks;
         dawn::launch_scan_filter_i8s(idx->d_i8, idx->d_i8meta, (uint32_t)idx->size, idx->d_q, 1, idx->d_cand_s, idx->d_cand_p, gh,

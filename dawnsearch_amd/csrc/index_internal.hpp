@@ -73,7 +73,22 @@ struct dawn_index {
     int use_i8 = 1;              // option "i8_shadow"
     int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
     bool i8_failed = false;
-    int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 = the int8 / f16 shadow allocation fails
+    // 6-bit shadow (ROW_I6S, scan_i6.hip: 288 B/row + 8 B per 32 rows) read by the single-query stream of an index of at
+    // least i6_min_rows rows instead of the int8 shadow (which the matrix-core pass keeps using): three quarters of its
+    // bytes, the stream is HBM-bound.  Kept current by the mutations like the int8 shadow; if it cannot be allocated (or
+    // "i6_shadow" = 0) single queries stream the int8 shadow.
+    char* d_i6 = nullptr;
+    float* d_i6meta = nullptr;
+    size_t i6_cap = 0, i6_rows = 0;
+    int use_i6 = 1;              // option "i6_shadow"
+    size_t i6_min_rows = dawn::kShadowSmallRows;  // option "i6_min_rows" (tests: 0)
+    bool i6_failed = false;
+    // its stream: `threads` / 64 waves per CU, `unroll` = fragments of 768 B in flight per wave (options "i6_scan_threads",
+    // "i6_scan_ring"); exact lists of the workgroups' epilogues [blocks][64]
+    dawn::ScanGeom geom_i6{256, 192, 12};
+    float* d_cand_es = nullptr;
+    uint32_t* d_cand_ep = nullptr;
+    int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 / 2 = the int8 / f16 / 6-bit shadow allocation fails
     float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records
     size_t stage_bytes = 0;
     size_t row_bytes() const { return dtype == DAWN_DTYPE_BF16 ? dawn::EM * 2 : dawn::EM * 4; }

@@ -1,0 +1,256 @@
+"""GPU parity tests of the 6-bit filter shadow and its single-query stream (dawnsearch_amd/csrc/scan_i6.hip).
+
+The default single-query search of a large index (>= 6 Mi rows) streams a 6-bit copy of the rows (288 B per row), rescoring
+every workgroup's 64-row shortlist exactly in the kernel's epilogue and merging the exact lists under one certificate.  Here the
+path is forced on small indexes (option "i6_min_rows" = 0) and held against the CPU oracle (oracle/dawn_oracle.c, a restatement
+of src/search/vector.rs:128-134 + exact top-k): BIT-EXACT distances, identical label order, as for every other path.  The
+full-size checks (100 M rows against the oracle's own scan) are in test_full_size_gpu.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+from test_scan_gpu import _adversarial_rows, _assert_same  # noqa: E402
+
+
+def _mk(dawn, n, dtype="f32", seed=1):
+    idx = dawn.VectorIndex(0, dtype=dtype)
+    idx.set_option("i6_min_rows", 0)
+    idx.fill_synthetic(seed, 0, n, 1)
+    return idx
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 4097, 100_003, 300_001])
+@pytest.mark.parametrize("k", [1, 10, 20, 64])
+def test_i6_stream_matches_oracle_sizes(dawn, oracle, n, k):
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 3), synth.planted_queries(1, [n // 2], 4)])
+    for q in Q:
+        lab, dist = idx.search(q, k)
+        assert len(lab) == min(k, n)
+        _assert_same(lab, dist, *oracle.scan_topk(x, ids, q, k))
+    assert idx.stats()["searches"] == 4
+    # (k = 64 of a small index whose rows all fall to one or two workgroups: the 64th listed bound is the bound of the 65th
+    # row too, the certificate fails by construction and the exact pass answers — as for every other stream)
+    if k <= 20 and (n <= 64 or n >= 1000):
+        assert idx.stats()["fallbacks"] == 0
+
+
+def test_i6_is_the_default_of_large_indexes_only(dawn, oracle):
+    """Below i6_min_rows (6 Mi by default) no 6-bit shadow is built; the option / the size crossing the limit builds it, and
+    switching it off gives the memory back.  Same results either way."""
+    n = 200_000
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    m0 = idx.memory()["shadows"]
+    q = synth.planted_queries(1, [77], 3)[0]
+    want = idx.search(q, 10)
+    idx.set_option("i6_min_rows", 100_000)
+    m1 = idx.memory()["shadows"]
+    assert m1 - m0 >= n * 288 and m1 - m0 < (n + 4096) * 290
+    got = idx.search(q, 10)
+    _assert_same(got[0], got[1], want[0], want[1])
+    sc, _ = idx.debug_stream_lists(q)
+    assert len(sc) == 256  # the 6-bit stream's grid
+    idx.set_option("i6_shadow", 0)
+    assert idx.memory()["shadows"] == m0
+    got = idx.search(q, 10)
+    _assert_same(got[0], got[1], want[0], want[1])
+    idx.set_option("i6_shadow", 1)
+    assert idx.memory()["shadows"] == m1
+    x = oracle.unit_rows(1, 0, n)
+    _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, np.arange(1, n + 1, dtype=np.uint64), q, 20))
+
+
+@pytest.mark.parametrize("n", [127, 5000, 300_001])
+def test_i6_lists_are_upper_bounds_and_cover_everything_above_T(dawn, n):
+    """What the certificate of merge_exact_kernel relies on: every listed score is an UPPER BOUND of its row's exact dot (within
+    the rounding allowance that is part of FILTER_EPS_I8), each list is descending, no row is listed twice, and every row whose
+    exact score exceeds T = the largest 64th entry of any list IS listed.  The 6-bit slack is ~4x the int8 shadow's."""
+    idx = _mk(dawn, n)
+    x = synth.unit_rows(1, 0, n)
+    for q in list(synth.unit_rows(2, 0, 2)) + [synth.planted_queries(1, [n // 2], 4)[0]]:
+        sc, rows = idx.debug_stream_lists(q)
+        valid = rows != 0xFFFFFFFF
+        assert np.all(np.isneginf(sc[~valid]))
+        got = rows[valid].astype(np.int64)
+        assert got.max() < n and len(np.unique(got)) == len(got)
+        exact = x.astype(np.float64) @ q.astype(np.float64)
+        diff = sc[valid].astype(np.float64) - exact[got]
+        assert diff.min() > -4e-6 and diff.max() < 0.08, (diff.min(), diff.max())
+        for b in range(len(sc)):
+            nv = int(valid[b].sum())
+            assert np.all(valid[b][:nv]) and np.all(np.diff(sc[b][:nv]) <= 0)
+        if n > 64:
+            T = sc[:, 63].max()
+            need = np.nonzero(exact > T + 4e-6)[0]
+            assert set(need.tolist()) <= set(got.tolist())
+        else:
+            assert len(got) == n
+
+
+@pytest.mark.parametrize("n_base", [3000, 200_000])
+def test_i6_bounds_and_results_on_adversarial_rows(dawn, oracle, n_base):
+    """Rows that hurt a per-sub-tile quantiser (one-hot, sparse, near-duplicates, a row and its negation): the bounds hold and
+    the results equal the oracle's and the int8 path's."""
+    rows, base, extra = _adversarial_rows(n_base)
+    ids = np.arange(1, len(rows) + 1, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.set_option("i6_min_rows", 0)
+    idx.add_batch(ids, rows)
+    onehot = np.zeros(384, np.float32); onehot[5] = 1.0
+    Q = np.stack([synth.unit_rows(2, 0, 1)[0], onehot, extra[7], base[9], synth.planted_queries(1, [9], 5)[0], -base[9]])
+    for q in Q:
+        sc, lr = idx.debug_stream_lists(q)
+        valid = lr != 0xFFFFFFFF
+        got = lr[valid].astype(np.int64)
+        exact = rows[got].astype(np.float64) @ q.astype(np.float64)
+        assert (sc[valid].astype(np.float64) - exact).min() > -4e-6
+    for k in (10, 20):
+        for q in Q:
+            idx.set_option("i6_shadow", 1)
+            l1, d1 = idx.search(q, k)
+            idx.set_option("i6_shadow", 0)
+            l0, d0 = idx.search(q, k)
+            _assert_same(l1, d1, l0, d0)
+            _assert_same(l1, d1, *oracle.scan_topk(rows, ids, q, k))
+
+
+def test_i6_duplicates_fail_the_certificate_and_stay_exact(dawn, oracle):
+    """More equal rows at the top than the workgroups list (20 000 copies of the best row: > 64 per workgroup): the bound T of
+    the unlisted rows reaches the k-th score, the certificate fails, the exact pass answers — earlier-added rows first."""
+    base = synth.unit_rows(1, 0, 500)
+    q = synth.planted_queries(1, [7], 3)[0]
+    rows = np.concatenate([base, np.repeat(base[7:8], 20_000, axis=0), base[:100]])
+    ids = np.arange(1000, 1000 + len(rows), dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.set_option("i6_min_rows", 0)
+    idx.add_batch(ids, rows)
+    lab, dist = idx.search(q, 20)
+    _assert_same(lab, dist, *oracle.scan_topk(rows, ids, q, 20))
+    assert lab[0] == 1007 and list(lab[1:5]) == [1500, 1501, 1502, 1503]
+    assert idx.stats()["fallbacks"] == 1
+    # a few duplicates stay on the fast path
+    rows2 = np.concatenate([base, base[7:8], base[7:8]])
+    ids2 = np.arange(1, len(rows2) + 1, dtype=np.uint64)
+    idx2 = dawn.VectorIndex(0)
+    idx2.set_option("i6_min_rows", 0)
+    idx2.add_batch(ids2, rows2)
+    lab, dist = idx2.search(q, 10)
+    _assert_same(lab, dist, *oracle.scan_topk(rows2, ids2, q, 10))
+    assert list(lab[:3]) == [8, 501, 502] and idx2.stats()["fallbacks"] == 0
+
+
+def test_i6_forced_fallback_and_distance_limit(dawn, oracle):
+    n = 50_000
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    q = synth.unit_rows(2, 0, 1)[0]
+    want = oracle.scan_topk(x, ids, q, 20)
+    lab, dist = idx.search_limited(q, 20, float(want[1][9]))
+    keep = want[1] < want[1][9]  # udp_service.rs:196-199: strictly closer than the limit
+    _assert_same(lab, dist, want[0][keep], want[1][keep])
+    idx.set_option("force_fallback", 1)
+    _assert_same(*idx.search(q, 20), *want)
+    assert idx.stats()["fallbacks"] == 1
+
+
+def test_i6_shadow_tracks_adds_and_growth(dawn, oracle):
+    """Ragged adds (the last sub-tile is re-quantised with its new rows, growth re-quantises everything) and single-row adds
+    staged on the host: every search in between equals the oracle."""
+    x = synth.unit_rows(1, 0, 5000)
+    ids = np.arange(1, 5001, dtype=np.uint64)
+    idx = dawn.VectorIndex(0)
+    idx.set_option("i6_min_rows", 0)
+    q = synth.planted_queries(1, [3], 5)[0]
+    done = 0
+    for step in (1, 30, 1, 33, 64, 1000, 7, 2864, 990):
+        idx.add_batch(ids[done:done + step], x[done:done + step])
+        done += step
+        for qq in (q, synth.unit_rows(2, done, 1)[0]):
+            _assert_same(*idx.search(qq, 10), *oracle.scan_topk(x[:done], ids[:done], qq, 10))
+    for i in range(done, 5000):
+        idx.add(int(ids[i]), x[i])
+    _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20))
+    assert idx.size() == 5000 and idx.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("threads,ring", [(64, 12), (128, 6), (192, 12), (256, 4), (320, 3), (384, 6), (512, 12)])
+def test_i6_geometries_agree(dawn, oracle, threads, ring):
+    n = 150_001
+    idx = _mk(dawn, n)
+    idx.set_option("i6_scan_threads", threads)
+    idx.set_option("i6_scan_ring", ring)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    for q in np.concatenate([synth.unit_rows(2, 0, 2), synth.planted_queries(1, [n - 1], 4)]):
+        _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20))
+    idx.set_option("i6_scan_blocks", 40)
+    q = synth.unit_rows(2, 5, 1)[0]
+    _assert_same(*idx.search(q, 10), *oracle.scan_topk(x, ids, q, 10))
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_i6_on_a_bf16_index(dawn, oracle):
+    """A bf16 index keeps a 6-bit shadow of its (bf16-rounded) rows; the exact side scores the rows as stored."""
+    n = 120_000
+    idx = _mk(dawn, n, dtype="bf16")
+    x = synth.round_bf16(oracle.unit_rows(1, 0, n))
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    sc, _ = idx.debug_stream_lists(synth.unit_rows(2, 0, 1)[0])
+    assert len(sc) == 256
+    for q in np.concatenate([synth.unit_rows(2, 0, 3), synth.planted_queries(1, [n // 3], 4)]):
+        for k in (10, 20):
+            _assert_same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_i6_allocation_failure_falls_back_to_the_int8_stream(dawn, oracle):
+    n = 80_000
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    q = synth.planted_queries(1, [5], 4)[0]
+    want = oracle.scan_topk(x, ids, q, 10)
+    m_all = idx.memory()["shadows"]
+    idx.set_option("debug_fail_alloc", 4)  # the 6-bit shadow cannot be allocated: single queries stream the int8 shadow
+    assert idx.memory()["shadows"] < m_all
+    _assert_same(*idx.search(q, 10), *want)
+    idx.add_batch(np.arange(n + 1, n + 101, dtype=np.uint64), synth.unit_rows(3, 0, 100))
+    x2 = np.concatenate([x, synth.unit_rows(3, 0, 100)])
+    ids2 = np.arange(1, n + 101, dtype=np.uint64)
+    _assert_same(*idx.search(q, 10), *oracle.scan_topk(x2, ids2, q, 10))
+    idx.set_option("debug_fail_alloc", 0)
+    assert idx.memory()["shadows"] >= m_all
+    _assert_same(*idx.search(q, 10), *oracle.scan_topk(x2, ids2, q, 10))
+
+
+def test_i6_behind_a_sharded_handle(dawn, oracle):
+    """Every shard of a one-process multi-device handle streams its own 6-bit shadow; the merged answer is the single index's."""
+    n = 90_000
+    idx = dawn.VectorIndex(0, devices=[0, 0, 0])
+    idx.set_option("i6_min_rows", 0)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    for q in np.concatenate([synth.unit_rows(2, 0, 2), synth.planted_queries(1, [n // 2], 4)]):
+        _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20))
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_i6_scan_1m(dawn, oracle):
+    n = 1_000_000
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 4), synth.planted_queries(1, [0, 12345, n - 1], 9)])
+    for q in Q:
+        for k in (10, 64):
+            _assert_same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k, threads=8))
+    assert idx.stats()["fallbacks"] == 0

@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <type_traits>
 #include <vector>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -139,6 +141,75 @@ __global__ void fill_kernel(uint32_t* x, size_t n_words) {
     }
 }
 
+
+// ---- 6-bit shadow layout (round 3): a fragment is 64 lanes x 12 B (global_load_dwordx3), a sub-tile 12 x 768 B = 9 KiB.
+// Same ring discipline as read_kernel; W3 = true: dwordx3 per lane; false: the same bytes as 9 dwordx4 loads per sub-tile
+// (three per group of four fragments).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+template <bool W3, int RING>
+__global__ __launch_bounds__(1024) void read6_kernel(const char* __restrict__ x, uint32_t n_sub, uint32_t* __restrict__ out) {
+    constexpr uint32_t SUB6 = 9216;
+    constexpr int NL = W3 ? 12 : 9;              // loads per sub-tile
+    constexpr uint32_t LB = W3 ? 12 : 16;        // bytes per lane and load
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint32_t acc = 0;
+    uint32_t t = blockIdx.x * nwaves + wave;
+    const uint32_t stride = gridDim.x * nwaves;
+    if (t < n_sub) {
+        const char* p = x + (size_t)t * SUB6 + lane * LB;
+        typedef typename std::conditional<W3, u32x3, u32x4>::type V;
+        V a[RING];
+#pragma unroll
+        for (int d = 0; d < RING; ++d) a[d] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p + d * 64 * LB));
+        for (;;) {
+            const uint32_t tn = t + stride;
+            const bool more = tn < n_sub;
+            const char* pn = more ? x + (size_t)tn * SUB6 + lane * LB : p;
+#pragma unroll
+            for (int f = 0; f < NL; ++f) {
+                const V v = a[f % RING];
+                acc ^= v[0] ^ v[1] ^ v[2];
+                if constexpr (!W3) acc ^= v[3];
+                if (f + RING < NL) a[f % RING] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p + (f + RING) * 64 * LB));
+                else a[f % RING] = __builtin_nontemporal_load(reinterpret_cast<const V*>(pn + (f + RING - NL) * 64 * LB));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!more) break;
+            t = tn;
+            p = pn;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <bool W3, int RING>
+void row6(const char* x, uint32_t n_sub6, uint32_t* out, int blocks, int threads, int reps) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int r = -1; r < reps; ++r) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((read6_kernel<W3, RING>), dim3(blocks), dim3(threads), 0, 0, x, n_sub6, out);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t = 0;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 0) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double bytes = (double)n_sub6 * 9216.0;
+    const double g = bytes / (ms.front() * 1e-3) / 1e9;
+    std::printf("6-bit stream %-9s %4d x %4d ring %2d (%5.1f KiB/CU)  best %8.3f ms  median %8.3f ms   %7.1f GB/s  (%.3f of 8 TB/s)\n",
+                W3 ? "dwordx3" : "dwordx4x9", blocks, threads, RING,
+                RING * (W3 ? 0.75 : 1.0) * (threads / 64) * (blocks / 256), ms.front(), ms[ms.size() / 2], g, g / 8000.0);
+    std::fflush(stdout);
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+}
+
 struct Result {
     double best_ms, med_ms;
 };
@@ -223,6 +294,26 @@ int main(int argc, char** argv) {
     std::printf("# %s, %d CUs; buffer %.3f GB = %u sub-tiles of 12 KiB; %d timed launches per line after 1 warm-up\n", pr.name,
                 pr.multiProcessorCount, bytes / 1e9, n_sub, reps);
     double best = 0;
+    if (argc > 3 && std::string(argv[3]) == "i6") {
+        // the 6-bit shadow of the same 100 M rows: 28.8 GB in 9-KiB sub-tiles
+        const uint32_t n6 = (uint32_t)(bytes / 9216);
+        std::printf("# --- 6-bit stream: %u sub-tiles of 9 KiB = %.3f GB\n", n6, n6 * 9216.0 / 1e9);
+        row6<true, 6>(x, n6, out, 256, 256, reps);
+        row6<true, 12>(x, n6, out, 256, 256, reps);
+        row6<true, 12>(x, n6, out, 256, 128, reps);
+        row6<true, 6>(x, n6, out, 256, 512, reps);
+        row6<true, 4>(x, n6, out, 256, 512, reps);
+        row6<true, 12>(x, n6, out, 256, 192, reps);
+        row6<true, 6>(x, n6, out, 256, 384, reps);
+        row6<false, 9>(x, n6, out, 256, 256, reps);
+        row6<false, 9>(x, n6, out, 256, 128, reps);
+        row6<false, 9>(x, n6, out, 256, 192, reps);
+        row6<false, 3>(x, n6, out, 256, 512, reps);
+        row6<false, 3>(x, n6, out, 256, 256, reps);
+        row<-2, 0, 6>(x, n_sub, out, 256, 256, reps, &best);
+        row<-2, 0>(x, n_sub, out, 256, 128, reps, &best);
+        return 0;
+    }
     if (quick) {
         for (int threads : {128, 256, 512}) row<-2, 0>(x, n_sub, out, 256, threads, reps, &best);
         row<-2, 0, 6>(x, n_sub, out, 256, 256, reps, &best);
