@@ -198,20 +198,33 @@ bool i8_shadow_sync(dawn_index* idx) {
     return true;
 }
 
-// Bring the 6-bit shadow up to date (indexes of at least i6_min_rows rows); false when it is not wanted or does not fit.
+// The 6-bit shadow is wanted by single-query searches of an index of at least i6_min_rows rows ("i8_shadow" = 0 switches
+// both integer shadows off: the 16-bit filters are then what the caller asked for).
+bool i6_wanted(const dawn_index* idx) {
+    return idx->use_i6 && idx->use_i8 && !idx->i6_failed && idx->shadow_small_batches && idx->size > 0 &&
+           idx->size >= idx->i6_min_rows;
+}
+void i6_release(dawn_index* idx) {
+    if (!idx->d_i6 && !idx->d_i6meta) return;
+    (void)hipDeviceSynchronize();  // nothing reads the buffers any more
+    if (idx->d_i6) (void)hipFree(idx->d_i6);
+    if (idx->d_i6meta) (void)hipFree(idx->d_i6meta);
+    idx->d_i6 = nullptr;
+    idx->d_i6meta = nullptr;
+    idx->i6_cap = idx->i6_rows = 0;
+}
+// Bring the 6-bit shadow up to date; when it is not wanted (any more) its memory goes back (28.8 GB per 100 M rows: next to
+// the int8 shadow there is no room for the f16 shadow of 100 M rows otherwise).  false: not live.
 bool i6_shadow_sync(dawn_index* idx) {
     hipStream_t stream = idx->stream;
-    if (!idx->use_i6 || idx->i6_failed || idx->size < idx->i6_min_rows || idx->size == 0) return false;
+    if (!i6_wanted(idx)) {
+        i6_release(idx);
+        return false;
+    }
     if (idx->i6_cap < idx->cap_phys) {
         const size_t prow = padded_rows(idx->cap_phys) + 128;
         const size_t bytes = prow * 288, mbytes = (prow / 32 + 1) * 8;
-        (void)hipDeviceSynchronize();  // nothing reads the old buffers any more
-        if (idx->d_i6) (void)hipFree(idx->d_i6);
-        if (idx->d_i6meta) (void)hipFree(idx->d_i6meta);
-        idx->d_i6 = nullptr;
-        idx->d_i6meta = nullptr;
-        idx->i6_cap = 0;
-        idx->i6_rows = 0;
+        i6_release(idx);
         char* ns = nullptr;
         float* nm = nullptr;
         if ((idx->debug_fail_alloc & 4) || !enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
@@ -234,10 +247,7 @@ bool i6_shadow_sync(dawn_index* idx) {
     return true;
 }
 
-bool i6_live(const dawn_index* idx) {
-    return idx->use_i6 && !idx->i6_failed && idx->d_i6 && idx->size >= idx->i6_min_rows && idx->i6_rows == idx->size &&
-           idx->shadow_small_batches;
-}
+bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size; }
 bool i8_live(const dawn_index* idx) {
     return idx->use_i8 && !idx->i8_failed && idx->i8_rows == idx->size && (idx->d_i8 || idx->size == 0);
 }
@@ -268,7 +278,7 @@ int index_prepare_search(dawn_index* idx) {
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
     if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
-    if (idx->shadow_small_batches) (void)i6_shadow_sync(idx);  // single queries of a large index stream the 6-bit shadow
+    (void)i6_shadow_sync(idx);  // single queries of a large index stream the 6-bit shadow (released when not wanted)
     if (idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed) {
         const bool batched_needs = !(i8_ok && idx->i8_batched);
         const bool small_needs = idx->shadow_small_batches && !i8_ok;
@@ -720,15 +730,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "i6_shadow") {  // single queries of a large index stream the 6-bit shadow (scan_i6.hip); 0: the int8 shadow
         idx->use_i6 = value != 0;
         if (value) idx->i6_failed = false;
-        if (!value && idx->d_i6) {  // give the memory back (28.8 GB per 100 M rows)
-            DAWN_HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(idx->d_i6);
-            (void)hipFree(idx->d_i6meta);
-            idx->d_i6 = nullptr;
-            idx->d_i6meta = nullptr;
-            idx->i6_cap = idx->i6_rows = 0;
-        }
-        return reprepare();
+        return reprepare();  // (0: the shadow's memory goes back — i6_shadow_sync)
     }
     if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 6 Mi; tests: 0)
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "i6_min_rows must be >= 0");

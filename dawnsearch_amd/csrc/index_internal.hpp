@@ -84,8 +84,11 @@ struct dawn_index {
     size_t i6_min_rows = dawn::kShadowSmallRows;  // option "i6_min_rows" (tests: 0)
     bool i6_failed = false;
     // its stream: `threads` / 64 waves per CU, `unroll` = fragments of 768 B in flight per wave (options "i6_scan_threads",
-    // "i6_scan_ring"); exact lists of the workgroups' epilogues [blocks][64]
-    dawn::ScanGeom geom_i6{256, 192, 12};
+    // "i6_scan_ring"); exact lists of the workgroups' epilogues [blocks][64].  tools/stream_i6_ab.py, 100 M rows, three boxes
+    // (profiles/r03/stream_i6_ab_100M_*.log, stream_i6_parts_off_100M.log; us per launch, the int8 stream on the same box
+    // 5542 / 5585 / -): 8 waves x 4 fragments 4237 / - / 4130, 8 x 3 4194 / - / 4196, 8 x 6 4288 / - / 4149, 4 x 12 4302 / - / 4146,
+    // 3 x 12 4304 / - / 4152, 4 x 6 4417, 2 x 12 4677: everything with >= 24 KiB in flight per CU lands within 2 %
+    dawn::ScanGeom geom_i6{256, 512, 4};
     float* d_cand_es = nullptr;
     uint32_t* d_cand_ep = nullptr;
     int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 / 2 = the int8 / f16 / 6-bit shadow allocation fails

@@ -299,10 +299,11 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                 av[1] = (int)(w1 & 0x3F3F3F3Fu);
                 av[2] = (int)(w2 & 0x3F3F3F3Fu);
                 av[3] = (int)(((w0 >> 6) & 0x03030303u) | ((w1 >> 4) & 0x0C0C0C0Cu) | ((w2 >> 2) & 0x30303030u));
-                // (the ring slot is free once it is unpacked: its next load goes out in front of the MFMA)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[f], acc, 0, 0, 0);
+                // (the reload BEHIND the MFMA: in front of it — the slot is free once unpacked — rings of 3-4 fragments lose 1-2 %,
+                // rings of 12 gain nothing: profiles/r03/stream_i6_parts_off_100M.log, DBG = 8)
                 if (f + PD < 12) a[f % PD] = frag_load(p + (f + PD) * I6_FRAG_DW);
                 else a[f % PD] = frag_load(pn + (f + PD - 12) * I6_FRAG_DW);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[f], acc, 0, 0, 0);
                 if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -168,7 +168,8 @@ int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_c
 /* ... of the second_chances, those a deeper round settled (the cheap kind: ~10 us per round). */
 int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
- * so far (int8: 384 B/row + 8 B per 32 rows; f16: 768 B/row), everything else (labels, search workspaces, staging). */
+ * so far (int8: 384 B/row + 8 B per 32 rows; 6-bit: 288 B/row + 8 B per 32 rows, indexes of >= 6 Mi rows; f16: 768 B/row),
+ * everything else (labels, search workspaces, staging). */
 int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
  * rows [0, n), n = min(size, 8192): out [B][n].  Lets a test check the bound the certificate relies on. */
@@ -190,8 +191,15 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *                      pipelined kernels switched off, wrong results by design — only exist in `make EXPERIMENTS=1`
  *                      builds; the release library rejects them.)
  *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (1024; twice that for count > 32)
- *   "i8_shadow"        0: no int8 shadow (384 B/row, scan_i8.hip) of the index rows: the filters read the f16 shadow of
- *                      an f32 index / the rows of a bf16 index themselves.  Default 1, or env DAWN_I8_SHADOW at creation
+ *   "i8_shadow"        0: no integer shadows (int8: 384 B/row, scan_i8.hip; 6-bit: 288 B/row, scan_i6.hip) of the index rows: the
+ *                      filters read the f16 shadow of an f32 index / the rows of a bf16 index themselves.  Default 1, or env
+ *                      DAWN_I8_SHADOW at creation
+ *   "i6_shadow"        0: no 6-bit shadow: single queries stream the int8 shadow (its memory is released; 1 rebuilds it).
+ *                      Default 1, or env DAWN_I6_SHADOW at creation
+ *   "i6_min_rows"      single queries of an index of at least this many rows stream the 6-bit shadow (default 6 Mi, or env
+ *                      DAWN_I6_MIN_ROWS at creation; below it the fixed costs of a search dominate and the shadow is not kept)
+ *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the 6-bit stream: workgroups, 64..512 threads, fragments
+ *                      of 768 B in flight per wave (12 / 6 / 4 / 3 / 2); same results whatever the geometry
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow
@@ -203,8 +211,9 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "force_fallback"   1: every query also takes the exact pass (tests)
  *   "debug_i8_levels"  experiment hook (process-wide): quantise the int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
  *                      what a coarser shadow would cost the certificates (tools/coarse_shadow_probe.py); results stay exact
- *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (int8 shadow -> f16 shadow -> the rows themselves):
- *                      bit 0 / bit 1 make the int8 / f16 shadow allocation fail as if the card were full; 0 = normal
+ *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (6-bit shadow -> int8 shadow -> f16 shadow -> the
+ *                      rows themselves): bit 0 / bit 1 / bit 2 make the int8 / f16 / 6-bit shadow allocation fail as if the card
+ *                      were full; 0 = normal
  *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
  *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);

@@ -1,7 +1,7 @@
 """BASELINE.json's full single-GPU size — 100 M x 384 f32 rows resident in HBM — checked against the oracle's own scan of
 all 100 M rows (generated chunk by chunk on the host: test_100m_default_path_equals_the_oracle_scan_of_all_rows) and
-through properties that do not need the CPU at all: independent GPU paths must agree bit for bit (f16-shadow MFMA stream, f32-row
-stream, matrix-core batched pass, forced exact pass: four different kernels over the same rows), planted rows must
+through properties that do not need the CPU at all: independent GPU paths must agree bit for bit (6-bit, int8 and f16-shadow MFMA
+streams, f32-row stream, matrix-core batched pass, forced exact pass: four different kernels over the same rows), planted rows must
 come back first with the distance the oracle computes for that ONE row, results are ascending, in range, idempotent,
 and equal to the merge of two half-index searches (the sharded identity).  The card must hold the index: on a GPU with
 less than 245 GB of free HBM these tests FAIL (this is the only 100 M evidence of the suite — a skip would hide its absence);
@@ -45,7 +45,8 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     idx = big
     Q, planted = _queries()
     assert idx.size() == N
-    # (1) batch-1 stream over the int8 shadow (default)
+    # (1) batch-1 stream over the 6-bit shadow (default from 6 Mi rows up: scan_i6.hip)
+    assert idx.memory()["shadows"] > N * (384 + 288)  # both integer shadows are resident
     res1 = [idx.search(q, K) for q in Q]
     for lab, dist in res1:
         assert len(lab) == K and np.all(np.diff(dist) >= 0) and lab.min() >= 1 and lab.max() <= N
@@ -59,6 +60,16 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     # idempotent
     lab, dist = idx.search(Q[0], K)
     assert np.array_equal(lab, res1[0][0]) and np.array_equal(dist.view(np.uint32), res1[0][1].view(np.uint32))
+    # (1b) ... and over the int8 shadow (the 6-bit one switched off: its 28.8 GB go back and are rebuilt afterwards)
+    idx.set_option("i6_shadow", 0)
+    try:
+        assert idx.memory()["shadows"] < N * (384 + 100)
+        for b in (0, 5, 6, 10, 15):
+            lab, dd = idx.search(Q[b], K)
+            assert np.array_equal(lab, res1[b][0]) and np.array_equal(dd.view(np.uint32), res1[b][1].view(np.uint32))
+    finally:
+        idx.set_option("i6_shadow", 1)
+    assert idx.memory()["shadows"] > N * (384 + 288)
     # (2) all 16 at once: the matrix-core path (pipelined kernel at this size)
     labels, dist, found = idx.search_batch(Q, K)
     for b in range(len(Q)):
@@ -73,7 +84,7 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     assert np.array_equal(l8, labels[:8]) and np.array_equal(d8.view(np.uint32), dist[:8].view(np.uint32))
     l3, d3, f3 = idx.search_batch(Q[5:8], K)
     assert np.array_equal(l3, labels[5:8]) and np.array_equal(d3.view(np.uint32), dist[5:8].view(np.uint32))
-    # (3b) the f16 shadow instead of the int8 one: stream (batch 1) and matrix-core path (all 16)
+    # (3b) the f16 shadow instead of the integer ones: stream (batch 1) and matrix-core path (all 16)
     idx.set_option("i8_shadow", 0)
     try:
         for b in (0, 7, 15):
@@ -143,9 +154,11 @@ def test_100m_batch256_all_paths_agree(dawn, big):
 def test_100m_default_path_equals_the_oracle_scan_of_all_rows(dawn, oracle, big):
     """Parity at BASELINE's metric size against the oracle ITSELF: the C oracle scans all 100 M synthetic rows (generated
     chunk by chunk on the host cores — orc_scan_topk_synth — since 153.6 GB do not fit host memory) for six queries, k = 20;
-    the default int8 path must return exactly that — labels and distance bits — at batch 1 (k = 10 and k = 20) and for the
-    same queries inside a 256-batch (k = 10 and k = 20)."""
+    the default paths must return exactly that — labels and distance bits — at batch 1 (the 6-bit stream, and the int8 stream
+    with the 6-bit shadow switched off; k = 10 and k = 20) and for the same queries inside a 256-batch (the int8 matrix-core
+    pass; k = 10 and k = 20)."""
     idx = big
+    assert idx.memory()["shadows"] > N * (384 + 288)  # (the 6-bit shadow is live: batch 1 below is its stream)
     fallbacks_before = idx.stats()["fallbacks"]
     Qp, planted = _queries()
     Q6 = np.concatenate([Qp[:3], Qp[[6, 10, 15]]])  # three plain queries; planted on rows 0, 12 345 678 and N - 1
@@ -155,6 +168,14 @@ def test_100m_default_path_equals_the_oracle_scan_of_all_rows(dawn, oracle, big)
         for k in (10, 20):
             lab, dist = idx.search(Q6[b], k)
             assert np.array_equal(lab, ol[b, :k]) and np.array_equal(dist.view(np.uint32), od[b, :k].view(np.uint32)), (b, k)
+    idx.set_option("i6_shadow", 0)
+    try:
+        for b in range(6):
+            for k in (10, 20):
+                lab, dist = idx.search(Q6[b], k)
+                assert np.array_equal(lab, ol[b, :k]) and np.array_equal(dist.view(np.uint32), od[b, :k].view(np.uint32)), (b, k)
+    finally:
+        idx.set_option("i6_shadow", 1)
     Q = synth.unit_rows(3, 0, 256)
     slots = [0, 41, 127, 128, 200, 255]
     Q[slots] = Q6
@@ -227,9 +248,16 @@ def test_125m_bf16_shard_paths_agree(dawn, oracle):
     labels, dist, found = idx.search_batch(Q, K)  # matrix-core pass (12 queries)
     for b in range(len(Q)):
         assert found[b] == K and np.all(np.diff(dist[b]) >= 0) and labels[b].max() <= n
-    for b in (0, 7, 8, 11):  # batch-1 stream
+    for b in (0, 7, 8, 11):  # batch-1 stream (6-bit shadow of the bf16 rows)
         lab, dd = idx.search(Q[b], K)
         assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    idx.set_option("i6_shadow", 0)  # ... and the int8 shadow's stream
+    try:
+        for b in (0, 11):
+            lab, dd = idx.search(Q[b], K)
+            assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
+    finally:
+        idx.set_option("i6_shadow", 1)
     for i, r in enumerate(planted):
         assert labels[8 + i][0] == r + 1
         row = synth.round_bf16(synth.unit_rows(1, int(r), 1))

@@ -6,10 +6,15 @@ path is forced on small indexes (option "i6_min_rows" = 0) and held against the 
 of src/search/vector.rs:128-134 + exact top-k): BIT-EXACT distances, identical label order, as for every other path.  The
 full-size checks (100 M rows against the oracle's own scan) are in test_full_size_gpu.py.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from dawnsearch_amd import synth  # noqa: E402
 
