@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ROW_BYTES = 384 * 4
-I6_MIN_ROWS = 6 << 20  # indexes of at least this many rows answer single queries from the 6-bit shadow (option i6_min_rows)
+I6_MIN_ROWS = 512 << 10  # indexes of at least this many rows answer single queries from the 6-bit shadow (option i6_min_rows)
 
 
 def parse():
@@ -358,7 +358,7 @@ def main():
         #   "i8"  384.25: the int8 shadow of the index rows (+ 8 B of scale/bound per 32 rows), every batch size
         #   "f16" 768: the f16 shadow of an f32 index, or the rows of a bf16 index themselves (i8_shadow = 0)
         #   "f32" 1536: the f32 rows themselves (both shadows switched off for small batches)
-        #   "i6"  288.25: the 6-bit shadow (+ the same 8 B per 32 rows): single queries of an index of >= 6 Mi rows (scan_i6.hip)
+        #   "i6"  288.25: the 6-bit shadow (+ the same 8 B per 32 rows): single queries of an index of >= 512 Ki rows (scan_i6.hip)
         if rows_read == "default":
             rows_read = "i6" if (Bq == 1 and rows_here >= I6_MIN_ROWS) else "i8"
         row_bytes = {"i6": ROW_BYTES * 3 / 16 + 0.25, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]

@@ -82,7 +82,7 @@ int ensure_room(dawn_index* idx, size_t extra) {
 }
 
 size_t ws_lists_needed(const dawn_index* idx) {
-    return (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks, idx->geom_i6.blocks});
+    return (size_t)std::max({idx->geom.blocks, idx->geom_h.blocks, idx->geom_h_small.blocks, idx->geom_i8.blocks, idx->geom_i6.blocks, idx->geom_i6_small.blocks});
 }
 
 // Search workspaces for batches of up to B queries (creation: kMaxBatch; a search_device call with more queries in one
@@ -110,6 +110,8 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     if (idx->d_flags) (void)hipFree(idx->d_flags);
     if (idx->d_cand_es) (void)hipFree(idx->d_cand_es);
     if (idx->d_cand_ep) (void)hipFree(idx->d_cand_ep);
+    if (idx->d_cand_tb) (void)hipFree(idx->d_cand_tb);
+    idx->d_cand_tb = nullptr;
     idx->d_cand_s = nullptr;
     idx->d_cand_p = nullptr;
     idx->d_flags = nullptr;
@@ -119,6 +121,7 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     const size_t n = B * lists * dawn::LIST;
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_es, lists * dawn::LIST * sizeof(float)));  // (6-bit stream: one query)
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_ep, lists * dawn::LIST * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_tb, lists * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, 2 * B * sizeof(uint32_t)));  // flags[B] | arrival counters of the exact pass[B]
@@ -161,6 +164,16 @@ void f16_shadow_sync(dawn_index* idx) {
                                       stream);
         idx->shadow_rows = idx->size;
     }
+}
+
+// The f16 shadow's memory goes back when no search can read it any more (both integer shadows live again, or "f16_shadow" = 0):
+// 76.8 GB per 100 M rows — next to the rows and the two integer shadows a card holds nothing else otherwise.
+void f16_shadow_release(dawn_index* idx) {
+    if (!idx->d_shadow) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(idx->d_shadow);
+    idx->d_shadow = nullptr;
+    idx->shadow_cap = idx->shadow_rows = 0;
 }
 
 // Bring the int8 shadow up to date; false when it does not fit.
@@ -223,7 +236,7 @@ bool i6_shadow_sync(dawn_index* idx) {
     }
     if (idx->i6_cap < idx->cap_phys) {
         const size_t prow = padded_rows(idx->cap_phys) + 128;
-        const size_t bytes = prow * 288, mbytes = (prow / 32 + 1) * 8;
+        const size_t bytes = prow * idx->i6_row_bytes(), mbytes = (prow / 32 + 1) * 8;
         i6_release(idx);
         char* ns = nullptr;
         float* nm = nullptr;
@@ -241,13 +254,15 @@ bool i6_shadow_sync(dawn_index* idx) {
         idx->i6_cap = idx->cap_phys;
     }
     if (idx->i6_rows < idx->size) {
-        dawn::launch_rows_to_i6s(idx->d_x, idx->dtype, idx->d_i6, idx->d_i6meta, idx->i6_rows, idx->size, stream);
+        dawn::launch_rows_to_i6s(idx->d_x, idx->dtype, idx->i6_bits, idx->d_i6, idx->d_i6meta, idx->i6_rows, idx->size, stream);
         idx->i6_rows = idx->size;
     }
     return true;
 }
 
-bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size; }
+bool i8_live(const dawn_index* idx);
+// (its stream refines the listed rows on the int8 shadow: no int8 shadow, no packed stream)
+bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size && i8_live(idx); }
 bool i8_live(const dawn_index* idx) {
     return idx->use_i8 && !idx->i8_failed && idx->i8_rows == idx->size && (idx->d_i8 || idx->size == 0);
 }
@@ -278,12 +293,17 @@ int index_prepare_search(dawn_index* idx) {
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
     if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
-    (void)i6_shadow_sync(idx);  // single queries of a large index stream the 6-bit shadow (released when not wanted)
+    // what is not wanted any more gives its memory back BEFORE anything new is built (100 M rows: the rows and all three shadows
+    // do not fit one card together)
+    bool f16_needed = false;
     if (idx->dtype == DAWN_DTYPE_F32 && idx->use_shadow && !idx->shadow_failed) {
         const bool batched_needs = !(i8_ok && idx->i8_batched);
         const bool small_needs = idx->shadow_small_batches && !i8_ok;
-        if (batched_needs || small_needs) f16_shadow_sync(idx);
+        f16_needed = batched_needs || small_needs;
     }
+    if (!f16_needed) f16_shadow_release(idx);
+    (void)i6_shadow_sync(idx);  // single queries stream the 6-bit shadow (released when not wanted)
+    if (f16_needed) f16_shadow_sync(idx);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }
@@ -327,8 +347,8 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     } else if (B == 1 && i6_live(idx)) {
         // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
         // stream's epilogue, one merge + certificate (scan_i6.hip)
-        launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_cand_s, idx->d_cand_p,
-                       idx->d_cand_es, idx->d_cand_ep, idx->geom_i6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+        launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
+                       idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                        idx->force_fallback, true, stream, e0, e1);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
@@ -367,6 +387,7 @@ int index_create_single(int dtype, int device, dawn_index** out) {
     idx->dtype = dtype;
     if (const char* e = getenv("DAWN_I8_SHADOW")) idx->use_i8 = atoi(e) != 0;  // default of the "i8_shadow" option
     if (const char* e = getenv("DAWN_I6_SHADOW")) idx->use_i6 = atoi(e) != 0;  // default of the "i6_shadow" option
+    if (const char* e = getenv("DAWN_I6_BITS")) idx->i6_bits = atoi(e) == 6 ? 6 : 5;
     if (const char* e = getenv("DAWN_I6_MIN_ROWS")) idx->i6_min_rows = (size_t)std::max(0ll, atoll(e));
     hipDeviceProp_t prop{};
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -375,6 +396,7 @@ int index_create_single(int dtype, int device, dawn_index** out) {
         idx->geom_h_small.blocks = prop.multiProcessorCount;
         idx->geom_i8.blocks = prop.multiProcessorCount;
         idx->geom_i6.blocks = prop.multiProcessorCount;
+        idx->geom_i6_small.blocks = prop.multiProcessorCount;
         idx->mfma_blocks = prop.multiProcessorCount;
     }
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -415,7 +437,7 @@ void index_destroy_single(dawn_index* idx) {
     }
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
                     idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
@@ -668,7 +690,7 @@ int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_
     }
     if (idx->d_i6) {
         const uint64_t prow = padded_rows(idx->i6_cap) + 128;
-        shadows += prow * 288 + (prow / 32 + 1) * 8;
+        shadows += prow * idx->i6_row_bytes() + (prow / 32 + 1) * 8;
     }
     uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
     if (idx->d_cand_s) other += (uint64_t)idx->ws_B * idx->ws_lists * LIST * 8 + 2 * idx->ws_B * 4 + 16;
@@ -732,22 +754,38 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         if (value) idx->i6_failed = false;
         return reprepare();  // (0: the shadow's memory goes back — i6_shadow_sync)
     }
-    if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 6 Mi; tests: 0)
+    if (n == "i6_bits") {  // 5 (240 B/row, default) or 6 (288 B/row) bits per component of the packed shadow; rebuilt
+        if (value != 5 && value != 6) return fail(DAWN_ERR_INVALID_ARG, "i6_bits must be 5 or 6");
+        if ((int)value != idx->i6_bits) {
+            i6_release(idx);
+            idx->i6_bits = (int)value;
+            idx->i6_failed = false;
+        }
+        return reprepare();
+    }
+    if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 512 Ki; tests: 0)
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "i6_min_rows must be >= 0");
         idx->i6_min_rows = (size_t)value;
         return reprepare();
+    }
+    if (n == "i6_refine") {  // entries of its coarse list a wave of the packed stream refines: 1..64; 0 = from N and k (default)
+        if (value < 0 || value > 64) return fail(DAWN_ERR_INVALID_ARG, "i6_refine must be 0..64");
+        idx->geom_i6.refine = idx->geom_i6_small.refine = (int)value;
+        return DAWN_OK;
     }
     if (n == "i6_scan_threads" || n == "i6_scan_ring" || n == "i6_scan_blocks") {
         if (n == "i6_scan_threads") {
             if (value < 64 || value > 512 || value % 64) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_threads must be 64..512, a multiple of 64");
             idx->geom_i6.threads = (int)value;
         } else if (n == "i6_scan_ring") {
-            if (value != 12 && value != 6 && value != 4 && value != 3 && value != 2) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_ring must be 12, 6, 4, 3 or 2");
+            if (value != 12 && value != 8 && value != 6 && value != 4 && value != 3 && value != 2)
+                return fail(DAWN_ERR_INVALID_ARG, "i6_scan_ring must be 12, 8, 6, 4, 3 or 2");
             idx->geom_i6.unroll = (int)value;
         } else {
             if (value < 1 || value > 65535) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_blocks out of range");
             idx->geom_i6.blocks = (int)value;
         }
+        idx->geom_i6_pinned = true;
         return reprepare();
     }
     if (n == "i8_batched") {
@@ -1357,9 +1395,10 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, query, dawn::EM * sizeof(float), hipMemcpyHostToDevice, stream));
     size_t blocks;
     if (i6_live(idx)) {
-        blocks = idx->geom_i6.blocks;
-        dawn::launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->d_x, idx->dtype, idx->d_ids, (uint32_t)idx->size, idx->d_q, idx->d_cand_s,
-                             idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->geom_i6, 0, nullptr, nullptr, nullptr, nullptr, 0,
+        blocks = (size_t)idx->i6_geom().blocks;
+        dawn::launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
+                             (uint32_t)idx->size, idx->d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
+                             idx->i6_geom(), 0, nullptr, nullptr, nullptr, nullptr, 0,
                              false, stream, nullptr, nullptr);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         const dawn::ScanGeom& gh = idx->i8_geom();
@@ -1384,6 +1423,25 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
     DAWN_HIP_TRY(hipMemcpyAsync(out_rows, idx->d_cand_p, blocks * dawn::LIST * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     DAWN_HIP_TRY(hipStreamSynchronize(stream));
     return DAWN_OK;
+}
+
+// Test hook: the certificate bound of the packed-shadow stream for the query of the last dawn_index_debug_stream_lists call —
+// T = the largest of the workgroups' bounds on their unlisted rows (scan_i6.hip: every row in no list scores <= T).
+int dawn_index_debug_stream_bound(dawn_index* idx, float* bound) {
+    if (!idx || !bound) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
+    return dawn::guarded([&] {
+        DAWN_TRY(set_device(idx));
+        if (!i6_live(idx)) return fail(DAWN_ERR_UNSUPPORTED, "the packed shadow is not live on this index");
+        const size_t blocks = (size_t)idx->i6_geom().blocks;
+        std::vector<float> tb(blocks);
+        DAWN_HIP_TRY(hipDeviceSynchronize());
+        DAWN_HIP_TRY(hipMemcpy(tb.data(), idx->d_cand_tb, blocks * sizeof(float), hipMemcpyDeviceToHost));
+        float m = -__builtin_inff();
+        for (float v : tb) m = std::max(m, v);
+        *bound = m;
+        return DAWN_OK;
+    });
 }
 
 // Timing hook: mean duration (ms) of the matrix-core full pass alone over `iters` launches for B queries, with the

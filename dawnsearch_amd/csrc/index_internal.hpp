@@ -18,6 +18,8 @@ constexpr size_t kMaxBatch = 256;        // queries per internal pass of the hos
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
 constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
 constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
+constexpr size_t kI6MinRows = 512u << 10;      // indexes of at least this many rows keep the 6-bit shadow for their single queries
+constexpr size_t kI6SmallRows = 32u << 20;     // below this the 6-bit stream uses geom_i6_small
 constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host before they travel together
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
 }  // namespace dawn
@@ -73,23 +75,33 @@ struct dawn_index {
     int use_i8 = 1;              // option "i8_shadow"
     int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
     bool i8_failed = false;
-    // 6-bit shadow (ROW_I6S, scan_i6.hip: 288 B/row + 8 B per 32 rows) read by the single-query stream of an index of at
-    // least i6_min_rows rows instead of the int8 shadow (which the matrix-core pass keeps using): three quarters of its
-    // bytes, the stream is HBM-bound.  Kept current by the mutations like the int8 shadow; if it cannot be allocated (or
-    // "i6_shadow" = 0) single queries stream the int8 shadow.
+    // Packed shadow (ROW_I6S, scan_i6.hip: 5 bits per component = 240 B/row, or 6 = 288 B/row, + 8 B per 32 rows) read by the
+    // single-query stream of an index of at least i6_min_rows rows instead of the int8 shadow (which the matrix-core pass keeps
+    // using): the stream is HBM-bound, fewer bytes per row are the only thing that makes it faster.  Kept current by the
+    // mutations like the int8 shadow; if it cannot be allocated (or "i6_shadow" = 0) single queries stream the int8 shadow.
     char* d_i6 = nullptr;
     float* d_i6meta = nullptr;
     size_t i6_cap = 0, i6_rows = 0;
     int use_i6 = 1;              // option "i6_shadow"
-    size_t i6_min_rows = dawn::kShadowSmallRows;  // option "i6_min_rows" (tests: 0)
+    int i6_bits = 5;             // option "i6_bits": 5 (default) or 6
+    size_t i6_row_bytes() const { return i6_bits == 6 ? 288 : 240; }
+    size_t i6_min_rows = dawn::kI6MinRows;  // option "i6_min_rows" (tests: 0)
     bool i6_failed = false;
-    // its stream: `threads` / 64 waves per CU, `unroll` = fragments of 768 B in flight per wave (options "i6_scan_threads",
-    // "i6_scan_ring"); exact lists of the workgroups' epilogues [blocks][64].  tools/stream_i6_ab.py, 100 M rows, three boxes
+    // its stream: `threads` / 64 waves per CU, `unroll` = loads in flight per wave (options "i6_scan_threads", "i6_scan_ring");
+    // exact lists of the workgroups' epilogues [lists][64].  6-bit form, tools/stream_i6_ab.py, 100 M rows, three boxes
     // (profiles/r03/stream_i6_ab_100M_*.log, stream_i6_parts_off_100M.log; us per launch, the int8 stream on the same box
     // 5542 / 5585 / -): 8 waves x 4 fragments 4237 / - / 4130, 8 x 3 4194 / - / 4196, 8 x 6 4288 / - / 4149, 4 x 12 4302 / - / 4146,
-    // 3 x 12 4304 / - / 4152, 4 x 6 4417, 2 x 12 4677: everything with >= 24 KiB in flight per CU lands within 2 %
+    // 3 x 12 4304 / - / 4152, 4 x 6 4417, 2 x 12 4677: everything with >= 24 KiB in flight per CU lands within 2 %.  Below
+    // kI6SmallRows rows 8 waves x 12 fragments (72 KiB in flight per CU: a short stream is start-up and tail, it wants its requests
+    // out at once): 1 M rows 79 us against 88 (8 x 4), 3 M 158 / 172, 12.5 M 566 / 574 — and against the int8 stream's
+    // 78 / 186 / 725 us, whose one-workgroup tail costs ~8 us more per search than merge_exact_kernel
+    // (profiles/r03/stream_i6_ab_small_sizes.log).  5-bit form: 8 waves x 4 loads (half a sub-tile ahead) / x 8 (a whole one).
     dawn::ScanGeom geom_i6{256, 512, 4};
+    dawn::ScanGeom geom_i6_small{256, 512, 12};
+    bool geom_i6_pinned = false;
+    const dawn::ScanGeom& i6_geom() const { return (!geom_i6_pinned && size < dawn::kI6SmallRows) ? geom_i6_small : geom_i6; }
     float* d_cand_es = nullptr;
+    float* d_cand_tb = nullptr;   // [blocks] the workgroups' bounds on their unlisted rows
     uint32_t* d_cand_ep = nullptr;
     int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 / 2 = the int8 / f16 / 6-bit shadow allocation fails
     float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records

@@ -54,7 +54,7 @@ constexpr int ROW_F16S = 2;
 // rotation the shadow and the query images go through (2 x 1.1e-6 x 1.0201, scan_i8.hip) and the reference's own
 // sequential-sum error (gamma_384 * 1.0201 = 2.34e-5): 2.67e-5.
 constexpr int ROW_I8S = 3;
-// 6-bit shadow of the rows (scan_i6.hip): 32-row sub-tiles of 12 fragments x 64 lanes x 12 B (288 B/row) + {1 / s, E} per sub-tile
+// packed 5- / 6-bit shadow of the rows (scan_i6.hip): 32-row sub-tiles of 7680 / 9216 B (240 / 288 B/row) + {1 / s, E} per sub-tile
 constexpr int ROW_I6S = 4;
 constexpr float FILTER_EPS_I8 = 2.9e-5f;
 
@@ -83,6 +83,7 @@ struct ScanGeom {
     int blocks;           // scan grid (== number of candidate lists per query)
     int threads;          // 1024 / 512 / 256
     int unroll = 2;       // row pairs per wave iteration (batch-1 kernel)
+    int refine = 0;       // packed-shadow stream only: entries of its list a wave keeps and refines (0: chosen from N and k)
 };
 
 // Filter pass: approximate scores for all rows, per-block top-64 lists.
@@ -101,14 +102,16 @@ void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n
 extern float g_i8_levels;  // quantiser levels of the int8 shadow (127; "debug_i8_levels": fewer, experiments on coarser shadows)
 void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream);
-// 6-bit shadow (scan_i6.hip): conversion, and the whole single-query search on it (stream with exact rescoring of every
-// workgroup's shortlist in its epilogue, merge of the exact lists + certificate; merge = false: the stream alone)
-void launch_rows_to_i6s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
+// Packed shadow of 5 or 6 bits per component (scan_i6.hip): conversion, and the whole single-query search on it (stream with
+// exact rescoring of every workgroup's shortlist(s) in its epilogue, merge of the exact lists + certificate; merge = false:
+// the stream alone).  d_i8 / d_i8meta: the int8 shadow, which refines the bounds of the listed rows; tb [blocks].
+void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream);
-void launch_scan_i6(const void* d_i6, const void* d_meta, const void* d_rows, int dtype, const uint64_t* d_ids, uint32_t n_rows,
-                    const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s, uint32_t* ex_p, const ScanGeom& g, uint32_t k,
-                    uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, bool merge,
-                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
+                    int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
+                    uint32_t* ex_p, float* tb, const ScanGeom& g,
+                    uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,

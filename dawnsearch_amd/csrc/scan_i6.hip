@@ -23,30 +23,54 @@
 // merge_exact_kernel merges the exact lists and checks ONE certificate: rows in no list have ub <= T = the largest 64th
 // upper bound of any workgroup, i.e. distance >= fl(1 - up(T + eps)); if that exceeds the k-th exact distance strictly
 // the result is exact, otherwise the query takes the exact pass (scan_exact_kernel) like any failed certificate.
+#include <cmath>
 #include <type_traits>
 
 #include "kernels.hpp"
 #include "rotate384.hpp"
 #include "wave_topk.hpp"
 
+// FIVE bits (240 B per row, BITS = 5 below — the default; the 6-bit form stays selectable): the same with 15 levels, codes X + 16.
+//   * a sub-tile is 7680 B in consumption order: [H0 | N0 N1 N2 | H1 | N3 N4 N5]; N_p (64 lanes x 16 B, one global_load_dwordx4)
+//     holds the low nibbles of fragment PAIR p (fragments 2p, 2p + 1): dwords {0, 1} = fragment 2p, {2, 3} = fragment 2p + 1, a
+//     dword = two unpacked dwords interleaved (low nibble of byte b: value b of A_{2i}, high nibble: value b of A_{2i+1});
+//     H_g (64 lanes x 12 B, one global_load_dwordx3) holds the fifth bits of pairs 3g .. 3g + 2, one dword per pair: byte b,
+//     bit 4 + j = bit 4 of value b of A_j of fragment 2p, bit j = the same of fragment 2p + 1 — so that
+//     A_j = lo_j | ((H >> j) & 0x10101010) and A'_j = lo'_j | ((H << (4 - j)) & 0x10101010): 13-14 VALU per fragment;
+//   * E doubles again (~0.06 on unit vectors with the clipped scale below): the certificate needs T (the largest 64th bound of
+//     any list) a further 0.03 below the k-th score, i.e. lists twice as deep: a workgroup of eight waves keeps TWO lists (waves
+//     0-3 and 4-7) and rescores both, 512 lists = 32 768 rows in all.
+// Both forms choose the scale of a sub-tile by MEASUREMENT: s = c * max|x'| / levels for c in {1, .92, .84, .76, .68, .60}, the c
+// with the smallest resulting E wins — clipping the few largest components (they saturate; their error is part of the measured
+// E) buys a finer step for all the others: E -14 % at 6 bits, -23 % at 5 (the optimum of a uniform quantiser on near-Gaussian
+// data lies at 3.0-3.3 sigma, the sub-tile maximum at ~4 sigma).
 namespace dawn {
 
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_u __attribute__((aligned(4)));  // (fragments are 12-B lane slots: 4-B aligned)
 
-constexpr float I6_LEVELS = 31.0f;
-constexpr uint32_t I6_FRAG_DW = 64 * 3;            // dwords per fragment
-constexpr uint32_t I6_SUB_DW = 12 * I6_FRAG_DW;    // dwords per sub-tile (9216 B)
+constexpr uint32_t I6_FRAG_DW = 64 * 3;            // 6-bit form: dwords per fragment
+constexpr uint32_t I6_SUB_DW = 12 * I6_FRAG_DW;    // ... per sub-tile (9216 B)
+constexpr uint32_t I5_SUB_DW = 1920;               // 5-bit form: dwords per sub-tile (7680 B)
+constexpr uint32_t I5_HALF_DW = 960;               // [H (192 dwords) | N N N (256 dwords each)]
+template <int BITS> struct PackedShadow {
+    static constexpr float LEVELS = BITS == 6 ? 31.0f : 15.0f;
+    static constexpr int OFFSET = BITS == 6 ? 32 : 16;  // code = value + OFFSET
+    static constexpr uint32_t SUB_DW = BITS == 6 ? I6_SUB_DW : I5_SUB_DW;
+};
 constexpr float I6_K2_PER_SQ = 1.35f * 19.6f * I8_QRES;
 
 // ------------------------------------------------------------------------------------------------
 // conversion: rows -> 6-bit sub-tiles + {1 / s, E} per sub-tile (rows_to_i8s_kernel with the packing above)
 // ------------------------------------------------------------------------------------------------
-template <int RT>
+template <int RT, int BITS>
 __global__ __launch_bounds__(256) void rows_to_i6s_kernel(const void* __restrict__ xv, uint32_t* __restrict__ out,
                                                            float2* __restrict__ meta, uint32_t first_sub, uint32_t n_valid) {
+    typedef PackedShadow<BITS> PS;
+    constexpr int NC = 6;  // candidate scales
     __shared__ float sh[4];
+    __shared__ float sh_e[4][NC];
     const uint32_t sub = first_sub + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = tid >> 3, part = tid & 7;
@@ -76,11 +100,49 @@ __global__ __launch_bounds__(256) void rows_to_i6s_kernel(const void* __restrict
     if (lane == 0) sh[wave] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    // the scale: the candidate with the smallest measured E = max over the rows of ||x' - s X||_2 (clipped components included)
+    const float s0 = fmaxf(amax, 1e-20f) / PS::LEVELS;
+    float e2c[NC];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const float s = s0 * (1.0f - 0.08f * ci);
+        float e2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = rintf(vv[i] / s);
+                t = fminf(fmaxf(t, -PS::LEVELS), PS::LEVELS);
+                const float dx = vv[i] - s * t;
+                e2 = __builtin_fmaf(dx, dx, e2);
+            }
+        }
+        e2 += __shfl_xor(e2, 1);  // row sum over its 8 threads (fixed order), then the maximum over the wave's 8 rows
+        e2 += __shfl_xor(e2, 2);
+        e2 += __shfl_xor(e2, 4);
+#pragma unroll
+        for (int o2 = 32; o2 >= 8; o2 >>= 1) e2 = fmaxf(e2, __shfl_xor(e2, o2));
+        e2c[ci] = e2;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) sh_e[wave][ci] = e2c[ci];
+    }
     __syncthreads();
-    const float s = fmaxf(amax, 1e-20f) / I6_LEVELS;
-    float e2 = 0.f;
-    uint32_t* o = out + (size_t)sub * I6_SUB_DW;
+    float best_e2 = 0.f, s = s0;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {  // (every thread takes the same decision)
+        const float m = fmaxf(fmaxf(sh_e[0][ci], sh_e[1][ci]), fmaxf(sh_e[2][ci], sh_e[3][ci]));
+        if (ci == 0 || m < best_e2) {
+            best_e2 = m;
+            s = s0 * (1.0f - 0.08f * ci);
+        }
+    }
+    uint32_t* o = out + (size_t)sub * PS::SUB_DW;
     const uint32_t h = (part >> 2) & 1u, dj = part & 3u;
+    const uint32_t ln = h * 32u + r;  // the lane of the stream's wave that owns these 16 values
+    [[maybe_unused]] uint32_t hb_prev = 0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {  // float4 chunk part + 8 j = dword dj of lane (h, r) of fragment j
         uint32_t w = 0;
@@ -88,39 +150,52 @@ __global__ __launch_bounds__(256) void rows_to_i6s_kernel(const void* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float t = rintf(vv[i] / s);
-            t = fminf(fmaxf(t, -I6_LEVELS), I6_LEVELS);
-            const float dx = vv[i] - s * t;
-            e2 = __builtin_fmaf(dx, dx, e2);
-            w |= (uint32_t)((int)t + 32) << (8 * i);
+            t = fminf(fmaxf(t, -PS::LEVELS), PS::LEVELS);
+            w |= (uint32_t)((int)t + PS::OFFSET) << (8 * i);
         }
-        // the fourth dword of the lane (values 12..15) is spread over the top two bits of the other three
-        const uint32_t w3 = __shfl(w, lane | 3);
-        if (dj < 3u) o[j * I6_FRAG_DW + (h * 32u + r) * 3u + dj] = w | (((w3 >> (2u * dj)) & 0x03030303u) << 6);
+        const int base = lane & ~3;
+        if constexpr (BITS == 6) {
+            // the fourth dword of the lane (values 12..15) is spread over the top two bits of the other three
+            const uint32_t w3 = __shfl(w, base + 3);
+            if (dj < 3u) o[j * I6_FRAG_DW + ln * 3u + dj] = w | (((w3 >> (2u * dj)) & 0x03030303u) << 6);
+        } else {
+            const uint32_t w0 = __shfl(w, base), w1 = __shfl(w, base + 1), w2 = __shfl(w, base + 2), w3 = __shfl(w, base + 3);
+            const uint32_t nd0 = (w0 & 0x0F0F0F0Fu) | ((w1 & 0x0F0F0F0Fu) << 4);
+            const uint32_t nd1 = (w2 & 0x0F0F0F0Fu) | ((w3 & 0x0F0F0F0Fu) << 4);
+            const uint32_t hb = ((w0 >> 4) & 0x01010101u) | (((w1 >> 4) & 0x01010101u) << 1) | (((w2 >> 4) & 0x01010101u) << 2) |
+                                (((w3 >> 4) & 0x01010101u) << 3);  // bit d of byte b: the fifth bit of value b of A_d
+            const uint32_t pr = (uint32_t)j >> 1, hf = pr / 3u, m = pr % 3u;
+            uint32_t* half = o + hf * I5_HALF_DW;
+            if (dj == 0u) half[192u + m * 256u + ln * 4u + 2u * (j & 1)] = nd0;
+            if (dj == 1u) half[192u + m * 256u + ln * 4u + 2u * (j & 1) + 1u] = nd1;
+            if ((j & 1) && dj == 2u) half[ln * 3u + m] = (hb_prev << 4) | hb;
+            hb_prev = hb;
+        }
     }
-    e2 += __shfl_xor(e2, 1);
-    e2 += __shfl_xor(e2, 2);
-    e2 += __shfl_xor(e2, 4);
-#pragma unroll
-    for (int o2 = 32; o2 >= 8; o2 >>= 1) e2 = fmaxf(e2, __shfl_xor(e2, o2));
-    if (lane == 0) sh[wave] = e2;
-    __syncthreads();
     if (tid == 0) {
-        const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-        meta[sub] = float2{1.0f / s, sqrtf(m) * 1.0101f * 1.001f + 1e-9f};  // as rows_to_i8s_kernel
+        // 1.0101: ||q||_2 < 1.01 (gate); 1.001 + 1e-9: the f32 evaluation of dx, the sum and the square root
+        meta[sub] = float2{1.0f / s, sqrtf(best_e2) * 1.0101f * 1.001f + 1e-9f};
     }
 }
 
-void launch_rows_to_i6s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
+void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream) {
     const uint32_t first_sub = (uint32_t)(first_row / 32);  // the sub-tile holding first_row is re-quantised whole
     const uint32_t end_sub = (uint32_t)((n_valid + 31) / 32);
     if (end_sub <= first_sub) return;
-    if (rt == ROW_BF16)
-        hipLaunchKernelGGL(rows_to_i6s_kernel<1>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
-    else
-        hipLaunchKernelGGL(rows_to_i6s_kernel<0>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid);
+    uint32_t* o = reinterpret_cast<uint32_t*>(d_shadow);
+    float2* mt = reinterpret_cast<float2*>(d_meta);
+#define DAWN_I6_BUILD(RT_, BITS_)                                                                                          \
+    hipLaunchKernelGGL((rows_to_i6s_kernel<RT_, BITS_>), dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows, o, mt, first_sub, \
+                       (uint32_t)n_valid)
+    if (rt == ROW_BF16) {
+        if (bits == 6) DAWN_I6_BUILD(1, 6);
+        else DAWN_I6_BUILD(1, 5);
+    } else {
+        if (bits == 6) DAWN_I6_BUILD(0, 6);
+        else DAWN_I6_BUILD(0, 5);
+    }
+#undef DAWN_I6_BUILD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,17 +226,23 @@ __device__ __forceinline__ void block_merge_any(float& s, uint32_t& p, float (*s
     }
 }
 
-// RT: row type of the index (0 f32, 1 bf16) for the exact rescore; PD: fragments in flight per wave (ring)
-template <int RT, int PD>
+// RT: row type of the index (0 f32, 1 bf16) for the exact rescore; BITS: 6 or 5; PD: loads in flight per wave — 6 bits: 12 / 6 /
+// 4 / 3 / 2 fragments of 768 B; 5 bits: 8 (a whole sub-tile ahead, 7.5 KiB) or 4 (half a sub-tile: one H and three N loads)
+template <int RT, int BITS, int PD>
 __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __restrict__ x, const float2* __restrict__ meta,
                                                                uint32_t n_rows, const float* __restrict__ q,
-                                                               const void* __restrict__ rows, float* __restrict__ out_s,
+                                                               const void* __restrict__ rows, const unsigned char* __restrict__ x8,
+                                                               const float2* __restrict__ meta8, float* __restrict__ out_s,
                                                                uint32_t* __restrict__ out_p, float* __restrict__ out_es,
-                                                               uint32_t* __restrict__ out_ep) {
-    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+                                                               uint32_t* __restrict__ out_ep, float* __restrict__ out_t,
+                                                               int n_refine) {
+    static_assert(BITS == 6 ? 12 % PD == 0 : (PD == 8 || PD == 4), "ring depth");
+    typedef PackedShadow<BITS> PS;
     __shared__ float sh_s[8][LIST];
     __shared__ uint32_t sh_p[8][LIST];
     __shared__ uint32_t sh_rows[LIST];
+    __shared__ float sh_strip[8][32];  // a sub-tile's 32 upper bounds, one strip per wave (slow_path)
+    __shared__ float sh_tw[8];         // the waves' bounds on their unlisted rows
     extern __shared__ __attribute__((aligned(16))) unsigned char rescore_stage[];  // RescoreStage<RT>::BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,13 +251,32 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t c = lane & 31, h = lane >> 5;
     uint32_t t = blockIdx.x * nwaves + wave;
     const uint32_t t_stride = gridDim.x * nwaves, t_end = n_sub;
-    // the first fragments fly while the query images are made
-    const uint32_t* p = x + (size_t)(t < t_end ? t : 0) * I6_SUB_DW + lane * 3;
-    u32x3 a[PD];
+    // the first loads fly while the query images are made.  6 bits: a[] = ring of fragments (lane slot: 3 dwords);
+    // 5 bits: hq[] = ring of H loads (lane slot: 3 dwords), nq[] = ring of N loads (lane slot: 4 dwords)
+    constexpr int NA = BITS == 6 ? PD : 1, NH = BITS == 5 ? PD / 4 : 1, NN = BITS == 5 ? 3 * PD / 4 : 1;
+    const uint32_t* p = x + (size_t)(t < t_end ? t : 0) * PS::SUB_DW;
+    [[maybe_unused]] u32x3 a[NA];
+    [[maybe_unused]] u32x3 hq[NH];
+    [[maybe_unused]] u32x4 nq[NN];
+    auto load_h = [&](const uint32_t* sub, int g) __attribute__((always_inline)) {
+        return frag_load(sub + g * I5_HALF_DW + lane * 3);
+    };
+    auto load_n = [&](const uint32_t* sub, int pr) __attribute__((always_inline)) {  // pr = pair 0..5
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sub + (pr / 3) * I5_HALF_DW + 192 + (pr % 3) * 256 + lane * 4));
+    };
     float2 mt = {0.f, 0.f};
     if (t < t_end) {
+        if constexpr (BITS == 6) {
 #pragma unroll
-        for (int d = 0; d < PD; ++d) a[d] = frag_load(p + d * I6_FRAG_DW);
+            for (int d = 0; d < PD; ++d) a[d] = frag_load(p + d * I6_FRAG_DW + lane * 3);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NH; ++g) {
+                hq[g] = load_h(p, g);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) nq[3 * g + m] = load_n(p, 3 * g + m);
+            }
+        }
         mt = meta[t];
     }
 
@@ -228,7 +328,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     }
     const float sq = sh_sq;
     const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq, k2 = I6_K2_PER_SQ * sq;
-    const int acc0 = col_live ? -32 * sh_sum[c == 8 ? 1 : 0] : 0;  // codes are value + 32
+    const int acc0 = col_live ? -PS::OFFSET * sh_sum[c == 8 ? 1 : 0] : 0;  // codes are value + OFFSET
     float ls = NEG_INF, tau = NEG_INF;
     uint32_t lp = NO_POS;
     const bool tested = c == 0;
@@ -242,19 +342,57 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         int thr = 0, mx = 0;
 
         auto slow_path = [&]() __attribute__((always_inline)) {
+            // Many hits in one sub-tile — the first sub-tiles of every wave, while its list fills: the j-th still contributes
+            // 64 / (j + 1) rows — are merged as ONE sorted batch (scan_filter_i8s_kernel: the 32 upper bounds, held by the two
+            // lanes of column 0, go through a 128-B strip of LDS to one per lane, a bitonic sort and one merge64) instead of one
+            // ballot-and-shift insertion each.  Same list afterwards (rows arrive in ascending order).
+            int nh = 0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
-                unsigned long long m = __ballot(C[e] > thr && prow + roff + 4u * h < n_rows);
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float cf = (float)__builtin_amdgcn_readlane(C[e], l);
-                    const uint32_t row = prow + roff + 4u * (uint32_t)(l >> 5);
-                    const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254, pmt.y + k2);
+            for (int e = 0; e < 16; ++e)
+                nh += (C[e] > thr && prow + (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h < n_rows) ? 1 : 0;
+            const int total = __builtin_amdgcn_readlane(nh, 0) + __builtin_amdgcn_readlane(nh, 32);
+            if (total > 6) {
+                float* strip = &sh_strip[wave][0];
+                if (c == 0) {  // lanes 0 (h = 0) and 32 (h = 1)
+                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = pmt.y + k2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
+                        const bool ok = C[e] > thr && prow + roff < n_rows;
+                        strip[roff] = ok ? __builtin_fmaf((float)C[e], g1, g0) : NEG_INF;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private strip: LDS operations of a wave are in order)
+                float d = POS_INF;
+                uint32_t row = NO_POS;
+                if (lane < 32) {
+                    const float sc = strip[lane];
                     if (sc > tau) {
-                        wave_insert(ls, lp, sc, row, lane);
-                        tau = read_lane63(ls);
+                        d = -sc;
+                        row = prow + (uint32_t)lane;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                sort64_asc(d, row, lane);
+                const float os = -__shfl(d, 63 - lane);
+                const uint32_t op = __shfl(row, 63 - lane);
+                merge64(ls, lp, os, op, lane);
+                tau = read_lane63(ls);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2));
+                    unsigned long long m = __ballot(C[e] > thr && prow + roff + 4u * h < n_rows);
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float cf = (float)__builtin_amdgcn_readlane(C[e], l);
+                        const uint32_t row = prow + roff + 4u * (uint32_t)(l >> 5);
+                        const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254, pmt.y + k2);
+                        if (sc > tau) {
+                            wave_insert(ls, lp, sc, row, lane);
+                            tau = read_lane63(ls);
+                        }
                     }
                 }
             }
@@ -283,31 +421,66 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         bool more;
         auto round = [&](auto with_test, auto parity) __attribute__((always_inline)) {
             constexpr int P = decltype(parity)::value;
+            constexpr bool TEST = decltype(with_test)::value;
             i32x16_t& acc = accs[P];
             const uint32_t tn = t + t_stride;
             more = tn < t_end;
-            const uint32_t* pn = more ? x + (size_t)tn * I6_SUB_DW + lane * 3 : p;
+            // (the last sub-tile re-reads its own first bytes: no branch in the stream)
+            const uint32_t* pn = more ? x + (size_t)tn * PS::SUB_DW : p;
             const float2 mtn = meta[more ? tn : t];
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = acc0;
+            if constexpr (BITS == 6) {
 #pragma unroll
-            for (int f = 0; f < 12; ++f) {
-                const u32x3 w = a[f % PD];
-                const uint32_t w0 = w.x, w1 = w.y, w2 = w.z;
-                i32x4_t av;
-                av[0] = (int)(w0 & 0x3F3F3F3Fu);
-                av[1] = (int)(w1 & 0x3F3F3F3Fu);
-                av[2] = (int)(w2 & 0x3F3F3F3Fu);
-                av[3] = (int)(((w0 >> 6) & 0x03030303u) | ((w1 >> 4) & 0x0C0C0C0Cu) | ((w2 >> 2) & 0x30303030u));
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[f], acc, 0, 0, 0);
-                // (the reload BEHIND the MFMA: in front of it — the slot is free once unpacked — rings of 3-4 fragments lose 1-2 %,
-                // rings of 12 gain nothing: profiles/r03/stream_i6_parts_off_100M.log, DBG = 8)
-                if (f + PD < 12) a[f % PD] = frag_load(p + (f + PD) * I6_FRAG_DW);
-                else a[f % PD] = frag_load(pn + (f + PD - 12) * I6_FRAG_DW);
-                if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int f = 0; f < 12; ++f) {
+                    const u32x3 w = a[f % PD];
+                    const uint32_t w0 = w.x, w1 = w.y, w2 = w.z;
+                    i32x4_t av;
+                    av[0] = (int)(w0 & 0x3F3F3F3Fu);
+                    av[1] = (int)(w1 & 0x3F3F3F3Fu);
+                    av[2] = (int)(w2 & 0x3F3F3F3Fu);
+                    av[3] = (int)(((w0 >> 6) & 0x03030303u) | ((w1 >> 4) & 0x0C0C0C0Cu) | ((w2 >> 2) & 0x30303030u));
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[f], acc, 0, 0, 0);
+                    // (the reload BEHIND the MFMA: in front of it — the slot is free once unpacked — rings of 3-4 fragments lose
+                    // 1-2 %, rings of 12 gain nothing: profiles/r03/stream_i6_parts_off_100M.log, DBG = 8)
+                    if (f + PD < 12) a[f % PD] = frag_load(p + (f + PD) * I6_FRAG_DW + lane * 3);
+                    else a[f % PD] = frag_load(pn + (f + PD - 12) * I6_FRAG_DW + lane * 3);
+                    if constexpr (TEST) test_slice(f, accs[1 - P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {  // fragment pairs
+                    const int g = pr / 3, m = pr % 3;
+                    const u32x4 nw = nq[pr % NN];
+                    const u32x3 hw = hq[g % NH];
+                    const uint32_t H = m == 0 ? hw.x : m == 1 ? hw.y : hw.z;
+                    const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z, n3 = nw.w;
+                    i32x4_t av, bv;
+                    av[0] = (int)((n0 & 0x0F0F0F0Fu) | (H & 0x10101010u));
+                    av[1] = (int)(((n0 >> 4) & 0x0F0F0F0Fu) | ((H >> 1) & 0x10101010u));
+                    av[2] = (int)((n1 & 0x0F0F0F0Fu) | ((H >> 2) & 0x10101010u));
+                    av[3] = (int)(((n1 >> 4) & 0x0F0F0F0Fu) | ((H >> 3) & 0x10101010u));
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[2 * pr], acc, 0, 0, 0);
+                    if constexpr (TEST) test_slice(2 * pr, accs[1 - P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bv[0] = (int)((n2 & 0x0F0F0F0Fu) | ((H << 4) & 0x10101010u));
+                    bv[1] = (int)(((n2 >> 4) & 0x0F0F0F0Fu) | ((H << 3) & 0x10101010u));
+                    bv[2] = (int)((n3 & 0x0F0F0F0Fu) | ((H << 2) & 0x10101010u));
+                    bv[3] = (int)(((n3 >> 4) & 0x0F0F0F0Fu) | ((H << 1) & 0x10101010u));
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bv, qf[2 * pr + 1], acc, 0, 0, 0);
+                    // reloads: the same slot NN pairs / NH halves further down the stream
+                    if (pr + NN < 6) nq[pr % NN] = load_n(p, pr + NN);
+                    else nq[pr % NN] = load_n(pn, pr + NN - 6);
+                    if (m == 2) {
+                        if (g + NH < 2) hq[g % NH] = load_h(p, g + NH);
+                        else hq[g % NH] = load_h(pn, g + NH - 2);
+                    }
+                    if constexpr (TEST) test_slice(2 * pr + 1, accs[1 - P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if constexpr (decltype(with_test)::value)
+            if constexpr (TEST)
                 if (__any(mx > thr)) slow_path();
             pmt = mt;
             prow = t * 32u;
@@ -336,25 +509,86 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         if (__any(mx > thr)) slow_path();
     }
 
-    block_merge_any(ls, lp, sh_s, sh_p, wave, lane, nwaves);
-    const size_t o = (size_t)blockIdx.x * LIST + lane;
-    if (wave == 0) {
-        out_s[o] = ls;  // upper bounds, descending: lane 63 = the bound on every row of this workgroup that is not listed
-        out_p[o] = lp;
-        sh_rows[lane] = lp;
+    // ---- epilogue 1: REFINEMENT.  The wave's list holds its 64 best rows by the packed shadow's bound; every row of the wave
+    // that is not listed is bounded by the list's last entry (tw; -inf while the list is not full).  The listed rows get the
+    // int8 shadow's bound instead (scan_i8.hip: a quarter of the slack) — a lane per row: its 24 16-B pieces of the int8 sub-tile
+    // against the query's two int8 images in LDS, v_dot4_i32_i8 — and the list is re-sorted by it: what the workgroup then merges
+    // and rescores are its 64 best rows by the TIGHT bound, chosen among nwaves x 64 candidates of the coarse one.
+    // Only the wave's best n_refine entries are kept (1 .. 64, chosen by the host from the index size and k: i6_refine_count):
+    // a short list is a shallow one — its bound tw sits higher —, but every kept row costs a 3-KB gather, and the depth the
+    // certificate needs grows with the index.
+    float tw;
+    if (n_refine < LIST) {
+        const bool more_rows = __builtin_amdgcn_readlane((int)lp, n_refine) != (int)NO_POS;
+        tw = more_rows ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), n_refine)) : NEG_INF;
+        if (lane >= n_refine) {
+            ls = NEG_INF;
+            lp = NO_POS;
+        }
+    } else {
+        const bool full = __builtin_amdgcn_readlane((int)lp, 63) != (int)NO_POS;
+        tw = full ? read_lane63(ls) : NEG_INF;
     }
-    // ---- epilogue: the workgroup's 64 rows, exactly (block_exact_dots of wave_topk.hpp for any block size)
+    {
+        float ub8 = NEG_INF;
+        if (lp != NO_POS) {
+            const uint32_t t8 = lp >> 5, r8 = lp & 31u;
+            const i32x4_t* xs = reinterpret_cast<const i32x4_t*>(x8 + (size_t)t8 * 12288u) + r8;
+            const i32x4_t* ih = reinterpret_cast<const i32x4_t*>(&sh_img[0][0]);
+            const i32x4_t* il = reinterpret_cast<const i32x4_t*>(&sh_img[1][0]);
+            int ch = 0, cl = 0;
+#pragma unroll 6
+            for (int j = 0; j < 24; ++j) {  // piece j = fragment j / 2, half j % 2: k = 16 j .. 16 j + 15
+                const i32x4_t xv = xs[(j >> 1) * 64 + (j & 1) * 32];
+                const i32x4_t hv = ih[j], lv = il[j];
+                ch = __builtin_amdgcn_sdot4(xv[0], hv[0], ch, false);
+                ch = __builtin_amdgcn_sdot4(xv[1], hv[1], ch, false);
+                ch = __builtin_amdgcn_sdot4(xv[2], hv[2], ch, false);
+                ch = __builtin_amdgcn_sdot4(xv[3], hv[3], ch, false);
+                cl = __builtin_amdgcn_sdot4(xv[0], lv[0], cl, false);
+                cl = __builtin_amdgcn_sdot4(xv[1], lv[1], cl, false);
+                cl = __builtin_amdgcn_sdot4(xv[2], lv[2], cl, false);
+                cl = __builtin_amdgcn_sdot4(xv[3], lv[3], cl, false);
+            }
+            const float2 m8 = meta8[t8];  // {1 / s, E} of the int8 sub-tile
+            const int c8 = ch * 254 + cl;
+            ub8 = __builtin_fmaf((float)c8, __builtin_amdgcn_rcpf(m8.x) * sq254, m8.y + I8_K2_PER_SQ * sq);
+        }
+        float d = lp != NO_POS ? -ub8 : POS_INF;
+        uint32_t pr = lp;
+        sort64_asc(d, pr, lane);
+        ls = -d;  // descending by the int8 bound, ties -> lower row; fillers (-inf, NO_POS) last
+        lp = pr;
+    }
+    if (lane == 0) sh_tw[wave] = tw;  // (visible after block_merge's barriers)
+
+    // ---- epilogue 2: the workgroup's list — upper bounds (descending: lane 63 bounds every refined row that is not listed) —
+    // and the same 64 rows rescored exactly (block_exact_dots of wave_topk.hpp for any block size) as (-distance descending, row)
+    block_merge_any(ls, lp, sh_s, sh_p, wave, lane, nwaves);
     typedef RescoreStage<RT> S;
     float* sh_q = reinterpret_cast<float*>(rescore_stage + S::ROWS_BYTES);
     for (int i = threadIdx.x; i < EM; i += blockDim.x) sh_q[i] = q[i];
-    __syncthreads();
     const u32x4* xr = reinterpret_cast<const u32x4*>(rows);
+    const size_t o = (size_t)blockIdx.x * LIST + lane;
+    if (wave == 0) {
+        out_s[o] = ls;
+        out_p[o] = lp;
+        sh_rows[lane] = lp;
+        if (lane == 0) {
+            // the bound on every row of this workgroup that is in no list: the coarse bound of the rows its waves dropped, the
+            // tight one of the rows the merge dropped
+            float tb = (__builtin_amdgcn_readlane((int)lp, 63) != (int)NO_POS) ? read_lane63(ls) : NEG_INF;
+            for (int w = 0; w < nwaves; ++w) tb = fmaxf(tb, sh_tw[w]);
+            out_t[blockIdx.x] = tb;
+        }
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
-        const int r = i / S::CH, ch = i % S::CH;
+        const int r = i / S::CH, chn = i % S::CH;
         const uint32_t row = sh_rows[r];
         if (row != NO_POS)
-            *reinterpret_cast<u32x4*>(rescore_stage + r * S::STRIDE + ch * 16) =
-                RT == 1 ? xr[frag_chunk(row, ch)] : xr[(size_t)row * S::CH + ch];
+            *reinterpret_cast<u32x4*>(rescore_stage + r * S::STRIDE + chn * 16) =
+                RT == 1 ? xr[frag_chunk(row, chn)] : xr[(size_t)row * S::CH + chn];
     }
     __syncthreads();
     if (wave == 0) {
@@ -380,7 +614,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
 // merge of the exact per-workgroup lists + the certificate
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __restrict__ ids, uint32_t n_rows,
-                                                            const float* __restrict__ ub_s, const float* __restrict__ ex_s,
+                                                            const float* __restrict__ tb, const float* __restrict__ ex_s,
                                                             const uint32_t* __restrict__ ex_p, int n_lists, uint32_t k,
                                                             uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
                                                             uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags,
@@ -402,7 +636,7 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
             const int l = l0 + j * nwaves;
             os[j] = l < n_lists ? ex_s[(size_t)l * LIST + 63 - lane] : NEG_INF;
             op[j] = l < n_lists ? ex_p[(size_t)l * LIST + 63 - lane] : NO_POS;
-            tl[j] = l < n_lists ? ub_s[(size_t)l * LIST + 63] : NEG_INF;  // (-inf: the list is not full, nothing was left out)
+            tl[j] = l < n_lists ? tb[l] : NEG_INF;  // the workgroup's bound on its unlisted rows (-inf: nothing was left out)
         }
 #pragma unroll
         for (int j = 0; j < INF; ++j) {
@@ -440,20 +674,56 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
     }
 }
 
-// One query: stream + epilogue, merge + certificate.  ub_s / ub_p: the upper-bound lists [blocks][64] (what the other
-// streams hand to merge_rescore_kernel; kept for the test hooks), ex_s / ex_p: the exact lists.  geom.unroll: 12 / 6 / 4 / 3 / 2
-// fragments of 768 B in flight per wave.
-void launch_scan_i6(const void* d_i6, const void* d_meta, const void* d_rows, int dtype, const uint64_t* d_ids, uint32_t n_rows,
-                    const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s, uint32_t* ex_p, const ScanGeom& g, uint32_t k,
-                    uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, bool merge,
-                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+// How many entries of its coarse list a wave keeps and refines.  The certificate needs the bound on every unlisted row — the
+// exact score at depth D = waves x n of the index plus the packed shadow's slack E — below the k-th best score: with scores
+// ~ N(0, 1/384) (the thinnest top a real index can have: uniform or Gaussian rows; clustered data has wider gaps) that is
+// z_D <= z_k - (E + margin) * sqrt(384), D = N (1 - Phi(z_D)); twice that depth is asked for.  A wrong guess costs time (the
+// certificate fails, the exact pass answers), never correctness.
+int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
+    static uint32_t c_n = 0, c_k = 0;
+    static int c_bits = 0, c_waves = 0, c_out = LIST;
+    if (n_rows == c_n && k == c_k && bits == c_bits && waves == c_waves) return c_out;
+    auto tail = [](double z) { return 0.5 * std::erfc(z / 1.4142135623730951); };
+    const double kk = k < 1 ? 1.0 : (double)k;
+    double out = LIST;
+    if ((double)n_rows > 4.0 * kk) {
+        double lo = 0.0, hi = 8.0;  // z_k: tail(z_k) = k / N
+        for (int i = 0; i < 60; ++i) {
+            const double mid = 0.5 * (lo + hi);
+            if (tail(mid) * n_rows > kk) lo = mid;
+            else hi = mid;
+        }
+        const double slack = (bits == 6 ? 0.040 : 0.082) + 0.012;
+        const double zd = lo - slack * 19.5959;
+        const double depth = 2.0 * tail(zd) * n_rows;
+        const double n_sub = std::ceil(n_rows / 32.0);  // (a small index does not reach every wave)
+        const double holders = n_sub < (double)waves ? n_sub : (double)(waves > 0 ? waves : 1);
+        out = std::ceil(depth / holders);
+    }
+    int n = out < 8.0 ? 8 : out > (double)LIST ? LIST : (int)out;
+    n = (n + 7) & ~7;
+    c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n;
+    return n;
+}
+
+// One query: stream + epilogue, merge + certificate.  ub_s / ub_p: the upper-bound lists [blocks][64] (what the other streams
+// hand to merge_rescore_kernel; kept for the test hooks), ex_s / ex_p: the exact lists, tb [blocks]: the workgroups' bounds on
+// their unlisted rows; d_i8 / d_i8meta: the int8 shadow (refinement).  geom.unroll: loads in flight per wave —
+// 6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 (anything else: 8) loads of 768 B - 1 KiB.
+void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
+                    int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
+                    uint32_t* ex_p, float* tb, const ScanGeom& g,
+                    uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     static bool attr_set = false;
     const uint32_t* x = reinterpret_cast<const uint32_t*>(d_i6);
     const float2* mt = reinterpret_cast<const float2*>(d_meta);
-#define DAWN_I6_EACH(F) F(0, 12) F(0, 6) F(0, 4) F(0, 3) F(0, 2) F(1, 12) F(1, 6) F(1, 4) F(1, 3) F(1, 2)
+#define DAWN_I6_EACH(F)                                                                                              \
+    F(0, 6, 12) F(0, 6, 6) F(0, 6, 4) F(0, 6, 3) F(0, 6, 2) F(1, 6, 12) F(1, 6, 6) F(1, 6, 4) F(1, 6, 3) F(1, 6, 2) \
+    F(0, 5, 8) F(0, 5, 4) F(1, 5, 8) F(1, 5, 4)
     if (!attr_set) {
-#define DAWN_I6_ATTR(RT_, PD_)                                                                                 \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_filter_i6s_kernel<RT_, PD_>),                \
+#define DAWN_I6_ATTR(RT_, BITS_, PD_)                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_filter_i6s_kernel<RT_, BITS_, PD_>),         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<RT_>::BYTES);
         DAWN_I6_EACH(DAWN_I6_ATTR)
 #undef DAWN_I6_ATTR
@@ -461,17 +731,22 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, const void* d_rows, in
     }
     if (ev0) (void)hipEventRecord(ev0, stream);
     const int rt = dtype == ROW_BF16 ? 1 : 0;
-    const int pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
-#define DAWN_I6_LAUNCH(RT_, PD_)                                                                                          \
-    if (rt == RT_ && pd == PD_)                                                                                           \
-        hipLaunchKernelGGL((scan_filter_i6s_kernel<RT_, PD_>), dim3(g.blocks), dim3(g.threads), RescoreStage<RT_>::BYTES, \
-                           stream, x, mt, n_rows, d_q, d_rows, ub_s, ub_p, ex_s, ex_p);
+    const int n_refine = g.refine > 0 ? (g.refine > LIST ? LIST : g.refine) : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
+    int pd;
+    if (bits == 6) pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
+    else pd = g.unroll == 4 ? 4 : 8;
+#define DAWN_I6_LAUNCH(RT_, BITS_, PD_)                                                                                  \
+    if (rt == RT_ && bits == BITS_ && pd == PD_)                                                                         \
+        hipLaunchKernelGGL((scan_filter_i6s_kernel<RT_, BITS_, PD_>), dim3(g.blocks), dim3(g.threads),                  \
+                           RescoreStage<RT_>::BYTES, stream, x, mt, n_rows, d_q, d_rows,                                 \
+                           reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_i8meta), ub_s, ub_p,  \
+                           ex_s, ex_p, tb, n_refine);
     DAWN_I6_EACH(DAWN_I6_LAUNCH)
 #undef DAWN_I6_LAUNCH
 #undef DAWN_I6_EACH
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (merge)
-        hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, ub_s, ex_s, ex_p, g.blocks, k,
+        hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, tb, ex_s, ex_p, g.blocks, k,
                            d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8);
 }
 

@@ -175,6 +175,16 @@ class VectorIndex:
         check(lib.dawn_index_debug_stream_lists(self._h, _ptr(q), _ptr(sc), _ptr(rows), cap_blocks, C.byref(n)))
         return sc[:n.value], rows[:n.value]
 
+def _debug_stream_bound(self) -> float:
+    """Test hook: the certificate bound T of the packed-shadow stream for the last debug_stream_lists query."""
+    b = C.c_float(0.0)
+    check(lib.dawn_index_debug_stream_bound(self._h, C.byref(b)))
+    return b.value
+
+
+VectorIndex.debug_stream_bound = _debug_stream_bound
+
+
 def topk_merge_device(device: int, G: int, B: int, count: int, d_in_labels: int, d_in_dist: int, d_in_found: int,
                       d_labels: int, d_dist: int, d_found: int, stream: int = 0):
     check(lib.dawn_topk_merge_device(device, G, B, count, d_in_labels, d_in_dist, d_in_found, d_labels, d_dist,

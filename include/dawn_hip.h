@@ -168,7 +168,7 @@ int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_c
 /* ... of the second_chances, those a deeper round settled (the cheap kind: ~10 us per round). */
 int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
- * so far (int8: 384 B/row + 8 B per 32 rows; 6-bit: 288 B/row + 8 B per 32 rows, indexes of >= 6 Mi rows; f16: 768 B/row),
+ * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 512 Ki rows; f16: 768 B/row),
  * everything else (labels, search workspaces, staging). */
 int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
@@ -182,6 +182,9 @@ int dawn_index_debug_time_full_pass(dawn_index *idx, size_t B, int iters, double
 /* Test hook: per-workgroup candidate lists of the batch-1 streaming filter (scores descending, rows; [blocks][64]). */
 int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *out_scores, uint32_t *out_rows,
                                   size_t cap_blocks, size_t *n_blocks);
+/* Test hook: the certificate bound T of the packed-shadow stream (scan_i6.hip) for the query of the last
+ * dawn_index_debug_stream_lists call: every row that is in no list scores <= T. */
+int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
 /* Tuning knobs (tests and tools sweep them; the defaults are the tuned values):
  *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 2)
  *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
@@ -194,12 +197,16 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  *   "i8_shadow"        0: no integer shadows (int8: 384 B/row, scan_i8.hip; 6-bit: 288 B/row, scan_i6.hip) of the index rows: the
  *                      filters read the f16 shadow of an f32 index / the rows of a bf16 index themselves.  Default 1, or env
  *                      DAWN_I8_SHADOW at creation
- *   "i6_shadow"        0: no 6-bit shadow: single queries stream the int8 shadow (its memory is released; 1 rebuilds it).
+ *   "i6_shadow"        0: no packed shadow: single queries stream the int8 shadow (its memory is released; 1 rebuilds it).
  *                      Default 1, or env DAWN_I6_SHADOW at creation
- *   "i6_min_rows"      single queries of an index of at least this many rows stream the 6-bit shadow (default 6 Mi, or env
+ *   "i6_refine"        entries of its coarse list a wave of the packed stream keeps and refines on the int8 shadow: 1..64, or 0 =
+ *                      chosen from the index size and k (default); too few cost a failed certificate (exact pass), never a result
+ *   "i6_bits"          bits per component of the packed shadow: 5 (240 B/row, default; env DAWN_I6_BITS) or 6 (288 B/row)
+ *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 512 Ki, or env
  *                      DAWN_I6_MIN_ROWS at creation; below it the fixed costs of a search dominate and the shadow is not kept)
- *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the 6-bit stream: workgroups, 64..512 threads, fragments
- *                      of 768 B in flight per wave (12 / 6 / 4 / 3 / 2); same results whatever the geometry
+ *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the packed stream: workgroups, 64..512 threads, loads in
+ *                      flight per wave (6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 loads of 768 B - 1 KiB); same
+ *                      results whatever the geometry
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow

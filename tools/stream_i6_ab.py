@@ -13,6 +13,8 @@ from dawnsearch_amd import synth  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+bits = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+os.environ["DAWN_I6_BITS"] = str(bits)
 idx = dawn.VectorIndex(0)
 idx.set_option("i6_min_rows", 0)
 idx.fill_synthetic(1, 0, rows, 1)
@@ -21,8 +23,10 @@ Q = np.concatenate([synth.unit_rows(2, 0, 5), synth.planted_queries(1, [rows // 
 idx.set_option("i6_shadow", 0)
 want = {k: [idx.search(q, k) for q in Q] for k in (10, 20)}
 idx.set_option("i6_shadow", 1)
-cfgs = [("i8", 0, 0), ("i6", 192, 12), ("i6", 256, 12), ("i6", 256, 6), ("i6", 384, 6), ("i6", 512, 6), ("i6", 512, 4),
-        ("i6", 512, 3), ("i6", 512, 2), ("i6", 384, 4), ("i6", 448, 3), ("i6", 384, 3)]
+if bits == 6:
+    cfgs = [("i8", 0, 0), ("i6", 256, 12), ("i6", 384, 12), ("i6", 512, 12), ("i6", 384, 6), ("i6", 512, 6), ("i6", 512, 4), ("i6", 512, 3)]
+else:
+    cfgs = [("i8", 0, 0), ("i6", 512, 8), ("i6", 512, 4), ("i6", 256, 8), ("i6", 384, 8)]
 acc = {c: [] for c in cfgs}
 wall = {c: [] for c in cfgs}
 iters = 8 if rows > 10_000_000 else 100
@@ -49,8 +53,8 @@ for r in range(rounds):
 for cfg, v in acc.items():
     kind, t, ring = cfg
     k = min(v)
-    bpr = 384.25 if kind == "i8" else 288.25
+    bpr = 384.25 if kind == "i8" else (288.25 if bits == 6 else 240.25)
     print(f"{kind} threads={t:4d} ring={ring:2d}  kernel best {k * 1e3:8.1f} us  all {[round(x * 1e3, 1) for x in v]}  "
           f"{rows * bpr / k / 1e6:8.1f} GB/s = {rows * bpr / k / 1e6 / 8000:.3f} of 8 TB/s   per search (host) {min(wall[cfg]):.3f} ms",
           flush=True)
-print(idx.stats())
+print("bits", bits, idx.stats())
