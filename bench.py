@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ROW_BYTES = 384 * 4
-I6_MIN_ROWS = 512 << 10  # indexes of at least this many rows answer single queries from the 6-bit shadow (option i6_min_rows)
+I6_MIN_ROWS = 2 << 20  # indexes of at least this many rows answer single queries from the packed 5-bit shadow (option i6_min_rows)
 
 
 def parse():
@@ -147,7 +147,7 @@ def read_ceiling_probe(timeout_s: float = 120.0):
                 "lines": [ln for ln in lines if "GB/s" in ln],
                 "what": "tools/probes/hbm_read.hip quick mode: best of the bare 16 B/lane nt read streams (2 / 4 / 8 waves per CU, "
                         "rings of 6 and 12 fragments, chip-wide window and per-XCD ranges) over 38.4 GB, 4 launches each; "
-                        "GBps_12B_per_lane: the same for the 6-bit shadow's access pattern (global_load_dwordx3, 768-B "
+                        "GBps_12B_per_lane: the same for 12 B/lane loads (global_load_dwordx3, 768-B "
                         "fragments, 3 / 4 / 8 waves per CU)"}
     except Exception as e:
         return {"error": repr(e)}
@@ -358,10 +358,11 @@ def main():
         #   "i8"  384.25: the int8 shadow of the index rows (+ 8 B of scale/bound per 32 rows), every batch size
         #   "f16" 768: the f16 shadow of an f32 index, or the rows of a bf16 index themselves (i8_shadow = 0)
         #   "f32" 1536: the f32 rows themselves (both shadows switched off for small batches)
-        #   "i6"  288.25: the 6-bit shadow (+ the same 8 B per 32 rows): single queries of an index of >= 512 Ki rows (scan_i6.hip)
+        #   "i5"  240.25: the packed 5-bit shadow (+ the same 8 B per 32 rows): single queries of an index of >= 2 Mi rows
+        #         (scan_i6.hip; "i6" 288.25: its 6-bit form, option i6_bits = 6)
         if rows_read == "default":
-            rows_read = "i6" if (Bq == 1 and rows_here >= I6_MIN_ROWS) else "i8"
-        row_bytes = {"i6": ROW_BYTES * 3 / 16 + 0.25, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
+            rows_read = "i5" if (Bq == 1 and rows_here >= I6_MIN_ROWS) else "i8"
+        row_bytes = {"i5": 240.25, "i6": 288.25, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
         leg["row_bytes_streamed"] = row_bytes
         algo = int(rows_here * row_bytes) * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
@@ -510,9 +511,10 @@ def main():
     if B >= 2:
         kernel = "scan_i8_pipe16_kernel<append> (int8 shadow tiles by LDS-DMA, 4 waves x 64 queries, v_mfma_i32_16x16x64_i8)"
     elif head["row_bytes_streamed"] < 300:
-        kernel = ("scan_filter_i6s_kernel (6-bit shadow fragments: global_load_dwordx3 -> 9 VALU of unpacking -> "
-                  "v_mfma_i32_32x32x32_i8, threshold test of sub-tile t-1 in the shadow of sub-tile t's MFMAs; scores are upper "
-                  "bounds; epilogue: every workgroup rescores its 64 best rows exactly)")
+        kernel = ("scan_filter_i6s_kernel<BITS = 5> (packed 5-bit shadow: nibble planes by global_load_dwordx4, fifth-bit planes by "
+                  "global_load_dwordx3 -> 13 VALU of unpacking per fragment -> v_mfma_i32_32x32x32_i8, threshold test of sub-tile "
+                  "t-1 in the shadow of sub-tile t's MFMAs; scores are upper bounds; epilogue: every wave refines its best rows on "
+                  "the int8 shadow, every workgroup rescores its 64 best rows exactly)")
     else:
         kernel = ("scan_filter_i8s_pipe_kernel (int8 shadow fragments, global load -> v_mfma_i32_32x32x32_i8, threshold test of "
                   "sub-tile t-1 in the shadow of sub-tile t's MFMAs, 4 waves per CU x 6 KiB in flight; scores are upper bounds)")
@@ -521,9 +523,9 @@ def main():
         "metric": "queries/sec, exact cosine top-k over a 384-d f32 index resident in HBM",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32 (scores, exact rescore); 6-bit / int8 -> i32 MFMA upper-bound filter", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (scores, exact rescore); 5-bit / int8 -> i32 MFMA upper-bound filter", "data": "synthetic",
         "config": {"workload": f"{args.rows}x384 f32 index, batch={B}, k={k}, brute-force cosine scan + top-k "
-                               "(integer upper-bound filter over a quantised shadow copy of every row — 6-bit for single "
+                               "(integer upper-bound filter over a quantised shadow copy of every row — 5-bit for single "
                                "queries, int8 for batches — + exact f32 rescore + certificate: results bit-identical to the "
                                "f32 scan)",
                    "rows_total": args.rows, "rows_per_gpu": rows_local, "batch": B, "k": k,
@@ -540,7 +542,7 @@ def main():
                      # the same launch priced in the f32 rows of SURVEY 8(d) (1536 B/row: what a scan of the index itself
                      # would have to read): the int8 shadow is an algorithmic saving on top of the kernel's HBM efficiency
                      "bytes_basis": (f"shadow rows actually streamed ({head['row_bytes_streamed']} B per row incl. 8 B of scale / "
-                                     "bound per 32 rows: 288 B = the 6-bit shadow, 384 B = the int8 shadow); the f32 index rows "
+                                     "bound per 32 rows: 240 B = the packed 5-bit shadow, 384 B = the int8 shadow); the f32 index rows "
                                      "(1536 B/row) are only touched by the exact rescore (64 rows per workgroup / per query)"),
                      "f32_row_equivalent_GBps": (rows_local * ROW_BYTES * scan_passes(B) / (scan_avg_ms * 1e-3) / 1e9
                                                  if scan_avg_ms > 0 else 0.0),
@@ -565,7 +567,7 @@ def main():
         ceil = read_ceiling_probe()
         out["roofline"]["measured_read_ceiling"] = ceil
         if ceil and ceil.get("GBps"):
-            # against the best bare read of either access pattern (16 B/lane and the 6-bit stream's 12 B/lane)
+            # against the best bare read of either access pattern (16 B/lane and 12 B/lane loads: the packed stream issues both)
             out["roofline"]["frac_of_measured_read_ceiling"] = achieved / max(ceil["GBps"], ceil.get("GBps_12B_per_lane") or 0.0)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
@@ -588,8 +590,13 @@ def main():
         legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="f32")
         idx.set_option("f16_shadow_b1", 1)
         extra["batch1_streaming_f32_rows"] = legf
-        # ... streaming the int8 shadow (384 B/row; the 6-bit shadow off: the round-2 / early round-3 headline path)
+        # ... streaming the packed shadow's 6-bit form (288 B/row), and the int8 shadow (384 B/row; the packed shadow off: the
+        # round-2 / early round-3 headline path)
         if rows_local >= I6_MIN_ROWS:
+            idx.set_option("i6_bits", 6)
+            legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="i6")
+            idx.set_option("i6_bits", 5)
+            extra["batch1_streaming_i6_shadow"] = legf
             idx.set_option("i6_shadow", 0)
             legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="i8")
             idx.set_option("i6_shadow", 1)

@@ -344,7 +344,9 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                                 idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0, idx->d_flags + b0,
                                 idx->force_fallback, stream, b0 == 0 ? e0 : nullptr, b0 == 0 ? e1 : nullptr);
         }
-    } else if (B == 1 && i6_live(idx)) {
+    } else if (B == 1 && i6_live(idx) &&
+               (idx->i6_geom().refine > 0 ||
+                i6_refine_count(n, (uint32_t)k, idx->i6_bits, idx->i6_geom().blocks * (idx->i6_geom().threads / 64)) > 0)) {
         // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
         // stream's epilogue, one merge + certificate (scan_i6.hip)
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
@@ -763,7 +765,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         }
         return reprepare();
     }
-    if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 512 Ki; tests: 0)
+    if (n == "i6_min_rows") {  // indexes of at least this many rows keep the 6-bit shadow (default 2 Mi; tests: 0)
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "i6_min_rows must be >= 0");
         idx->i6_min_rows = (size_t)value;
         return reprepare();

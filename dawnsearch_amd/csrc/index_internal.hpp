@@ -18,8 +18,9 @@ constexpr size_t kMaxBatch = 256;        // queries per internal pass of the hos
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
 constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
 constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
-constexpr size_t kI6MinRows = 512u << 10;      // indexes of at least this many rows keep the 6-bit shadow for their single queries
-constexpr size_t kI6SmallRows = 32u << 20;     // below this the 6-bit stream uses geom_i6_small
+constexpr size_t kI6MinRows = 2u << 20;        // indexes of at least this many rows keep the packed shadow for their single queries
+                                               // (1 M rows: 0.130 ms per search against the int8 stream's 0.124; 3 M: 0.199 / 0.234)
+constexpr size_t kI6SmallRows = 32u << 20;     // below this the packed stream uses geom_i6_small
 constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host before they travel together
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
 }  // namespace dawn
@@ -95,7 +96,10 @@ struct dawn_index {
     // kI6SmallRows rows 8 waves x 12 fragments (72 KiB in flight per CU: a short stream is start-up and tail, it wants its requests
     // out at once): 1 M rows 79 us against 88 (8 x 4), 3 M 158 / 172, 12.5 M 566 / 574 — and against the int8 stream's
     // 78 / 186 / 725 us, whose one-workgroup tail costs ~8 us more per search than merge_exact_kernel
-    // (profiles/r03/stream_i6_ab_small_sizes.log).  5-bit form: 8 waves x 4 loads (half a sub-tile ahead) / x 8 (a whole one).
+    // (profiles/r03/stream_i6_ab_small_sizes.log).  5-bit form (the ring codes 4 / anything else = 4 / 8 loads = half a sub-tile
+    // / a whole one ahead; profiles/r03/stream_i5_ab_*.log): 100 M rows 8 waves x 4 loads 3551 us, 4 x 8 3523 (but half the waves
+    // = half the depth of the coarse lists), 8 x 8 3622, 6 x 8 3670, int8 stream 5607; 12.5 M: 8 x 8 511, 8 x 4 516, int8 714;
+    // 3 M: 159 / 174 / 186; 1 M: 90 / 95 / 75.
     dawn::ScanGeom geom_i6{256, 512, 4};
     dawn::ScanGeom geom_i6_small{256, 512, 12};
     bool geom_i6_pinned = false;

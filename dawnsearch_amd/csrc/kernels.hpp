@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace dawn {
 
 constexpr int EM = 384;        // src/search/vector.rs:26
@@ -63,6 +65,24 @@ constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass mus
 constexpr uint32_t FLAG_SECOND = 2;    // first certificate failed, the 1024-deep second one held: result is exact
 constexpr uint32_t FLAG_DEEP = 3;      // first certificate failed, a deeper round (128 .. 256 rows) held: result is exact
 
+// Function attributes (hipFuncSetAttribute: the dynamic-LDS limit of a kernel) belong to the CURRENT device's copy of the
+// kernel: a process that drives several devices (dawn_sharded.cpp) has to set them on each.  once_per_device(state, fn) runs fn
+// the first time it is called with a given device current; `state` is a per-call-site OncePerDevice.
+struct OncePerDevice {
+    std::mutex mu;
+    uint64_t done = 0;  // bit d: device d has been served (devices >= 64 are served every time)
+};
+template <class Fn>
+inline void once_per_device(OncePerDevice& st, Fn fn) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(st.mu);
+    const uint64_t bit = dev >= 0 && dev < 64 ? (1ull << dev) : 0;
+    if (bit && (st.done & bit)) return;
+    fn();
+    st.done |= bit;
+}
+
 struct BatchWorkspace {
     _Float16* qh;    // [BATCH_QT][384] scaled f16 queries (int8 path: int8 images [256][384] | {s_q, K2}[256])
     float* tau;      // [BATCH_QT]
@@ -107,6 +127,9 @@ void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta
 // the stream alone).  d_i8 / d_i8meta: the int8 shadow, which refines the bounds of the listed rows; tb [blocks].
 void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
                         hipStream_t stream);
+// entries of its coarse list a wave keeps (8 .. 64), chosen from the index size and k; 0: the packed stream cannot certify this
+// search (too many rows above the bound for a 64-entry list: large k on a very large index) — stream the int8 shadow instead
+int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves);
 void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, const ScanGeom& g,

@@ -1241,7 +1241,7 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target_per
     return pl;
 }
 
-static bool g_lds_attr_set = false;
+static OncePerDevice g_lds_attr_once;
 
 
 // Kernel choice and threshold target travel in the index's BatchWorkspace (ws.sched / ws.target / ws.diag: per index, not
@@ -1330,19 +1330,19 @@ static hipError_t set_lds_attr_rt() {
     return hipSuccess;
 }
 
-int batched_init() {
-    if (g_lds_attr_set) return 0;
-    hipError_t e = set_lds_attr_rt();
-    const void* tails[] = {reinterpret_cast<const void*>(select_rescore_kernel<true, 0>),
-                           reinterpret_cast<const void*>(select_rescore_kernel<false, 0>),
-                           reinterpret_cast<const void*>(select_rescore_kernel<true, 1>),
-                           reinterpret_cast<const void*>(select_rescore_kernel<false, 1>)};
-    for (int i = 0; i < 4 && e == hipSuccess; ++i)
-        e = hipFuncSetAttribute(tails[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                i < 2 ? RescoreStage<0>::BYTES : RescoreStage<1>::BYTES);
-    if (e != hipSuccess) return (int)e;
-    g_lds_attr_set = true;
-    return 0;
+int batched_init() {  // (on the current device: every shard of a multi-device handle calls it with its own device set)
+    hipError_t e = hipSuccess;
+    once_per_device(g_lds_attr_once, [&e] {
+        e = set_lds_attr_rt();
+        const void* tails[] = {reinterpret_cast<const void*>(select_rescore_kernel<true, 0>),
+                               reinterpret_cast<const void*>(select_rescore_kernel<false, 0>),
+                               reinterpret_cast<const void*>(select_rescore_kernel<true, 1>),
+                               reinterpret_cast<const void*>(select_rescore_kernel<false, 1>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(tails[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    i < 2 ? RescoreStage<0>::BYTES : RescoreStage<1>::BYTES);
+    });
+    return (int)e;
 }
 
 // f32 rows -> the filter's shadow copy (ROW_F16S, kernels.hpp): value * 2^8 rounded to nearest even, stored tile by

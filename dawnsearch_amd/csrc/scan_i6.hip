@@ -674,18 +674,20 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
     }
 }
 
-// How many entries of its coarse list a wave keeps and refines.  The certificate needs the bound on every unlisted row — the
-// exact score at depth D = waves x n of the index plus the packed shadow's slack E — below the k-th best score: with scores
-// ~ N(0, 1/384) (the thinnest top a real index can have: uniform or Gaussian rows; clustered data has wider gaps) that is
-// z_D <= z_k - (E + margin) * sqrt(384), D = N (1 - Phi(z_D)); twice that depth is asked for.  A wrong guess costs time (the
-// certificate fails, the exact pass answers), never correctness.
+// How many entries of its coarse list a wave keeps and refines.  The certificate needs the bound on every unlisted row — an
+// exact score plus the packed shadow's slack E — below the k-th best score s_k, i.e. no wave may drop a row scoring above
+// s_k - E - margin.  With scores ~ N(0, 1/384) (the thinnest top an index can have: uniform or Gaussian rows; clustered data has
+// wider gaps) a wave holds Poisson(lambda) such rows, lambda = (N / waves) * (1 - Phi(z_k - (E + margin) sqrt(384))); n is the
+// smallest list length that all waves together exceed with probability < 1 % (0: no list length does).  A wrong guess costs
+// time (the certificate fails, the exact pass answers), never correctness.
 int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
-    static uint32_t c_n = 0, c_k = 0;
-    static int c_bits = 0, c_waves = 0, c_out = LIST;
+    // (the last answer is kept per thread: a sharded handle issues its shards' searches from worker threads)
+    thread_local uint32_t c_n = 0, c_k = 0;
+    thread_local int c_bits = 0, c_waves = 0, c_out = LIST;
     if (n_rows == c_n && k == c_k && bits == c_bits && waves == c_waves) return c_out;
     auto tail = [](double z) { return 0.5 * std::erfc(z / 1.4142135623730951); };
     const double kk = k < 1 ? 1.0 : (double)k;
-    double out = LIST;
+    int n = LIST;
     if ((double)n_rows > 4.0 * kk) {
         double lo = 0.0, hi = 8.0;  // z_k: tail(z_k) = k / N
         for (int i = 0; i < 60; ++i) {
@@ -694,14 +696,24 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
             else hi = mid;
         }
         const double slack = (bits == 6 ? 0.040 : 0.082) + 0.012;
-        const double zd = lo - slack * 19.5959;
-        const double depth = 2.0 * tail(zd) * n_rows;
         const double n_sub = std::ceil(n_rows / 32.0);  // (a small index does not reach every wave)
         const double holders = n_sub < (double)waves ? n_sub : (double)(waves > 0 ? waves : 1);
-        out = std::ceil(depth / holders);
+        const double lambda = tail(lo - slack * 19.5959) * n_rows / holders;
+        const double allowed = 0.01 / holders;
+        double term = std::exp(-lambda), cdf = term;  // P(X <= 0)
+        n = 0;
+        while (n < LIST && 1.0 - cdf > allowed) {  // smallest n with P(X > n) <= allowed
+            ++n;
+            term *= lambda / n;
+            cdf += term;
+        }
+        // not even a full list is deep enough (k = 64 on 100 M rows at 5 bits): 0 — the caller streams the int8 shadow, whose
+        // 64-row certificate has deeper rounds to fall back on, instead of paying an exact pass for a certificate that must fail
+        if (1.0 - cdf > 0.05) n = -1;
     }
-    int n = out < 8.0 ? 8 : out > (double)LIST ? LIST : (int)out;
-    n = (n + 7) & ~7;
+    if (n < 0) n = 0;
+    else n = n < 8 ? 8 : ((n + 7) & ~7);
+    if (n > LIST) n = LIST;
     c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n;
     return n;
 }
@@ -715,23 +727,23 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
                     uint32_t* ex_p, float* tb, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                     bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    static bool attr_set = false;
+    static OncePerDevice attr_once;
     const uint32_t* x = reinterpret_cast<const uint32_t*>(d_i6);
     const float2* mt = reinterpret_cast<const float2*>(d_meta);
 #define DAWN_I6_EACH(F)                                                                                              \
     F(0, 6, 12) F(0, 6, 6) F(0, 6, 4) F(0, 6, 3) F(0, 6, 2) F(1, 6, 12) F(1, 6, 6) F(1, 6, 4) F(1, 6, 3) F(1, 6, 2) \
     F(0, 5, 8) F(0, 5, 4) F(1, 5, 8) F(1, 5, 4)
-    if (!attr_set) {
+    once_per_device(attr_once, [] {
 #define DAWN_I6_ATTR(RT_, BITS_, PD_)                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_filter_i6s_kernel<RT_, BITS_, PD_>),         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<RT_>::BYTES);
         DAWN_I6_EACH(DAWN_I6_ATTR)
 #undef DAWN_I6_ATTR
-        attr_set = true;
-    }
+    });
     if (ev0) (void)hipEventRecord(ev0, stream);
     const int rt = dtype == ROW_BF16 ? 1 : 0;
-    const int n_refine = g.refine > 0 ? (g.refine > LIST ? LIST : g.refine) : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
+    int n_refine = g.refine > 0 ? g.refine : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
+    if (n_refine < 1 || n_refine > LIST) n_refine = LIST;  // (callers ask i6_refine_count first and go elsewhere on 0)
     int pd;
     if (bits == 6) pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
     else pd = g.unroll == 4 ? 4 : 8;

@@ -519,14 +519,13 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
                           hipStream_t stream) {
-    static bool attr_set = false;  // the f32 stage (97 KiB) is above the default dynamic-LDS limit
-    if (!attr_set) {
+    static OncePerDevice attr_once;  // the f32 stage (97 KiB) is above the default dynamic-LDS limit
+    once_per_device(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<0>::BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, RescoreStage<1>::BYTES);
-        attr_set = true;
-    }
+    });
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x, d_ids, n_rows,
                            d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);

@@ -168,7 +168,7 @@ int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_c
 /* ... of the second_chances, those a deeper round settled (the cheap kind: ~10 us per round). */
 int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
- * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 512 Ki rows; f16: 768 B/row),
+ * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 2 Mi rows; f16: 768 B/row),
  * everything else (labels, search workspaces, staging). */
 int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
@@ -202,7 +202,7 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "i6_refine"        entries of its coarse list a wave of the packed stream keeps and refines on the int8 shadow: 1..64, or 0 =
  *                      chosen from the index size and k (default); too few cost a failed certificate (exact pass), never a result
  *   "i6_bits"          bits per component of the packed shadow: 5 (240 B/row, default; env DAWN_I6_BITS) or 6 (288 B/row)
- *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 512 Ki, or env
+ *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 2 Mi, or env
  *                      DAWN_I6_MIN_ROWS at creation; below it the fixed costs of a search dominate and the shadow is not kept)
  *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the packed stream: workgroups, 64..512 threads, loads in
  *                      flight per wave (6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 loads of 768 B - 1 KiB); same

@@ -206,8 +206,8 @@ def test_configs3_shard_12p5m_rows_batch256_vs_oracle(dawn, oracle):
     sample = [0, 1, 2, 3, 64, 129, 200, 255]
     ol, od = oracle.scan_topk_synth(1, first, n, first + 1, Q[sample], 20)
     assert np.array_equal(labels[sample], ol) and np.array_equal(dist[sample].view(np.uint32), od.view(np.uint32))
-    assert idx.memory()["shadows"] > n * (384 + 288)  # a shard of this size keeps the 6-bit shadow for its single queries
-    for j, b in enumerate(sample[:4]):  # the same queries one at a time: the 6-bit stream; k = 10
+    assert idx.memory()["shadows"] > n * (384 + 240)  # a shard of this size keeps the packed 5-bit shadow for its single queries
+    for j, b in enumerate(sample[:4]):  # the same queries one at a time: the packed stream; k = 10
         l1, d1 = idx.search(Q[b], 10)
         assert np.array_equal(l1, ol[j, :10]) and np.array_equal(d1.view(np.uint32), od[j, :10].view(np.uint32))
     idx.set_option("i6_shadow", 0)  # ... and the int8 stream

@@ -45,8 +45,8 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     idx = big
     Q, planted = _queries()
     assert idx.size() == N
-    # (1) batch-1 stream over the 6-bit shadow (default from 512 Ki rows up: scan_i6.hip)
-    assert idx.memory()["shadows"] > N * (384 + 288)  # both integer shadows are resident
+    # (1) batch-1 stream over the packed shadow (default from 2 Mi rows up: scan_i6.hip)
+    assert idx.memory()["shadows"] > N * (384 + 240)  # both integer shadows are resident
     res1 = [idx.search(q, K) for q in Q]
     for lab, dist in res1:
         assert len(lab) == K and np.all(np.diff(dist) >= 0) and lab.min() >= 1 and lab.max() <= N
@@ -60,7 +60,7 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     # idempotent
     lab, dist = idx.search(Q[0], K)
     assert np.array_equal(lab, res1[0][0]) and np.array_equal(dist.view(np.uint32), res1[0][1].view(np.uint32))
-    # (1b) ... and over the int8 shadow (the 6-bit one switched off: its 28.8 GB go back and are rebuilt afterwards)
+    # (1b) ... and over the int8 shadow (the packed one switched off: its 24 GB go back and are rebuilt afterwards)
     idx.set_option("i6_shadow", 0)
     try:
         assert idx.memory()["shadows"] < N * (384 + 100)
@@ -69,7 +69,7 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
             assert np.array_equal(lab, res1[b][0]) and np.array_equal(dd.view(np.uint32), res1[b][1].view(np.uint32))
     finally:
         idx.set_option("i6_shadow", 1)
-    assert idx.memory()["shadows"] > N * (384 + 288)
+    assert idx.memory()["shadows"] > N * (384 + 240)
     # (2) all 16 at once: the matrix-core path (pipelined kernel at this size)
     labels, dist, found = idx.search_batch(Q, K)
     for b in range(len(Q)):
@@ -154,11 +154,11 @@ def test_100m_batch256_all_paths_agree(dawn, big):
 def test_100m_default_path_equals_the_oracle_scan_of_all_rows(dawn, oracle, big):
     """Parity at BASELINE's metric size against the oracle ITSELF: the C oracle scans all 100 M synthetic rows (generated
     chunk by chunk on the host cores — orc_scan_topk_synth — since 153.6 GB do not fit host memory) for six queries, k = 20;
-    the default paths must return exactly that — labels and distance bits — at batch 1 (the 6-bit stream, and the int8 stream
-    with the 6-bit shadow switched off; k = 10 and k = 20) and for the same queries inside a 256-batch (the int8 matrix-core
+    the default paths must return exactly that — labels and distance bits — at batch 1 (the packed stream, and the int8 stream
+    with the packed shadow switched off; k = 10 and k = 20) and for the same queries inside a 256-batch (the int8 matrix-core
     pass; k = 10 and k = 20)."""
     idx = big
-    assert idx.memory()["shadows"] > N * (384 + 288)  # (the 6-bit shadow is live: batch 1 below is its stream)
+    assert idx.memory()["shadows"] > N * (384 + 240)  # (the packed shadow is live: batch 1 below is its stream)
     fallbacks_before = idx.stats()["fallbacks"]
     Qp, planted = _queries()
     Q6 = np.concatenate([Qp[:3], Qp[[6, 10, 15]]])  # three plain queries; planted on rows 0, 12 345 678 and N - 1
@@ -248,7 +248,7 @@ def test_125m_bf16_shard_paths_agree(dawn, oracle):
     labels, dist, found = idx.search_batch(Q, K)  # matrix-core pass (12 queries)
     for b in range(len(Q)):
         assert found[b] == K and np.all(np.diff(dist[b]) >= 0) and labels[b].max() <= n
-    for b in (0, 7, 8, 11):  # batch-1 stream (6-bit shadow of the bf16 rows)
+    for b in (0, 7, 8, 11):  # batch-1 stream (packed shadow of the bf16 rows)
         lab, dd = idx.search(Q[b], K)
         assert np.array_equal(lab, labels[b]) and np.array_equal(dd.view(np.uint32), dist[b].view(np.uint32))
     idx.set_option("i6_shadow", 0)  # ... and the int8 shadow's stream

@@ -72,7 +72,7 @@ def test_scan_1m_batch1_and_batch(dawn, oracle):
         _assert_same(labels[b], dist[b], olab, odist)
     # planted queries: the planted row is the nearest neighbour
     assert labels[5][0] == 1 and labels[6][0] == 12346 and labels[7][0] == n
-    lab1, d1 = idx.search(Q[0], 20)  # (an index of this size keeps the 6-bit shadow: its stream)
+    lab1, d1 = idx.search(Q[0], 20)  # (an index of this size keeps the packed shadow: its stream)
     olab, odist = oracle.scan_topk(x, ids, Q[0], 20, threads=8)
     _assert_same(lab1, d1, olab, odist)
     idx.set_option("i6_shadow", 0)  # ... and the int8 shadow's
