@@ -711,8 +711,10 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
         // 64-row certificate has deeper rounds to fall back on, instead of paying an exact pass for a certificate that must fail
         if (1.0 - cdf > 0.05) n = -1;
     }
+    // twice the model's answer (real rows cluster: pages of one site arrive together and land in one wave's sub-tiles; a
+    // refined entry costs ~0.1 ns of a search): 100 M rows, k = 10: 2 x 48 -> 64; 12.5 M: 2 x 32; 3 M: 2 x 24
     if (n < 0) n = 0;
-    else n = n < 8 ? 8 : ((n + 7) & ~7);
+    else n = n < 8 ? 16 : ((2 * n + 7) & ~7);
     if (n > LIST) n = LIST;
     c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n;
     return n;
