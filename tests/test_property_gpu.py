@@ -4,8 +4,8 @@ The generated indexes are built to stress exactly that machinery: exact duplicat
 below every filter bound, tight clusters around the query (more than 64 rows inside the filter's error band), sparse
 vectors with tiny components (f16 subnormal territory), antipodal and orthogonal rows, batches that mix all of them,
 rows that stretch the int8 quantiser (one-hot / two-hot rows that set the scale of their whole sub-tile, Gaussian rows),
-any k up to 64, both index types, both filter sources (int8 upper-bound shadow, 16-bit rows), every batch size class
-(stream 1..3, matrix-core 4+, forced 8-per-pass stream)."""
+any k up to 64, both index types, every filter source (packed 5- / 6-bit shadow forced on these small indexes — single queries —,
+int8 upper-bound shadow, 16-bit rows), every batch size class (stream 1..3, matrix-core 4+, forced 8-per-pass stream)."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -72,8 +72,8 @@ _EXAMPLES = int(os.environ.get("DAWN_HYP_EXAMPLES", "150"))  # soak runs: DAWN_H
        B=st.sampled_from([1, 2, 3, 4, 7, 9, 33, 70]),
        kind=st.sampled_from(["random", "duplicates", "cluster", "sparse", "antipodal", "onehot", "heavy"]),
        dtype=st.sampled_from(["f32", "bf16"]), force_stream=st.booleans(), sched=st.sampled_from([4, 5, 1]),
-       i8=st.booleans(), shards=st.sampled_from([0, 0, 2, 3]))
-def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched, i8, shards):
+       i8=st.booleans(), shards=st.sampled_from([0, 0, 2, 3]), packed=st.sampled_from([0, 0, 5, 6]))
+def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kind, dtype, force_stream, sched, i8, shards, packed):
     rng = np.random.default_rng(seed)
     Q = synth.unit_rows(int(rng.integers(1, 1 << 30)), 0, B)
     rows = _build_rows(rng, n, kind, Q[0])
@@ -90,10 +90,18 @@ def test_any_index_any_batch_matches_the_oracle(dawn, oracle, seed, n, k, B, kin
         idx.add_batch(ids, rows)
         stored = synth.round_bf16(rows) if dtype == "bf16" else rows
         idx.set_option("i8_shadow", int(i8))  # False: filter on the f16 shadow / the bf16 rows themselves
+        if packed:  # single queries stream the packed shadow (scan_i6.hip) whatever the size of the index
+            idx.set_option("i6_bits", packed)
+            idx.set_option("i6_min_rows", 0)
         if force_stream:
             idx.set_option("mfma_min_batch", 100000)
         idx.set_option("mfma_sched", sched)  # 5: the pipelined matrix-core kernel for every pass, 1: the 8-wave kernel
         labels, dist, found = idx.search_batch(Q, k)
+        if packed and B > 1:  # the batch went to the matrix-core pass / the int8 stream: every query once more on its own
+            for b in range(B):
+                l1, d1 = idx.search(Q[b], k)
+                assert np.array_equal(l1, labels[b][:found[b]]) and np.array_equal(d1.view(np.uint32), dist[b][:found[b]].view(np.uint32)), \
+                    (kind, dtype, n, k, B, b, packed)
         for b in range(B):
             olab, odist = oracle.scan_topk(stored, ids, Q[b], k)
             assert found[b] == min(k, n)
