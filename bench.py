@@ -144,11 +144,13 @@ def read_ceiling_probe(timeout_s: float = 120.0):
         js = json.loads(lines[-1])
         best = js["hbm_read_ceiling_GBps"]
         return {"GBps": best, "frac_of_spec": best / HBM_PEAK_GBS, "GBps_12B_per_lane": js.get("hbm_read_ceiling_12B_GBps"),
+                "GBps_packed_stream_pattern": js.get("hbm_read_ceiling_i5_pattern_GBps"),
                 "lines": [ln for ln in lines if "GB/s" in ln],
                 "what": "tools/probes/hbm_read.hip quick mode: best of the bare 16 B/lane nt read streams (2 / 4 / 8 waves per CU, "
                         "rings of 6 and 12 fragments, chip-wide window and per-XCD ranges) over 38.4 GB, 4 launches each; "
                         "GBps_12B_per_lane: the same for 12 B/lane loads (global_load_dwordx3, 768-B "
-                        "fragments, 3 / 4 / 8 waves per CU)"}
+                        "fragments, 3 / 4 / 8 waves per CU); GBps_packed_stream_pattern: the headline kernel's own mix of loads (per "
+                        "7680-B sub-tile two dwordx3 and six dwordx4 loads, rings of 4 and 8) with nothing but the loads"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -568,7 +570,8 @@ def main():
         out["roofline"]["measured_read_ceiling"] = ceil
         if ceil and ceil.get("GBps"):
             # against the best bare read of either access pattern (16 B/lane and 12 B/lane loads: the packed stream issues both)
-            out["roofline"]["frac_of_measured_read_ceiling"] = achieved / max(ceil["GBps"], ceil.get("GBps_12B_per_lane") or 0.0)
+            out["roofline"]["frac_of_measured_read_ceiling"] = achieved / max(ceil["GBps"], ceil.get("GBps_12B_per_lane") or 0.0,
+                                                                              ceil.get("GBps_packed_stream_pattern") or 0.0)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
