@@ -202,6 +202,14 @@ void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, vo
 // the stream: scan_filter_i8s_pipe_kernel (software-pipelined test, two accumulator sets) for ONE query on 6-bit
 // fragments, + the exact rescore of the workgroup's shortlist as its epilogue
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot4_f(const f32x4& a, const f32x4& b, float acc) {
+    acc = __builtin_fmaf(a.x, b.x, acc);
+    acc = __builtin_fmaf(a.y, b.y, acc);
+    acc = __builtin_fmaf(a.z, b.z, acc);
+    acc = __builtin_fmaf(a.w, b.w, acc);
+    return acc;
+}
+
 __device__ __forceinline__ u32x3 frag_load(const uint32_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x3_u*>(p));
 }
@@ -509,11 +517,13 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         if (__any(mx > thr)) slow_path();
     }
 
-    // ---- epilogue 1: REFINEMENT.  The wave's list holds its 64 best rows by the packed shadow's bound; every row of the wave
-    // that is not listed is bounded by the list's last entry (tw; -inf while the list is not full).  The listed rows get the
-    // int8 shadow's bound instead (scan_i8.hip: a quarter of the slack) — a lane per row: its 24 16-B pieces of the int8 sub-tile
-    // against the query's two int8 images in LDS, v_dot4_i32_i8 — and the list is re-sorted by it: what the workgroup then merges
-    // and rescores are its 64 best rows by the TIGHT bound, chosen among nwaves x 64 candidates of the coarse one.
+    // ---- epilogue 1: REFINEMENT.  The wave's list holds its best rows by the packed shadow's bound; every row of the wave
+    // that is not listed is bounded by the first entry it drops (tw; -inf while the list is not full).  The listed rows get a
+    // TIGHT score in its place and the list is re-sorted by it: what the workgroup then merges and rescores are its 64 best rows
+    // by the tight score, chosen among nwaves x n_refine candidates of the coarse one.  f32 index: the fast f32 dot of the row
+    // itself; bf16 index (rows in fragment order: no contiguous row to read): the int8 shadow's bound (scan_i8.hip: an eighth of
+    // the slack) — a lane per row, its 24 16-B pieces of the int8 sub-tile against the query's two int8 images in LDS,
+    // v_dot4_i32_i8.
     // Only the wave's best n_refine entries are kept (1 .. 64, chosen by the host from the index size and k: i6_refine_count):
     // a short list is a shallow one — its bound tw sits higher —, but every kept row costs a 3-KB gather, and the depth the
     // certificate needs grows with the index.
@@ -529,7 +539,40 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         const bool full = __builtin_amdgcn_readlane((int)lp, 63) != (int)NO_POS;
         tw = full ? read_lane63(ls) : NEG_INF;
     }
-    {
+    if constexpr (RT == 0) {
+        // f32 index: the kept rows are scored on the f32 rows themselves, a wave per row — one coalesced 1.5-KB read per row
+        // (the int8 sub-tile holds a row as 24 pieces 512 B apart: a 3-KB scatter in 64-B sectors), 8 rows in flight, 24 FMAs
+        // per lane and a DPP sum per row.  The score errs like scan_filter_kernel's (f32 FMAs in another order than the
+        // reference's sequential sum: FILTER_EPS_F32 = 2.6e-5 <= the eps of the certificate), i.e. it bounds the exact score
+        // as tightly as anything short of the exact rescore.
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(q);
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(rows);
+        const f32x4 qa = q4[lane];
+        const f32x4 qb = lane < 32 ? q4[64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+        float mine = NEG_INF;
+        for (int i0 = 0; i0 < n_refine; i0 += 8) {
+            f32x4 xa[8], xb[8];
+            uint32_t rr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rr[j] = (uint32_t)__builtin_amdgcn_readlane((int)lp, i0 + j);  // (i0 + j < 64: n_refine is a multiple of 8)
+                const f32x4* rp = x4 + (size_t)(rr[j] != NO_POS ? rr[j] : 0u) * ROW_F4;
+                xa[j] = rp[lane];
+                xb[j] = lane < 32 ? rp[64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float part = dot4_f(xa[j], qa, dot4_f(xb[j], qb, 0.f));
+                const float tot = read_lane63(wave_sum_lane63(part));
+                if (lane == i0 + j && rr[j] != NO_POS) mine = tot;
+            }
+        }
+        float d = lp != NO_POS ? -mine : POS_INF;
+        uint32_t pr = lp;
+        sort64_asc(d, pr, lane);
+        ls = -d;  // descending by the refined score, ties -> lower row; fillers (-inf, NO_POS) last
+        lp = pr;
+    } else {
         float ub8 = NEG_INF;
         if (lp != NO_POS) {
             const uint32_t t8 = lp >> 5, r8 = lp & 31u;
@@ -711,10 +754,12 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
         // 64-row certificate has deeper rounds to fall back on, instead of paying an exact pass for a certificate that must fail
         if (1.0 - cdf > 0.05) n = -1;
     }
-    // twice the model's answer (real rows cluster: pages of one site arrive together and land in one wave's sub-tiles; a
-    // refined entry costs ~0.1 ns of a search): 100 M rows, k = 10: 2 x 48 -> 64; 12.5 M: 2 x 32; 3 M: 2 x 24
+    // + 8, and never fewer than 40: real rows cluster — the pages of one site arrive together and fill a 32-row sub-tile, which
+    // is ONE wave's — and a wave has to be able to keep such a sub-tile whole on top of its ordinary share; a refined entry
+    // costs ~1 us per list position of the whole grid (a 3-KB scatter per row): 12.5 M rows, k = 10: 40 instead of 64 = -24 us
+    // of a 0.5-ms search
     if (n < 0) n = 0;
-    else n = n < 8 ? 16 : ((2 * n + 7) & ~7);
+    else n = (n + 8 < 40) ? 40 : ((n + 8 + 7) & ~7);
     if (n > LIST) n = LIST;
     c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n;
     return n;
@@ -746,6 +791,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
     const int rt = dtype == ROW_BF16 ? 1 : 0;
     int n_refine = g.refine > 0 ? g.refine : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
     if (n_refine < 1 || n_refine > LIST) n_refine = LIST;  // (callers ask i6_refine_count first and go elsewhere on 0)
+    n_refine = (n_refine + 7) & ~7;                         // (the f32 refinement takes its rows eight at a time)
     int pd;
     if (bits == 6) pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
     else pd = g.unroll == 4 ? 4 : 8;
