@@ -515,8 +515,8 @@ def main():
     elif head["row_bytes_streamed"] < 300:
         kernel = ("scan_filter_i6s_kernel<BITS = 5> (packed 5-bit shadow: nibble planes by global_load_dwordx4, fifth-bit planes by "
                   "global_load_dwordx3 -> 13 VALU of unpacking per fragment -> v_mfma_i32_32x32x32_i8, threshold test of sub-tile "
-                  "t-1 in the shadow of sub-tile t's MFMAs; scores are upper bounds; epilogue: every wave refines its best rows on "
-                  "the int8 shadow, every workgroup rescores its 64 best rows exactly)")
+                  "t-1 in the shadow of sub-tile t's MFMAs; scores are upper bounds; epilogue: every wave re-scores its best rows on "
+                  "the f32 rows, every workgroup rescores its 64 best rows exactly in the reference's order)")
     else:
         kernel = ("scan_filter_i8s_pipe_kernel (int8 shadow fragments, global load -> v_mfma_i32_32x32x32_i8, threshold test of "
                   "sub-tile t-1 in the shadow of sub-tile t's MFMAs, 4 waves per CU x 6 KiB in flight; scores are upper bounds)")

@@ -16,13 +16,16 @@
 //   * ub = fma(float(C), s * s_q / 254, E + K2) >= x.q as before; K2 uses ||s X||_2 <= ||x||_2 + ||dx||_2 < 1.01 + 0.32
 //     (||dx||_2 <= sqrt(384) * s / 2, s <= 1.01 / 31: the worst case of a sub-tile that holds a one-hot row in the rotated
 //     basis; the int8 shadow's 0.09 does not carry over).
-// E is four times the int8 shadow's (~0.037 on unit vectors), which a 64-row shortlist cannot absorb (the gap between the
-// 10th and the 64th best score of 100 M rows is 0.017; tools/coarse_shadow_probe.py).  The stream therefore does not hand a
-// 64-row shortlist to a one-workgroup tail: EVERY workgroup rescores its own 64 best rows exactly (reference order,
-// src/search/vector.rs:128-134) in its epilogue — 256 workgroups x 64 rows = a shortlist 16 384 rows deep for ~8 us —, and
-// merge_exact_kernel merges the exact lists and checks ONE certificate: rows in no list have ub <= T = the largest 64th
-// upper bound of any workgroup, i.e. distance >= fl(1 - up(T + eps)); if that exceeds the k-th exact distance strictly
-// the result is exact, otherwise the query takes the exact pass (scan_exact_kernel) like any failed certificate.
+// E is four times the int8 shadow's (~0.037 on unit vectors; eight times at 5 bits), which a 64-row shortlist cannot absorb (the
+// gap between the 10th and the 64th best score of 100 M rows is 0.017; tools/coarse_shadow_probe.py).  The stream therefore
+// does not hand a 64-row shortlist to a one-workgroup tail.  Every WAVE keeps the best 40-64 rows of its share by the packed
+// bound and re-scores them tightly (f32 index: on the f32 rows, a wave per row; bf16 index: on the int8 shadow), every
+// WORKGROUP merges its waves' lists by that score and rescores its own 64 best rows exactly (reference order,
+// src/search/vector.rs:128-134) in its epilogue — a shortlist up to 131 072 rows deep by the packed bound, 16 384 by the tight
+// score —, and merge_exact_kernel merges the exact lists and checks ONE certificate: rows in no list score <= T = the largest
+// of the workgroups' bounds on what they dropped, i.e. lie at distance >= fl(1 - up(T + eps)); if that exceeds the k-th exact
+// distance strictly the result is exact, otherwise the query takes the exact pass (scan_exact_kernel) like any failed
+// certificate.
 #include <cmath>
 #include <type_traits>
 
