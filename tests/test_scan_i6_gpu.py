@@ -309,3 +309,37 @@ def test_i6_on_gaussian_and_heavy_tailed_rows(dawn, oracle, dist):
             _assert_same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k, threads=8))
     assert idx.search(Q[5], 1)[0][0] == 4243
     assert idx.stats()["fallbacks"] == 0
+
+
+def test_i6_survives_save_load_and_follows_the_int8_switch(dawn, oracle, tmp_path, bits):
+    """The packed shadow is rebuilt by `load` like every other shadow; "i8_shadow" = 0 asks for the 16-bit filters: BOTH integer
+    shadows stop being read and the packed one's memory goes back (the f16 shadow is built instead, and released again when the
+    integer shadows return) — same answers throughout."""
+    n = 150_000
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    q = synth.planted_queries(1, [n // 3], 4)[0]
+    want = oracle.scan_topk(x, ids, q, 20)
+    path = str(tmp_path / "index.dawn")
+    idx.save(path)
+    other = dawn.VectorIndex(0)
+    other.set_option("i6_min_rows", 0)
+    other.load(path)
+    assert other.size() == n
+    _assert_same(*other.search(q, 20), *want)
+    sc, _ = other.debug_stream_lists(q)
+    assert np.isfinite(other.debug_stream_bound()) and len(sc) == 256  # (the packed stream is what answered)
+    rb = 288 if bits == 6 else 240
+    m_int = other.memory()["shadows"]
+    assert m_int >= n * (384 + rb)
+    other.set_option("i8_shadow", 0)
+    m_f16 = other.memory()["shadows"]
+    assert n * (384 + 768) <= m_f16 < (n + 4096) * (384 + 768 + 8)  # int8 kept, packed released, f16 built
+    _assert_same(*other.search(q, 20), *want)
+    with pytest.raises(Exception):
+        other.debug_stream_bound()  # not live
+    other.set_option("i8_shadow", 1)
+    assert other.memory()["shadows"] == m_int  # f16 released, packed rebuilt
+    _assert_same(*other.search(q, 20), *want)
+    assert other.stats()["fallbacks"] == 0
