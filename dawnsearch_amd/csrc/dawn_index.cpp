@@ -101,6 +101,10 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, 4 * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMemset(idx->d_stats, 0, 4 * sizeof(uint32_t)));
     }
+    if (!idx->d_i6_pool) {  // chunk counters of the packed stream: zero between searches (merge_exact_kernel resets them)
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->d_i6_pool, 32 * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMemset(idx->d_i6_pool, 0, 32 * sizeof(uint32_t)));
+    }
     const size_t lists = ws_lists_needed(idx);
     if (B <= idx->ws_B && lists <= idx->ws_lists) return DAWN_OK;
     B = std::max(B, idx->ws_B);
@@ -350,7 +354,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
         // stream's epilogue, one merge + certificate (scan_i6.hip)
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
-                       idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                       idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                        idx->force_fallback, true, stream, e0, e1);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
@@ -439,7 +443,7 @@ void index_destroy_single(dawn_index* idx) {
     }
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
                     idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
@@ -1400,7 +1404,7 @@ int dawn_index_debug_stream_lists(dawn_index* idx, const float* query, float* ou
         blocks = (size_t)idx->i6_geom().blocks;
         dawn::launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
                              (uint32_t)idx->size, idx->d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
-                             idx->i6_geom(), 0, nullptr, nullptr, nullptr, nullptr, 0,
+                             idx->d_i6_pool, idx->i6_geom(), 0, nullptr, nullptr, nullptr, nullptr, 0,
                              false, stream, nullptr, nullptr);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         const dawn::ScanGeom& gh = idx->i8_geom();

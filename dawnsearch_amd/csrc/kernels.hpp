@@ -132,7 +132,7 @@ void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, vo
 int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves);
 void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
-                    uint32_t* ex_p, float* tb, const ScanGeom& g,
+                    uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                     bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);

@@ -47,6 +47,19 @@
 // with the smallest resulting E wins — clipping the few largest components (they saturate; their error is part of the measured
 // E) buys a finer step for all the others: E -14 % at 6 bits, -23 % at 5 (the optimum of a uniform quantiser on near-Gaussian
 // data lies at 3.0-3.3 sigma, the sub-tile maximum at ~4 sigma).
+#ifdef DAWN_EXPERIMENTS
+// timestamps (100-MHz counter) of every wave of scan_filter_i6s_kernel: [0] entry, [1] stream starts, [2] stream done,
+// [3] refined, [4] workgroup done (dawn_debug_read_ts_i6; tools/stream_i5_ts.py)
+static __device__ unsigned long long dawn_ts_i6[2048 * 5];
+#define DAWN_TS6(i)                                                                                      \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 2048)       \
+            dawn_ts_i6[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 5 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DAWN_TS6(i)
+#endif
+
 namespace dawn {
 
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                                                                const float2* __restrict__ meta8, float* __restrict__ out_s,
                                                                uint32_t* __restrict__ out_p, float* __restrict__ out_es,
                                                                uint32_t* __restrict__ out_ep, float* __restrict__ out_t,
-                                                               int n_refine) {
+                                                               int n_refine, uint32_t* __restrict__ pool) {
     static_assert(BITS == 6 ? 12 % PD == 0 : (PD == 8 || PD == 4), "ring depth");
     typedef PackedShadow<BITS> PS;
     __shared__ float sh_s[8][LIST];
@@ -262,6 +275,38 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t c = lane & 31, h = lane >> 5;
     uint32_t t = blockIdx.x * nwaves + wave;
     const uint32_t t_stride = gridDim.x * nwaves, t_end = n_sub;
+    DAWN_TS6(0);
+    // Work assignment.  Static and interleaved — wave w takes sub-tiles w, w + W, w + 2W, ... — for the first 7/8 of the index;
+    // the last eighth is handed out in CHUNKS of 16 sub-tiles on demand.  The waves' shares of a static assignment are equal,
+    // their speeds are not: the first wave of a 100 M-row launch is done 260-340 us before the last (tools/stream_i5_ts.py,
+    // profiles/r03/stream_i5_wave_timestamps_100M_static.log) — 4 % of the kernel during which the memory system runs half empty.
+    //   * a chunk is STRIDED: chunk j = sub-tiles D0 + j + i C, i < 16 (C = number of chunks): never two consecutive sub-tiles
+    //     in one wave — a run of similar rows in one wave is what the list length is sized against;
+    //   * a chunk is fetched with a SCALAR atomic (s_atomic_add, returns through lgkmcnt): a returning vector atomic in this
+    //     loop makes hipcc drain the load ring — with one sub-tile per atomic that cost 2 x the kernel (7.4 ms,
+    //     stream_i5_wave_timestamps_100M_atomic_pool_experiment.log), and same-address atomics retire at only ~13 M/s on
+    //     this chip (512 of them took 40 us): hence chunks, and 32 counters — counter (b / 8) % 32 serves the chunks of that
+    //     residue: its eight workgroups run on the eight XCDs (workgroup b: XCD b % 8), whose memory speeds differ too;
+    //   * a rotated static interleave (round i of wave w = sub-tile i W + ((w + 37 i) mod W)) changes nothing: the speed
+    //     differences belong to the waves' places on the chip, not to their addresses (..._rotated_interleave_experiment.log).
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    constexpr uint32_t CHUNK = 16, POOLS = 32;
+    uint32_t static_left = NONE;  // further static sub-tiles of this wave (NONE: static to the end)
+    uint32_t dyn0 = 0, n_chunks = 0, chunk_base = 0, chunk_i = CHUNK;
+    uint32_t* my_pool = nullptr;
+    if (pool != nullptr && n_sub / t_stride >= 16u) {
+        const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds / 8u;
+        dyn0 = t_stride * i_static;
+        n_chunks = (n_sub - dyn0 + CHUNK - 1u) / CHUNK;
+        my_pool = pool + ((blockIdx.x >> 3) % POOLS);
+        static_left = i_static - 1u;
+    }
+    auto fetch_chunk = [&]() __attribute__((always_inline)) -> uint32_t {  // the next chunk of this wave's pool, or NONE
+        uint32_t v = 1u;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(my_pool));
+        const uint32_t j = ((blockIdx.x >> 3) % POOLS) + POOLS * v;
+        return j < n_chunks ? j : NONE;
+    };
     // the first loads fly while the query images are made.  6 bits: a[] = ring of fragments (lane slot: 3 dwords);
     // 5 bits: hq[] = ring of H loads (lane slot: 3 dwords), nq[] = ring of N loads (lane slot: 4 dwords)
     constexpr int NA = BITS == 6 ? PD : 1, NH = BITS == 5 ? PD / 4 : 1, NN = BITS == 5 ? 3 * PD / 4 : 1;
@@ -345,6 +390,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const bool tested = c == 0;
     float tau_m = tested ? NEG_INF : __builtin_inff();
 
+    DAWN_TS6(1);
     if (t < t_end) {
         i32x16_t accs[2];
         float2 pmt = mt;
@@ -434,7 +480,21 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
             constexpr int P = decltype(parity)::value;
             constexpr bool TEST = decltype(with_test)::value;
             i32x16_t& acc = accs[P];
-            const uint32_t tn = t + t_stride;
+            uint32_t tn;
+            if (static_left != 0u) {
+                tn = t + t_stride;
+                if (static_left != NONE) --static_left;
+            } else {
+                tn = chunk_i + 1u < CHUNK ? chunk_base + (chunk_i + 1u) * n_chunks : NONE;
+                if (tn < t_end) {
+                    ++chunk_i;
+                } else {
+                    const uint32_t j = fetch_chunk();
+                    chunk_base = dyn0 + j;
+                    chunk_i = 0u;
+                    tn = j != NONE ? chunk_base : NONE;
+                }
+            }
             more = tn < t_end;
             // (the last sub-tile re-reads its own first bytes: no branch in the stream)
             const uint32_t* pn = more ? x + (size_t)tn * PS::SUB_DW : p;
@@ -520,6 +580,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         if (__any(mx > thr)) slow_path();
     }
 
+    DAWN_TS6(2);
     // ---- epilogue 1: REFINEMENT.  The wave's list holds its best rows by the packed shadow's bound; every row of the wave
     // that is not listed is bounded by the first entry it drops (tw; -inf while the list is not full).  The listed rows get a
     // TIGHT score in its place and the list is re-sorted by it: what the workgroup then merges and rescores are its 64 best rows
@@ -607,6 +668,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         lp = pr;
     }
     if (lane == 0) sh_tw[wave] = tw;  // (visible after block_merge's barriers)
+    DAWN_TS6(3);
 
     // ---- epilogue 2: the workgroup's list — upper bounds (descending: lane 63 bounds every refined row that is not listed) —
     // and the same 64 rows rescored exactly (block_exact_dots of wave_topk.hpp for any block size) as (-distance descending, row)
@@ -654,6 +716,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         out_es[o] = -d;  // (-distance descending, row ascending among equals)
         out_ep[o] = pr;
     }
+    DAWN_TS6(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -664,10 +727,11 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
                                                             const uint32_t* __restrict__ ex_p, int n_lists, uint32_t k,
                                                             uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
                                                             uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags,
-                                                            int force_fallback, float eps) {
+                                                            int force_fallback, float eps, uint32_t* __restrict__ pool) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ float sh_t[16];
+    if (threadIdx.x < 32) pool[threadIdx.x] = 0;  // the stream's chunk counters, for the next search
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -770,11 +834,11 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
 
 // One query: stream + epilogue, merge + certificate.  ub_s / ub_p: the upper-bound lists [blocks][64] (what the other streams
 // hand to merge_rescore_kernel; kept for the test hooks), ex_s / ex_p: the exact lists, tb [blocks]: the workgroups' bounds on
-// their unlisted rows; d_i8 / d_i8meta: the int8 shadow (refinement).  geom.unroll: loads in flight per wave —
+// their unlisted rows; d_i8 / d_i8meta: the int8 shadow (refinement); pool [32]: the stream's chunk counters (zero between searches).  geom.unroll: loads in flight per wave —
 // 6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 (anything else: 8) loads of 768 B - 1 KiB.
 void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
-                    uint32_t* ex_p, float* tb, const ScanGeom& g,
+                    uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                     bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     static OncePerDevice attr_once;
@@ -803,14 +867,25 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
         hipLaunchKernelGGL((scan_filter_i6s_kernel<RT_, BITS_, PD_>), dim3(g.blocks), dim3(g.threads),                  \
                            RescoreStage<RT_>::BYTES, stream, x, mt, n_rows, d_q, d_rows,                                 \
                            reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_i8meta), ub_s, ub_p,  \
-                           ex_s, ex_p, tb, n_refine);
+                           ex_s, ex_p, tb, n_refine, pool);
     DAWN_I6_EACH(DAWN_I6_LAUNCH)
 #undef DAWN_I6_LAUNCH
 #undef DAWN_I6_EACH
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (merge)
         hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, tb, ex_s, ex_p, g.blocks, k,
-                           d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8);
+                           d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8, pool);
+    else
+        (void)hipMemsetAsync(pool, 0, 32 * sizeof(uint32_t), stream);  // (the test hook's stream-only launch)
 }
 
 }  // namespace dawn
+
+#ifdef DAWN_EXPERIMENTS
+extern "C" int dawn_debug_read_ts_i6(unsigned long long* out, int n) {
+    static unsigned long long h[2048 * 5];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_i6), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 2048 * 5; ++i) out[i] = h[i];
+    return 0;
+}
+#endif
