@@ -293,18 +293,21 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     constexpr uint32_t CHUNK = 16, POOLS = 32;
     uint32_t static_left = NONE;  // further static sub-tiles of this wave (NONE: static to the end)
     uint32_t dyn0 = 0, n_chunks = 0, chunk_base = 0, chunk_i = CHUNK;
+    // counters in use: one per group of eight workgroups, at most POOLS (a counter nobody reads would strand its chunks)
+    const uint32_t n_pools = ((gridDim.x + 7u) >> 3) < POOLS ? ((gridDim.x + 7u) >> 3) : POOLS;
+    const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
     uint32_t* my_pool = nullptr;
     if (pool != nullptr && n_sub / t_stride >= 16u) {
         const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds / 8u;
         dyn0 = t_stride * i_static;
         n_chunks = (n_sub - dyn0 + CHUNK - 1u) / CHUNK;
-        my_pool = pool + ((blockIdx.x >> 3) % POOLS);
+        my_pool = pool + pool_id;
         static_left = i_static - 1u;
     }
     auto fetch_chunk = [&]() __attribute__((always_inline)) -> uint32_t {  // the next chunk of this wave's pool, or NONE
         uint32_t v = 1u;
         asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(my_pool));
-        const uint32_t j = ((blockIdx.x >> 3) % POOLS) + POOLS * v;
+        const uint32_t j = pool_id + n_pools * v;
         return j < n_chunks ? j : NONE;
     };
     // the first loads fly while the query images are made.  6 bits: a[] = ring of fragments (lane slot: 3 dwords);

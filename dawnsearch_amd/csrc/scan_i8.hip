@@ -48,6 +48,8 @@
 // timestamp probes (100-MHz counter) of scan_filter_i8s_kernel: workgroups 0 / 85 / 170 / 255, first and last wave, 8 points
 // (dawn_debug_read_ts_i8; tools/stream_ts.py)
 static __device__ unsigned long long dawn_ts_i8[4 * 2 * 8];
+// ... and the time every wave of scan_i8_pipe16_kernel leaves its last launch (dawn_debug_read_ts_pass; tools/pass_ts.py)
+static __device__ unsigned long long dawn_ts_pass[256 * 4];
 #define DAWN_TSI(i)                                                                                            \
     do {                                                                                                       \
         if ((threadIdx.x & 63) == 0 && blockIdx.x % 85 == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == (blockDim.x >> 6) - 1)) \
@@ -1533,6 +1535,9 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
     else run(C0());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
     if (!DENSE) flush_wave();
+#ifdef DAWN_EXPERIMENTS
+    if (lane == 0 && blockIdx.x < 256) dawn_ts_pass[blockIdx.x * 4 + wave] = __builtin_amdgcn_s_memrealtime();  // tools/pass_ts.py
+#endif
 #undef DAWN_I16_FOFF
 }
 
@@ -1645,6 +1650,12 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
 }  // namespace dawn
 
 #ifdef DAWN_EXPERIMENTS
+extern "C" int dawn_debug_read_ts_pass(unsigned long long* out, int n) {
+    unsigned long long h[1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_pass), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 1024; ++i) out[i] = h[i];
+    return 0;
+}
 extern "C" int dawn_debug_read_ts_i8(unsigned long long* out, int n) {
     unsigned long long h[64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_i8), sizeof(h)) != hipSuccess) return -1;

@@ -343,3 +343,28 @@ def test_i6_survives_save_load_and_follows_the_int8_switch(dawn, oracle, tmp_pat
     assert other.memory()["shadows"] == m_int  # f16 released, packed rebuilt
     _assert_same(*other.search(q, 20), *want)
     assert other.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("blocks,threads", [(256, 512), (40, 128), (100, 256), (7, 512), (8, 64), (300, 192)])
+def test_i6_dynamic_tail_covers_every_sub_tile(dawn, oracle, blocks, threads):
+    """From 16 rounds of the grid on, the last eighth of the index is handed out in strided chunks from shared counters: whatever the
+    grid, every sub-tile is scanned exactly once — queries planted all over the dynamic region (and the static one) come back first,
+    and the answers equal the oracle's."""
+    n = 1_200_003
+    idx = _mk(dawn, n)
+    idx.set_option("i6_scan_blocks", blocks)
+    idx.set_option("i6_scan_threads", threads)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    planted = np.array([0, 31, 500_000, 1_049_999, 1_050_000, 1_100_017, 1_150_000, 1_190_000, n - 40_000, n - 33, n - 1])
+    Q = synth.planted_queries(1, planted, 5)
+    for r, q in zip(planted, Q):
+        lab, dist = idx.search(q, 10)
+        assert lab[0] == r + 1, (r, lab)
+        _assert_same(lab, dist, *oracle.scan_topk(x, ids, q, 10, threads=8))
+    for q in synth.unit_rows(2, 0, 3):  # ... twice: the counters are back at zero after every search
+        for _ in range(2):
+            _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20, threads=8))
+    sc, rows = idx.debug_stream_lists(Q[3])  # (the stream-only hook resets the counters itself)
+    _assert_same(*idx.search(Q[3], 10), *oracle.scan_topk(x, ids, Q[3], 10, threads=8))
+    assert idx.stats()["fallbacks"] == 0
