@@ -96,6 +96,8 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.cnt, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMalloc(&idx->bws.cand, (size_t)dawn::BATCH_QT * dawn::BATCH_CAP * 8));
         DAWN_HIP_TRY(hipMemset(idx->bws.cnt, 0, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bws.pool, 32 * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMemset(idx->bws.pool, 0, 32 * sizeof(uint32_t)));
     }
     if (!idx->d_stats) {
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, 4 * sizeof(uint32_t)));
@@ -444,7 +446,7 @@ void index_destroy_single(dawn_index* idx) {
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
     void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
-                    idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->d_q,
+                    idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->bws.pool, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -734,6 +736,10 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_min_batch") {
         if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (n == "mfma_dynamic_tail") {  // 0: every tile of the int8 append pass is assigned statically (A/B of the dynamic tail)
+        idx->bws.dyn_tail = value != 0;
         return DAWN_OK;
     }
     if (n == "mfma_blocks") {

@@ -1005,7 +1005,7 @@ template <bool DENSE>
 __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restrict__ dense,
                                                          const uint2* __restrict__ cand,
                                                          uint32_t* __restrict__ cnt, uint32_t dense_count,
-                                                         uint32_t m, float* __restrict__ tau) {
+                                                         uint32_t m, float* __restrict__ tau, uint32_t* __restrict__ pool) {
     // The m-th largest of a query's <= 8192 sample scores by radix selection on the order-preserving key (three digits of
     // 11 + 11 + 10 bits, LDS histograms, one block scan per digit): every thread keeps its <= 8 values in registers and
     // touches memory once.  (Round 2 kept a sorted 64-entry list per wave — a bitonic sort, up to eight insert rounds and
@@ -1088,6 +1088,8 @@ __global__ __launch_bounds__(1024) void tau_select_kernel(const float* __restric
     if (tid == 0) tau[b] = t;
     // (every thread read its segments' counts at the top)
     if (tid < BATCH_CAND_SEGS) cnt[(size_t)b * BATCH_CAND_SEGS + tid] = 0u;
+    // ... and the chunk counters of the int8 append pass's dynamically assigned tail (scan_i8_pipe16_kernel)
+    if (b == 0 && tid < 32 && pool != nullptr) pool[tid] = 0u;
 }
 
 // Final: shortlist = top-64 candidates by filter score; exact rescore in the reference order; certificate.
@@ -1445,9 +1447,9 @@ void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     if (dense_pass)
-        hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, dense_count, m, ws.tau);
+        hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, dense_count, m, ws.tau, ws.pool);
     else
-        hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, m, ws.tau);
+        hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, m, ws.tau, ws.pool);
 }
 
 // d_x/dtype: the index rows (exact rescore); d_frows/frt: the filter's row source (the same rows, or the scaled f16
@@ -1470,11 +1472,11 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
     }
     launch_pass<true>(d_frows, frt, n_rows, 0, pl.s1_stride, pl.s1_tiles, ws, B, grid, stream);
     hipLaunchKernelGGL((tau_select_kernel<true>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt,
-                       pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau);
+                       pl.s1_tiles * TILE_ROWS, pl.m1, ws.tau, ws.pool);
     if (pl.s2_tiles) {  // (the counters were left at zero by tau_select)
         launch_pass<false>(d_frows, frt, n_rows, 0, pl.s2_stride, pl.s2_tiles, ws, B, grid, stream);
         hipLaunchKernelGGL((tau_select_kernel<false>), dim3(B), dim3(1024), 0, stream, dense, cand, ws.cnt, 0u, pl.m2,
-                           ws.tau);
+                           ws.tau, ws.pool);
     }
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_pass<false>(d_frows, frt, n_rows, 0, 1, pl.n_tiles_total, ws, B, grid, stream);
