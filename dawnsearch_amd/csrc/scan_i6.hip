@@ -702,13 +702,22 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                 RT == 1 ? xr[frag_chunk(row, chn)] : xr[(size_t)row * S::CH + chn];
     }
     __syncthreads();
+    if (RT == 0) {  // products in place by everyone, the sequential adds by wave 0 (block_exact_dots)
+        for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
+            const int r = i / S::CH, chn = i % S::CH;
+            f32x4* px = reinterpret_cast<f32x4*>(rescore_stage + r * S::STRIDE + chn * 16);
+            const f32x4 xv = *px, qq = reinterpret_cast<const f32x4*>(sh_q)[chn];
+            *px = f32x4{__fmul_rn(qq.x, xv.x), __fmul_rn(qq.y, xv.y), __fmul_rn(qq.z, xv.z), __fmul_rn(qq.w, xv.w)};
+        }
+        __syncthreads();
+    }
     if (wave == 0) {
         float d = POS_INF;
         uint32_t pr = lp;
         if (lp != NO_POS) {
             float dot;
             if (RT == 1) dot = exact_dot_seq_bf16<8>(sh_q, reinterpret_cast<const u32x4*>(rescore_stage + lane * S::STRIDE));
-            else dot = exact_dot_seq<16>(sh_q, reinterpret_cast<const f32x4*>(rescore_stage + lane * S::STRIDE));
+            else dot = sum_seq(reinterpret_cast<const f32x4*>(rescore_stage + lane * S::STRIDE));
             d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
             if (!(d == d)) {
                 d = POS_INF;

@@ -161,6 +161,20 @@ __device__ __forceinline__ float exact_dot_seq(const float* __restrict__ qv, con
     return acc;
 }
 
+// The adds of the same sum over products already rounded one by one (block_exact_dots): acc = fl(acc + p[i]), i ascending.
+__device__ __forceinline__ float sum_seq(const f32x4* __restrict__ prod) {
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int c = 0; c < ROW_F4; ++c) {
+        const f32x4 pv = prod[c];
+        acc = __fadd_rn(acc, pv.x);
+        acc = __fadd_rn(acc, pv.y);
+        acc = __fadd_rn(acc, pv.z);
+        acc = __fadd_rn(acc, pv.w);
+    }
+    return acc;
+}
+
 // ---- bf16 rows (DAWN_DTYPE_BF16): 384 x bf16 = 768 B = 48 16-B chunks of 8 values; element k of a chunk word w:
 // even k in the low half, odd k in the high half (little endian).  Widening to f32 is exact.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -246,9 +260,20 @@ __device__ __forceinline__ float block_exact_dots(float q_val, const void* __res
     __syncthreads();
     DAWN_TS(4);
     float dot = 0.0f;
-    if (wave == 0 && p != NO_POS) {
-        if (RT == 1) dot = exact_dot_seq_bf16<8>(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
-        else dot = exact_dot_seq<16>(sh_q, reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
+    if (RT == 0) {
+        // The reference's sum is sequential in the ADDS only: result += a[i] * b[i] rounds every product on its own.  So all
+        // threads turn the staged rows into their products in place (fl(q_i x_i), the same __fmul_rn the chain would do) and
+        // wave 0 is left with 384 dependent adds per row instead of 384 multiply-add pairs fed by two LDS reads each: 4.4 -> ~1.5 us.
+        for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
+            const int r = i / S::CH, c = i % S::CH;
+            f32x4* px = reinterpret_cast<f32x4*>(stage + r * S::STRIDE + c * 16);
+            const f32x4 xv = *px, qq = reinterpret_cast<const f32x4*>(sh_q)[c];
+            *px = f32x4{__fmul_rn(qq.x, xv.x), __fmul_rn(qq.y, xv.y), __fmul_rn(qq.z, xv.z), __fmul_rn(qq.w, xv.w)};
+        }
+        __syncthreads();
+        if (wave == 0 && p != NO_POS) dot = sum_seq(reinterpret_cast<const f32x4*>(stage + lane * S::STRIDE));
+    } else if (wave == 0 && p != NO_POS) {
+        dot = exact_dot_seq_bf16<8>(sh_q, reinterpret_cast<const u32x4*>(stage + lane * S::STRIDE));
     }
     DAWN_TS(5);
     return dot;
