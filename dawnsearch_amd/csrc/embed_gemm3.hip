@@ -470,13 +470,12 @@ int g_gemm3_pingpong = 1;  // tuning: 1 = the two waves of a SIMD run half a ste
 template <int PP>
 static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
                             uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static OncePerDevice attr;  // (the attribute belongs to the current device's copy of the kernel: kernels.hpp)
+    once_per_device(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<1, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<2, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
-        attr = true;
-    }
+    });
     const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
     int blocks = (n_tiles + 7) / 8 * 8;
     if (g_gemm3_persistent > 0 && blocks > g_gemm3_persistent) blocks = g_gemm3_persistent;  // one block per CU walks the tiles
@@ -507,16 +506,15 @@ int g_gemm3_stages = 2;  // tuning: ring depth of the bf16x3 kernel (2 .. 4)
 template <int STAGES>
 static void launch_g3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
                       uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static OncePerDevice attr;
+    once_per_device(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<0, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<1, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<2, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * G3_BUF);
-        attr = true;
-    }
+    });
     const int n_tiles = (N / G3T) * ((M + G3T - 1) / G3T);
     dim3 grid((n_tiles + 7) / 8 * 8), block(256);
     const size_t lds = (size_t)STAGES * G3_BUF;
