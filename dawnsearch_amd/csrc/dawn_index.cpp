@@ -356,7 +356,8 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
         // stream's epilogue, one merge + certificate (scan_i6.hip)
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
-                       idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                       idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->stream_dyn_tail ? idx->d_i6_pool : nullptr,
+                       idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                        idx->force_fallback, true, stream, e0, e1);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
@@ -376,9 +377,11 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                              own ? FILTER_EPS_BF16_STREAM : FILTER_EPS_F16, stream);
     } else {
         // the f32 rows themselves (1536 B/row)
-        launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1);
+        uint32_t* pool = idx->stream_dyn_tail ? idx->d_i6_pool : nullptr;
+        launch_scan_filter(idx->d_x, idx->dtype, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom, stream, e0, e1, pool);
         launch_merge_rescore(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_cand_s, idx->d_cand_p, idx->geom.blocks,
-                             (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_F32, stream);
+                             (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_F32, stream,
+                             pool);
     }
     launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
                       idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
@@ -736,6 +739,10 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_min_batch") {
         if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (n == "stream_dynamic_tail") {  // 0: the single-query streams assign every sub-tile statically (A/B of the dynamic tails)
+        idx->stream_dyn_tail = value != 0;
         return DAWN_OK;
     }
     if (n == "mfma_dynamic_tail") {  // 0: every tile of the int8 append pass is assigned statically (A/B of the dynamic tail)

@@ -106,7 +106,8 @@ struct dawn_index {
     const dawn::ScanGeom& i6_geom() const { return (!geom_i6_pinned && size < dawn::kI6SmallRows) ? geom_i6_small : geom_i6; }
     float* d_cand_es = nullptr;
     float* d_cand_tb = nullptr;   // [blocks] the workgroups' bounds on their unlisted rows
-    uint32_t* d_i6_pool = nullptr;  // [32] chunk counters of the stream's dynamically assigned tail
+    uint32_t* d_i6_pool = nullptr;  // [32] chunk counters of the dynamically assigned tail of the packed and the f32-row streams
+    int stream_dyn_tail = 1;        // option "stream_dynamic_tail"
     uint32_t* d_cand_ep = nullptr;
     int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 / 2 = the int8 / f16 / 6-bit shadow allocation fails
     float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records

@@ -112,7 +112,7 @@ struct ScanGeom {
 //   cand_s/cand_p: [B][geom.blocks][64]
 void launch_scan_filter(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                         uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0,
-                        hipEvent_t ev1);
+                        hipEvent_t ev1, uint32_t* pool = nullptr);
 // The same over fragment-ordered 16-bit rows — rt = ROW_F16S: the scaled-f16 shadow of an f32 index (filter error
 // FILTER_EPS_F16), ROW_BF16: a bf16 index (FILTER_EPS_BF16_STREAM) —, 8 queries per pass; d_q = the f32 queries
 // (converted in the kernel).
@@ -142,7 +142,7 @@ void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipS
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
-                          int force_fallback, float eps, hipStream_t stream);
+                          int force_fallback, float eps, hipStream_t stream, uint32_t* pool = nullptr);
 // Batched search on the matrix cores (mfma_min_batch <= B <= BATCH_QT) over 16-bit rows: f16 / bf16 MFMA filter with sampled thresholds,
 // candidate append, exact rescore + certificate (scan_batched.hip).  ev0/ev1 bracket the full pass.
 struct BatchPlan {

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ float sh_t[16];
-    if (threadIdx.x < 32) pool[threadIdx.x] = 0;  // the stream's chunk counters, for the next search
+    if (pool != nullptr && threadIdx.x < 32) pool[threadIdx.x] = 0;  // the stream's chunk counters, for the next search
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -887,7 +887,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
     if (merge)
         hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, tb, ex_s, ex_p, g.blocks, k,
                            d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8, pool);
-    else
+    else if (pool != nullptr)
         (void)hipMemsetAsync(pool, 0, 32 * sizeof(uint32_t), stream);  // (the test hook's stream-only launch)
 }
 

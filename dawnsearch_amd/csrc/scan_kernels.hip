@@ -53,7 +53,8 @@ template <int QB, int U>
 __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restrict__ x, uint32_t n_rows,
                                                            const float* __restrict__ q,
                                                            float* __restrict__ out_s,
-                                                           uint32_t* __restrict__ out_p, uint32_t q_stride_lists) {
+                                                           uint32_t* __restrict__ out_p, uint32_t q_stride_lists,
+                                                           uint32_t* __restrict__ pool) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
     const uint32_t gwave = blockIdx.x * nwaves + wave;
     const uint32_t total_waves = gridDim.x * nwaves;
     const uint32_t n_pairs = (n_rows + 1u) >> 1;
-    const uint32_t n_chunks = (n_pairs + U - 1) / U;
+    const uint32_t n_chunks = (n_pairs + U - 1) / U;  // iterations ("chunks" of U row pairs) in all
 
     f32x4 qa[QB], qb[QB], qc[QB];
     float ls[QB], tau[QB];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
     }
     const bool lo_half = lane < 32;
 
-    for (uint32_t c = gwave; c < n_chunks; c += total_waves) {
+    auto process = [&](uint32_t c) __attribute__((always_inline)) {
         const f32x4* p = x + (size_t)c * (U * 192) + lane;
         f32x4 v[U][3];
 #pragma unroll
@@ -113,6 +114,32 @@ __global__ __launch_bounds__(1024) void scan_filter_kernel(const f32x4* __restri
                 }
             }
         }
+    };
+    // Static and interleaved (iteration gwave, gwave + W, ...) — and, in a long single-query launch (pool != NULL), only for the
+    // first 7/8 of the index: the waves' shares are equal, their speeds are not (scan_i6.hip: the first wave of a 100 M-row stream
+    // is done ~300 us before the last), so the last eighth is handed out on demand in blocks of 16 consecutive iterations, each
+    // fetched with a scalar atomic (returns through lgkmcnt: the loads in flight are not drained) from one of 32 counters —
+    // one per group of eight workgroups, i.e. per set of one CU on every XCD; merge_rescore_kernel leaves them at zero.
+    constexpr uint32_t DCH = 16, NONE = 0xFFFFFFFFu;
+    const uint32_t rounds = n_chunks / total_waves;
+    if (pool != nullptr && rounds >= 32u) {
+        const uint32_t i_static = rounds - rounds / 8u, d0 = total_waves * i_static;
+        const uint32_t n_blocks = (n_chunks - d0 + DCH - 1u) / DCH;
+        const uint32_t n_pools = ((gridDim.x + 7u) >> 3) < 32u ? ((gridDim.x + 7u) >> 3) : 32u;
+        const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
+        uint32_t* my_pool = pool + pool_id;
+        for (uint32_t i = 0; i < i_static; ++i) process(gwave + i * total_waves);
+        for (;;) {
+            uint32_t v = 1u;
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(my_pool));
+            const uint32_t j = pool_id + n_pools * v;
+            if (j >= n_blocks) break;
+            const uint32_t c0 = d0 + j * DCH;
+            for (uint32_t i = 0; i < DCH && c0 + i < n_chunks; ++i) process(c0 + i);
+        }
+        (void)NONE;
+    } else {
+        for (uint32_t c = gwave; c < n_chunks; c += total_waves) process(c);
     }
 
 #pragma unroll
@@ -365,23 +392,26 @@ void launch_scan_filter_f16s(const void* d_shadow, int rt, uint32_t n_rows, cons
 
 template <int QB, int U>
 static void launch_filter_qbu(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
-                              const ScanGeom& g, hipStream_t stream) {
+                              const ScanGeom& g, hipStream_t stream, uint32_t* pool) {
     hipLaunchKernelGGL((scan_filter_kernel<QB, U>), dim3(g.blocks), dim3(g.threads), 0, stream,
-                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, cand_s, cand_p, (uint32_t)g.blocks);
+                       reinterpret_cast<const f32x4*>(d_x), n_rows, d_q, cand_s, cand_p, (uint32_t)g.blocks, pool);
 }
 
 template <int QB>
 static void launch_filter_qb(const float* d_x, uint32_t n_rows, const float* d_q, float* cand_s, uint32_t* cand_p,
-                             const ScanGeom& g, hipStream_t stream) {
-    if (QB == 1 && g.unroll == 1) launch_filter_qbu<1, 1>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else if (QB == 1 && g.unroll == 3) launch_filter_qbu<1, 3>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else if (QB == 1 && g.unroll == 4) launch_filter_qbu<1, 4>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
-    else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream);
+                             const ScanGeom& g, hipStream_t stream, uint32_t* pool) {
+    if (QB == 1 && g.unroll == 1) launch_filter_qbu<1, 1>(d_x, n_rows, d_q, cand_s, cand_p, g, stream, pool);
+    else if (QB == 1 && g.unroll == 3) launch_filter_qbu<1, 3>(d_x, n_rows, d_q, cand_s, cand_p, g, stream, pool);
+    else if (QB == 1 && g.unroll == 4) launch_filter_qbu<1, 4>(d_x, n_rows, d_q, cand_s, cand_p, g, stream, pool);
+    else launch_filter_qbu<QB, 2>(d_x, n_rows, d_q, cand_s, cand_p, g, stream, pool);
 }
 
 // f32 rows streamed directly (no shadow): 1 / 2 / 4 queries per pass
+// pool: 32 zeroed counters for the dynamically assigned tail of a single-query launch (left at zero again by
+// merge_rescore_kernel), or NULL: every iteration statically assigned; batches of several launches are always static
 void launch_scan_filter(const void* d_xv, int dtype, uint32_t n_rows, const float* d_q, int B, float* cand_s,
-                        uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                        uint32_t* cand_p, const ScanGeom& g, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* pool) {
+    if (B != 1) pool = nullptr;
     (void)dtype;  // ROW_F32 (a bf16 index streams through launch_scan_filter_f16s)
     const float* d_x = reinterpret_cast<const float*>(d_xv);
     if (ev0) (void)hipEventRecord(ev0, stream);
@@ -393,13 +423,13 @@ void launch_scan_filter(const void* d_xv, int dtype, uint32_t n_rows, const floa
         float* cs = cand_s + (size_t)b * per_q;
         uint32_t* cp = cand_p + (size_t)b * per_q;
         if (rem >= 4) {
-            launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<4>(d_x, n_rows, q, cs, cp, g, stream, pool);
             b += 4;
         } else if (rem >= 2) {
-            launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<2>(d_x, n_rows, q, cs, cp, g, stream, pool);
             b += 2;
         } else {
-            launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream);
+            launch_filter_qb<1>(d_x, n_rows, q, cs, cp, g, stream, pool);
             b += 1;
         }
     }
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const void* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
     uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
-    uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
+    uint32_t* __restrict__ out_flags, int force_fallback, float eps, uint32_t* __restrict__ pool) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ uint32_t sh_rows[LIST];
@@ -423,6 +453,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
+    if (pool != nullptr && b == 0 && threadIdx.x < 32) pool[threadIdx.x] = 0;  // the stream's work counters, for the next search
 
     const float* cs = cand_s + (size_t)b * n_lists * LIST;
     const uint32_t* cp = cand_p + (size_t)b * n_lists * LIST;
@@ -518,7 +549,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
-                          hipStream_t stream) {
+                          hipStream_t stream, uint32_t* pool) {
     static OncePerDevice attr_once;  // the f32 stage (97 KiB) is above the default dynamic-LDS limit
     once_per_device(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<0>),
@@ -528,10 +559,10 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
     });
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x, d_ids, n_rows,
-                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool);
     else
         hipLaunchKernelGGL(merge_rescore_kernel<0>, dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x, d_ids, n_rows,
-                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps);
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -193,6 +193,8 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      16x16x64, the shape the chip clocks higher under load; same results).  (The timing experiments 2 / 41..55 — parts of the
  *                      pipelined kernels switched off, wrong results by design — only exist in `make EXPERIMENTS=1`
  *                      builds; the release library rejects them.)
+ *   "stream_dynamic_tail" 0: the single-query streams (packed shadow, f32 rows) assign every unit of work statically (default 1:
+ *                      the last eighth of a long stream is handed out on demand; same results)
  *   "mfma_dynamic_tail" 0: every tile of the int8 matrix-core pass is assigned statically (default 1: the last eighth of a pass of
  *                      >= 256 tiles per workgroup is handed out on demand — whole XCDs otherwise finish hundreds of us apart)
  *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (1024; twice that for count > 32)
