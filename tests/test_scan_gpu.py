@@ -870,3 +870,56 @@ def test_out_of_memory_order_of_the_filter_sources(dawn, oracle):
     assert seen[2] == 0                                          # nothing: the filters stream the f32 rows
     assert seen[3] >= i8_bytes and seen[3] < f16_bytes and seen[4] >= i8_bytes
     assert idx.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("blocks", [256, 40, 7])
+def test_f32_stream_dynamic_tail_covers_every_row(dawn, oracle, blocks):
+    """The f32-row stream (shadows switched off for single queries) hands the last eighth of a long launch out on demand in
+    blocks of 16 iterations: whatever the grid, every row is scanned exactly once — queries planted all over the index come back
+    first — and the answers equal the oracle's and the static assignment's (option "stream_dynamic_tail" = 0)."""
+    n = 1_200_003
+    idx = _mk_index(dawn, n)
+    idx.set_option("f16_shadow_b1", 0)
+    idx.set_option("scan_blocks", blocks)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    planted = np.array([0, 5, 600_000, 1_049_999, 1_050_001, 1_100_017, 1_150_000, n - 40_000, n - 7, n - 1])
+    Q = synth.planted_queries(1, planted, 5)
+    for r, q in zip(planted, Q):
+        lab, dist = idx.search(q, 10)
+        assert lab[0] == r + 1, (r, lab)
+        _assert_same(lab, dist, *oracle.scan_topk(x, ids, q, 10, threads=8))
+    q = synth.unit_rows(2, 0, 1)[0]
+    want = oracle.scan_topk(x, ids, q, 20, threads=8)
+    for mode in (1, 0, 1):
+        idx.set_option("stream_dynamic_tail", mode)
+        for _ in range(2):  # (twice: the counters are back at zero after every search)
+            _assert_same(*idx.search(q, 20), *want)
+    assert idx.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("blocks,n", [(8, 300_000), (5, 200_003), (16, 600_000)])
+def test_int8_pass_dynamic_tile_sequence(dawn, oracle, blocks, n):
+    """The int8 matrix-core pass generates its tile sequence three units ahead and takes the last eighth of a long pass (>= 256
+    tiles per workgroup — reached here with a small grid, option "mfma_blocks") in chunks from shared counters: every tile
+    exactly once — planted rows in the static part, the dynamic part and the last, ragged tile come back first —, results equal
+    to the oracle's and to the static assignment's (option "mfma_dynamic_tail" = 0), batch after batch."""
+    idx = _mk_index(dawn, n)
+    idx.set_option("mfma_blocks", blocks)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    B = 70
+    Q = synth.unit_rows(2, 0, B)
+    planted = np.array([0, 127, 128, n // 2, (n * 7) // 8 - 3, (n * 7) // 8 + 300, (n * 15) // 16, n - 129, n - 2, n - 1])
+    Q[:len(planted)] = synth.planted_queries(1, planted, 5)
+    ref = None
+    for mode in (1, 0, 1, 1):
+        idx.set_option("mfma_dynamic_tail", mode)
+        labels, dist, found = idx.search_batch(Q, 20)
+        assert np.all(found == 20) and np.array_equal(labels[:len(planted), 0], planted + 1)
+        if ref is None:
+            ref = (labels, dist)
+            for b in (0, 3, 5, 9, 20, 69):
+                _assert_same(labels[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 20, threads=8))
+        assert np.array_equal(labels, ref[0]) and np.array_equal(dist.view(np.uint32), ref[1].view(np.uint32))
+    assert idx.stats()["fallbacks"] == 0
