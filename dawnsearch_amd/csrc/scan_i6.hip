@@ -479,6 +479,15 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         int C[16];
         int thr = 0, mx = 0;
 
+        // The wave's threshold: only its best n_refine rows are refined, and the bound on everything else is the best row it
+        // does NOT keep — entry n_refine of the list.  Rows below that entry can neither enter the kept part nor raise the bound,
+        // so they are not inserted at all (entries behind it go stale and are discarded with it): a list of 40 takes a third
+        // fewer insertions than one of 64 on a 12.5 M-row index — same-box A/B against the 64th entry as the threshold
+        // (profiles/r03/stream_i5_threshold_ab.log): 3 M rows 175 -> 165 us, 12.5 M 499 -> 487, 100 M 3631 -> 3617.
+        const int tau_lane = n_refine < LIST ? n_refine : LIST - 1;
+        auto list_tau = [&]() __attribute__((always_inline)) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), tau_lane));
+        };
         auto slow_path = [&]() __attribute__((always_inline)) {
             // Many hits in one sub-tile — the first sub-tiles of every wave, while its list fills: the j-th still contributes
             // 64 / (j + 1) rows — are merged as ONE sorted batch (scan_filter_i8s_kernel: the 32 upper bounds, held by the two
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                 const float os = -__shfl(d, 63 - lane);
                 const uint32_t op = __shfl(row, 63 - lane);
                 merge64(ls, lp, os, op, lane);
-                tau = read_lane63(ls);
+                tau = list_tau();
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                         const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254, pmt.y + k2);
                         if (sc > tau) {
                             wave_insert(ls, lp, sc, row, lane);
-                            tau = read_lane63(ls);
+                            tau = list_tau();
                         }
                     }
                 }
