@@ -745,10 +745,6 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->stream_dyn_tail = value != 0;
         return DAWN_OK;
     }
-    if (n == "mfma_dynamic_tail") {  // 0: every tile of the int8 append pass is assigned statically (A/B of the dynamic tail)
-        idx->bws.dyn_tail = value != 0;
-        return DAWN_OK;
-    }
     if (n == "mfma_blocks") {
         if (value < 1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "mfma_blocks out of range");
         idx->mfma_blocks = (int)value;

@@ -98,7 +98,6 @@ struct BatchWorkspace {
     // score even when the sampled estimate comes out low (plan_batched_tiles); a candidate costs the pass ~80 clk.
     int target = 1024;
     uint32_t* pool = nullptr;  // [32] chunk counters of the int8 append pass's dynamic tail (tau_select leaves them at zero)
-    int dyn_tail = 1;          // option "mfma_dynamic_tail": the last eighth of a long int8 append pass is handed out on demand
     unsigned long long* diag = nullptr;  // DAWN_EXPERIMENTS, sched 2: [grid][8 waves][8] phase stamps
 };
 struct ScanGeom {

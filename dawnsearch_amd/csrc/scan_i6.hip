@@ -356,8 +356,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         for (;;) {
             const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
             const uint32_t cq = n >> chunk_sh, o = n & (CHUNK - 1u);
-            if (n == 0u || o == (CHUNK >> 2)) {  // this ticket's duty: the id of chunk 0 / of the next chunk
-                const uint32_t cf = n == 0u ? 0u : cq + 1u;
+            // this ticket's duty, if it has one: the id of chunk 0 (before anything can be read) / of the next chunk (AFTER its own
+            // chunk's id is in registers: the global fetch may take long enough for the ring slot to be reused)
+            auto fetch_for = [&](uint32_t cf) __attribute__((always_inline)) {
                 const uint32_t j = fetch_chunk();
                 if (lane == 0) {
                     volatile uint32_t* e = &dq_ring[cf & 3u][0];
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     e[0] = cf;
                 }
-            }
+            };
+            if (n == 0u) fetch_for(0u);
             if (cq != dq_c) {  // the first ticket this wave draws of chunk cq: its id, once (tag and id in one 8-byte read)
                 const volatile unsigned long long* e = reinterpret_cast<const volatile unsigned long long*>(&dq_ring[cq & 3u][0]);
                 uint32_t polls = 0;
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                 dq_c = cq;
                 dq_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
             }
+            if (n != 0u && o == (CHUNK >> 2)) fetch_for(cq + 1u);
             const uint32_t j = dq_j;
             if (j == NONE) return NONE;  // the pool is empty
             const uint32_t sub = dyn_sub(j, o);

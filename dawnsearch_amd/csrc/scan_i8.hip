@@ -1167,8 +1167,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
                                                             uint32_t n_tiles, const i32x4_t* __restrict__ qi,
                                                             const float2* __restrict__ qmeta, int n_q,
                                                             const float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                            uint2* __restrict__ cand, float* __restrict__ dense,
-                                                            uint32_t* __restrict__ pool) {
+                                                            uint2* __restrict__ cand, float* __restrict__ dense) {
     constexpr int NW = 4, PD = 8, DPW = 48 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char img[3 * I8_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW * I16_ECAP * I16_EDW];  // 12 KiB beside the 144-KiB ring
@@ -1205,90 +1204,14 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
 
     const uint32_t src_off0 = (uint32_t)(DPW * wave) * 1024u + (uint32_t)lane * 16u;
     const uint32_t G = gridDim.x;
-    // The workgroup's sequence of tiles ("units").  Static and strided — unit u = tile first_tile + (b + u G) tile_stride — except
-    // in a long append pass, whose last eighth is handed out on demand in chunks of 32 consecutive tiles: whole XCDs finish a
-    // 100 M-row pass 300-580 us apart under the static assignment (tools/pass_ts.py,
-    // profiles/r03/pass_wave_timestamps_100M_b256_static.log: their clocks are managed separately, a different one is the slow one
-    // in every batch).  The four waves must agree on every tile three tiles ahead of its use, so the sequence is GENERATED three
-    // units ahead into a window of uniform registers (w_m1 .. w_p2 = the tiles of units t - 1 .. t + 2), and a new chunk id travels
-    // wave 0 -> LDS -> everyone across a barrier the pipeline has anyway: wave 0 takes it with a SCALAR atomic (returns through
-    // lgkmcnt; a vector atomic would share vmcnt with the LDS-DMA) one chunk before it is needed.
-    constexpr uint32_t NONE = 0xFFFFFFFFu, POOLS = 32;
-    uint32_t CH = 32;  // tiles per chunk: 1/64 of a workgroup's share, 4 .. 32
-    __shared__ uint32_t chunk_slot[2];
-    uint32_t units_static = (n_tiles - blockIdx.x + G - 1) / G;  // units generated by the static formula
-    uint32_t n_units = units_static, dyn_tile0 = 0, n_chunks = 0;
-    bool dynamic = false;
-    if (!DENSE && pool != nullptr && tile_stride == 1u && first_tile == 0u) {
-        const uint32_t st = ((n_tiles - n_tiles / 8u) / G) * G;  // static tiles: the same number of units for every workgroup
-        if (st / G >= 256u) {  // (shorter passes: a chunk would be a visible share of a workgroup's work)
-            CH = st / G / 64u;
-            CH = CH < 4u ? 4u : CH > 32u ? 32u : CH;
-            dynamic = true;
-            units_static = st / G;
-            dyn_tile0 = st;
-            n_chunks = (n_tiles - st + CH - 1u) / CH;
-            n_units = NONE;  // (known once the generator runs out of chunks)
-        }
-    }
-    const uint32_t n_pools = ((G + 7u) >> 3) < POOLS ? ((G + 7u) >> 3) : POOLS;  // a counter per group of eight workgroups
-    const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
-    uint32_t fetches = 0;          // chunk ids asked for so far (slot = fetches & 1)
-    bool pending = false;          // a chunk id is on its way through chunk_slot: read it behind the next P1
-    uint32_t nxt_chunk = NONE;     // the chunk after the current one
-    uint32_t cur_tile = 0, cur_left = 0;
-    uint32_t u_next = 0, last_tile = 0;
-    const uint32_t slot_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)chunk_slot;
-    auto fetch_publish = [&]() __attribute__((always_inline)) {  // wave 0 asks for the next chunk and leaves it in LDS
-        if (wave == 0) {
-            uint32_t v = 1u;
-            uint32_t* pp = pool + pool_id;
-            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(pp));
-            const uint32_t j = pool_id + n_pools * v;
-            const uint32_t id = j < n_chunks ? j : NONE;
-            const uint32_t ad = slot_base + (fetches & 1u) * 4u;
-            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(ad), "v"(id));
-        }
-        ++fetches;
-        pending = true;
-    };
-    auto read_published = [&]() __attribute__((always_inline)) {  // everyone, behind a barrier that followed fetch_publish
-        const uint32_t ad = slot_base + ((fetches - 1u) & 1u) * 4u;
-        uint32_t id;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(id) : "v"(ad));
-        nxt_chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
-        pending = false;
-    };
-    auto gen_next = [&]() __attribute__((always_inline)) -> uint32_t {  // the tile of unit u_next (past the end: the last tile again)
-        uint32_t tile;
-        if (u_next < units_static) {
-            tile = first_tile + (blockIdx.x + u_next * G) * tile_stride;
-        } else if (!dynamic) {
-            return last_tile;
-        } else {
-            if (cur_left == 0u) {
-                if (nxt_chunk == NONE) {
-                    if (n_units == NONE) n_units = u_next;
-                    return last_tile;
-                }
-                cur_tile = dyn_tile0 + nxt_chunk * CH;
-                cur_left = n_tiles - cur_tile < CH ? n_tiles - cur_tile : CH;
-                nxt_chunk = NONE;
-                fetch_publish();
-            }
-            tile = cur_tile++;
-            --cur_left;
-        }
-        ++u_next;
-        last_tile = tile;
-        return tile;
-    };
-    if (dynamic) fetch_publish();  // the first chunk id: read behind the prologue's barrier
-    uint32_t w_m1 = 0, w_0 = gen_next(), w_p1 = gen_next(), w_p2 = gen_next();  // tiles of units t - 1, t, t + 1, t + 2
-    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * I8_TILE_ROWS; };  // (dense passes: always static)
+    const uint32_t n_units = (n_tiles - blockIdx.x + G - 1) / G;
+    const uint32_t last = n_units - 1;
+    auto unit_tile = [&](uint32_t t) { return first_tile + (blockIdx.x + t * G) * tile_stride; };
+    auto unit_row0 = [&](uint32_t t) { return unit_tile(t) * I8_TILE_ROWS; };
+    auto unit_slot0 = [&](uint32_t t) { return (blockIdx.x + t * G) * I8_TILE_ROWS; };
     constexpr int NGP = DPW / 4;
-    auto dma = [&](uint32_t tile, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
-        const unsigned char* base = xs + (size_t)tile * I8_TILE_BYTES + src_off0;
+    auto dma = [&](uint32_t t, uint32_t image, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
         unsigned char* dst = img + image * I8_TILE_BYTES + wave * (DPW * 1024);
 #pragma unroll
         for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
@@ -1302,8 +1225,8 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
             __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 2);
         }
     };
-    auto dma_setup = [&](uint32_t tile, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
-        const unsigned char* base = xs + (size_t)tile * I8_TILE_BYTES + src_off0;
+    auto dma_setup = [&](uint32_t t, const unsigned char* (&gp)[NGP]) __attribute__((always_inline)) {
+        const unsigned char* base = xs + (size_t)unit_tile(t) * I8_TILE_BYTES + src_off0;
 #pragma unroll
         for (int j = 0; j < NGP; ++j) gp[j] = base + j * 4096;
     };
@@ -1438,19 +1361,18 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
     const uint32_t o0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
     const f32x4* meta4 = reinterpret_cast<const f32x4*>(meta);  // 2 per tile
 
-    ml0 = meta4[(size_t)w_0 * 2];
-    ml1 = meta4[(size_t)w_0 * 2 + 1];
+    ml0 = meta4[(size_t)unit_tile(0) * 2];
+    ml1 = meta4[(size_t)unit_tile(0) * 2 + 1];
     asm volatile("" : "+v"(ml0), "+v"(ml1));
     mu0 = ml0;
     mu1 = ml1;
     const unsigned char* gp0[NGP];
     const unsigned char* gp1[NGP];
-    dma(w_0, 0, gp0);
-    dma(w_p1, 1, gp1);
+    dma(0, 0, gp0);
+    dma(last < 1u ? last : 1u, 1, gp1);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
     keep(gp0);
     keep(gp1);
-    if (pending) read_published();  // (uniform) the first dynamic chunk
     // byte offset of this lane's 16 bytes of fragment step f within a tile image
     const uint32_t lane_off = q4 * 512u + r16 * 16u;
 #define DAWN_I16_FOFF(F) ((((F) / 12) * 12 + 2 * ((F) % 6)) * 1024 + 256 * (((F) / 6) & 1))
@@ -1524,7 +1446,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
                         bool hit = mx[0] > thr[0] || mx[1] > thr[1];
                         if (NL > 1) hit = hit || mx[2] > thr[2] || mx[3] > thr[3];
                         if (__builtin_expect(__any(hit), 0)) {  // (unlikely: keeps the slow paths out of the hot instruction stream)
-                            const uint32_t rb = sub16 == 0 ? w_m1 * I8_TILE_ROWS + 112 : w_0 * I8_TILE_ROWS + 16 * (sub16 - 1);
+                            const uint32_t rb = sub16 == 0 ? unit_row0(t - 1) + 112 : unit_row0(t) + 16 * (sub16 - 1);
                             if (set == 0) slow(C1(), nl_c, J16, rb);
                             else slow(C0(), nl_c, J16, rb);
                         }
@@ -1532,7 +1454,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
                 }
                 if (DENSE && s == 1 && have_prev) {
                     asm volatile("s_nop 7");
-                    const uint32_t rb = sub16 == 0 ? w_m1 * I8_TILE_ROWS + 112 : w_0 * I8_TILE_ROWS + 16 * (sub16 - 1);
+                    const uint32_t rb = sub16 == 0 ? unit_row0(t - 1) + 112 : unit_row0(t) + 16 * (sub16 - 1);
                     const uint32_t sb = sub16 == 0 ? unit_slot0(t - 1) + 112 : unit_slot0(t) + 16 * (sub16 - 1);
                     if (set == 0) tail_dense(C1(), nl_c, J16, rb, sb);
                     else tail_dense(C0(), nl_c, J16, rb, sb);
@@ -1547,13 +1469,12 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
             if (f == 12) {  // P1: every wave has left tile t-1, its image may be overwritten
                 asm volatile("s_barrier");
                 __builtin_amdgcn_sched_barrier(0);
-                if (pending) read_published();  // (uniform, once per chunk) the id wave 0 left in LDS before this barrier
                 // {s, E} of tile t+1, IN FRONT of the DMA of tile t+2: P2's vmcnt(DPW) covers them
-                const f32x4* mp = meta4 + (size_t)w_p1 * 2;
+                const f32x4* mp = meta4 + (size_t)unit_tile(t + 1 < n_units ? t + 1 : last) * 2;
                 asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                              : "=&v"(ml0), "=&v"(ml1)
                              : "v"(mp));
-                dma_setup(w_p2, gp);
+                dma_setup(t + 2 < n_units ? t + 2 : last, gp);
             }
             if (f == 13) dma_one(std::integral_constant<int, 0>(), wr, gp);
             if (f == 14) dma_one(std::integral_constant<int, 1>(), wr, gp);
@@ -1584,10 +1505,6 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
         }
         keep(gp);
         ++t;
-        w_m1 = w_0;
-        w_0 = w_p1;
-        w_p1 = w_p2;
-        w_p2 = gen_next();
     };
     auto run = [&](auto nl_c) __attribute__((always_inline)) {
         constexpr int NL = decltype(nl_c)::value;
@@ -1602,7 +1519,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15");  // the ring's look-ahead reads; the last MFMAs
         __builtin_amdgcn_sched_barrier(0);
         if (NL > 0) {  // the last 16-row tile (t = last, sub16 7, accumulator set 1); mu holds tile `last` since its f == 5
-            const uint32_t rb = w_m1 * I8_TILE_ROWS + 112, sb = unit_slot0(n_units - 1u) + 112;  // (w_m1: the last unit's tile)
+            const uint32_t rb = unit_row0(last) + 112, sb = unit_slot0(last) + 112;
             if (DENSE) {
                 tail_dense(C1(), nl_c, 7, rb, sb);
             } else {
@@ -1644,8 +1561,7 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 32: DAWN_I8_PIPE(0); break;  // the 32x32x32 form (option "mfma_sched" = 32)
         default:
             hipLaunchKernelGGL(scan_i8_pipe16_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
-                               qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand),
-                               ws.dyn_tail ? ws.pool : static_cast<uint32_t*>(nullptr));
+                               qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
             break;
     }
 #undef DAWN_I8_PIPE
@@ -1660,8 +1576,7 @@ static void launch_i8_dense(const unsigned char* xs, const float2* mt, uint32_t 
                            B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
     else
         hipLaunchKernelGGL(scan_i8_pipe16_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, qi,
-                           qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand),
-                           static_cast<uint32_t*>(nullptr));
+                           qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
 }
 
 // Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
@@ -1674,7 +1589,6 @@ void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t 
     (void)hipEventRecord(ev0, stream);
     for (int i = 0; i < iters; ++i) {
         (void)hipMemsetAsync(ws.cnt, 0, BATCH_QT * BATCH_CAND_SEGS * sizeof(uint32_t), stream);
-        (void)hipMemsetAsync(ws.pool, 0, 32 * sizeof(uint32_t), stream);
         launch_i8_append(reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 1u,
                          pl.n_tiles_total, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream);
     }

@@ -195,8 +195,6 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      builds; the release library rejects them.)
  *   "stream_dynamic_tail" 0: the single-query streams (packed shadow, f32 rows) assign every unit of work statically (default 1:
  *                      the last eighth of a long stream is handed out on demand; same results)
- *   "mfma_dynamic_tail" 0: every tile of the int8 matrix-core pass is assigned statically (default 1: the last eighth of a pass of
- *                      >= 256 tiles per workgroup is handed out on demand — whole XCDs otherwise finish hundreds of us apart)
  *   "mfma_target"      candidates per query the sampled thresholds of the matrix-core path aim for (1024; twice that for count > 32)
  *   "i8_shadow"        0: no integer shadows (int8: 384 B/row, scan_i8.hip; 6-bit: 288 B/row, scan_i6.hip) of the index rows: the
  *                      filters read the f16 shadow of an f32 index / the rows of a bf16 index themselves.  Default 1, or env
@@ -211,6 +209,10 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the packed stream: workgroups, 64..512 threads, loads in
  *                      flight per wave (6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 loads of 768 B - 1 KiB); same
  *                      results whatever the geometry
+ *   "i6_dyn_share" / "i6_dyn_chunk" / "i6_dyn_queue" / "i6_dyn_window"   the part of the packed stream that is handed out on
+ *                      demand: sixteenths of the index (1..12), sub-tiles per chunk (1..128), a chunk per wave (1) or shared by the
+ *                      waves of a workgroup through a ticket counter in LDS (2), log2 of the chunks interleaved in one window;
+ *                      0 each = chosen from the index size (default); same results whatever the assignment
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow

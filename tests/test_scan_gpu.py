@@ -899,11 +899,10 @@ def test_f32_stream_dynamic_tail_covers_every_row(dawn, oracle, blocks):
 
 
 @pytest.mark.parametrize("blocks,n", [(8, 300_000), (5, 200_003), (16, 600_000)])
-def test_int8_pass_dynamic_tile_sequence(dawn, oracle, blocks, n):
-    """The int8 matrix-core pass generates its tile sequence three units ahead and takes the last eighth of a long pass (>= 256
-    tiles per workgroup — reached here with a small grid, option "mfma_blocks") in chunks from shared counters: every tile
-    exactly once — planted rows in the static part, the dynamic part and the last, ragged tile come back first —, results equal
-    to the oracle's and to the static assignment's (option "mfma_dynamic_tail" = 0), batch after batch."""
+def test_int8_pass_long_tile_sequences_on_small_grids(dawn, oracle, blocks, n):
+    """The int8 matrix-core pass on a small grid (option "mfma_blocks"): every workgroup walks a long, strided sequence of tiles
+    (>= 256 of them) — planted rows in the first tile, in the middle, in the last, ragged tile come back first —, results equal
+    to the oracle's, batch after batch."""
     idx = _mk_index(dawn, n)
     idx.set_option("mfma_blocks", blocks)
     x = oracle.unit_rows(1, 0, n)
@@ -913,8 +912,7 @@ def test_int8_pass_dynamic_tile_sequence(dawn, oracle, blocks, n):
     planted = np.array([0, 127, 128, n // 2, (n * 7) // 8 - 3, (n * 7) // 8 + 300, (n * 15) // 16, n - 129, n - 2, n - 1])
     Q[:len(planted)] = synth.planted_queries(1, planted, 5)
     ref = None
-    for mode in (1, 0, 1, 1):
-        idx.set_option("mfma_dynamic_tail", mode)
+    for _ in range(3):
         labels, dist, found = idx.search_batch(Q, 20)
         assert np.all(found == 20) and np.array_equal(labels[:len(planted), 0], planted + 1)
         if ref is None:
