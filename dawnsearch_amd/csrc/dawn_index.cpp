@@ -788,26 +788,6 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->geom_i6.refine = idx->geom_i6_small.refine = (int)value;
         return DAWN_OK;
     }
-    if (n == "i6_dyn_share") {  // sixteenths of the index the packed stream hands out on demand: 1..12; 0 = chosen from N (default)
-        if (value < 0 || value > 12) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_share must be 0..12");
-        idx->geom_i6.dyn_share = idx->geom_i6_small.dyn_share = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "i6_dyn_chunk") {  // ... in chunks of so many sub-tiles: 1..64; 0 = chosen from N (default)
-        if (value < 0 || value > 128) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_chunk must be 0..128");
-        idx->geom_i6.dyn_chunk = idx->geom_i6_small.dyn_chunk = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "i6_dyn_window") {  // log2 of the number of chunks interleaved in one window of the dynamic part (0: default)
-        if (value < 0 || value > 15) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_window must be 0..15");
-        idx->geom_i6.dyn_window = idx->geom_i6_small.dyn_window = (int)value;
-        return DAWN_OK;
-    }
-    if (n == "i6_dyn_queue") {  // 1: a chunk per wave; 2: the waves of a workgroup share its chunks sub-tile by sub-tile; 0: from N
-        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_queue must be 0..2");
-        idx->geom_i6.dyn_queue = idx->geom_i6_small.dyn_queue = (int)value;
-        return DAWN_OK;
-    }
     if (n == "i6_scan_threads" || n == "i6_scan_ring" || n == "i6_scan_blocks") {
         if (n == "i6_scan_threads") {
             if (value < 64 || value > 512 || value % 64) return fail(DAWN_ERR_INVALID_ARG, "i6_scan_threads must be 64..512, a multiple of 64");

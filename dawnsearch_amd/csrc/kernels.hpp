@@ -105,11 +105,6 @@ struct ScanGeom {
     int threads;          // 1024 / 512 / 256
     int unroll = 2;       // row pairs per wave iteration (batch-1 kernel)
     int refine = 0;       // packed-shadow stream only: entries of its list a wave keeps and refines (0: chosen from N and k)
-    int dyn_share = 0;    // packed-shadow stream only: sixteenths of the index handed out on demand (0: chosen from N; 1 .. 12)
-    int dyn_chunk = 0;    // ... in chunks of so many sub-tiles (0: chosen from N; 1 .. 128)
-    int dyn_window = 0;   // ... log2 of the chunks interleaved in one window (0: 8)
-    int dyn_queue = 0;    // ... 1: a chunk per wave, 2: a chunk is shared by the waves of a workgroup, sub-tile by sub-tile (LDS
-                          // ticket counter); 0: chosen from N
 };
 
 // Filter pass: approximate scores for all rows, per-block top-64 lists.

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                                                                const float2* __restrict__ meta8, float* __restrict__ out_s,
                                                                uint32_t* __restrict__ out_p, float* __restrict__ out_es,
                                                                uint32_t* __restrict__ out_ep, float* __restrict__ out_t,
-                                                               int n_refine, uint32_t* __restrict__ pool, uint32_t dyn_share,
-                                                               uint32_t dyn_chunk) {
+                                                               int n_refine, uint32_t* __restrict__ pool) {
     static_assert(BITS == 6 ? 12 % PD == 0 : (PD == 8 || PD == 4), "ring depth");
     typedef PackedShadow<BITS> PS;
     __shared__ float sh_s[8][LIST];
@@ -278,37 +277,28 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t t_stride = gridDim.x * nwaves, t_end = n_sub;
     DAWN_TS6(0);
     // Work assignment.  Static and interleaved — wave w takes sub-tiles w, w + W, w + 2W, ... — for the first 7/8 of the index;
-    // the last eighth is handed out on demand in CHUNKS.  The waves' shares of a static assignment are equal, their speeds are
-    // not: the first wave of a 100 M-row launch is done 260-340 us before the last (tools/stream_i5_ts.py,
-    // profiles/r03/stream_i5_wave_timestamps_100M_static.log) — 4 % of the kernel during which the memory system runs half
-    // empty; at 12.5 M rows it is 15 % of the stream, and the younger of the two waves of a SIMD trails the older one by 5-11 us.
-    //   * a chunk id is fetched with a SCALAR atomic (s_atomic_add, returns through lgkmcnt): a returning vector atomic in this
+    // the last eighth is handed out in CHUNKS of 16 sub-tiles on demand.  The waves' shares of a static assignment are equal,
+    // their speeds are not: the first wave of a 100 M-row launch is done 260-340 us before the last (tools/stream_i5_ts.py,
+    // profiles/r03/stream_i5_wave_timestamps_100M_static.log) — 4 % of the kernel during which the memory system runs half empty.
+    //   * a chunk is STRIDED: chunk j = sub-tiles D0 + j + i C, i < 16 (C = number of chunks): never two consecutive sub-tiles
+    //     in one wave — a run of similar rows in one wave is what the list length is sized against;
+    //   * a chunk is fetched with a SCALAR atomic (s_atomic_add, returns through lgkmcnt): a returning vector atomic in this
     //     loop makes hipcc drain the load ring — with one sub-tile per atomic that cost 2 x the kernel (7.4 ms,
     //     stream_i5_wave_timestamps_100M_atomic_pool_experiment.log), and same-address atomics retire at only ~13 M/s on
-    //     this chip (512 of them took 40 us; chunks of 2-4 sub-tiles per wave are atomic-bound: stream_dyn_sweep.log): hence
-    //     chunks, and 32 counters — counter (b / 8) % 32 serves the chunks of that residue: its eight workgroups run on the
-    //     eight XCDs (workgroup b: XCD b % 8), whose memory speeds differ too;
-    //   * two ways to consume a chunk (launch_scan_i6 chooses by the index size): a chunk of 16 sub-tiles PER WAVE, or chunks of
-    //     32 shared by the waves of a WORKGROUP, sub-tile by sub-tile, through a ticket counter in LDS (dyn_queue below);
+    //     this chip (512 of them took 40 us): hence chunks, and 32 counters — counter (b / 8) % 32 serves the chunks of that
+    //     residue: its eight workgroups run on the eight XCDs (workgroup b: XCD b % 8), whose memory speeds differ too;
     //   * a rotated static interleave (round i of wave w = sub-tile i W + ((w + 37 i) mod W)) changes nothing: the speed
     //     differences belong to the waves' places on the chip, not to their addresses (..._rotated_interleave_experiment.log).
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    constexpr uint32_t POOLS = 32;
-    // dyn_share: sixteenths of the rounds that are handed out; dyn_chunk: sub-tiles per chunk (a power of two when dyn_queue)
-    const uint32_t CHUNK = dyn_chunk & 0xFFu;
-    const bool dyn_queue = (dyn_chunk & 0x100u) != 0u;  // chunks are shared by the workgroup's waves through a ticket counter in LDS
-    const uint32_t chunk_sh = 31u - (uint32_t)__builtin_clz(CHUNK | 1u);
+    constexpr uint32_t CHUNK = 16, POOLS = 32;
     uint32_t static_left = NONE;  // further static sub-tiles of this wave (NONE: static to the end)
     uint32_t dyn0 = 0, n_chunks = 0, chunk_base = 0, chunk_i = CHUNK;
     // counters in use: one per group of eight workgroups, at most POOLS (a counter nobody reads would strand its chunks)
     const uint32_t n_pools = ((gridDim.x + 7u) >> 3) < POOLS ? ((gridDim.x + 7u) >> 3) : POOLS;
     const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
     uint32_t* my_pool = nullptr;
-    if (pool != nullptr && n_sub / t_stride >= 8u) {
-        const uint32_t rounds = n_sub / t_stride;
-        uint32_t n_dyn = (rounds * dyn_share) / 16u;
-        n_dyn = n_dyn < 1u ? 1u : n_dyn;
-        const uint32_t i_static = rounds - n_dyn;
+    if (pool != nullptr && n_sub / t_stride >= 16u) {
+        const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds / 8u;
         dyn0 = t_stride * i_static;
         n_chunks = (n_sub - dyn0 + CHUNK - 1u) / CHUNK;
         my_pool = pool + pool_id;
@@ -319,77 +309,6 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(my_pool));
         const uint32_t j = pool_id + n_pools * v;
         return j < n_chunks ? j : NONE;
-    };
-    // Position o of chunk j.  Chunks are interleaved W = 256 at a time: chunk j = W B + r is the sub-tiles r, r + W, r + 2 W, ...
-    // of the B-th window of W * CHUNK sub-tiles (the last window: as many chunks as are left) — a wave never takes two
-    // neighbouring sub-tiles (a run of similar rows in ONE wave is what the list length is sized against), and the chunks in
-    // flight stay inside a window of a few hundred MB that moves through the index like the static part's: chunks strided over
-    // the whole dynamic part stream 10 % slower (address translation; tools/stream_dyn_sweep.py).
-    const uint32_t DW = 1u << ((dyn_chunk >> 12) & 15u);
-    auto dyn_sub = [&](uint32_t j, uint32_t o) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t b0 = j & ~(DW - 1u), r = j & (DW - 1u);
-        const uint32_t wb = n_chunks - b0 < DW ? n_chunks - b0 : DW;
-        return dyn0 + b0 * CHUNK + o * wb + r;
-    };
-    // The workgroup's queue (dyn_queue): its waves take TICKETS from one LDS counter — ticket n = position n % CHUNK of the
-    // workgroup's (n / CHUNK)-th chunk — so that inside a workgroup the unit of balancing is ONE sub-tile (the two waves of a SIMD
-    // do not run at the same speed: the older one is issued first) and a global fetch is paid once per chunk and workgroup, by
-    // the wave that draws position CHUNK / 4 of the chunk before (position 0 of the first chunk fetches its own).  The chunk ids
-    // travel through a ring of four {tag, id} pairs: tickets in flight span at most two chunks (eight waves, two tickets each,
-    // CHUNK >= 32).  A reader that does not see its tag within ~1 M polls gives up and POISONS the wave's bound on its unlisted
-    // rows (+inf: the certificate fails, the exact pass answers) instead of hanging the GPU.
-    __shared__ uint32_t dq_cnt;
-    __shared__ __attribute__((aligned(8))) uint32_t dq_ring[4][2];
-    if (threadIdx.x < 4) {
-        dq_ring[threadIdx.x][0] = NONE;
-        dq_ring[threadIdx.x][1] = NONE;
-        if (threadIdx.x == 0) dq_cnt = 0;
-    }  // (visible after the barrier behind the query images)
-    uint32_t tk = 0;        // lane 0: the ticket drawn for the next round
-    uint32_t tn_dyn = NONE;  // the sub-tile of that ticket
-    uint32_t dq_c = NONE, dq_j = NONE;  // the chunk this wave drew its last ticket from, and its id
-    bool dq_primed = false, dq_poison = false;
-    auto ticket_issue = [&]() __attribute__((always_inline)) {
-        if (lane == 0) tk = __hip_atomic_fetch_add(&dq_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto ticket_resolve = [&]() __attribute__((always_inline)) -> uint32_t {
-        for (;;) {
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-            const uint32_t cq = n >> chunk_sh, o = n & (CHUNK - 1u);
-            // this ticket's duty, if it has one: the id of chunk 0 (before anything can be read) / of the next chunk (AFTER its own
-            // chunk's id is in registers: the global fetch may take long enough for the ring slot to be reused)
-            auto fetch_for = [&](uint32_t cf) __attribute__((always_inline)) {
-                const uint32_t j = fetch_chunk();
-                if (lane == 0) {
-                    volatile uint32_t* e = &dq_ring[cf & 3u][0];
-                    e[1] = j;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    e[0] = cf;
-                }
-            };
-            if (n == 0u) fetch_for(0u);
-            if (cq != dq_c) {  // the first ticket this wave draws of chunk cq: its id, once (tag and id in one 8-byte read)
-                const volatile unsigned long long* e = reinterpret_cast<const volatile unsigned long long*>(&dq_ring[cq & 3u][0]);
-                uint32_t polls = 0;
-                unsigned long long v = *e;
-                while ((uint32_t)v != cq && ++polls < (1u << 20)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    v = *e;
-                }
-                if ((uint32_t)v != cq) {
-                    dq_poison = true;
-                    return NONE;
-                }
-                dq_c = cq;
-                dq_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-            }
-            if (n != 0u && o == (CHUNK >> 2)) fetch_for(cq + 1u);
-            const uint32_t j = dq_j;
-            if (j == NONE) return NONE;  // the pool is empty
-            const uint32_t sub = dyn_sub(j, o);
-            if (sub < t_end) return sub;
-            ticket_issue();  // (a position of the last, ragged chunks beyond the index: draw again)
-        }
     };
     // the first loads fly while the query images are made.  6 bits: a[] = ring of fragments (lane slot: 3 dwords);
     // 5 bits: hq[] = ring of H loads (lane slot: 3 dwords), nq[] = ring of N loads (lane slot: 4 dwords)
@@ -485,8 +404,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         // The wave's threshold: only its best n_refine rows are refined, and the bound on everything else is the best row it
         // does NOT keep — entry n_refine of the list.  Rows below that entry can neither enter the kept part nor raise the bound,
         // so they are not inserted at all (entries behind it go stale and are discarded with it): a list of 40 takes a third
-        // fewer insertions than one of 64 on a 12.5 M-row index — same-box A/B against the 64th entry as the threshold
-        // (profiles/r03/stream_i5_threshold_ab.log): 3 M rows 175 -> 165 us, 12.5 M 499 -> 487, 100 M 3631 -> 3617.
+        // fewer insertions than one of 64 on a 12.5 M-row index (profiles/r03/stream_i5_threshold_ab.log).
         const int tau_lane = n_refine < LIST ? n_refine : LIST - 1;
         auto list_tau = [&]() __attribute__((always_inline)) -> float {
             return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), tau_lane));
@@ -577,23 +495,15 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
             if (static_left != 0u) {
                 tn = t + t_stride;
                 if (static_left != NONE) --static_left;
-            } else if (dyn_queue) {
-                if (!dq_primed) {
-                    ticket_issue();
-                    tn_dyn = ticket_resolve();
-                    dq_primed = true;
-                }
-                tn = tn_dyn;
-                if (tn != NONE) ticket_issue();  // for the round after this one: resolved behind this round's MFMAs
             } else {
-                tn = chunk_i + 1u < CHUNK ? dyn_sub(chunk_base, chunk_i + 1u) : NONE;
+                tn = chunk_i + 1u < CHUNK ? chunk_base + (chunk_i + 1u) * n_chunks : NONE;
                 if (tn < t_end) {
                     ++chunk_i;
                 } else {
                     const uint32_t j = fetch_chunk();
-                    chunk_base = j;
+                    chunk_base = dyn0 + j;
                     chunk_i = 0u;
-                    tn = j != NONE ? dyn_sub(j, 0u) : NONE;
+                    tn = j != NONE ? chunk_base : NONE;
                 }
             }
             more = tn < t_end;
@@ -652,7 +562,6 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (dyn_queue && dq_primed && tn != NONE) tn_dyn = ticket_resolve();
             if constexpr (TEST)
                 if (__any(mx > thr)) slow_path();
             pmt = mt;
@@ -769,7 +678,6 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         ls = -d;  // descending by the int8 bound, ties -> lower row; fillers (-inf, NO_POS) last
         lp = pr;
     }
-    if (dq_poison) tw = POS_INF;      // (the queue gave up on a chunk id: no certificate)
     if (lane == 0) sh_tw[wave] = tw;  // (visible after block_merge's barriers)
     DAWN_TS6(3);
 
@@ -971,19 +879,6 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
     int n_refine = g.refine > 0 ? g.refine : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
     if (n_refine < 1 || n_refine > LIST) n_refine = LIST;  // (callers ask i6_refine_count first and go elsewhere on 0)
     n_refine = (n_refine + 7) & ~7;                         // (the f32 refinement takes its rows eight at a time)
-    // The share of the index that is handed out on demand, and in what pieces (the kernel's "Work assignment";
-    // tools/stream_dyn_sweep.py, profiles/r03/stream_dyn_sweep.log): an eighth; below 40 M rows through the workgroups' ticket
-    // queues in chunks of 32 sub-tiles (3 M - 25 M rows: -2 ... -3 % against the static assignment, where a chunk per wave gains
-    // nothing: a wave's whole share is 45 - 380 sub-tiles), above in chunks of 16 per wave (the queue's ticket per sub-tile
-    // costs what its finer balance gains once the tail is under 2 % of the launch).
-    uint32_t dyn_share = g.dyn_share >= 1 && g.dyn_share <= 12 ? (uint32_t)g.dyn_share : 2u;
-    const bool queue = g.dyn_queue == 2 || (g.dyn_queue == 0 && n_rows < 40000000u);
-    uint32_t dyn_chunk = g.dyn_chunk >= 1 && g.dyn_chunk <= 128 ? (uint32_t)g.dyn_chunk : (queue ? 32u : 16u);
-    if (queue) {  // the workgroup queue wants a power of two >= 32 (tickets in flight span two chunks at most)
-        dyn_chunk = dyn_chunk >= 128u ? 128u : dyn_chunk >= 64u ? 64u : 32u;
-        dyn_chunk |= 0x100u;
-    }
-    dyn_chunk |= (uint32_t)(g.dyn_window >= 1 && g.dyn_window <= 15 ? g.dyn_window : 8) << 12;
     int pd;
     if (bits == 6) pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
     else pd = g.unroll == 4 ? 4 : 8;
@@ -992,7 +887,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
         hipLaunchKernelGGL((scan_filter_i6s_kernel<RT_, BITS_, PD_>), dim3(g.blocks), dim3(g.threads),                  \
                            RescoreStage<RT_>::BYTES, stream, x, mt, n_rows, d_q, d_rows,                                 \
                            reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_i8meta), ub_s, ub_p,  \
-                           ex_s, ex_p, tb, n_refine, pool, dyn_share, dyn_chunk);
+                           ex_s, ex_p, tb, n_refine, pool);
     DAWN_I6_EACH(DAWN_I6_LAUNCH)
 #undef DAWN_I6_LAUNCH
 #undef DAWN_I6_EACH

@@ -209,10 +209,6 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the packed stream: workgroups, 64..512 threads, loads in
  *                      flight per wave (6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 loads of 768 B - 1 KiB); same
  *                      results whatever the geometry
- *   "i6_dyn_share" / "i6_dyn_chunk" / "i6_dyn_queue" / "i6_dyn_window"   the part of the packed stream that is handed out on
- *                      demand: sixteenths of the index (1..12), sub-tiles per chunk (1..128), a chunk per wave (1) or shared by the
- *                      waves of a workgroup through a ticket counter in LDS (2), log2 of the chunks interleaved in one window;
- *                      0 each = chosen from the index size (default); same results whatever the assignment
  *   "i8_batched"       0: only batches below mfma_min_batch filter on the int8 shadow
  *   "f16_shadow"       0: an f32 index keeps no f16 shadow either (filters read / convert the f32 rows)
  *   "f16_shadow_b1"    0: batches below mfma_min_batch stream the f32 rows instead of a shadow

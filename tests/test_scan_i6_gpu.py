@@ -345,19 +345,15 @@ def test_i6_survives_save_load_and_follows_the_int8_switch(dawn, oracle, tmp_pat
     assert other.stats()["fallbacks"] == 0
 
 
-@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("blocks,threads", [(256, 512), (40, 128), (100, 256), (7, 512), (8, 64), (300, 192)])
-def test_i6_dynamic_tail_covers_every_sub_tile(dawn, oracle, blocks, threads, mode):
-    """From 8 rounds of the grid on, the last eighth of the index (option "i6_dyn_share": more) is handed out on demand — mode 1: a
-    chunk of 16 sub-tiles per wave from shared counters; mode 2: chunks of 32 shared by the waves of a workgroup through a ticket
-    counter in LDS (the default below 40 M rows).  Whatever the grid, every sub-tile is scanned exactly once: a query planted on
-    the first row of every 5th sub-tile of the dynamic part (and on rows all over the static one) comes back first, and the
-    answers equal the oracle's."""
+def test_i6_dynamic_tail_covers_every_sub_tile(dawn, oracle, blocks, threads):
+    """From 16 rounds of the grid on, the last eighth of the index is handed out in strided chunks from shared counters: whatever the
+    grid, every sub-tile is scanned exactly once — queries planted all over the dynamic region (and the static one) come back first,
+    and the answers equal the oracle's."""
     n = 1_200_003
     idx = _mk(dawn, n)
     idx.set_option("i6_scan_blocks", blocks)
     idx.set_option("i6_scan_threads", threads)
-    idx.set_option("i6_dyn_queue", mode)
     x = oracle.unit_rows(1, 0, n)
     ids = np.arange(1, n + 1, dtype=np.uint64)
     planted = np.array([0, 31, 500_000, 1_049_999, 1_050_000, 1_100_017, 1_150_000, 1_190_000, n - 40_000, n - 33, n - 1])
@@ -366,14 +362,6 @@ def test_i6_dynamic_tail_covers_every_sub_tile(dawn, oracle, blocks, threads, mo
         lab, dist = idx.search(q, 10)
         assert lab[0] == r + 1, (r, lab)
         _assert_same(lab, dist, *oracle.scan_topk(x, ids, q, 10, threads=8))
-    for share in (2, 9):
-        idx.set_option("i6_dyn_share", share)
-        first = (n * (15 - share) // 16) // 32 * 32  # (the dynamic part begins on a multiple of the grid near (16 - share) / 16)
-        cover = np.arange(first, n, 5 * 32)
-        for r, q in zip(cover, synth.planted_queries(1, cover, 6)):
-            lab, _ = idx.search(q, 3)
-            assert lab[0] == r + 1, (share, r, lab)
-    idx.set_option("i6_dyn_share", 0)
     for q in synth.unit_rows(2, 0, 3):  # ... twice: the counters are back at zero after every search
         for _ in range(2):
             _assert_same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20, threads=8))

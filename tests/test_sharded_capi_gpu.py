@@ -67,6 +67,32 @@ def test_concurrent_shard_searches_on_one_device_stay_exact(dawn):
     assert sh.stats()["fallbacks"] == 0
 
 
+def test_concurrent_packed_streams_on_one_device_stay_exact(dawn, oracle):
+    """The same for the packed single-query stream with its dynamically assigned part (scalar atomics on per-index counters, the
+    workgroups' ticket queues): three logical shards of 600 k rows stream concurrently on one device — 150 queries against the
+    single index and a sample against the oracle, bit for bit, no exact passes."""
+    G, n = 3, 1_800_000
+    full = dawn.VectorIndex(0)
+    full.set_option("i6_min_rows", 100_000)
+    full.fill_synthetic(1, 0, n, 1)
+    sh = dawn.VectorIndex(devices=[0] * G)
+    sh.set_option("i6_min_rows", 100_000)
+    sh.fill_synthetic(1, 0, n, 1)
+    Q = np.concatenate([synth.unit_rows(2, 0, 20), synth.planted_queries(1, [5, n // 3 + 7, n - 3], 3)])
+    want = [full.search(q, 10) for q in Q]
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    for b in (0, 21):
+        ol, od = oracle.scan_topk(x, ids, Q[b], 10, threads=8)
+        assert np.array_equal(want[b][0], ol) and np.array_equal(want[b][1].view(np.uint32), od.view(np.uint32))
+    for it in range(150):
+        l, d = sh.search(Q[it % len(Q)], 10)
+        w = want[it % len(Q)]
+        assert np.array_equal(l, w[0]) and np.array_equal(d.view(np.uint32), w[1].view(np.uint32)), it
+    assert sh.stats()["fallbacks"] == 0 and full.stats()["fallbacks"] == 0
+    assert sh.memory()["shadows"] > n * 384 + n * 200  # (the shards keep the packed shadow beside the int8 one)
+
+
 def test_sharded_ties_follow_insertion_order_across_shards(dawn, oracle):
     """Duplicates of one row land on different shards (chunk 64, 4 shards): equal distances must come out in insertion
     order — the merge compares insertion positions, not shard numbers."""
