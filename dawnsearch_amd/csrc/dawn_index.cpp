@@ -100,8 +100,8 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         DAWN_HIP_TRY(hipMemset(idx->bws.pool, 0, 32 * sizeof(uint32_t)));
     }
     if (!idx->d_stats) {
-        DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, 4 * sizeof(uint32_t)));
-        DAWN_HIP_TRY(hipMemset(idx->d_stats, 0, 4 * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, dawn::N_STAT_SLOTS * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMemset(idx->d_stats, 0, dawn::N_STAT_SLOTS * sizeof(uint32_t)));
     }
     if (!idx->d_i6_pool) {  // chunk counters of the packed stream: zero between searches (merge_exact_kernel resets them)
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_i6_pool, 32 * sizeof(uint32_t)));
@@ -383,6 +383,13 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                              (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_F32, stream,
                              pool);
     }
+    // The ladder behind a failed certificate (both predicated on the query's flag, launch-only): the bounded exact pass on the
+    // int8 shadow (scan_bounded.hip: 384 B per row + the rows that can still matter), then — only if that did not answer — the
+    // exact pass over all rows.  force_fallback = 1 (tests of the exact pass) skips the first rung; 2 forces the flags only.
+    if (idx->bounded_pass && idx->force_fallback != 1 && i8_live(idx) && n > 0)
+        launch_scan_bounded(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags,
+                            idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
+                            d_dist, d_found, stream);
     launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
                       idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
     DAWN_HIP_TRY(hipGetLastError());
@@ -679,15 +686,17 @@ int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total
 
 // The certificate counters live on the device (scan_exact_kernel bumps them at the end of every search, whichever entry
 // point issued it); reading them synchronises the device.
-int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened) {
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
+                       uint64_t* bounded) {
     DAWN_TRY(set_device(idx));
-    uint32_t st[4] = {0, 0, 0, 0};
+    uint32_t st[N_STAT_SLOTS] = {};
     DAWN_HIP_TRY(hipDeviceSynchronize());
     if (idx->d_stats) DAWN_HIP_TRY(hipMemcpy(st, idx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
     if (searches) *searches = idx->n_searches;
     if (second) *second = (uint64_t)st[FLAG_SECOND] + st[FLAG_DEEP];
     if (fallbacks) *fallbacks = st[FLAG_FALLBACK];
     if (deepened) *deepened = st[FLAG_DEEP];
+    if (bounded) *bounded = st[FLAG_BOUNDED];
     return DAWN_OK;
 }
 
@@ -722,12 +731,17 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
         return DAWN_OK;
     };
-    if (n == "force_fallback") {
-        idx->force_fallback = value != 0;
+    if (n == "force_fallback") {  // 1: every query takes the exact pass; 2: every certificate is made to fail, the ladder answers
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "force_fallback must be 0, 1 or 2");
+        idx->force_fallback = (int)value;
         return DAWN_OK;
     }
-    if (n == "synth_dist") {  // dawn_index_fill_synthetic: 0 the spec's uniform rows, 1 Gaussian, 2 / 3 heavy-tailed
-        if (value < 0 || value > 3) return fail(DAWN_ERR_INVALID_ARG, "synth_dist must be 0..3");
+    if (n == "bounded_pass") {  // 0: a failed certificate goes straight to the exact pass over all rows (round 3; A/B)
+        idx->bounded_pass = value != 0;
+        return DAWN_OK;
+    }
+    if (n == "synth_dist") {  // dawn_index_fill_synthetic: 0 the spec's uniform rows, 1 Gaussian, 2 / 3 heavy-tailed, 4 / 5 topical mixture
+        if (value < 0 || value > 5) return fail(DAWN_ERR_INVALID_ARG, "synth_dist must be 0..5");
         idx->synth_dist = (int)value;
         return DAWN_OK;
     }
@@ -1350,7 +1364,14 @@ int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_c
                        : dawn::index_stats_single(idx, searches, second_chances, fallbacks, nullptr);
 }
 
-// ... and, of those, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled
+// ... the queries whose certificates all failed and which the bounded exact pass answered (scan_bounded.hip; NOT in `fallbacks`)
+int dawn_index_stats_bounded(dawn_index* idx, uint64_t* bounded) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, nullptr, bounded)
+                       : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, nullptr, bounded);
+}
+
+// ... and, of the second chances, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled
 int dawn_index_stats_deep(dawn_index* idx, uint64_t* deepened) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, deepened)

@@ -532,16 +532,19 @@ int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes
     return DAWN_OK;
 }
 
-int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened) {
+int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
+                  uint64_t* bounded) {
     ShardSet& S = *idx->shards;
-    uint64_t s2 = 0, fb = 0, dp = 0;
+    uint64_t s2 = 0, fb = 0, dp = 0, bd = 0;
     for (dawn_index* sh : S.sh) {  // (per-shard events: one query can fall back on one shard and not on another)
-        uint64_t a = 0, b = 0, c = 0;
-        DAWN_TRY(index_stats_single(sh, nullptr, &a, &b, &c));
+        uint64_t a = 0, b = 0, c = 0, d = 0;
+        DAWN_TRY(index_stats_single(sh, nullptr, &a, &b, &c, &d));
         s2 += a;
         fb += b;
         dp += c;
+        bd += d;
     }
+    if (bounded) *bounded = bd;
     if (searches) *searches = S.n_searches;
     if (second) *second = s2;
     if (fallbacks) *fallbacks = fb;

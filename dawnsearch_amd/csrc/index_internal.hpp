@@ -150,7 +150,8 @@ struct dawn_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     uint64_t n_searches = 0;
-    int force_fallback = 0;
+    int force_fallback = 0;      // option "force_fallback": 1 = every query takes the exact pass, 2 = every certificate fails (ladder)
+    int bounded_pass = 1;        // option "bounded_pass": a failed certificate is answered from the int8 shadow (scan_bounded.hip)
     int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)
 
     // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,
@@ -207,7 +208,8 @@ int index_prepare_search(dawn_index* idx);
 int index_set_option_single(dawn_index* idx, const char* name, int64_t value);
 int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
-int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened);
+int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
+                       uint64_t* bounded = nullptr);
 int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total_ms);
 int index_profile_enable_single(dawn_index* idx, int enable);
 
@@ -230,7 +232,8 @@ int sharded_fill_synthetic(dawn_index* idx, uint64_t seed, uint64_t first_row, s
 int sharded_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int sharded_set_option(dawn_index* idx, const char* name, int64_t value);
 int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
-int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened);
+int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
+                  uint64_t* bounded = nullptr);
 int sharded_profile_enable(dawn_index* idx, int enable);
 int sharded_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms);
 int sharded_dtype(const dawn_index* idx);

@@ -64,6 +64,8 @@ constexpr uint32_t FLAG_OK = 0;        // certificate holds: result is exact
 constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass must (and will) run
 constexpr uint32_t FLAG_SECOND = 2;    // first certificate failed, the 1024-deep second one held: result is exact
 constexpr uint32_t FLAG_DEEP = 3;      // first certificate failed, a deeper round (128 .. 256 rows) held: result is exact
+constexpr uint32_t FLAG_BOUNDED = 4;   // every certificate failed, the bounded exact pass (scan_bounded.hip) answered: result is exact
+constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query
 
 // Function attributes (hipFuncSetAttribute: the dynamic-LDS limit of a kernel) belong to the CURRENT device's copy of the
 // kernel: a process that drives several devices (dawn_sharded.cpp) has to set them on each.  once_per_device(state, fn) runs fn
@@ -182,6 +184,13 @@ void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_r
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                        const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
                        int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+
+// Bounded exact pass (scan_bounded.hip; predicated per query on d_flags[b] == FLAG_FALLBACK, in front of the exact pass): streams
+// the int8 shadow, scores exactly every row whose upper bound can still reach the k-th best distance known so far (d_dist of
+// the failed stage), sets FLAG_BOUNDED.  cand_s / cand_p [B][n_lists][64]; d_done [B] arrival counters (zero before and after).
+void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
+                         const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
+                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.

@@ -1,0 +1,341 @@
+// scan_bounded.hip — the BOUNDED EXACT PASS: the rung of the search ladder between a failed certificate and the exact pass
+// over all rows (scan_kernels.hip: scan_exact_kernel).
+//
+// Every filter of this library ends in a certificate: "no row outside the shortlist can beat the k-th exact distance".  It fails
+// when more rows crowd the top of a query — within the filter's slack — than the fixed-size lists hold: 64 rows per workgroup on the
+// int8 shadow (slack E + K2 ~ 0.012), 40-64 rows per WAVE on the packed 5-bit shadow (slack ~ 0.09).  On isotropic synthetic rows
+// that never happens; on topical data it is ordinary: a query inside a cluster of a million pages whose mutual cosine is 0.9 has
+// the whole cluster within 0.09 of its 10th best score (tools/clustered_probe.py).  Round 3 sent such a query to the exact pass:
+// 1536 B per row, 22-33 ms per 100 M rows behind a 3.5-ms search.
+//
+// This pass answers it from the int8 shadow instead, without lists and therefore without a way to fail:
+//   * it streams the int8 shadow exactly like the single-query filter (scan_i8.hip: global load -> v_mfma_i32_32x32x32_i8, the
+//     query as two int8 images, threshold test of sub-tile t - 1 in the shadow of sub-tile t's MFMAs): 384 B per row;
+//   * a row's upper bound ub >= x.q is compared with a THRESHOLD instead of a list: D = the k-th best exact distance known so far
+//     — the failed stage's own result is the first one: its rows are real rows with exact distances, so its k-th distance bounds
+//     the final one from above —; a row with ub <= (1 - D) - 1e-4 lies at distance > D (the certificate's arithmetic: dot <= ub +
+//     FILTER_EPS_I8, d = fl(1 - dot) >= fl(1 - up(ub + eps)); 1e-4 covers eps = 2.9e-5 and every rounding on the way) and is
+//     skipped; every other row is scored EXACTLY, in the reference's order (src/search/vector.rs:128-134), a lane per row, 64
+//     rows per wave at a time, and enters the wave's exact top-64;
+//   * D tightens as the wave finds better rows (its own k-th best distance is an upper bound of the final one too);
+//   * the last workgroup to finish merges the exact lists and checks the ONE assumption it made: that the threshold it was given
+//     was a valid upper bound — its own k-th distance must not exceed it.  (It cannot, unless the failed stage's result was not
+//     k distinct rows; then the flag stays FLAG_FALLBACK and the exact pass answers.)
+// Cost: one int8 stream (100 M rows: 5.5 ms) + 1536 B for every row within the int8 slack of the k-th score — a few hundred rows on
+// isotropic data, the dense part of a cluster on topical data — read at the exact pass's rate (lane-per-row walks, 4.6 TB/s with
+// every wave of the chip at it): it degrades towards the exact pass's cost as the data gets denser, never beyond it + 5.5 ms.
+// Predicated per query on d_flags[b] == FLAG_FALLBACK like the exact pass (launch-only searches: no host decision).
+#include <type_traits>
+
+#include "kernels.hpp"
+#include "rotate384.hpp"
+#include "wave_topk.hpp"
+
+namespace dawn {
+
+constexpr float BOUNDED_MARGIN = 1.0e-4f;
+constexpr int kBoundedMaxFlags = 256;
+
+template <int RT, int PD>
+__global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+                                                               const void* __restrict__ rows, const uint64_t* __restrict__ ids,
+                                                               uint32_t n_rows, const float* __restrict__ q, int n_q,
+                                                               uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
+                                                               float* __restrict__ out_s, uint32_t* __restrict__ out_p,
+                                                               uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
+                                                               float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
+    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    __shared__ float sh_s[4][LIST];
+    __shared__ uint32_t sh_p[4][LIST];
+    __shared__ uint32_t sh_queue[4][LIST];  // rows waiting for their exact score, per wave
+    __shared__ float sh_strip[4][32];       // a sub-tile's 32 upper bounds, one strip per wave
+    __shared__ __attribute__((aligned(16))) signed char sh_img[2][EM];
+    __shared__ __attribute__((aligned(16))) float sh_q[EM];
+    __shared__ float sh_sq;
+    __shared__ uint32_t sh_last;
+    __shared__ unsigned long long sh_mask[kBoundedMaxFlags / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const uint32_t n_sub = (n_rows + 31u) >> 5;
+    const uint32_t c = lane & 31, h = lane >> 5;
+    const uint32_t t_stride = gridDim.x * nwaves;
+    {
+        const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
+        const unsigned long long m = __ballot(myflag == FLAG_FALLBACK);
+        if (lane == 0) sh_mask[wave] = m;
+    }
+    __syncthreads();
+    for (int w = 0; w < kBoundedMaxFlags / 64; ++w) {
+      unsigned long long todo = sh_mask[w];  // block-uniform
+      while (todo) {
+        const int b = w * 64 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float* qv = q + (size_t)b * EM;
+        const uint32_t found = n_rows < k ? n_rows : k;
+        // the failed stage's k-th distance (what it wrote for a query it flagged: the best rows it found, exact distances)
+        const float d_in = found > 0 ? out_dist[(size_t)b * k + found - 1] : POS_INF;
+
+        uint32_t t = blockIdx.x * nwaves + wave;
+        const u32x4* p = x + (size_t)(t < n_sub ? t : 0) * (12 * 64) + lane;
+        u32x4 a[PD];
+        float2 mt = {0.f, 0.f};
+        if (t < n_sub) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+            mt = meta[t];
+        }
+        // the query: f32 copy for the exact scores, two int8 images for the bounds (scan_filter_i8s_kernel)
+        for (int i = threadIdx.x; i < EM; i += blockDim.x) sh_q[i] = qv[i];
+        if (wave == 0) {
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = qv[lane + 64 * j];
+            rotate384_wave(v, lane);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+            const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float tt = v[j] / sq;
+                const float H = fminf(fmaxf(rintf(tt), -127.f), 127.f);
+                const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
+                sh_img[0][lane + 64 * j] = (signed char)(int)H;
+                sh_img[1][lane + 64 * j] = (signed char)(int)L;
+            }
+            if (lane == 0) sh_sq = sq;
+        }
+        __syncthreads();
+        i32x4_t qf[12];
+        const bool col_live = c == 0 || c == 8;
+        {
+            const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&sh_img[c == 8 ? 1 : 0][0]);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) qf[f] = col_live ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
+        }
+        const float sq = sh_sq;
+        const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq, k2 = I8_K2_PER_SQ * sq;
+        const bool tested = c == 0;
+
+        // the wave's exact list (key = -distance, descending) and the score threshold below which a row is skipped
+        float ls = NEG_INF;
+        uint32_t lp = NO_POS;
+        float tau = d_in < POS_INF ? __fsub_rn(__fsub_rn(1.0f, d_in), BOUNDED_MARGIN) : NEG_INF;  // (NaN: nothing passes, the check fails)
+        float tau_m = POS_INF;
+        auto set_tau_m = [&]() __attribute__((always_inline)) {
+            if (tested) {
+                const float tk = tau - k2;
+                tau_m = tk - fabsf(tk) * 1e-6f;
+            }
+        };
+        set_tau_m();
+        uint32_t n_wait = 0;  // rows in the wave's queue (wave-uniform)
+        uint32_t* queue = &sh_queue[wave][0];
+
+        auto flush = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private queue: LDS operations of a wave are in order)
+            float key = NEG_INF;
+            uint32_t row = NO_POS;
+            if ((uint32_t)lane < n_wait) {
+                row = queue[lane];
+                const float dot = exact_dot_row<RT>(sh_q, rows, row);
+                const float d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+                if (d == d) key = -d;
+                else row = NO_POS;
+            }
+            n_wait = 0;
+            // rows arrive in ascending order (queue order = stream order), so a later row never displaces an equal key
+            const float t64 = read_lane63(ls);
+            unsigned long long hits = __ballot(row != NO_POS && key > t64);
+            if (__popcll(hits) > 8) {
+                float d = (row != NO_POS && key > t64) ? -key : POS_INF;
+                uint32_t pr = (row != NO_POS && key > t64) ? row : NO_POS;
+                sort64_asc(d, pr, lane);
+                const float os = -__shfl(d, 63 - lane);
+                const uint32_t op = __shfl(pr, 63 - lane);
+                merge64(ls, lp, os, op, lane);
+            } else {
+                float tl = t64;
+                while (hits) {
+                    const int src = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
+                    const uint32_t kr = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
+                    if (ks > tl) {
+                        wave_insert(ls, lp, ks, kr, lane);
+                        tl = read_lane63(ls);
+                    }
+                }
+            }
+            // the wave's own k-th best distance bounds the final one from above as well
+            if (found > 0 && (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)found - 1) != NO_POS) {
+                const float dkw = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), (int)found - 1));
+                const float tw = __fsub_rn(__fsub_rn(1.0f, dkw), BOUNDED_MARGIN);
+                if (tw > tau) {
+                    tau = tw;
+                    set_tau_m();
+                }
+            }
+        };
+
+        if (t < n_sub) {
+            i32x16_t accs[2];
+            float2 pmt = mt;
+            uint32_t prow = 0;
+            int C[16];
+            int thr = 0, mx = 0;
+
+            auto slow_path = [&]() __attribute__((always_inline)) {
+                float* strip = &sh_strip[wave][0];
+                if (c == 0) {  // lanes 0 (h = 0) and 32 (h = 1) hold the sub-tile's 32 sums
+                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = pmt.y + k2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
+                        const bool ok = C[e] > thr && prow + roff < n_rows;
+                        strip[roff] = ok ? __builtin_fmaf((float)C[e], g1, g0) : NEG_INF;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const bool hit = lane < 32 && strip[lane & 31] > tau;
+                asm volatile("" ::: "memory");
+                const unsigned long long m = __ballot(hit);
+                if (hit) queue[n_wait + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = prow + (uint32_t)lane;
+                n_wait += (uint32_t)__popcll(m);
+                if (n_wait > 32u) flush();  // (a sub-tile adds at most 32)
+            };
+            auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
+                if (s == 0) {
+                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                    float thr_f = __builtin_fmaf(u, pmt.x * rsq254, -2.0f);
+                    thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
+                    if (!tested) thr_f = 2.0e9f;
+                    thr = (int)floorf(thr_f);
+                } else if (s <= 8) {
+#pragma unroll
+                    for (int e = 2 * (s - 1); e < 2 * s; ++e) {
+                        const int ae = pacc[e];
+                        C[e] = __mul24(ae, 254) + __builtin_amdgcn_update_dpp(0, ae, 0x108, 0xf, 0xf, true);
+                        mx = e == 0 ? C[0] : max(mx, C[e]);
+                    }
+                }
+            };
+            bool more;
+            auto round = [&](auto with_test, auto parity) __attribute__((always_inline)) {
+                constexpr int P = decltype(parity)::value;
+                i32x16_t& acc = accs[P];
+                const uint32_t tn = t + t_stride;
+                more = tn < n_sub;
+                const u32x4* pn = more ? x + (size_t)tn * (12 * 64) + lane : p;
+                const float2 mtn = meta[more ? tn : t];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0;
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
+                    if (f + PD < 12) a[f % PD] = __builtin_nontemporal_load(p + (f + PD) * 64);
+                    else a[f % PD] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
+                    if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (decltype(with_test)::value)
+                    if (__any(mx > thr)) slow_path();
+                pmt = mt;
+                prow = t * 32u;
+                t = tn;
+                p = pn;
+                mt = mtn;
+            };
+            using P0 = std::integral_constant<int, 0>;
+            using P1 = std::integral_constant<int, 1>;
+            round(std::false_type{}, P0{});
+            int last = 0;
+            while (more) {
+                round(std::true_type{}, P1{});
+                last = 1;
+                if (!more) break;
+                round(std::true_type{}, P0{});
+                last = 0;
+            }
+            if (last) {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) test_slice(s, accs[1]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) test_slice(s, accs[0]);
+            }
+            if (__any(mx > thr)) slow_path();
+        }
+        if (n_wait > 0u) flush();
+
+        block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
+        if (wave == 0) {
+            const size_t o = ((size_t)b * n_lists + blockIdx.x) * LIST + lane;
+            out_s[o] = ls;
+            out_p[o] = lp;
+        }
+        __threadfence();  // this workgroup's list is visible device-wide before it counts itself in
+        __syncthreads();
+        if (threadIdx.x == 0) sh_last = atomicAdd(&done[b], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (sh_last) {  // block-uniform: every other workgroup's list of query b is complete
+            __threadfence();
+            float s = NEG_INF;
+            uint32_t pp = NO_POS;
+            const float* cs = out_s + (size_t)b * n_lists * LIST;
+            const uint32_t* cp = out_p + (size_t)b * n_lists * LIST;
+            for (uint32_t l = wave; l < gridDim.x; l += nwaves)
+                merge64(s, pp, cs[(size_t)l * LIST + 63 - lane], cp[(size_t)l * LIST + 63 - lane], lane);
+            block_merge(s, pp, sh_s, sh_p, wave, lane, nwaves);
+            if (wave == 0) {
+                const uint32_t have = __popcll(__ballot(pp != NO_POS));
+                bool valid = have >= found;
+                if (valid && found > 0) {
+                    const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)found - 1));
+                    valid = dk <= d_in;  // the threshold this pass started from was an upper bound of the k-th distance
+                }
+                if (valid) {
+                    if ((uint32_t)lane < found) {
+                        out_labels[(size_t)b * k + lane] = ids[pp];
+                        out_dist[(size_t)b * k + lane] = -s;
+                    }
+                    if (lane == 0) {
+                        out_found[b] = found;
+                        flags[b] = FLAG_BOUNDED;
+                    }
+                }
+                if (lane == 0) done[b] = 0u;
+            }
+        }
+        __syncthreads();  // the shared state is reused by the next query
+      }
+    }
+}
+
+// Per query b < B with d_flags[b] == FLAG_FALLBACK: the exact top-k through the int8 shadow, flag -> FLAG_BOUNDED; every other
+// query is left alone (one nearly empty launch when no flag is set).  cand_s / cand_p: the per-workgroup lists [B][n_lists][64]
+// (the filter's own, free by now); d_done [B]: arrival counters, zero before and after.  B <= 256 per launch.
+void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
+                         const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
+                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
+    const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
+    const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
+    for (int b0 = 0; b0 < B; b0 += kBoundedMaxFlags) {
+        const int nb = B - b0 < kBoundedMaxFlags ? B - b0 : kBoundedMaxFlags;
+        if (dtype == ROW_BF16)
+            hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, x8, mt, d_x, d_ids, n_rows,
+                               d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,
+                               cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k,
+                               d_dist + (size_t)b0 * k, d_found + b0);
+        else
+            hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, x8, mt, d_x, d_ids, n_rows,
+                               d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,
+                               cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k,
+                               d_dist + (size_t)b0 * k, d_found + b0);
+    }
+}
+
+}  // namespace dawn

@@ -812,10 +812,35 @@ __device__ __forceinline__ float synth_uniform(uint64_t key, uint64_t idx) {
 //   2  heavy-tailed, fixed dimensions: Gaussian with dimensions {7, 101, 213, 340} scaled x5 — sentence-embedding models
 //      have a handful of dimensions that are large in every vector
 //   3  heavy-tailed, per-row dimensions: Gaussian with 4 pseudo-random dimensions per row scaled x5
+//   4  topical mixture — the one distribution besides 0 that IS restated on the CPU (dawnsearch_amd/synth.py:
+//      unit_rows_topical, oracle: orc_synth_topical_row; integer hashing and single f32 operations in a fixed order):
+//      Zipf-sized clusters (12 octaves, 4095 clusters: cluster j of octave o holds 1 / (12 * 2^o) of the rows) around
+//      bell-shaped centroids, row = normalise(centroid + t_j * noise) with the cosine between two rows of a cluster
+//      0.5 ... 0.95 — dense semantic neighbourhoods, what the filters' slack is measured against
+//   5  the same with runs of 256 consecutive rows per cluster: the pages of one site are inserted back to back
+//      (src/index/warc.rs:75-86, src/search/search_provider.rs:250-286)
+__device__ __forceinline__ float synth_g4(uint64_t key, uint64_t i) {
+    float g = __fadd_rn(synth_uniform(key, 4 * i), synth_uniform(key, 4 * i + 1));
+    g = __fadd_rn(g, synth_uniform(key, 4 * i + 2));
+    g = __fadd_rn(g, synth_uniform(key, 4 * i + 3));
+    return __fmul_rn(g, 0.8660254f);
+}
 template <int DIST>
 __device__ __forceinline__ float synth_value(uint64_t key, uint64_t row, uint32_t col) {
     const uint64_t idx = row * (uint64_t)EM + col;
     if (DIST == 0) return synth_uniform(key, idx);
+    if (DIST == 4 || DIST == 5) {
+        const uint64_t unit = DIST == 5 ? row >> 8 : row;
+        const uint64_t h = splitmix64(key ^ (unit * 0xD1B54A32D192ED03ULL) ^ 0x746F706963730001ULL);
+        const uint32_t o = (uint32_t)((h >> 32) % 12u);
+        const uint32_t j = ((1u << o) - 1u) + ((uint32_t)h & ((1u << o) - 1u));
+        const uint64_t hj = splitmix64(key ^ ((uint64_t)j * 0xD6E8FEB86659FD93ULL) ^ 0x746F706963730002ULL);
+        const uint32_t lv = (uint32_t)((hj >> 20) % 6u);
+        const float t = lv == 0 ? 1.0f : lv == 1 ? 0.8164966f : lv == 2 ? 0.6546537f : lv == 3 ? 0.5f : lv == 4 ? 0.33333334f : 0.22941573f;
+        const uint64_t ckey = splitmix64(key ^ 0x746F706963730003ULL);
+        const float cen = synth_g4(ckey, (uint64_t)j * EM + col);
+        return __fadd_rn(cen, __fmul_rn(t, synth_g4(key, idx)));
+    }
     const float u1 = synth_uniform(key, 2 * idx), u2 = synth_uniform(key, 2 * idx + 1);
     const float a = 0.5f * u1 + 0.5f;  // (0, 1)
     float g = sqrtf(-2.0f * __logf(a)) * __cosf(3.14159265f * u2);
@@ -931,6 +956,8 @@ void launch_fill_synth(uint64_t seed, uint64_t first_row, uint32_t n, float* d_o
         case 1: fill_synth_dist<1>(key, first_row, n, d_out, d_len, stream); break;
         case 2: fill_synth_dist<2>(key, first_row, n, d_out, d_len, stream); break;
         case 3: fill_synth_dist<3>(key, first_row, n, d_out, d_len, stream); break;
+        case 4: fill_synth_dist<4>(key, first_row, n, d_out, d_len, stream); break;
+        case 5: fill_synth_dist<5>(key, first_row, n, d_out, d_len, stream); break;
         default: fill_synth_dist<0>(key, first_row, n, d_out, d_len, stream); break;
     }
 }

@@ -137,8 +137,12 @@ class VectorIndex:
         check(lib.dawn_index_stats_ext(self._h, C.byref(s), C.byref(c2), C.byref(f)))
         dp = C.c_uint64(0)
         check(lib.dawn_index_stats_deep(self._h, C.byref(dp)))
-        # second_chances: the 64-row certificate failed, no exact pass needed; deepened: those settled by a deeper round
-        return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value}
+        bd = C.c_uint64(0)
+        check(lib.dawn_index_stats_bounded(self._h, C.byref(bd)))
+        # second_chances: the 64-row certificate failed, no exact pass needed; deepened: those settled by a deeper round;
+        # bounded: every certificate failed, the bounded exact pass on the int8 shadow answered (no pass over all rows)
+        return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value,
+                "bounded": bd.value}
 
     def memory(self):
         """HBM bytes held by the index: rows, filter shadows built so far, everything else."""

@@ -70,6 +70,72 @@ def unit_rows_normal(seed: int, first_row: int, n: int, heavy_dims=(), heavy_sca
     return normalize_rows(g)
 
 
+# ---- topical mixture ("synth_dist" 4 / 5): what a crawl's page vectors look like to the filters ----
+# Zipf-sized clusters around bell-shaped centroids; a row = normalise(centroid + t * noise), t per cluster so that the
+# cosine between two pages of one topic is 0.5 ... 0.95.  Integer hashing and f32 adds / multiplies in a fixed order only:
+# bit-identical in numpy, the C oracle (orc_synth_topical_row) and the GPU generator (scan_kernels.hip: synth_value<4 / 5>).
+#   unit(r)    = r (dist 4: topics interleaved row by row) or r >> 8 (dist 5: runs of 256 consecutive rows share a topic — the
+#                pages of one site are inserted back to back, src/index/warc.rs:75-86, search_provider.rs:250-286)
+#   h          = splitmix64(key ^ unit * 0xD1B54A32D192ED03 ^ TOPIC_SALT),  key = splitmix64(seed)
+#   octave o   = (h >> 32) % 12;  cluster j = 2^o - 1 + (h & (2^o - 1))  in [0, 4095): mass 1 / (12 * 2^o) ~ Zipf(1)
+#   t_j        = TOPIC_T[(splitmix64(key ^ j * 0xD6E8FEB86659FD93 ^ LEVEL_SALT) >> 20) % 6]   (cosine .5 .6 .7 .8 .9 .95)
+#   centroid   = g4(splitmix64(key ^ CENTROID_SALT); j * 384 + col),  noise = g4(key; r * 384 + col)
+#   g4(k; i)   = (((u(4i) + u(4i+1)) + u(4i+2)) + u(4i+3)) * 0.8660254   (unit variance, |g| <= 3.47)
+#   value      = centroid + t_j * noise, then the reference's sequential-sum normalisation
+TOPIC_SALT = np.uint64(0x746F706963730001)
+LEVEL_SALT = np.uint64(0x746F706963730002)
+CENTROID_SALT = np.uint64(0x746F706963730003)
+TOPIC_MUL = np.uint64(0xD1B54A32D192ED03)
+LEVEL_MUL = np.uint64(0xD6E8FEB86659FD93)
+TOPIC_OCTAVES = 12
+TOPIC_T = np.array([1.0, 0.8164966, 0.6546537, 0.5, 0.33333334, 0.22941573], dtype=np.float32)
+TOPIC_RUN_SHIFT = 8
+
+
+def _uniform_key(key: np.uint64, idx: np.ndarray) -> np.ndarray:
+    """uniform() on an already-hashed stream key."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = splitmix64(key + idx * _GOLDEN)
+    u = (h >> np.uint64(40)).astype(np.int64)
+    n = 2 * u + 1 - (1 << 24)
+    return (n.astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def _g4_key(key: np.uint64, i: np.ndarray) -> np.ndarray:
+    i4 = np.asarray(i, dtype=np.uint64) * np.uint64(4)
+    u0, u1, u2, u3 = (_uniform_key(key, i4 + np.uint64(j)) for j in range(4))
+    g = (((u0 + u1).astype(np.float32) + u2).astype(np.float32) + u3).astype(np.float32)
+    return (g * np.float32(0.8660254)).astype(np.float32)
+
+
+def topical_cluster(seed: int, rows: np.ndarray, runs: bool = False):
+    """(cluster id, noise level t) of the rows `rows` (absolute row numbers) of stream `seed`."""
+    rows = np.asarray(rows, dtype=np.uint64)
+    key = splitmix64(np.uint64(seed))
+    unit = rows >> np.uint64(TOPIC_RUN_SHIFT) if runs else rows
+    with np.errstate(over="ignore"):
+        h = splitmix64(key ^ (unit * TOPIC_MUL) ^ TOPIC_SALT)
+        o = (h >> np.uint64(32)) % np.uint64(TOPIC_OCTAVES)
+        one = np.uint64(1)
+        j = ((one << o) - one) + (h & ((one << o) - one))
+        hj = splitmix64(key ^ (j * LEVEL_MUL) ^ LEVEL_SALT)
+    t = TOPIC_T[((hj >> np.uint64(20)) % np.uint64(len(TOPIC_T))).astype(np.int64)]
+    return j, t
+
+
+def unit_rows_topical(seed: int, first_row: int, n: int, runs: bool = False) -> np.ndarray:
+    """[n, 384] unit rows of the topical mixture (synth_dist 4; runs = True: 5) starting at row `first_row`."""
+    rows = np.uint64(first_row) + np.arange(n, dtype=np.uint64)
+    key = splitmix64(np.uint64(seed))
+    j, t = topical_cluster(seed, rows, runs)
+    cols = np.arange(EM_LEN, dtype=np.uint64)[None, :]
+    cen = _g4_key(splitmix64(key ^ CENTROID_SALT), j[:, None] * np.uint64(EM_LEN) + cols)
+    noi = _g4_key(key, rows[:, None] * np.uint64(EM_LEN) + cols)
+    v = (cen + (t[:, None] * noi).astype(np.float32)).astype(np.float32)
+    return normalize_rows(v)
+
+
 def round_bf16(a: np.ndarray) -> np.ndarray:
     """f32 -> nearest-even bf16 -> f32 (what a DAWN_DTYPE_BF16 index stores and scores)."""
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)

@@ -167,6 +167,11 @@ int dawn_index_stats(dawn_index *idx, uint64_t *searches, uint64_t *fallbacks);
 int dawn_index_stats_ext(dawn_index *idx, uint64_t *searches, uint64_t *second_chances, uint64_t *fallbacks);
 /* ... of the second_chances, those a deeper round settled (the cheap kind: ~10 us per round). */
 int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
+/* ... and the queries whose certificates all failed and which the BOUNDED EXACT PASS answered: one stream of the int8 shadow
+ * plus an exact score for every row whose upper bound reaches the k-th best distance found so far — no lists, cannot fail,
+ * costs the int8 stream + the rows that crowd the top of the query (topical data: the dense part of a cluster).  These are
+ * not counted in `fallbacks` (the exact pass over all rows did not run for them). */
+int dawn_index_stats_bounded(dawn_index *idx, uint64_t *bounded);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
  * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 2 Mi rows; f16: 768 B/row),
  * everything else (labels, search workspaces, staging). */
@@ -217,14 +222,18 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      stream's unroll code picks the kernel: 1-4 the round-2 kernel with rings of 3 / 4 / 12 / 6 fragments, 5 the
  *                      same with plain loads, 6 / 8 / 9 / 10 the software-pipelined kernel with rings of 12 / 6 / 4 / 3 (8 = default
  *                      at 4 waves per CU), 7 pipelined + per-XCD address ranges; same results whatever the code
- *   "force_fallback"   1: every query also takes the exact pass (tests)
+ *   "force_fallback"   1: every query also takes the exact pass (tests); 2: every certificate is made to fail and the ladder
+ *                      behind it answers (bounded exact pass first)
+ *   "bounded_pass"     0: a failed certificate goes straight to the exact pass over all rows (A/B of the ladder); default 1
  *   "debug_i8_levels"  experiment hook (process-wide): quantise the int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
  *                      what a coarser shadow would cost the certificates (tools/coarse_shadow_probe.py); results stay exact
  *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (6-bit shadow -> int8 shadow -> f16 shadow -> the
  *                      rows themselves): bit 0 / bit 1 / bit 2 make the int8 / f16 / 6-bit shadow allocation fail as if the card
  *                      were full; 0 = normal
  *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
- *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails */
+ *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails; 4 topical mixture
+ *                      (Zipf-sized clusters, cosine 0.5 .. 0.95 inside a cluster; restated on the CPU: dawnsearch_amd/synth.py),
+ *                      5 the same with runs of 256 consecutive rows per cluster (one site's pages inserted back to back) */
 int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -279,6 +279,13 @@ size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const flo
  * host): out_labels / out_distances are [nq][k]; returns min(k, n). */
 size_t orc_scan_topk_synth(uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, int bf16, const float *q,
                            size_t nq, size_t k, uint64_t *out_labels, float *out_distances, int threads) {
+    return orc_scan_topk_synth_dist(seed, 0, first_row, n, first_id, bf16, q, nq, k, out_labels, out_distances, threads);
+}
+
+/* ... over the rows of distribution `dist` (0: the spec's uniform rows; 4 / 5: the topical mixture, orc_synth_topical_row) */
+size_t orc_scan_topk_synth_dist(uint64_t seed, int dist, uint64_t first_row, size_t n, uint64_t first_id, int bf16,
+                                const float *q, size_t nq, size_t k, uint64_t *out_labels, float *out_distances,
+                                int threads) {
     if (k == 0 || nq == 0) return 0;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
@@ -304,7 +311,8 @@ size_t orc_scan_topk_synth(uint64_t seed, uint64_t first_row, size_t n, uint64_t
             const size_t lo = c * CH, m = (lo + CH <= n) ? CH : n - lo;
             for (size_t r = 0; r < m; r++) {
                 float *row = buf + r * EM;
-                orc_synth_unit_row(seed, first_row + lo + r, row);
+                if (dist == 4 || dist == 5) orc_synth_topical_row(seed, first_row + lo + r, dist == 5, row);
+                else orc_synth_unit_row(seed, first_row + lo + r, row);
                 if (bf16)
                     for (int i = 0; i < EM; i++) { /* round to nearest even, as dawnsearch_amd/synth.py round_bf16 */
                         uint32_t u;
@@ -404,6 +412,51 @@ void orc_synth_unit_row(uint64_t seed, uint64_t row, float *out) {
 void orc_synth_unit_rows(uint64_t seed, uint64_t first_row, size_t n, float *out) {
 #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < n; r++) orc_synth_unit_row(seed, first_row + r, out + r * EM);
+}
+
+/* Topical mixture (dawnsearch_amd/synth.py: unit_rows_topical; the GPU generator's synth_dist 4 / 5): Zipf-sized clusters
+ * around bell-shaped centroids, row = normalise(centroid + t * noise), t per cluster (cosine between two rows of a cluster
+ * 0.5 ... 0.95); runs != 0: 256 consecutive rows share a cluster (one site's pages inserted back to back).  Integer hashing
+ * and single f32 operations in a fixed order only. */
+static float synth_uniform_key(uint64_t key, uint64_t idx) {
+    uint64_t h = orc_splitmix64(key + idx * 0x9E3779B97F4A7C15ULL);
+    int32_t u = (int32_t)(h >> 40);
+    int32_t n = 2 * u + 1 - (1 << 24);
+    return (float)n * (1.0f / 16777216.0f);
+}
+static float synth_g4_key(uint64_t key, uint64_t i) {
+    float g = synth_uniform_key(key, 4 * i) + synth_uniform_key(key, 4 * i + 1);
+    g = g + synth_uniform_key(key, 4 * i + 2);
+    g = g + synth_uniform_key(key, 4 * i + 3);
+    return g * 0.8660254f;
+}
+void orc_synth_topical_cluster(uint64_t seed, uint64_t row, int runs, uint32_t *cluster, float *t) {
+    static const float T[6] = {1.0f, 0.8164966f, 0.6546537f, 0.5f, 0.33333334f, 0.22941573f};
+    const uint64_t key = orc_splitmix64(seed);
+    const uint64_t unit = runs ? row >> 8 : row;
+    const uint64_t h = orc_splitmix64(key ^ (unit * 0xD1B54A32D192ED03ULL) ^ 0x746F706963730001ULL);
+    const uint32_t o = (uint32_t)((h >> 32) % 12u);
+    const uint32_t j = ((1u << o) - 1u) + ((uint32_t)h & ((1u << o) - 1u));
+    const uint64_t hj = orc_splitmix64(key ^ ((uint64_t)j * 0xD6E8FEB86659FD93ULL) ^ 0x746F706963730002ULL);
+    *cluster = j;
+    *t = T[(hj >> 20) % 6u];
+}
+void orc_synth_topical_row(uint64_t seed, uint64_t row, int runs, float *out) {
+    const uint64_t key = orc_splitmix64(seed);
+    const uint64_t ckey = orc_splitmix64(key ^ 0x746F706963730003ULL);
+    uint32_t j;
+    float t;
+    orc_synth_topical_cluster(seed, row, runs, &j, &t);
+    for (int c = 0; c < EM; c++) {
+        const float cen = synth_g4_key(ckey, (uint64_t)j * EM + (uint64_t)c);
+        const float noi = t * synth_g4_key(key, row * EM + (uint64_t)c);
+        out[c] = cen + noi;
+    }
+    orc_normalize(out, EM);
+}
+void orc_synth_topical_rows(uint64_t seed, uint64_t first_row, size_t n, int runs, float *out) {
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n; r++) orc_synth_topical_row(seed, first_row + r, runs, out + r * EM);
 }
 
 void orc_synth_scaled(uint64_t seed, size_t n, float scale, float offset, float *out) {

@@ -76,6 +76,9 @@ size_t orc_scan_topk_mt(const float *x, const uint64_t *ids, size_t n, const flo
 /* exact scan over rows generated on the fly (never materialised): see dawn_oracle.c */
 size_t orc_scan_topk_synth(uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, int bf16, const float *q,
                            size_t nq, size_t k, uint64_t *out_labels, float *out_distances, int threads);
+size_t orc_scan_topk_synth_dist(uint64_t seed, int dist, uint64_t first_row, size_t n, uint64_t first_id, int bf16,
+                                const float *q, size_t nq, size_t k, uint64_t *out_labels, float *out_distances,
+                                int threads);
 size_t orc_scan_examples_old(const uint8_t *page_entries, size_t n_entries, const float *q,
                              size_t *out_entry, float *out_score);
 
@@ -85,6 +88,10 @@ float orc_synth_uniform(uint64_t seed, uint64_t idx);                   /* 24-bi
 void orc_synth_unit_row(uint64_t seed, uint64_t row, float *out /*[384]*/); /* normalised as vector.rs:194-197 */
 void orc_synth_unit_rows(uint64_t seed, uint64_t first_row, size_t n, float *out);
 void orc_synth_scaled(uint64_t seed, size_t n, float scale, float offset, float *out); /* offset + scale*u */
+/* topical mixture (synth_dist 4; runs != 0: 5 — dawnsearch_amd/synth.py: unit_rows_topical) */
+void orc_synth_topical_cluster(uint64_t seed, uint64_t row, int runs, uint32_t *cluster, float *t);
+void orc_synth_topical_row(uint64_t seed, uint64_t row, int runs, float *out /*[384]*/);
+void orc_synth_topical_rows(uint64_t seed, uint64_t first_row, size_t n, int runs, float *out);
 
 /* ---- src/embedding/model.rs + embedding_service.rs --------------------------------------- */
 typedef struct {

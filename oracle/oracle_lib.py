@@ -77,6 +77,10 @@ def lib():
     L.orc_scan_topk_synth.restype = C.c_size_t
     L.orc_scan_examples_old.argtypes = [_u8p, C.c_size_t, _f32p, np.ctypeslib.ndpointer(dtype=np.uintp), _f32p]
     L.orc_scan_examples_old.restype = C.c_size_t
+    L.orc_scan_topk_synth_dist.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_size_t, C.c_uint64, C.c_int, _f32p, C.c_size_t,
+                                           C.c_size_t] + L.orc_scan_topk_synth.argtypes[8:]
+    L.orc_scan_topk_synth_dist.restype = C.c_size_t
+    L.orc_synth_topical_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, _f32p]
     L.orc_splitmix64.argtypes = [C.c_uint64]
     L.orc_splitmix64.restype = C.c_uint64
     L.orc_synth_uniform.argtypes = [C.c_uint64, C.c_uint64]
@@ -104,6 +108,13 @@ def unit_rows(seed: int, first_row: int, n: int) -> np.ndarray:
     return out
 
 
+def unit_rows_topical(seed: int, first_row: int, n: int, runs: bool = False) -> np.ndarray:
+    """Rows of the topical mixture (synth_dist 4; runs: 5) — dawnsearch_amd/synth.py: unit_rows_topical."""
+    out = np.empty((n, EM_LEN), dtype=np.float32)
+    lib().orc_synth_topical_rows(seed, first_row, n, int(runs), out)
+    return out
+
+
 def scan_topk(x: np.ndarray, ids, q: np.ndarray, k: int, threads: int = 1):
     """Exact (distance asc, position asc) top-k. Returns (labels u64[found], distances f32[found])."""
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -123,15 +134,15 @@ def scan_topk(x: np.ndarray, ids, q: np.ndarray, k: int, threads: int = 1):
 
 
 def scan_topk_synth(seed: int, first_row: int, n: int, first_id: int, Q: np.ndarray, k: int, bf16: bool = False,
-                    threads: int = 0):
+                    threads: int = 0, dist: int = 0):
     """Exact top-k of every query of Q over the synthetic rows [first_row, first_row + n) of stream `seed`, generated chunk
     by chunk on all host cores (the rows are never materialised): (labels u64 [nq][found], distances f32 [nq][found])."""
     Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float32)
     nq = Q.shape[0]
     labels = np.zeros((nq, k), dtype=np.uint64)
-    dist = np.zeros((nq, k), dtype=np.float32)
-    found = lib().orc_scan_topk_synth(seed, first_row, n, first_id, int(bf16), Q, nq, k, labels, dist, threads)
-    return labels[:, :found].copy(), dist[:, :found].copy()
+    dists = np.zeros((nq, k), dtype=np.float32)
+    found = lib().orc_scan_topk_synth_dist(seed, dist, first_row, n, first_id, int(bf16), Q, nq, k, labels, dists, threads)
+    return labels[:, :found].copy(), dists[:, :found].copy()
 
 
 class BestResults:

@@ -99,7 +99,7 @@ def test_exact_fallback_path_agrees(dawn, oracle, shadow):
 def test_duplicates_and_ties(dawn, oracle, shadow):
     """Duplicate rows => equal distances => earlier-added row first (KAT from SURVEY §8c).
     200 copies of the best row overflow the 64-entry shortlist band, so the certificate fails and the
-    exact pass decides — results must still equal the oracle."""
+    ladder behind it decides — results must still equal the oracle."""
     base = synth.unit_rows(1, 0, 500)
     q = synth.planted_queries(1, [7], 3)[0]
     rows = np.concatenate([base, np.repeat(base[7:8], 200, axis=0), base[:100]])
@@ -110,7 +110,9 @@ def test_duplicates_and_ties(dawn, oracle, shadow):
     olab, odist = oracle.scan_topk(rows, ids, q, 20)
     _assert_same(lab, dist, olab, odist)
     assert lab[0] == 1007 and list(lab[1:5]) == [1500, 1501, 1502, 1503]
-    assert idx.stats()["fallbacks"] == 1
+    # (with the int8 shadow the bounded exact pass answers a failed certificate — scan_bounded.hip —, without it the exact pass)
+    st = idx.stats()
+    assert (st["bounded"], st["fallbacks"]) == ((1, 0) if shadow == "i8" else (0, 1))
     # few duplicates: stays on the fast path
     rows2 = np.concatenate([base, base[7:8], base[7:8]])
     ids2 = np.arange(1, len(rows2) + 1, dtype=np.uint64)
@@ -612,7 +614,8 @@ def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, sha
     l3, d3, f3 = idx3.search_batch(Q, 20)
     for b in (0, 3, 15):
         _assert_same(l3[b], d3[b], *oracle.scan_topk(rows3, ids3, Q[b], 20))
-    assert idx3.stats()["fallbacks"] == 1
+    st3 = idx3.stats()
+    assert (st3["bounded"], st3["fallbacks"]) == ((1, 0) if shadow == "i8" else (0, 1))
 
 
 def test_batched_clustered_index_overflow_falls_back(dawn, oracle, shadow):
@@ -636,7 +639,8 @@ def test_batched_clustered_index_overflow_falls_back(dawn, oracle, shadow):
     for b in range(12):
         _assert_same(labels[b], dist[b], *oracle.scan_topk(rows, ids, Q[b], 10, threads=8))
     assert labels[4][0] == 2 * 64 * (123 // 64) + 123 % 64 + 1  # where base[123] landed
-    assert idx.stats()["fallbacks"] >= 1
+    st = idx.stats()
+    assert st["fallbacks"] + st["bounded"] >= 1 and (st["fallbacks"] == 0 if shadow == "i8" else st["bounded"] == 0)
 
 
 def test_batched_correlated_queries_burst(dawn, oracle, shadow):

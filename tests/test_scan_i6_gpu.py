@@ -139,7 +139,8 @@ def test_i6_bounds_and_results_on_adversarial_rows(dawn, oracle, n_base):
 
 def test_i6_duplicates_fail_the_certificate_and_stay_exact(dawn, oracle):
     """More equal rows at the top than the workgroups list (20 000 copies of the best row: > 64 per workgroup): the bound T of
-    the unlisted rows reaches the k-th score, the certificate fails, the exact pass answers — earlier-added rows first."""
+    the unlisted rows reaches the k-th score, the certificate fails, the bounded exact pass on the int8 shadow answers (no pass
+    over all rows) — earlier-added rows first."""
     base = synth.unit_rows(1, 0, 500)
     q = synth.planted_queries(1, [7], 3)[0]
     rows = np.concatenate([base, np.repeat(base[7:8], 20_000, axis=0), base[:100]])
@@ -150,7 +151,13 @@ def test_i6_duplicates_fail_the_certificate_and_stay_exact(dawn, oracle):
     lab, dist = idx.search(q, 20)
     _assert_same(lab, dist, *oracle.scan_topk(rows, ids, q, 20))
     assert lab[0] == 1007 and list(lab[1:5]) == [1500, 1501, 1502, 1503]
-    assert idx.stats()["fallbacks"] == 1
+    st = idx.stats()
+    assert st["bounded"] == 1 and st["fallbacks"] == 0
+    # ... and with that rung switched off the exact pass over all rows does, as in round 3
+    idx.set_option("bounded_pass", 0)
+    _assert_same(*idx.search(q, 20), *oracle.scan_topk(rows, ids, q, 20))
+    st = idx.stats()
+    assert st["bounded"] == 1 and st["fallbacks"] == 1
     # a few duplicates stay on the fast path
     rows2 = np.concatenate([base, base[7:8], base[7:8]])
     ids2 = np.arange(1, len(rows2) + 1, dtype=np.uint64)
