@@ -797,8 +797,9 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->i6_min_rows = (size_t)value;
         return reprepare();
     }
-    if (n == "i6_refine") {  // entries of its coarse list a wave of the packed stream refines: 1..64; 0 = from N and k (default)
-        if (value < 0 || value > 64) return fail(DAWN_ERR_INVALID_ARG, "i6_refine must be 0..64");
+    if (n == "i6_refine") {  // entries of its coarse list a wave of the packed stream refines: 1..64; 0 = from N and k (default);
+                             // -1 (tests): full lists, NOT refined — they keep the packed shadow's own bounds
+        if (value < -1 || value > 64) return fail(DAWN_ERR_INVALID_ARG, "i6_refine must be -1..64");
         idx->geom_i6.refine = idx->geom_i6_small.refine = (int)value;
         return DAWN_OK;
     }

@@ -315,26 +315,366 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass for the flagged queries of a BATCH, sixteen per stream of the shadow.  A batch of 256 topical queries can
+// leave a hundred certificates open (tools/clustered_probe.py: 108 of 256 on 12.5 M rows); one stream per query would cost
+// 100 x 0.7 ms behind a 1.2-ms batch.  The 32 columns of the integer MFMA hold the two int8 images of 16 queries — columns
+// c and c + 8 of each 16-lane row: H and L of one query, so that C = 254 acc_H + acc_L still comes from one DPP shift —, every
+// tested lane carries its own query's threshold, hits are queued as (row, query slot) and scored a lane per entry; the waves'
+// exact lists (16 x 64 entries per wave) live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int BQ = 16;          // queries per stream
+constexpr int BQ_QSTRIDE = 388; // floats per staged query (odd multiple of 4: lanes reading different queries hit different banks)
+constexpr int BQ_QCAP = 640;    // queue entries per wave (< 64 waiting + <= 32 rows x 16 queries of one sub-tile)
+struct BoundedMultiLds {
+    float q[BQ][BQ_QSTRIDE];
+    signed char img[2][BQ][EM];
+    float lists_s[4][BQ][LIST];
+    uint32_t lists_p[4][BQ][LIST];
+    uint2 queue[4][BQ_QCAP];
+    float merge_s[4][LIST];
+    uint32_t merge_p[4][LIST];
+    float sq[BQ];
+    float d_in[BQ];
+    uint32_t flagged[kBoundedMaxFlags];
+    unsigned long long mask[kBoundedMaxFlags / 64];
+    uint32_t last;
+};
+
+template <int RT, int PD>
+__global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+                                                                     const void* __restrict__ rows, const uint64_t* __restrict__ ids,
+                                                                     uint32_t n_rows, const float* __restrict__ q, int n_q,
+                                                                     uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
+                                                                     float* __restrict__ out_s, uint32_t* __restrict__ out_p,
+                                                                     uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
+                                                                     float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
+    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char bounded_lds[];
+    BoundedMultiLds& S = *reinterpret_cast<BoundedMultiLds*>(bounded_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;  // 4
+    const uint32_t n_sub = (n_rows + 31u) >> 5;
+    const uint32_t c = lane & 31, h = lane >> 5;
+    const uint32_t t_stride = gridDim.x * nwaves;
+    const uint32_t found = n_rows < k ? n_rows : k;
+    // the flagged queries, in order (every workgroup reads the flags before any of them is rewritten: a query is finished by
+    // the last workgroup to arrive, after all of them have been here)
+    {
+        const bool fl = (int)threadIdx.x < n_q && flags[threadIdx.x] == FLAG_FALLBACK;
+        const unsigned long long m = __ballot(fl);
+        if (lane == 0) S.mask[wave] = m;
+        __syncthreads();
+        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(S.mask[w]);
+        if (fl) S.flagged[rank] = threadIdx.x;
+        __syncthreads();
+    }
+    uint32_t n_flagged = 0;
+    for (int w = 0; w < kBoundedMaxFlags / 64; ++w) n_flagged += (uint32_t)__popcll(S.mask[w]);
+
+    const uint32_t slot = (c & 7u) + ((c >> 4) << 3);  // the query slot of this lane's column
+    for (uint32_t g0 = 0; g0 < n_flagged; g0 += BQ) {
+        const uint32_t ng = n_flagged - g0 < (uint32_t)BQ ? n_flagged - g0 : (uint32_t)BQ;
+        uint32_t t = blockIdx.x * nwaves + wave;
+        const u32x4* p = x + (size_t)(t < n_sub ? t : 0) * (12 * 64) + lane;
+        u32x4 a[PD];
+        float2 mt = {0.f, 0.f};
+        if (t < n_sub) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+            mt = meta[t];
+        }
+        // the group's queries: f32 copies, int8 images (a wave per query), the failed stages' k-th distances
+        for (uint32_t i = threadIdx.x; i < ng * EM; i += blockDim.x) {
+            const uint32_t sidx = i / EM, e = i % EM;
+            S.q[sidx][e] = q[(size_t)S.flagged[g0 + sidx] * EM + e];
+        }
+        if (threadIdx.x < (uint32_t)BQ)
+            S.d_in[threadIdx.x] = (threadIdx.x < ng && found > 0) ? out_dist[(size_t)S.flagged[g0 + threadIdx.x] * k + found - 1] : POS_INF;
+        for (uint32_t sidx = wave; sidx < (uint32_t)BQ; sidx += nwaves) {
+            float v[6];
+            const float* qv = q + (size_t)S.flagged[g0 + (sidx < ng ? sidx : 0)] * EM;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = sidx < ng ? qv[lane + 64 * j] : 0.f;
+            rotate384_wave(v, lane);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+            const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float tt = v[j] / sq;
+                const float H = fminf(fmaxf(rintf(tt), -127.f), 127.f);
+                const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
+                S.img[0][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)H : (signed char)0;
+                S.img[1][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)L : (signed char)0;
+            }
+            if (lane == 0) S.sq[sidx] = sq;
+        }
+        for (int i = lane; i < BQ * LIST; i += 64) {  // the wave's exact lists start empty
+            (&S.lists_s[wave][0][0])[i] = NEG_INF;
+            (&S.lists_p[wave][0][0])[i] = NO_POS;
+        }
+        __syncthreads();
+        i32x4_t qf[12];
+        const bool tested = (c & 8u) == 0u && slot < ng;
+        {
+            const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&S.img[(c & 8u) ? 1 : 0][slot][0]);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) qf[f] = slot < ng ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
+        }
+        const float sq_l = S.sq[slot];
+        const float sq254_l = sq_l / 254.0f, rsq254_l = 254.0f / sq_l, k2_l = I8_K2_PER_SQ * sq_l;
+        const float d_in_l = S.d_in[slot];
+        float tau_l = (tested && d_in_l < POS_INF) ? __fsub_rn(__fsub_rn(1.0f, d_in_l), BOUNDED_MARGIN) : NEG_INF;
+        float tau_m = POS_INF;
+        auto set_tau_m = [&]() __attribute__((always_inline)) {
+            if (tested) {
+                const float tk = tau_l - k2_l;
+                tau_m = tk - fabsf(tk) * 1e-6f;
+            }
+        };
+        set_tau_m();
+        uint32_t n_wait = 0;  // entries in the wave's queue (wave-uniform)
+        uint2* queue = &S.queue[wave][0];
+
+        // the top (up to) 64 entries of the queue: exact scores, a lane per entry, into the lists of their queries
+        auto flush64 = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private queue: LDS operations of a wave are in order)
+            const uint32_t n = n_wait < 64u ? n_wait : 64u;
+            const uint32_t base = n_wait - n;
+            n_wait = base;
+            float key = NEG_INF;
+            uint32_t row = NO_POS, es = 0;
+            if ((uint32_t)lane < n) {
+                const uint2 ent = queue[base + lane];
+                row = ent.x;
+                es = ent.y;
+                const float dot = exact_dot_row<RT>(&S.q[es][0], rows, row);
+                const float d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+                if (d == d) key = -d;
+                else row = NO_POS;
+            }
+            unsigned long long left = __ballot(row != NO_POS);
+            while (left) {
+                const int first = __builtin_ctzll(left);
+                const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)es, first);  // wave-uniform slot
+                const bool mine = row != NO_POS && es == s_u;
+                left &= ~__ballot(mine);
+                float ls = S.lists_s[wave][s_u][lane];
+                uint32_t lp = S.lists_p[wave][s_u][lane];
+                const float t64s = read_lane63(ls);
+                const uint32_t t64p = (uint32_t)__builtin_amdgcn_readlane((int)lp, 63);
+                const bool cand = mine && better(key, row, t64s, t64p);
+                unsigned long long hits = __ballot(cand);
+                if (!hits) continue;
+                if (__popcll(hits) > 8) {
+                    float d = cand ? -key : POS_INF;
+                    uint32_t pr = cand ? row : NO_POS;
+                    sort64_asc(d, pr, lane);
+                    const float os = -__shfl(d, 63 - lane);
+                    const uint32_t op = __shfl(pr, 63 - lane);
+                    merge64(ls, lp, os, op, lane);
+                } else {
+                    while (hits) {
+                        const int src = __builtin_ctzll(hits);
+                        hits &= hits - 1;
+                        const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
+                        const uint32_t kr = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
+                        if (better(ks, kr, read_lane63(ls), (uint32_t)__builtin_amdgcn_readlane((int)lp, 63)))
+                            wave_insert(ls, lp, ks, kr, lane);
+                    }
+                }
+                S.lists_s[wave][s_u][lane] = ls;
+                S.lists_p[wave][s_u][lane] = lp;
+                // the wave's own k-th best distance of this query bounds the final one from above as well
+                if (found > 0 && (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)found - 1) != NO_POS) {
+                    const float dkw = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), (int)found - 1));
+                    const float tw = __fsub_rn(__fsub_rn(1.0f, dkw), BOUNDED_MARGIN);
+                    if (tested && slot == s_u && tw > tau_l) {
+                        tau_l = tw;
+                        set_tau_m();
+                    }
+                }
+            }
+        };
+
+        if (t < n_sub) {
+            i32x16_t accs[2];
+            float2 pmt = mt;
+            uint32_t prow = 0;
+            int C[16];
+            int thr = 0, mx = 0;
+
+            auto slow_path = [&]() __attribute__((always_inline)) {
+                const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l, g0 = pmt.y + k2_l;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t row = prow + (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
+                    const bool hit = tested && C[e] > thr && row < n_rows && __builtin_fmaf((float)C[e], g1, g0) > tau_l;
+                    const unsigned long long m = __ballot(hit);
+                    if (m) {
+                        if (hit) queue[n_wait + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = uint2{row, slot};
+                        n_wait += (uint32_t)__popcll(m);
+                    }
+                }
+                while (n_wait >= 64u) flush64();
+            };
+            auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
+                if (s == 0) {
+                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                    float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l, -2.0f);
+                    thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
+                    if (!tested) thr_f = 2.0e9f;
+                    thr = (int)floorf(thr_f);
+                } else if (s <= 8) {
+#pragma unroll
+                    for (int e = 2 * (s - 1); e < 2 * s; ++e) {
+                        const int ae = pacc[e];
+                        C[e] = __mul24(ae, 254) + __builtin_amdgcn_update_dpp(0, ae, 0x108, 0xf, 0xf, true);
+                        mx = e == 0 ? C[0] : max(mx, C[e]);
+                    }
+                }
+            };
+            bool more;
+            auto round = [&](auto with_test, auto parity) __attribute__((always_inline)) {
+                constexpr int P = decltype(parity)::value;
+                i32x16_t& acc = accs[P];
+                const uint32_t tn = t + t_stride;
+                more = tn < n_sub;
+                const u32x4* pn = more ? x + (size_t)tn * (12 * 64) + lane : p;
+                const float2 mtn = meta[more ? tn : t];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0;
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
+                    if (f + PD < 12) a[f % PD] = __builtin_nontemporal_load(p + (f + PD) * 64);
+                    else a[f % PD] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
+                    if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (decltype(with_test)::value)
+                    if (__any(mx > thr)) slow_path();
+                pmt = mt;
+                prow = t * 32u;
+                t = tn;
+                p = pn;
+                mt = mtn;
+            };
+            using P0 = std::integral_constant<int, 0>;
+            using P1 = std::integral_constant<int, 1>;
+            round(std::false_type{}, P0{});
+            int last = 0;
+            while (more) {
+                round(std::true_type{}, P1{});
+                last = 1;
+                if (!more) break;
+                round(std::true_type{}, P0{});
+                last = 0;
+            }
+            if (last) {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) test_slice(s, accs[1]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) test_slice(s, accs[0]);
+            }
+            if (__any(mx > thr)) slow_path();
+        }
+        while (n_wait > 0u) flush64();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // the workgroup's list of every query of the group
+        for (uint32_t sidx = 0; sidx < ng; ++sidx) {
+            float ls = S.lists_s[wave][sidx][lane];
+            uint32_t lp = S.lists_p[wave][sidx][lane];
+            block_merge(ls, lp, S.merge_s, S.merge_p, wave, lane, nwaves);
+            if (wave == 0) {
+                const size_t o = ((size_t)S.flagged[g0 + sidx] * n_lists + blockIdx.x) * LIST + lane;
+                out_s[o] = ls;
+                out_p[o] = lp;
+            }
+        }
+        __threadfence();  // this workgroup's lists are visible device-wide before it counts itself in
+        __syncthreads();
+        const uint32_t b_first = S.flagged[g0];
+        if (threadIdx.x == 0) S.last = atomicAdd(&done[b_first], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (S.last) {  // block-uniform: every other workgroup's lists of this group are complete
+            __threadfence();
+            for (uint32_t sidx = 0; sidx < ng; ++sidx) {
+                const uint32_t b = S.flagged[g0 + sidx];
+                float s = NEG_INF;
+                uint32_t pp = NO_POS;
+                const float* cs = out_s + (size_t)b * n_lists * LIST;
+                const uint32_t* cp = out_p + (size_t)b * n_lists * LIST;
+                for (uint32_t l = wave; l < gridDim.x; l += nwaves)
+                    merge64(s, pp, cs[(size_t)l * LIST + 63 - lane], cp[(size_t)l * LIST + 63 - lane], lane);
+                block_merge(s, pp, S.merge_s, S.merge_p, wave, lane, nwaves);
+                if (wave == 0) {
+                    const uint32_t have = __popcll(__ballot(pp != NO_POS));
+                    bool valid = have >= found;
+                    if (valid && found > 0) {
+                        const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)found - 1));
+                        valid = dk <= S.d_in[sidx];
+                    }
+                    if (valid) {
+                        if ((uint32_t)lane < found) {
+                            out_labels[(size_t)b * k + lane] = ids[pp];
+                            out_dist[(size_t)b * k + lane] = -s;
+                        }
+                        if (lane == 0) {
+                            out_found[b] = found;
+                            flags[b] = FLAG_BOUNDED;
+                        }
+                    }
+                }
+            }
+            if (threadIdx.x == 0) done[b_first] = 0u;
+        }
+        __syncthreads();  // the shared state is reused by the next group
+    }
+}
+
 // Per query b < B with d_flags[b] == FLAG_FALLBACK: the exact top-k through the int8 shadow, flag -> FLAG_BOUNDED; every other
 // query is left alone (one nearly empty launch when no flag is set).  cand_s / cand_p: the per-workgroup lists [B][n_lists][64]
 // (the filter's own, free by now); d_done [B]: arrival counters, zero before and after.  B <= 256 per launch.
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
+    static OncePerDevice attr_once;
+    once_per_device(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
+    });
     const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
     const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
     for (int b0 = 0; b0 < B; b0 += kBoundedMaxFlags) {
         const int nb = B - b0 < kBoundedMaxFlags ? B - b0 : kBoundedMaxFlags;
-        if (dtype == ROW_BF16)
-            hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, x8, mt, d_x, d_ids, n_rows,
-                               d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,
-                               cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k,
-                               d_dist + (size_t)b0 * k, d_found + b0);
-        else
-            hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, x8, mt, d_x, d_ids, n_rows,
-                               d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,
-                               cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k,
-                               d_dist + (size_t)b0 * k, d_found + b0);
+#define DAWN_BOUNDED_ARGS                                                                                                      \
+    x8, mt, d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,       \
+        cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0
+        if (B == 1) {  // one query: its list stays in registers
+            if (dtype == ROW_BF16)
+                hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+            else
+                hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+        } else {       // a batch: its flagged queries, sixteen per stream of the shadow
+            if (dtype == ROW_BF16)
+                hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                   DAWN_BOUNDED_ARGS);
+            else
+                hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                   DAWN_BOUNDED_ARGS);
+        }
+#undef DAWN_BOUNDED_ARGS
     }
 }
 

@@ -13,9 +13,12 @@
 //     previous fragment's MFMA (64 clocks of matrix pipe);
 //   * codes are unsigned, so the accumulators start at -32 * sum_k Q_k (a constant per query image) instead of zero:
 //     sum_k (code_k - 32) Q_k is exact in the integers, and everything from C = 254 acc_H + acc_L on is the int8 stream's;
-//   * ub = fma(float(C), s * s_q / 254, E + K2) >= x.q as before; K2 uses ||s X||_2 <= ||x||_2 + ||dx||_2 < 1.01 + 0.32
-//     (||dx||_2 <= sqrt(384) * s / 2, s <= 1.01 / 31: the worst case of a sub-tile that holds a one-hot row in the rotated
-//     basis; the int8 shadow's 0.09 does not carry over).
+//   * ub = fma(float(C), s * s_q / 254, E + K2) >= x.q as before, with K2 >= |(s X).dq| taken from the sub-tile's own MEASURED
+//     error: ||s X||_2 <= ||x'||_2 + ||dx||_2 <= 1.015 + E (||x'||_2 < 1.01 by the gate, x 1.004 for a bf16 index's rounding;
+//     ||dx||_2 <= E / 1.0101 by construction of E), ||dq||_2 <= sqrt(384) * 2.0e-3 s_q:  K2 = (1.015 + E) * 19.6 * 2.0e-3 * s_q.
+//     (Round 3 used the constant 1.35 = 1.01 + sqrt(384) * s / 2 at s <= 1.01 / 31: right for 6 bits, 0.3 short for 5 — a
+//     sub-tile that holds a one-hot row next to rows of components (n + 1/2) s reaches ||s X||_2 = 1.4 - 1.6; the measured
+//     form holds whatever the rows and the chosen scale are: tests/test_scan_i6_gpu.py::test_k2_covers_the_worst_sub_tile.)
 // E is four times the int8 shadow's (~0.037 on unit vectors; eight times at 5 bits), which a 64-row shortlist cannot absorb (the
 // gap between the 10th and the 64th best score of 100 M rows is 0.017; tools/coarse_shadow_probe.py).  The stream therefore
 // does not hand a 64-row shortlist to a one-workgroup tail.  Every WAVE keeps the best 40-64 rows of its share by the packed
@@ -75,7 +78,9 @@ template <int BITS> struct PackedShadow {
     static constexpr int OFFSET = BITS == 6 ? 32 : 16;  // code = value + OFFSET
     static constexpr uint32_t SUB_DW = BITS == 6 ? I6_SUB_DW : I5_SUB_DW;
 };
-constexpr float I6_K2_PER_SQ = 1.35f * 19.6f * I8_QRES;
+// K2 of a sub-tile with measured error E and a query of scale s_q: (I6_XNORM + E) * I6_K2U_PER_SQ * s_q  (header)
+constexpr float I6_XNORM = 1.015f;
+constexpr float I6_K2U_PER_SQ = 19.6f * I8_QRES;
 
 // ------------------------------------------------------------------------------------------------
 // conversion: rows -> 6-bit sub-tiles + {1 / s, E} per sub-tile (rows_to_i8s_kernel with the packing above)
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                                                                const float2* __restrict__ meta8, float* __restrict__ out_s,
                                                                uint32_t* __restrict__ out_p, float* __restrict__ out_es,
                                                                uint32_t* __restrict__ out_ep, float* __restrict__ out_t,
-                                                               int n_refine, uint32_t* __restrict__ pool) {
+                                                               int n_refine_arg, uint32_t* __restrict__ pool) {
     static_assert(BITS == 6 ? 12 % PD == 0 : (PD == 8 || PD == 4), "ring depth");
     typedef PackedShadow<BITS> PS;
     __shared__ float sh_s[8][LIST];
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t c = lane & 31, h = lane >> 5;
     uint32_t t = blockIdx.x * nwaves + wave;
     const uint32_t t_stride = gridDim.x * nwaves, t_end = n_sub;
+    const int n_refine = n_refine_arg < 0 ? LIST : n_refine_arg;
     DAWN_TS6(0);
     // Work assignment.  Static and interleaved — wave w takes sub-tiles w, w + W, w + 2W, ... — for the first 7/8 of the index;
     // the last eighth is handed out in CHUNKS of 16 sub-tiles on demand.  The waves' shares of a static assignment are equal,
@@ -386,7 +392,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         for (int f = 0; f < 12; ++f) qf[f] = col_live ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
     }
     const float sq = sh_sq;
-    const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq, k2 = I6_K2_PER_SQ * sq;
+    // ub = C g1 + E + K2(E) = C g1 + E (1 + k2u) + k2c
+    const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq, k2u = I6_K2U_PER_SQ * sq, k2c = I6_XNORM * k2u;
+    const float emul = 1.0f + k2u, emul_thr = emul * 1.000001f;
     const int acc0 = col_live ? -PS::OFFSET * sh_sum[c == 8 ? 1 : 0] : 0;  // codes are value + OFFSET
     float ls = NEG_INF, tau = NEG_INF;
     uint32_t lp = NO_POS;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
             if (total > 6) {
                 float* strip = &sh_strip[wave][0];
                 if (c == 0) {  // lanes 0 (h = 0) and 32 (h = 1)
-                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = pmt.y + k2;
+                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = __builtin_fmaf(pmt.y, emul, k2c);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                         m &= m - 1;
                         const float cf = (float)__builtin_amdgcn_readlane(C[e], l);
                         const uint32_t row = prow + roff + 4u * (uint32_t)(l >> 5);
-                        const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254, pmt.y + k2);
+                        const float sc = __builtin_fmaf(cf, __builtin_amdgcn_rcpf(pmt.x) * sq254, __builtin_fmaf(pmt.y, emul, k2c));
                         if (sc > tau) {
                             wave_insert(ls, lp, sc, row, lane);
                             tau = list_tau();
@@ -465,13 +473,13 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                 }
             }
             if (tested) {
-                const float tk = tau - k2;
+                const float tk = tau - k2c;
                 tau_m = tk - fabsf(tk) * 1e-6f;
             }
         };
         auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
             if (s == 0) {
-                const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                const float u = __builtin_fmaf(-pmt.y, emul_thr, tau_m);
                 float thr_f = __builtin_fmaf(u, pmt.x * rsq254, -2.0f);
                 thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
                 if (!tested) thr_f = 2.0e9f;
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     // Only the wave's best n_refine entries are kept (1 .. 64, chosen by the host from the index size and k: i6_refine_count):
     // a short list is a shallow one — its bound tw sits higher —, but every kept row costs a 3-KB gather, and the depth the
     // certificate needs grows with the index.
+    const bool coarse_only = n_refine_arg < 0;  // test hook (option "i6_refine" = -1): the lists keep the packed shadow's own bounds
     float tw;
     if (n_refine < LIST) {
         const bool more_rows = __builtin_amdgcn_readlane((int)lp, n_refine) != (int)NO_POS;
@@ -614,7 +623,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
         const bool full = __builtin_amdgcn_readlane((int)lp, 63) != (int)NO_POS;
         tw = full ? read_lane63(ls) : NEG_INF;
     }
-    if constexpr (RT == 0) {
+    if (coarse_only) {
+        // (nothing: descending by the coarse bound already)
+    } else if constexpr (RT == 0) {
         // f32 index: the kept rows are scored on the f32 rows themselves, a wave per row — one coalesced 1.5-KB read per row
         // (the int8 sub-tile holds a row as 24 pieces 512 B apart: a 3-KB scatter in 64-B sectors), 8 rows in flight, 24 FMAs
         // per lane and a DPP sum per row.  The score errs like scan_filter_kernel's (f32 FMAs in another order than the
@@ -879,6 +890,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
     int n_refine = g.refine > 0 ? g.refine : i6_refine_count(n_rows, k, bits, g.blocks * (g.threads / 64));
     if (n_refine < 1 || n_refine > LIST) n_refine = LIST;  // (callers ask i6_refine_count first and go elsewhere on 0)
     n_refine = (n_refine + 7) & ~7;                         // (the f32 refinement takes its rows eight at a time)
+    if (g.refine < 0) n_refine = -1;                        // (test hook: coarse lists, no refinement)
     int pd;
     if (bits == 6) pd = g.unroll == 6 || g.unroll == 4 || g.unroll == 3 || g.unroll == 2 ? g.unroll : 12;
     else pd = g.unroll == 4 ? 4 : 8;

@@ -1,0 +1,203 @@
+"""GPU parity tests of the ladder behind a failed certificate, on the data that makes certificates fail.
+
+Every filter of the library ends in a certificate; on isotropic synthetic rows it always holds.  On TOPICAL rows — Zipf-sized
+clusters, cosine 0.5 .. 0.95 inside a cluster (dawnsearch_amd/synth.py: unit_rows_topical = option "synth_dist" 4; 5: runs of
+256 consecutive rows per cluster, as one site's pages arrive back to back: src/index/warc.rs:75-86,
+src/search/search_provider.rs:250-286) — a query inside a large cluster has more rows within the filter's slack of its k-th
+score than the fixed-size lists hold.  Round 3 answered those from the exact pass over all rows; now the bounded exact pass on
+the int8 shadow does (dawnsearch_amd/csrc/scan_bounded.hip).  Bar as everywhere: labels and distance BITS of the CPU oracle
+(oracle/dawn_oracle.c: src/search/vector.rs:128-134 + exact top-k), with dawn_index_stats* proving which rung answered.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dawnsearch_amd import synth  # noqa: E402
+
+QROW0 = 1 << 40  # queries: FURTHER rows of the same stream (new pages on the same topics)
+
+
+def _same(lab, dist, olab, odist):
+    assert len(lab) == len(olab)
+    assert np.array_equal(lab, olab), (lab, olab)
+    assert np.array_equal(np.asarray(dist).view(np.uint32), np.asarray(odist).view(np.uint32)), (dist, odist)
+
+
+def _topical_index(dawn, n, dist, packed=True, dtype="f32"):
+    idx = dawn.VectorIndex(0, dtype=dtype)
+    idx.set_option("synth_dist", dist)
+    if packed:
+        idx.set_option("i6_min_rows", 0)
+    idx.fill_synthetic(1, 0, n, 1)
+    return idx
+
+
+def _topical_queries(dist, nq, clusters=None):
+    """Rows QROW0 + i * 256 of the stream (a different run each, for dist 5).  clusters: keep only queries of these clusters."""
+    out = []
+    i = 0
+    while len(out) < nq:
+        r = QROW0 + i * 256
+        i += 1
+        if clusters is not None and int(synth.topical_cluster(1, np.array([r]), runs=(dist == 5))[0][0]) not in clusters:
+            continue
+        out.append(synth.unit_rows_topical(1, r, 1, runs=(dist == 5))[0])
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("dist", [4, 5])
+def test_topical_generator_matches_numpy_and_oracle(dawn, oracle, dist):
+    n = 3000
+    idx = _topical_index(dawn, n, dist, packed=False)
+    rows, ids = idx.get_rows(0, n)
+    assert np.array_equal(rows.view(np.uint32), synth.unit_rows_topical(1, 0, n, runs=(dist == 5)).view(np.uint32))
+    assert np.array_equal(rows.view(np.uint32), oracle.unit_rows_topical(1, 0, n, runs=(dist == 5)).view(np.uint32))
+    qi = dawn.VectorIndex(0)
+    qi.set_option("synth_dist", dist)
+    qi.fill_synthetic(1, QROW0 + 5, 70, 1)
+    got = qi.get_rows(0, 70)[0]
+    assert np.array_equal(got.view(np.uint32), synth.unit_rows_topical(1, QROW0 + 5, 70, runs=(dist == 5)).view(np.uint32))
+    assert np.all(np.abs(np.linalg.norm(rows.astype(np.float64), axis=1) - 1.0) < 1e-6)
+
+
+@pytest.mark.parametrize("dist", [4, 5])
+@pytest.mark.parametrize("k", [10, 20])
+def test_topical_index_every_rung_equals_the_oracle(dawn, oracle, dist, k):
+    """400 k topical rows, queries inside the three largest clusters (33 k, 17 k, 17 k rows) and anywhere.  The lists are sized
+    for 100 M rows; here the grids are shrunk until they are as short of this index's clusters as the full grids are of a
+    100 M-row index's (tools/clustered_probe.py: 28 % of such queries fail on 12.5 M rows): packed stream 4 workgroups x 8 waves x
+    8 entries, int8 stream 2 workgroups, 64 candidates per query in a batch.  Packed stream, int8 stream, a batch — all bit-equal
+    to the oracle's scan of the same rows, no exact pass anywhere, the bounded pass counted where certificates failed."""
+    n = 400_000
+    idx = _topical_index(dawn, n, dist)
+    idx.set_option("i6_scan_blocks", 4)
+    idx.set_option("i6_refine", 8)
+    idx.set_option("shadow_scan_blocks", 2)
+    idx.set_option("mfma_target", 64)
+    Q = np.concatenate([_topical_queries(dist, 6, clusters={0, 1, 2}), _topical_queries(dist, 6)])
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=dist)
+    # one query at a time on the packed shadow
+    for b, q in enumerate(Q):
+        _same(*idx.search(q, k), want[0][b], want[1][b])
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["bounded"] >= 3, st
+    # ... on the int8 shadow
+    idx.set_option("i6_shadow", 0)
+    for b, q in enumerate(Q):
+        _same(*idx.search(q, k), want[0][b], want[1][b])
+    st2 = idx.stats()
+    assert st2["fallbacks"] == 0 and st2["bounded"] > st["bounded"], st2
+    # ... and as one batch (matrix-core pass; its flagged queries share one stream of the bounded pass)
+    lab, dist_, found = idx.search_batch(Q, k)
+    for b in range(len(Q)):
+        assert found[b] == k
+        _same(lab[b], dist_[b], want[0][b], want[1][b])
+    st3 = idx.stats()
+    assert st3["fallbacks"] == 0 and st3["bounded"] > st2["bounded"], st3
+    # with the rung switched off the exact pass answers the same (round 3's behaviour)
+    idx.set_option("i6_shadow", 1)
+    idx.set_option("bounded_pass", 0)
+    for b in (0, 1, 7):
+        _same(*idx.search(Q[b], k), want[0][b], want[1][b])
+    st4 = idx.stats()
+    assert st4["bounded"] == st3["bounded"] and st4["fallbacks"] >= 1
+
+
+@pytest.mark.parametrize("n", [1, 31, 64, 65, 1000, 4097, 100_003])
+@pytest.mark.parametrize("k", [1, 10, 64])
+def test_forced_ladder_on_uniform_rows_sizes(dawn, oracle, n, k):
+    """force_fallback = 2: every certificate is made to fail and the ladder answers — the bounded pass for everything the int8
+    shadow covers.  Sizes around the sub-tile / list boundaries, k up to the list length."""
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 2), synth.planted_queries(1, [n // 2], 4)])
+    idx.set_option("force_fallback", 2)
+    for q in Q:
+        lab, dist = idx.search(q, k)
+        assert len(lab) == min(k, n)
+        _same(lab, dist, *oracle.scan_topk(x, ids, q, k))
+    lab, dist, found = idx.search_batch(Q, k)
+    for b, q in enumerate(Q):
+        _same(lab[b][:found[b]], dist[b][:found[b]], *oracle.scan_topk(x, ids, q, k))
+    st = idx.stats()
+    assert st["bounded"] == 6 and st["fallbacks"] == 0, st
+
+
+def test_forced_ladder_batch_of_256_and_groups_of_sixteen(dawn, oracle):
+    """A whole batch through the bounded pass: 256 flagged queries = 16 streams of 16 queries; 37 queries: two full groups and a
+    ragged one."""
+    n = 200_000
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 256)
+    Q[5] = synth.planted_queries(1, [777], 4)[0]
+    idx.set_option("force_fallback", 2)
+    for nb in (256, 37):
+        s0 = idx.stats()
+        lab, dist, found = idx.search_batch(Q[:nb], 10)
+        s1 = idx.stats()
+        assert s1["bounded"] - s0["bounded"] == nb and s1["fallbacks"] == 0
+        for b in list(range(0, nb, 9)) + [5, nb - 1]:
+            _same(lab[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10, threads=8))
+    assert lab[5][0] == 778
+
+
+def test_duplicates_beyond_every_list_take_the_bounded_pass(dawn, oracle):
+    """20 000 copies of the best row (the KAT of SURVEY 8c at a size no list holds): the bounded pass scores all of them exactly
+    and returns the earliest-added ones; a bf16 index likewise."""
+    base = synth.unit_rows(1, 0, 5000)
+    q = synth.planted_queries(1, [7], 3)[0]
+    rows = np.concatenate([base, np.repeat(base[7:8], 20_000, axis=0), base[:100]])
+    ids = np.arange(1000, 1000 + len(rows), dtype=np.uint64)
+    for dtype in ("f32", "bf16"):
+        ref = rows if dtype == "f32" else synth.round_bf16(rows)
+        for packed in (True, False):
+            idx = dawn.VectorIndex(0, dtype=dtype)
+            if packed:
+                idx.set_option("i6_min_rows", 0)
+            idx.add_batch(ids, rows)
+            for k in (20, 64):
+                _same(*idx.search(q, k), *oracle.scan_topk(ref, ids, q, k))
+            lab, dist, found = idx.search_batch(np.stack([q, base[3], q]), 20)
+            for b, qq in enumerate((q, base[3], q)):
+                _same(lab[b], dist[b], *oracle.scan_topk(ref, ids, qq, 20))
+            st = idx.stats()
+            assert st["fallbacks"] == 0 and st["bounded"] >= 4, (dtype, packed, st)
+
+
+def test_bounded_pass_behind_a_sharded_handle(dawn, oracle):
+    n = 300_000
+    sh = dawn.VectorIndex(devices=[0, 0, 0])
+    sh.set_option("shard_chunk", 4096)
+    sh.set_option("synth_dist", 4)
+    sh.set_option("i6_min_rows", 0)
+    sh.fill_synthetic(1, 0, n, 1)
+    Q = _topical_queries(4, 4, clusters={0, 1})
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, 10, dist=4)
+    sh.set_option("force_fallback", 2)  # every shard's certificate fails: every shard's bounded pass answers
+    for b, q in enumerate(Q):
+        _same(*sh.search(q, 10), want[0][b], want[1][b])
+    lab, dist, found = sh.search_batch(Q, 10)
+    for b in range(len(Q)):
+        _same(lab[b], dist[b], want[0][b], want[1][b])
+    st = sh.stats()
+    assert st["fallbacks"] == 0 and st["bounded"] == 3 * 8, st
+
+
+def test_without_the_int8_shadow_the_exact_pass_still_answers(dawn, oracle, monkeypatch):
+    """The bounded pass reads the int8 shadow; an index that does not keep one (i8_shadow = 0: f16 shadow) falls back as before."""
+    monkeypatch.setenv("DAWN_I8_SHADOW", "0")
+    n = 100_000
+    idx = _topical_index(dawn, n, 4, packed=False)
+    Q = _topical_queries(4, 3, clusters={0})
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, 10, dist=4)
+    idx.set_option("force_fallback", 2)
+    for b, q in enumerate(Q):
+        _same(*idx.search(q, 10), want[0][b], want[1][b])
+    st = idx.stats()
+    assert st["bounded"] == 0 and st["fallbacks"] == 3

@@ -225,3 +225,38 @@ def test_scan_oracle_vs_heavy_tailed_golden(oracle):
         l, d = oracle.scan_topk(X, ids, q, 20)
         assert np.array_equal(l, lab) and np.array_equal(d.view(np.uint32), dist.view(np.uint32))
     assert g["labels"][3][0] == 1235
+
+
+def test_topical_mixture_numpy_equals_c_and_its_statistics(oracle):
+    """The topical mixture (synth_dist 4 / 5: what the ladder behind the certificates is measured on) is defined by integer
+    hashing and single f32 operations: numpy and the C oracle agree bit for bit at any row number; cluster masses follow the
+    12-octave Zipf law, the cosine inside a cluster is 1 / (1 + t^2)."""
+    from dawnsearch_amd import synth
+    for runs in (False, True):
+        for first in (0, 99_991, (1 << 40) + 3):
+            a = synth.unit_rows_topical(1, first, 300, runs)
+            b = oracle.unit_rows_topical(1, first, 300, runs)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert np.all(np.abs(np.linalg.norm(a.astype(np.float64), axis=1) - 1.0) < 1e-6)
+    j, t = synth.topical_cluster(1, np.arange(600_000))
+    mass = np.bincount(j.astype(np.int64), minlength=4095) / len(j)
+    assert abs(mass[0] - 1 / 12) < 3e-3 and abs(mass[1:3].sum() - 1 / 12) < 3e-3 and abs(mass[2047:].sum() - 1 / 12) < 3e-3
+    j5, _ = synth.topical_cluster(1, np.arange(4096), runs=True)
+    assert np.all(j5.reshape(16, 256) == j5.reshape(16, 256)[:, :1])  # 256 consecutive rows share a cluster
+    x = oracle.unit_rows_topical(1, 0, 60_000)
+    for c in (0, 1):
+        m = np.nonzero(j[:60_000] == c)[0][:300]
+        g = x[m].astype(np.float64) @ x[m].astype(np.float64).T
+        want = 1.0 / (1.0 + float(t[m[0]]) ** 2)
+        assert abs(g[np.triu_indices(len(m), 1)].mean() - want) < 0.03
+    # the oracle's scan of rows generated on the fly = its scan of the same rows materialised = the numpy restatement's
+    n = 20_000
+    X = oracle.unit_rows_topical(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows_topical(1, 1 << 40, 3)
+    lab, dist = oracle.scan_topk_synth(1, 0, n, 1, Q, 10, dist=4)
+    for b in range(3):
+        l1, d1 = oracle.scan_topk(X, ids, Q[b], 10)
+        assert np.array_equal(lab[b], l1) and np.array_equal(dist[b].view(np.uint32), d1.view(np.uint32))
+        l2, d2 = NP.scan_topk(X, ids, Q[b], 10)
+        assert np.array_equal(l1, l2) and np.array_equal(d1.view(np.uint32), np.asarray(d2, dtype=np.float32).view(np.uint32))

@@ -29,10 +29,11 @@ for dist in dists:
     gen_ok = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
     qi = dawn.VectorIndex(0)
     qi.set_option("synth_dist", dist)
-    qi.fill_synthetic(1, QROW0, max(nq, 256), 1)
-    Q = qi.get_rows(0, max(nq, 256))[0]
+    nqq = max(nq, 256)
+    qi.fill_synthetic(1, QROW0, nqq * 256, 1)  # (every 256th row: a different run — site — each, for dist 5)
+    Q = qi.get_rows(0, nqq * 256)[0][::256].copy()
     qi.close()
-    cl, tl = synth.topical_cluster(1, QROW0 + np.arange(nq), runs=(dist == 5))
+    cl, tl = synth.topical_cluster(1, QROW0 + 256 * np.arange(nq), runs=(dist == 5))
     print(f"dist={dist} rows={rows}: fill {fill_s:.1f} s, generator == numpy: {gen_ok}; query clusters (first 16) "
           f"{cl[:16].tolist()}", flush=True)
     for mode, bounded, i6 in (("packed stream, exact pass behind it (round 3)", 0, 1), ("packed stream + bounded pass", 1, 1),
