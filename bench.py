@@ -466,41 +466,86 @@ def main():
         return res
 
     def realistic_leg(dist_id):
+        """100 M rows of another distribution (option synth_dist), k = 10 / 20, batch 1 / 256: ms per search and which rung of
+        the ladder answered.  dist 1-3: isotropic rows with realistic tails, random queries of the same distribution.  dist 4 / 5:
+        the TOPICAL mixture (Zipf-sized clusters, cosine 0.5-0.95 inside a cluster; 5: runs of 256 consecutive rows per cluster) with
+        queries that are further rows of the same stream — new pages on the same topics, most of them inside a large cluster:
+        the data certificates fail on."""
+        topical = dist_id >= 4
         ix = dawn.VectorIndex(local_rank)
         ix.set_option("synth_dist", dist_id)
+        t0 = time.perf_counter()
         ix.fill_synthetic(1, 0, args.rows, 1)
+        res = {"rows": args.rows, "fill_seconds": time.perf_counter() - t0}
         qi = dawn.VectorIndex(local_rank)
         qi.set_option("synth_dist", dist_id)
-        qi.fill_synthetic(2, 0, 256, 1)
-        Qh, _ = qi.get_rows(0, 256)
+        if topical:
+            qi.fill_synthetic(1, 1 << 40, 256 * 256, 1)  # (every 256th row: a different run each)
+            Qh = qi.get_rows(0, 256 * 256)[0][::256].copy()
+        else:
+            qi.fill_synthetic(2, 0, 256, 1)
+            Qh, _ = qi.get_rows(0, 256)
         qi.close()
         Qh[0] = ix.get_rows(4242 % args.rows, 1)[0][0]  # a row of the index itself: its label must come out first
         d_q = torch.from_numpy(Qh).to(dev)
-        res = {"rows": args.rows}
+        rates = {"second_chances": "second_chance_rate", "deepened": "deepened_rate", "fallbacks": "fallback_rate",
+                 "bounded": "bounded_rate", "packed_failures": "packed_failure_rate", "demoted": "demoted_rate"}
         for kk in (10, 20):
             for Bq in (1, 256):
                 nb = dawn.result_blob_bytes(Bq, kk)
                 blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
                 p = blob.data_ptr()
-                s0 = ix.stats()
-                steps = 16 if Bq == 1 else 4
-                for it in range(steps + 2):
-                    if it == 2:
+                steps = (96 if topical else 16) if Bq == 1 else 4
+                warm = 2
+                per = []
+                for it in range(steps + warm):
+                    if it == warm:
                         torch.cuda.synchronize()
+                        s0 = ix.stats()
                         t0 = time.perf_counter()
-                    qoff = (it % 64) * 384 * 4 if Bq == 1 else 0
+                    qoff = ((it - warm) % 64) * 384 * 4 if Bq == 1 else 0
+                    t1 = time.perf_counter()
                     ix.search_device(d_q.data_ptr() + qoff, Bq, kk, p, p + Bq * kk * 8, p + Bq * kk * 12, stream)
+                    if topical:  # (bimodal: every search is timed on its own)
+                        torch.cuda.synchronize()
+                        per.append(time.perf_counter() - t1)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
                 s1 = ix.stats()
-                nq = (steps + 2) * Bq
-                res[f"k{kk}_batch{Bq}"] = {
-                    "queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3,
-                    "second_chance_rate": (s1["second_chances"] - s0["second_chances"]) / nq,
-                    "deepened_rate": (s1["deepened"] - s0["deepened"]) / nq,
-                    "fallback_rate": (s1["fallbacks"] - s0["fallbacks"]) / nq}
+                nq = steps * Bq
+                leg = {"queries_per_s": steps * Bq / el, "ms_per_step": el / steps * 1e3}
+                for kk2, rname in rates.items():
+                    leg[rname] = (s1[kk2] - s0[kk2]) / nq
+                if topical:
+                    pa = np.array(per[warm:]) * 1e3
+                    leg["ms_p50"], leg["ms_p95"], leg["ms_max"] = (float(np.percentile(pa, 50)), float(np.percentile(pa, 95)),
+                                                                  float(pa.max()))
+                res[f"k{kk}_batch{Bq}"] = leg
         lab, _ = ix.search(Qh[0], 10)
         res["planted_top1_ok"] = bool(len(lab) and lab[0] == 1 + 4242 % args.rows)
+        if topical:
+            # the same single queries with the ladder's pieces switched off: what round 3 did (exact pass over all rows behind a
+            # failed certificate), and the ladder without its feedback
+            for name, opts in (("k10_batch1_no_feedback", {"ladder_feedback": 0}),
+                               ("k10_batch1_round3_exact_pass", {"ladder_feedback": 0, "bounded_pass": 0})):
+                for o, v in opts.items():
+                    ix.set_option(o, v)
+                nb = dawn.result_blob_bytes(1, 10)
+                blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+                p = blob.data_ptr()
+                torch.cuda.synchronize()
+                s0 = ix.stats()
+                t0 = time.perf_counter()
+                nst = 48
+                for it in range(nst):
+                    ix.search_device(d_q.data_ptr() + (it % 64) * 384 * 4, 1, 10, p, p + 80, p + 120, stream)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                s1 = ix.stats()
+                res[name] = {"ms_per_step": el / nst * 1e3, "fallback_rate": (s1["fallbacks"] - s0["fallbacks"]) / nst,
+                             "bounded_rate": (s1["bounded"] - s0["bounded"]) / nst}
+                ix.set_option("ladder_feedback", 1)
+                ix.set_option("bounded_pass", 1)
         ix.close()
         return res
 
@@ -717,7 +762,8 @@ def main():
             idxh.close()
             # ---- realistic score distributions (dawn_index_set_option "synth_dist"): Gaussian rows and heavy-tailed rows
             # (4 dimensions x5, as sentence embeddings have); k = 10 and the service's k = 20; certificate counters
-            for name, dist_id in (("gaussian", 1), ("heavy_tailed_4dims_x5", 2)):
+            for name, dist_id in (("gaussian", 1), ("heavy_tailed_4dims_x5", 2), ("clustered_topical", 4),
+                                  ("clustered_topical_runs256", 5)):
                 extra["rows_" + name] = realistic_leg(dist_id)
         out["extra"] = extra
         if world == 1 and rank == 0:

@@ -83,7 +83,7 @@ _SIGS = {
     "dawn_index_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "dawn_index_stats_ext": (_i32, [_vp, _vp, _vp, _vp]),
     "dawn_index_stats_deep": (_i32, [_vp, _vp]),
-    "dawn_index_stats_bounded": (_i32, [_vp, _vp]),
+    "dawn_index_stats_ladder": (_i32, [_vp, _vp, _vp, _vp]),
     "dawn_index_memory": (_i32, [_vp, _vp, _vp, _vp]),
     "dawn_index_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "dawn_index_debug_read_diag": (_i32, [_vp, _vp, _sz]),

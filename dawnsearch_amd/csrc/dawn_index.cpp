@@ -103,6 +103,10 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_stats, dawn::N_STAT_SLOTS * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMemset(idx->d_stats, 0, dawn::N_STAT_SLOTS * sizeof(uint32_t)));
     }
+    if (!idx->h_stats) {  // the counters' mirror in pinned host memory (ladder feedback)
+        DAWN_HIP_TRY(hipHostMalloc((void**)&idx->h_stats, dawn::N_STAT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+        std::memset(idx->h_stats, 0, dawn::N_STAT_SLOTS * sizeof(uint32_t));
+    }
     if (!idx->d_i6_pool) {  // chunk counters of the packed stream: zero between searches (merge_exact_kernel resets them)
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_i6_pool, 32 * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMemset(idx->d_i6_pool, 0, 32 * sizeof(uint32_t)));
@@ -296,6 +300,8 @@ namespace dawn {
 // idx->stream.  An option that needs a shadow the index does not hold yet builds it here — never inside a search.
 int index_prepare_search(dawn_index* idx) {
     DAWN_TRY(ensure_workspace(idx, std::max(idx->ws_B, kMaxBatch)));
+    idx->fb = dawn_index::LadderFeedback{};  // the rows (or the options) changed: what the certificates did before says nothing
+    if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
     if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
@@ -353,12 +359,50 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     } else if (B == 1 && i6_live(idx) &&
                (idx->i6_geom().refine > 0 ||
                 i6_refine_count(n, (uint32_t)k, idx->i6_bits, idx->i6_geom().blocks * (idx->i6_geom().threads / 64)) > 0)) {
-        // one query on the 6-bit shadow (288 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
+        // ladder feedback (index_internal.hpp): how often did the packed certificate fail lately?
+        bool demoted = false;
+        if (idx->ladder_feedback && idx->bounded_pass && !idx->force_fallback && idx->h_stats) {
+            auto& fb = idx->fb;
+            if (fb.demote_left == 0 && fb.issued - fb.win_issued0 >= kFbWindow) {
+                const uint32_t now = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
+                const double rate = (double)(now - fb.win_fail0) / (double)(fb.issued - fb.win_issued0);
+                if (rate > kFbDemote) {
+                    fb.demote_left = fb.demote_len;
+                    fb.demote_len = std::min(fb.demote_len * 2u, kFbDemoteMax);
+                } else {
+                    fb.demote_len = kFbDemoteMin;
+                }
+                if (rate > kFbBoost) fb.boosted = true;
+                fb.win_issued0 = fb.issued;
+                fb.win_fail0 = now;
+            }
+            if (fb.demote_left > 0) {
+                --fb.demote_left;
+                demoted = true;
+            } else {
+                ++fb.issued;
+            }
+        }
+        if (demoted) {
+            // a demoted index: the bounded exact pass is the whole search (384 B/row, no certificate to fail)
+            ++idx->n_demoted;
+            launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
+                                       idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
+                                       d_labels, d_dist, d_found, stream, e0, e1);
+            launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, 1, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
+                              idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream,
+                              idx->h_stats);
+            DAWN_HIP_TRY(hipGetLastError());
+            return DAWN_OK;
+        }
+        // one query on the packed shadow (240 B/row): upper-bound scores, every workgroup's shortlist rescored exactly in the
         // stream's epilogue, one merge + certificate (scan_i6.hip)
+        ScanGeom g6 = idx->i6_geom();
+        if (idx->fb.boosted && g6.refine == 0) g6.refine = LIST;
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
                        idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->stream_dyn_tail ? idx->d_i6_pool : nullptr,
-                       idx->i6_geom(), (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                       idx->force_fallback, true, stream, e0, e1);
+                       g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                       idx->force_fallback, true, stream, e0, e1, idx->d_stats);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
         const ScanGeom& gh = idx->i8_geom();
@@ -391,7 +435,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                             idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
                             d_dist, d_found, stream);
     launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
-                      idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream);
+                      idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream, idx->h_stats);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }
@@ -461,6 +505,7 @@ void index_destroy_single(dawn_index* idx) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
+    if (idx->h_stats) (void)hipHostFree(idx->h_stats);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
 }
@@ -687,7 +732,7 @@ int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total
 // The certificate counters live on the device (scan_exact_kernel bumps them at the end of every search, whichever entry
 // point issued it); reading them synchronises the device.
 int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
-                       uint64_t* bounded) {
+                       uint64_t* bounded, uint64_t* packed_failures, uint64_t* demoted) {
     DAWN_TRY(set_device(idx));
     uint32_t st[N_STAT_SLOTS] = {};
     DAWN_HIP_TRY(hipDeviceSynchronize());
@@ -697,6 +742,8 @@ int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, ui
     if (fallbacks) *fallbacks = st[FLAG_FALLBACK];
     if (deepened) *deepened = st[FLAG_DEEP];
     if (bounded) *bounded = st[FLAG_BOUNDED];
+    if (packed_failures) *packed_failures = st[STAT_PACKED_FAIL];
+    if (demoted) *demoted = idx->n_demoted;
     return DAWN_OK;
 }
 
@@ -734,6 +781,12 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "force_fallback") {  // 1: every query takes the exact pass; 2: every certificate is made to fail, the ladder answers
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "force_fallback must be 0, 1 or 2");
         idx->force_fallback = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "ladder_feedback") {  // 0: single queries of a large index always try the packed stream first (A/B, tests)
+        idx->ladder_feedback = value != 0;
+        idx->fb = dawn_index::LadderFeedback{};
+        if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
         return DAWN_OK;
     }
     if (n == "bounded_pass") {  // 0: a failed certificate goes straight to the exact pass over all rows (round 3; A/B)
@@ -1365,11 +1418,12 @@ int dawn_index_stats_ext(dawn_index* idx, uint64_t* searches, uint64_t* second_c
                        : dawn::index_stats_single(idx, searches, second_chances, fallbacks, nullptr);
 }
 
-// ... the queries whose certificates all failed and which the bounded exact pass answered (scan_bounded.hip; NOT in `fallbacks`)
-int dawn_index_stats_bounded(dawn_index* idx, uint64_t* bounded) {
+// ... the ladder behind the certificates: queries the bounded exact pass answered (scan_bounded.hip; NOT in `fallbacks`), single
+// queries whose packed-stream certificate failed, single queries a demoted index sent to the bounded pass directly
+int dawn_index_stats_ladder(dawn_index* idx, uint64_t* bounded, uint64_t* packed_failures, uint64_t* demoted) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, nullptr, bounded)
-                       : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, nullptr, bounded);
+    return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, nullptr, bounded, packed_failures, demoted)
+                       : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, nullptr, bounded, packed_failures, demoted);
 }
 
 // ... and, of the second chances, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled

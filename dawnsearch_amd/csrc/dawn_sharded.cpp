@@ -533,18 +533,22 @@ int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes
 }
 
 int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
-                  uint64_t* bounded) {
+                  uint64_t* bounded, uint64_t* packed_failures, uint64_t* demoted) {
     ShardSet& S = *idx->shards;
-    uint64_t s2 = 0, fb = 0, dp = 0, bd = 0;
+    uint64_t s2 = 0, fb = 0, dp = 0, bd = 0, pf = 0, dm = 0;
     for (dawn_index* sh : S.sh) {  // (per-shard events: one query can fall back on one shard and not on another)
-        uint64_t a = 0, b = 0, c = 0, d = 0;
-        DAWN_TRY(index_stats_single(sh, nullptr, &a, &b, &c, &d));
+        uint64_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+        DAWN_TRY(index_stats_single(sh, nullptr, &a, &b, &c, &d, &e, &f));
         s2 += a;
         fb += b;
         dp += c;
         bd += d;
+        pf += e;
+        dm += f;
     }
     if (bounded) *bounded = bd;
+    if (packed_failures) *packed_failures = pf;
+    if (demoted) *demoted = dm;
     if (searches) *searches = S.n_searches;
     if (second) *second = s2;
     if (fallbacks) *fallbacks = fb;

@@ -8,7 +8,7 @@
 #include <new>
 #include <string>
 
-#include "../../include/dawn_hip.h"
+#include "../../include/dawn_hip_debug.h"  // (dawn_hip.h + the test / measurement hooks this library also exports)
 
 namespace dawn {
 

@@ -23,6 +23,9 @@ constexpr size_t kI6MinRows = 2u << 20;        // indexes of at least this many 
 constexpr size_t kI6SmallRows = 32u << 20;     // below this the packed stream uses geom_i6_small
 constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host before they travel together
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
+constexpr uint32_t kFbWindow = 32;        // ladder feedback: packed single-query searches per window
+constexpr double kFbBoost = 0.05, kFbDemote = 0.35;  // failure rates that make the waves refine full lists / demote the index
+constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
 }  // namespace dawn
 
 struct dawn_index {
@@ -152,6 +155,22 @@ struct dawn_index {
     uint64_t n_searches = 0;
     int force_fallback = 0;      // option "force_fallback": 1 = every query takes the exact pass, 2 = every certificate fails (ladder)
     int bounded_pass = 1;        // option "bounded_pass": a failed certificate is answered from the int8 shadow (scan_bounded.hip)
+    // Ladder feedback.  The packed stream (240 B/row) followed by the bounded pass (384 B/row) costs 2.6 x the packed stream
+    // when its certificate fails; the bounded pass ALONE, started without a threshold, costs 1.6 x and cannot fail.  The index
+    // therefore watches how often the packed certificate fails — the device mirrors its counters into h_stats at the end of
+    // every search (scan_exact_kernel; pinned memory, no synchronisation, the host reads whatever has landed) — in windows of
+    // kFbWindow single-query searches: above kFbBoost the waves refine full lists (n_refine = 64), above kFbDemote the next
+    // demote_len single queries go to the bounded pass directly (doubling while the next probe window fails again, back to
+    // kFbDemoteMin once one passes).  Results never depend on it.  Reset by every mutation and option (index_prepare_search).
+    uint32_t* h_stats = nullptr;   // [N_STAT_SLOTS] pinned, device-visible
+    int ladder_feedback = 1;       // option "ladder_feedback"
+    struct LadderFeedback {
+        uint64_t issued = 0, win_issued0 = 0;  // packed single-query searches issued / at the start of the window
+        uint32_t win_fail0 = 0;                // h_stats[STAT_PACKED_FAIL] at the start of the window
+        uint32_t demote_left = 0, demote_len = 256;
+        bool boosted = false;
+    } fb;
+    uint64_t n_demoted = 0;        // single queries answered by the bounded pass directly
     int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)
 
     // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,
@@ -209,7 +228,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value);
 int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
 int index_stats_single(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
-                       uint64_t* bounded = nullptr);
+                       uint64_t* bounded = nullptr, uint64_t* packed_failures = nullptr, uint64_t* demoted = nullptr);
 int index_profile_read_single(dawn_index* idx, uint64_t* launches, double* total_ms);
 int index_profile_enable_single(dawn_index* idx, int enable);
 
@@ -233,7 +252,7 @@ int sharded_get_rows(dawn_index* idx, size_t first, size_t n, float* out_rows, u
 int sharded_set_option(dawn_index* idx, const char* name, int64_t value);
 int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
 int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
-                  uint64_t* bounded = nullptr);
+                  uint64_t* bounded = nullptr, uint64_t* packed_failures = nullptr, uint64_t* demoted = nullptr);
 int sharded_profile_enable(dawn_index* idx, int enable);
 int sharded_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms);
 int sharded_dtype(const dawn_index* idx);

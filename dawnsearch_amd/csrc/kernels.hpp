@@ -65,7 +65,8 @@ constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass mus
 constexpr uint32_t FLAG_SECOND = 2;    // first certificate failed, the 1024-deep second one held: result is exact
 constexpr uint32_t FLAG_DEEP = 3;      // first certificate failed, a deeper round (128 .. 256 rows) held: result is exact
 constexpr uint32_t FLAG_BOUNDED = 4;   // every certificate failed, the bounded exact pass (scan_bounded.hip) answered: result is exact
-constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query
+constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query ...
+constexpr int STAT_PACKED_FAIL = 5;    // ... and [5]: single-query searches whose packed-stream certificate failed (merge_exact_kernel)
 
 // Function attributes (hipFuncSetAttribute: the dynamic-LDS limit of a kernel) belong to the CURRENT device's copy of the
 // kernel: a process that drives several devices (dawn_sharded.cpp) has to set them on each.  once_per_device(state, fn) runs fn
@@ -137,7 +138,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
-                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats = nullptr);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
 // Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
@@ -181,9 +182,11 @@ void launch_scan_batched(const void* d_x, int dtype, const void* d_frows, int fr
 void launch_rows_f32_to_f16s(const float* d_rows, void* d_shadow, size_t first_row, size_t n_valid, hipStream_t stream);
 // Exact fallback (predicated per query on d_flags[b] == FLAG_FALLBACK): per-workgroup exact lists, merged and written out
 // by the last workgroup to arrive (d_done[B]: arrival counters, zero before and after).
+// stats_mirror (may be NULL): device-visible host memory [N_STAT_SLOTS] that receives a copy of d_stats at the end of the search
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                        const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
-                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
+                       uint32_t* stats_mirror = nullptr);
 
 // Bounded exact pass (scan_bounded.hip; predicated per query on d_flags[b] == FLAG_FALLBACK, in front of the exact pass): streams
 // the int8 shadow, scores exactly every row whose upper bound can still reach the k-th best distance known so far (d_dist of
@@ -191,6 +194,12 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+// ... as the WHOLE search of one query (a demoted index, dawn_index.cpp: ladder feedback): the flag is raised and the threshold
+// starts at +inf — the waves' own k-th best distances are the thresholds.  ev0 / ev1 bracket the pass.
+void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids,
+                                uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
+                                uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
+                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.

@@ -678,4 +678,24 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     }
 }
 
+__global__ void bounded_prime_kernel(uint32_t* __restrict__ flags, float* __restrict__ out_dist, uint32_t k, uint32_t found) {
+    if (threadIdx.x == 0) {
+        flags[0] = FLAG_FALLBACK;
+        if (found > 0) out_dist[found - 1] = POS_INF;
+    }
+    (void)k;
+}
+
+void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids,
+                                uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
+                                uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
+                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const uint32_t found = n_rows < k ? n_rows : k;
+    hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, k, found);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    launch_scan_bounded(d_i8, d_i8meta, d_x, dtype, d_ids, n_rows, d_q, 1, d_flags, d_done, cand_s, cand_p, n_lists, k, d_labels,
+                        d_dist, d_found, stream);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+}
+
 }  // namespace dawn

@@ -758,7 +758,8 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
                                                             const uint32_t* __restrict__ ex_p, int n_lists, uint32_t k,
                                                             uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
                                                             uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags,
-                                                            int force_fallback, float eps, uint32_t* __restrict__ pool) {
+                                                            int force_fallback, float eps, uint32_t* __restrict__ pool,
+                                                            uint32_t* __restrict__ stats) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ float sh_t[16];
@@ -804,10 +805,13 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
             if (!(d_bound > dk)) flag = FLAG_FALLBACK;
         }
     }
+    // (the index's ladder feedback watches how often this certificate fails on its own: dawn_index.cpp)
+    if (stats && lane == 0 && flag == FLAG_FALLBACK) atomicAdd(&stats[STAT_PACKED_FAIL], 1u);
     if (force_fallback && n_rows > 0) flag = FLAG_FALLBACK;
-    if ((uint32_t)lane < found && p != NO_POS) {
-        out_labels[lane] = ids[p];
-        out_dist[lane] = -s;
+    if ((uint32_t)lane < found) {
+        // (slots without a candidate — fewer rows found than asked for: the ladder takes over — read as "no threshold")
+        out_labels[lane] = p != NO_POS ? ids[p] : 0ull;
+        out_dist[lane] = p != NO_POS ? -s : POS_INF;
     }
     if (lane == 0) {
         out_found[0] = found;
@@ -871,7 +875,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
-                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats) {
     static OncePerDevice attr_once;
     const uint32_t* x = reinterpret_cast<const uint32_t*>(d_i6);
     const float2* mt = reinterpret_cast<const float2*>(d_meta);
@@ -906,7 +910,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (merge)
         hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, tb, ex_s, ex_p, g.blocks, k,
-                           d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8, pool);
+                           d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8, pool, d_stats);
     else if (pool != nullptr)
         (void)hipMemsetAsync(pool, 0, 32 * sizeof(uint32_t), stream);  // (the test hook's stream-only launch)
 }

@@ -579,7 +579,8 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
                                                         uint32_t* __restrict__ stats,
                                                         float* __restrict__ out_s, uint32_t* __restrict__ out_p,
                                                         uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
-                                                        float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
+                                                        float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
+                                                        uint32_t* __restrict__ mirror) {
     __shared__ float sh_s[4][LIST];
     __shared__ uint32_t sh_p[4][LIST];
     __shared__ uint32_t sh_last;
@@ -602,6 +603,9 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
         if (lane == 0) sh_mask[wave] = m;
     }
     __syncthreads();
+    // ... and a copy of the counters goes to the host (pinned, device-visible memory: posted stores, nobody waits) — what the
+    // index's ladder feedback reads without ever synchronising (dawn_index.cpp)
+    if (mirror && stats && blockIdx.x == 0 && threadIdx.x < (unsigned)N_STAT_SLOTS) mirror[threadIdx.x] = atomicAdd(&stats[threadIdx.x], 0u);
     for (int w = 0; w < kMaxFlags / 64; ++w) {
       unsigned long long todo = sh_mask[w];  // block-uniform
       while (todo) {
@@ -670,17 +674,18 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(const void* __restrict_
 
 void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                        const uint32_t* d_flags, uint32_t* d_done, uint32_t* d_stats, float* cand_s, uint32_t* cand_p,
-                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
+                       int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
+                       uint32_t* stats_mirror) {
     // one workgroup per list; it walks the batch's flags (LDS, one round trip) and scans for the flagged queries one after the
     // other.  (Round 2 launched 16 query slots side by side: 4096 workgroups whose launch alone took 12 us behind every 256-query
     // search, flags set or not; a flagged query's scan is HBM-bound with 256 workgroups, so the slots bought nothing.)
     const dim3 grid(n_lists, 1);
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL(scan_exact_kernel<1>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, d_stats,
-                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
+                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found, stats_mirror);
     else
         hipLaunchKernelGGL(scan_exact_kernel<0>, grid, dim3(256), 0, stream, d_x, d_ids, n_rows, d_q, B, d_flags, d_done, d_stats,
-                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found);
+                           cand_s, cand_p, (uint32_t)n_lists, k, d_labels, d_dist, d_found, stats_mirror);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -137,12 +137,14 @@ class VectorIndex:
         check(lib.dawn_index_stats_ext(self._h, C.byref(s), C.byref(c2), C.byref(f)))
         dp = C.c_uint64(0)
         check(lib.dawn_index_stats_deep(self._h, C.byref(dp)))
-        bd = C.c_uint64(0)
-        check(lib.dawn_index_stats_bounded(self._h, C.byref(bd)))
+        bd, pf, dm = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib.dawn_index_stats_ladder(self._h, C.byref(bd), C.byref(pf), C.byref(dm)))
         # second_chances: the 64-row certificate failed, no exact pass needed; deepened: those settled by a deeper round;
-        # bounded: every certificate failed, the bounded exact pass on the int8 shadow answered (no pass over all rows)
+        # bounded: every certificate failed (or the index is demoted), the bounded exact pass on the int8 shadow answered (no pass
+        # over all rows); packed_failures: single queries whose packed-stream certificate failed; demoted: single queries sent to
+        # the bounded pass directly by the ladder feedback
         return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value,
-                "bounded": bd.value}
+                "bounded": bd.value, "packed_failures": pf.value, "demoted": dm.value}
 
     def memory(self):
         """HBM bytes held by the index: rows, filter shadows built so far, everything else."""

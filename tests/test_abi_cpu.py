@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "dawn_hip.h")).read()
+    src = open(os.path.join(ROOT, "include", "dawn_hip.h")).read() + open(os.path.join(ROOT, "include", "dawn_hip_debug.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dawn_[a-z0-9_]+)\s*\(", src)))
 
@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(dawn):
     names = _declared_symbols()
     assert len(names) >= 35
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/dawn_hip.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/dawn_hip.h / dawn_hip_debug.h but not exported"
     from dawnsearch_amd import _lib
     assert sorted(_lib._SIGS) == names  # the ctypes table binds exactly the header
 

@@ -201,3 +201,44 @@ def test_without_the_int8_shadow_the_exact_pass_still_answers(dawn, oracle, monk
         _same(*idx.search(q, 10), want[0][b], want[1][b])
     st = idx.stats()
     assert st["bounded"] == 0 and st["fallbacks"] == 3
+
+
+def test_ladder_feedback_demotes_and_recovers(dawn, oracle):
+    """More than a third of the packed certificates failing over a window of 32 single queries: the index sends the next ones to
+    the bounded pass directly (one 384-B stream instead of a 240-B stream and then the 384-B one), probes the packed stream again
+    afterwards, starts afresh after a mutation, and never demotes queries that certify.  Same answers throughout."""
+    n = 200_000
+    idx = _topical_index(dawn, n, 4)
+    idx.set_option("i6_scan_blocks", 4)  # (lists as short of this index's clusters as the full grid is of a 100 M-row index's)
+    idx.set_option("i6_refine", 8)
+    Qbad = _topical_queries(4, 8, clusters={0, 1, 2})
+    want = oracle.scan_topk_synth(1, 0, n, 1, Qbad, 10, dist=4)
+    for it in range(12):  # 96 searches: window 1 (32 packed, all failing) -> demoted
+        for b, q in enumerate(Qbad):
+            _same(*idx.search(q, 10), want[0][b], want[1][b])
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["bounded"] == 96 and st["packed_failures"] == 32 and st["demoted"] == 64, st
+    # a mutation resets the feedback: the packed stream is tried again
+    extra = synth.unit_rows(9, 0, 1)
+    idx.add(n + 1, extra[0])
+    _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(
+        np.concatenate([oracle.unit_rows_topical(1, 0, n), extra]), np.arange(1, n + 2, dtype=np.uint64), Qbad[0], 10, threads=8))
+    st2 = idx.stats()
+    assert st2["packed_failures"] == 33 and st2["demoted"] == 64
+    # feedback off: every search tries the packed stream first
+    idx.set_option("ladder_feedback", 0)
+    for it in range(6):
+        for q in Qbad:
+            idx.search(q, 10)
+    st3 = idx.stats()
+    assert st3["demoted"] == 64 and st3["packed_failures"] == 33 + 48
+    # queries that certify are never demoted
+    idx2 = dawn.VectorIndex(0)
+    idx2.set_option("i6_min_rows", 0)
+    idx2.fill_synthetic(1, 0, n, 1)
+    Q = synth.unit_rows(2, 0, 8)
+    for it in range(10):
+        for q in Q:
+            idx2.search(q, 10)
+    st = idx2.stats()
+    assert st["demoted"] == 0 and st["packed_failures"] == 0 and st["bounded"] == 0 and st["fallbacks"] == 0

@@ -375,3 +375,109 @@ def test_i6_dynamic_tail_covers_every_sub_tile(dawn, oracle, blocks, threads):
     sc, rows = idx.debug_stream_lists(Q[3])  # (the stream-only hook resets the counters itself)
     _assert_same(*idx.search(Q[3], 10), *oracle.scan_topk(x, ids, Q[3], 10, threads=8))
     assert idx.stats()["fallbacks"] == 0
+
+
+# ---- the K2 term of the packed bound, on the sub-tile that stresses it ------------------------------------------------------
+def _rot_matrix():
+    """The shadows' rotation R (csrc/rotate384.hpp) as a 384 x 384 matrix: x' = R x."""
+    k = np.arange(384, dtype=np.uint64)
+    neg = ((k * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(19) & np.uint64(1)
+    D = np.diag(np.where(neg == 1, -1.0, 1.0))
+    M3 = (2.0 / 3.0) * np.ones((3, 3)) - np.eye(3)
+    i = np.arange(128)
+    H = np.where(np.array([[bin(a & b).count("1") & 1 for b in i] for a in i]) == 1, -1.0, 1.0) / np.sqrt(128.0)
+    return np.kron(np.eye(3), H) @ np.kron(M3, np.eye(128)) @ D
+
+
+def _packed_quantise(xr, levels, n_cand=6):
+    """rows_to_i6s_kernel in float64 on rotated rows xr [32, 384]: -> (s, E_true, X)."""
+    amax = np.abs(xr).max()
+    s0 = np.float32(max(amax, 1e-20)) / np.float32(levels)
+    best = None
+    for ci in range(n_cand):
+        s = float(np.float32(s0 * np.float32(1.0 - np.float32(0.08) * ci)))
+        X = np.clip(np.rint(xr / s), -levels, levels)
+        e = np.sqrt(((xr - s * X) ** 2).sum(axis=1)).max()
+        if best is None or e < best[1]:
+            best = (s, e, X)
+    return best
+
+
+def test_k2_covers_the_worst_sub_tile(dawn, oracle, bits):
+    """The packed bound is ub = s s_q / 254 C + E + K2 with K2 >= |(s X).dq| through Cauchy-Schwarz: ||s X||_2 ||dq||_2.
+    Round 3 took ||s X||_2 <= 1.35 — derived for 31 levels.  Here: a sub-tile built IN THE ROTATED BASIS — a one-hot row (it
+    pins the scale at the coarsest value a unit row allows) next to rows whose components all sit just above (n + 1/2) s for
+    each of the quantiser's candidate scales, and rows that combine a clipped component with such a body — and a query whose
+    int8 images leave the largest residual the format allows (every |dq_i| = 0.49 s_q / 254).  With 15 levels ||s X||_2 reaches
+    1.4 whatever scale the quantiser picks, and ||s X||_2 ||dq||_2 exceeds the old constant's K2; the measured form
+    (1.015 + E) x 19.6 x 2e-3 x s_q covers it.  Checked through the stream's own lists (option i6_refine = -1: coarse bounds
+    kept): K2 as the kernel applied it = ub - the integer term - E >= ||s X_r||_2 ||dq||_2 for every row, and ub >= x.q."""
+    levels = 15 if bits == 5 else 31
+    R = _rot_matrix()
+    assert np.abs(R @ R.T - np.eye(384)).max() < 1e-12
+    rng = np.random.default_rng(11)
+    amax = 1.0099
+    s0 = amax / levels
+    rows_r = [np.eye(384)[0] * amax]
+    for ci in range(6):
+        s = s0 * (1.0 - 0.08 * ci)
+        # (a) every component just above a half level: a at (n + 1/2) s, b at (n + 3/2) s, a + b = 384, norm ~ 1
+        n0 = int(np.floor(1.0 / (s * np.sqrt(384.0)) - 0.5))
+        lo, hi = (n0 + 0.5) ** 2, (n0 + 1.5) ** 2
+        b = min(max(int(round((1.0 / s ** 2 - 384.0 * lo) / (hi - lo))), 0), 384)
+        mag = np.concatenate([np.full(384 - b, (n0 + 0.5) * s + 0.001 * s), np.full(b, (n0 + 1.5) * s + 0.001 * s)])
+        rows_r.append(rng.permutation(mag) * rng.choice([-1.0, 1.0], 384))
+        # (b) one large component (clipped by the finer scales) + a body at 0.5 s
+        body = 0.5 * s * 1.002
+        big = np.sqrt(max(1.0 - 383 * body ** 2, 0.0))
+        v = np.full(384, body) * rng.choice([-1.0, 1.0], 384)
+        v[0] = min(big, amax * 0.999)
+        rows_r.append(v)
+    while len(rows_r) < 32:
+        v = rng.standard_normal(384)
+        rows_r.append(v / np.linalg.norm(v))
+    xr = np.stack(rows_r)
+    norms = np.linalg.norm(xr, axis=1)
+    assert np.all((norms > 0.992) & (norms < 1.00995)), norms
+    rows = (xr @ R).astype(np.float32)  # x = R^T x'
+    # the query: one component at 127 s_q, the rest H = 0, L random, residual 0.49 / 254 of s_q with the sign of X
+    s, e_true, X = _packed_quantise((R @ rows.astype(np.float64).T).T, levels)
+    worst = int(np.argmax(np.linalg.norm(s * X, axis=1)))
+    sq = 1.0 / np.sqrt(127.0 ** 2 + 383 * (60.0 / 254.0) ** 2)  # ~ 1 / 127.1: ||q'|| ~ 1
+    L = rng.integers(-100, 101, 384).astype(np.float64)
+    sign = np.where(X[worst] >= 0, 1.0, -1.0)
+    qr = sq * (L + 0.49 * sign) / 254.0
+    qr[1] = 127.0 * sq  # (component 1: the one-hot row lives in component 0)
+    q = (qr @ R).astype(np.float32)
+    assert 0.99 < np.linalg.norm(q) < 1.01
+    # numpy restatement of the query images (scan_filter_i6s_kernel)
+    qrot = R @ q.astype(np.float64)
+    sqk = float(np.float32(np.abs(qrot).max()) / np.float32(127.0))
+    Hq = np.clip(np.rint(qrot / sqk), -127, 127)
+    Lq = np.clip(np.rint((qrot / sqk - Hq) * 254.0), -127, 127)
+    dq = qrot - sqk * (Hq + Lq / 254.0)
+    assert np.abs(dq).max() < 2.0e-3 * sqk and np.linalg.norm(dq) > 0.9 * np.sqrt(383) * 0.49 / 254.0 * sqk
+    sx_norm = np.linalg.norm(s * X, axis=1)
+    need = sx_norm * np.linalg.norm(dq)
+    k2_old = 1.35 * 19.6 * 2.0e-3 * sqk
+    if bits == 5:  # the regime round 3's constant did not cover
+        assert sx_norm.max() > 1.38 and need.max() > k2_old, (sx_norm.max(), need.max(), k2_old)
+    idx = dawn.VectorIndex(0)
+    idx.set_option("i6_min_rows", 0)
+    idx.add_batch(np.arange(1, 33, dtype=np.uint64), rows)
+    idx.set_option("i6_refine", -1)
+    sc, lr = idx.debug_stream_lists(q)
+    valid = lr != 0xFFFFFFFF
+    got = lr[valid].astype(np.int64)
+    assert sorted(got.tolist()) == list(range(32))
+    ub = np.zeros(32)
+    ub[got] = sc[valid].astype(np.float64)
+    Cint = 254.0 * (X @ Hq) + X @ Lq
+    e_stored = e_true * 1.0101 * 1.001 + 1e-9
+    k2_applied = ub - s * sqk / 254.0 * Cint - e_stored
+    exact = rows.astype(np.float64) @ q.astype(np.float64)
+    assert np.all(ub >= exact - 4e-6)
+    assert np.all(k2_applied >= need - 4e-6), (k2_applied - need).min()
+    # ... and the search itself: exact, as always
+    idx.set_option("i6_refine", 0)
+    _assert_same(*idx.search(q, 10), *oracle.scan_topk(rows, np.arange(1, 33, dtype=np.uint64), q, 10))
