@@ -155,10 +155,15 @@ def read_ceiling_probe(timeout_s: float = 120.0):
         return {"error": repr(e)}
 
 
-def capi_sharded_leg(n_gpus: int, rows: int, k: int, timeout_s: float = 240.0):
+def capi_sharded_leg(n_gpus: int, rows: int, k: int, steps: int, warmup: int, batch: int, logical: bool = False,
+                     timeout_s: float = 420.0):
+    """The product's own multi-GPU form — ONE process, dawn_index_create_sharded over the N devices, RCCL inside the library —
+    measured by tools/sharded_capi_bench.py in a child process (it must own all N devices; this process is one of N ranks).
+    logical: a box with fewer GPUs than ranks — G logical shards on device 0 (functional check, not a measurement)."""
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_capi_bench.py"), "--gpus", str(n_gpus), "--rows", str(rows),
-           "--k", str(k)]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_capi_bench.py"), "--rows", str(rows), "--k", str(k),
+           "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch)]
+    cmd += ["--logical", str(n_gpus)] if logical else ["--gpus", str(n_gpus)]
     env = {kk: v for kk, v in os.environ.items()
            if kk not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                          "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
@@ -249,6 +254,16 @@ def main():
     from dawnsearch_amd import synth
 
     B, k = args.batch, args.k
+    # ---- N > 1: the HEADLINE is the product's own multi-GPU form, one process behind the C ABI (dawn_index_create_sharded over
+    # the N devices, RCCL all-gather inside the library), measured by a child of rank 0 that owns all devices while the ranks
+    # wait on the CPU (gloo; an NCCL barrier would spin a kernel on every GPU under the measurement) with nothing resident yet.
+    # The rank-per-GPU torch.distributed form below is then reported in extra.torch_distributed_ranks.
+    capi = None
+    if world > 1 and not args.no_capi_sharded:
+        ctl = None if oversub else dist.new_group(backend="gloo")
+        if rank == 0:
+            capi = capi_sharded_leg(world, args.rows, k, args.steps, args.warmup, B, logical=oversub)
+        dist.barrier(group=ctl)
     rows_local = args.rows // world
     first_row = rank * rows_local
     idx = dawn.VectorIndex(local_rank)
@@ -786,19 +801,47 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    if world > 1 and rank == 0 and not args.no_capi_sharded and not oversub:
-        # The same index behind the C ABI alone: ONE process, N GPUs (dawn_index_create_sharded, RCCL all-gather / peer
-        # copies inside the library).  A child process, bounded in time; the ranks have released their indexes.
-        leg = capi_sharded_leg(world, args.rows, k)
-        out.setdefault("extra", {})["single_process_sharded"] = leg
-        # both multi-GPU forms must return the same labels for the planted query (= the N = 1 labels: every form is
-        # bit-identical to the single index — tests/test_sharded_capi_gpu.py, tests/test_sharded_gpu.py)
+    if world > 1 and rank == 0 and capi is not None:
+        out.setdefault("extra", {})["single_process_sharded"] = capi
+        head_mode = next((m for m in capi.get("modes", []) if f"batch{B}" in m and "error" not in m), None)
+        # every multi-GPU form must return the labels of the planted query that the single index returns (every form is
+        # bit-identical to it — tests/test_sharded_capi_gpu.py, tests/test_sharded_gpu.py); the rank form's are in `head`
         want = head.get("planted_labels")
-        got = [m.get("batch1", {}).get("planted_labels") for m in leg.get("modes", []) if "batch1" in m]
+        got = [m.get(f"batch{B}", {}).get("planted_labels") for m in capi.get("modes", []) if f"batch{B}" in m]
         out["checks"]["single_process_sharded_labels_equal_rank_form"] = bool(got) and all(g == want for g in got)
         out["checks"]["single_process_sharded_qps"] = {m["mode"]: {"batch1": m.get("batch1", {}).get("queries_per_s"),
                                                                    "batch256": m.get("batch256", {}).get("queries_per_s")}
-                                                       for m in leg.get("modes", [])}
+                                                       for m in capi.get("modes", [])}
+        if head_mode is not None:
+            # the rank-per-GPU form's own line moves aside ...
+            out["extra"]["torch_distributed_ranks"] = {kk: out[kk] for kk in ("value", "ms_per_step", "steps", "warmup")}
+            out["extra"]["torch_distributed_ranks"].update(
+                {"config": out["config"], "roofline": out["roofline"], "checks": {kk: out["checks"].get(kk) for kk in
+                                                                                ("planted_top1_ok", "searches", "fallbacks")}})
+            # ... and the line is the product's: one process, N devices, the library's own collective
+            hl = head_mode[f"batch{B}"]
+            si = head_mode.get("shard_info", {})
+            out["value"] = hl["queries_per_s"]
+            out["ms_per_step"] = hl["ms_per_step"]
+            out["steps"], out["warmup"] = hl["steps"], hl["warmup"]
+            out["latency_ms"] = {"p50": hl["p50_ms"], "p95": hl["p95_ms"], "host_api_p50": hl["host_api_p50_ms"],
+                                 "what": "one dawn_index_search_device call on the sharded handle, synchronised every time "
+                                         "(unpipelined): N shard searches + gather + merge"}
+            gather = {1: "RCCL all-gather (ncclAllGather of the packed per-shard results, the library's own communicator)",
+                      2: "peer copies (hipMemcpyPeerAsync)", -1: "RCCL selected, not initialised", 0: "none"}.get(si.get("gather"), "?")
+            out["config"] = dict(out["config"], form="ONE process behind the C ABI: dawn_index_create_sharded over the N devices "
+                                                      "(what a Rust caller binds); tools/sharded_capi_bench.py",
+                                 ranks=1, shards=si.get("n_shards"), shard_rows=si.get("sizes"), gather=gather,
+                                 rccl_ranks=(si.get("n_shards") if si.get("gather") == 1 else 0),
+                                 collective_backend=("rccl" if si.get("gather") == 1 else "peer copies"), pipelined=False,
+                                 oversubscribed=bool(head_mode.get("logical_shards_on_one_device")))
+            out["checks"]["planted_top1_ok"] = bool(hl["planted_top1_ok"])
+            out["checks"]["labels_equal_rank_form"] = bool(hl["planted_labels"] == want)
+            out["checks"]["sharded_handle_stats"] = head_mode.get("stats")
+            out["roofline"]["note"] = ("per-shard kernel of the rank-per-GPU form (same kernel, same shard size: the sharded handle "
+                                       "launches it once per device)")
+        else:
+            out["checks"]["single_process_sharded_failed"] = capi.get("error") or [m.get("error") for m in capi.get("modes", [])]
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     if rank == 0:

@@ -1147,8 +1147,8 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     if (!heavy) return;
     __syncthreads();
 
-    // ---- second chance (wave_topk.hpp): every row scoring above tau is a candidate (DENSE: every row is one); the
-    // 1024 best are rescored exactly
+    // ---- second chance (wave_topk.hpp): every row scoring above tau is a candidate (DENSE: every row is one); ALL of them
+    // (up to the 8192 the buffer holds) are rescored exactly, 1024 per round
     const float* dense_q = dense + (size_t)b * BATCH_CAP;
     const uint2* cand_q = cand + (size_t)b * BATCH_CAP;
     const uint32_t* cnt_q = cnt + (size_t)b * BATCH_CAND_SEGS;
@@ -1168,9 +1168,10 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     };
     float s2;
     uint32_t p2;
+    static_assert(RescoreStage<RT>::BYTES >= (2048 + SECOND_CHANCE_K_ALL + 32) * 4, "second-chance scratch");
     const bool ok = second_chance<RT>(load, DENSE ? (n_rows < (uint32_t)BATCH_CAP ? n_rows : (uint32_t)BATCH_CAP) : (uint32_t)BATCH_CAP,
                                       DENSE ? NEG_INF : tau[b], q + (size_t)b * EM, x, found, eps, rescore_stage, sh_s, sh_p,
-                                      wave, lane, s2, p2);
+                                      wave, lane, s2, p2, SECOND_CHANCE_K_ALL);
     if (wave == 0 && ok) {
         if ((uint32_t)lane < found) {
             out_labels[(size_t)b * k + lane] = ids[p2];

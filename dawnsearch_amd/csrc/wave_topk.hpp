@@ -477,17 +477,21 @@ __device__ __forceinline__ uint32_t block_incl_scan_u32(uint32_t v, uint32_t* ld
     return (uint32_t)x + off;
 }
 
+// K: how many entries are rescored at most — 1024 (the streaming tails: the best 1024 of the workgroups' lists) or 8192 (the
+// matrix-core tails: EVERY candidate the pass appended, i.e. every row whose bound exceeds the pass's threshold — on topical
+// data a query inside a cluster of a few thousand near rows is settled here, 1024 rows per round, instead of by a stream of
+// the bounded pass).  scratch: (2048 + K + 32) * 4 bytes.
 constexpr uint32_t SECOND_CHANCE_K = 1024;
-constexpr int SECOND_CHANCE_LDS = (2048 + 1024 + 32) * 4;
+constexpr uint32_t SECOND_CHANCE_K_ALL = 8192;
 
 template <int RT, class LoadFn>
 __device__ __forceinline__ bool second_chance(LoadFn load, uint32_t n_entries, float base, const float* __restrict__ qv,
                                               const void* __restrict__ x, uint32_t found, float eps,
                                               unsigned char* scratch, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave,
-                                              int lane, float& out_s, uint32_t& out_p) {
+                                              int lane, float& out_s, uint32_t& out_p, const uint32_t K = SECOND_CHANCE_K) {
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* sel = hist + 2048;
-    uint32_t* misc = sel + 1024;  // [0] crossing bin (or ~0) [1] entries above it [2] selected count; [16..31] scan
+    uint32_t* misc = sel + K;  // [0] crossing bin (or ~0) [1] entries above it [2] selected count; [16..31] scan
     const uint32_t tid = threadIdx.x;
     uint32_t prefix = 0;       // bits fixed so far (pass 2: the crossing 11-bit bin of pass 1)
     uint32_t above_total = 0;  // entries strictly above the crossing bin(s)
@@ -510,7 +514,7 @@ __device__ __forceinline__ bool second_chance(LoadFn load, uint32_t n_entries, f
         const uint32_t c0 = hist[2047 - 2 * tid], c1 = hist[2046 - 2 * tid];
         const uint32_t incl = block_incl_scan_u32(c0 + c1, misc + 16, wave, lane);
         const uint32_t excl = incl - (c0 + c1);
-        const uint32_t budget = SECOND_CHANCE_K - above_total;  // entries that may still be taken
+        const uint32_t budget = K - above_total;  // entries that may still be taken
         if (excl <= budget && excl + c0 > budget) {
             misc[0] = 2047 - 2 * tid;
             misc[1] = excl;
@@ -540,24 +544,38 @@ __device__ __forceinline__ bool second_chance(LoadFn load, uint32_t n_entries, f
         if (!load(e, sc, row)) continue;
         if (take_all || (order_key(sc) >> 10) > edge22) {
             const uint32_t pos = atomicAdd(&misc[2], 1u);
-            if (pos < SECOND_CHANCE_K) sel[pos] = row;
+            if (pos < K) sel[pos] = row;
         }
     }
     __syncthreads();
     const uint32_t count = misc[2];
-    if (count > SECOND_CHANCE_K || count < found) return false;  // (the first cannot happen)
-    float d = POS_INF;
-    uint32_t row = NO_POS;
-    if (tid < count) {
-        row = sel[tid];
-        const float dd = __fsub_rn(1.0f, exact_dot_row<RT>(qv, x, row));
-        if (dd == dd) d = dd;
-        else row = NO_POS;
+    if (count > K || count < found) return false;  // (the first cannot happen)
+    // exact scores, 1024 rows per round (a thread per row), every round merged into the running top-64 held by wave 0
+    out_s = NEG_INF;
+    out_p = NO_POS;
+    for (uint32_t r0 = 0; r0 < count; r0 += 1024u) {
+        float d = POS_INF;
+        uint32_t row = NO_POS;
+        if (r0 + tid < count) {
+            row = sel[r0 + tid];
+            const float dd = __fsub_rn(1.0f, exact_dot_row<RT>(qv, x, row));
+            if (dd == dd) d = dd;
+            else row = NO_POS;
+        }
+        sort64_asc(d, row, lane);
+        float s = -d;
+        uint32_t pr = row;
+        if (wave == 0 && r0 > 0) {
+            const float os = __shfl(out_s, 63 - lane);
+            const uint32_t op = __shfl(out_p, 63 - lane);
+            merge64(s, pr, os, op, lane);
+        }
+        block_merge(s, pr, sh_s, sh_p, wave, lane, 16);
+        if (wave == 0) {
+            out_s = s;
+            out_p = pr;
+        }
     }
-    sort64_asc(d, row, lane);
-    out_s = -d;
-    out_p = row;
-    block_merge(out_s, out_p, sh_s, sh_p, wave, lane, 16);
     bool ok = false;
     if (wave == 0) {
         const uint32_t have = __popcll(__ballot(out_p != NO_POS));

@@ -606,7 +606,8 @@ def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, sha
     # 301 identical rows at the top: the 64-row certificate cannot hold, the 1024-row one does — no exact pass
     st = idx.stats()
     assert st["fallbacks"] == 0 and (st["second_chances"] == 1 if shadow != "i8" else 1 <= st["second_chances"] <= 8)
-    # 1500 identical rows are more than the second certificate looks at: the exact pass decides, same answer
+    # 1500 identical rows: more than the round-3 second certificate looked at (1024) — the second chance now rescores EVERY
+    # candidate of the pass (up to 8192): still no pass over the index
     rows3 = np.concatenate([base, np.repeat(base[11:12], 1500, axis=0)])
     ids3 = np.arange(1, len(rows3) + 1, dtype=np.uint64)
     idx3 = dawn.VectorIndex(0)
@@ -615,7 +616,18 @@ def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, sha
     for b in (0, 3, 15):
         _assert_same(l3[b], d3[b], *oracle.scan_topk(rows3, ids3, Q[b], 20))
     st3 = idx3.stats()
-    assert (st3["bounded"], st3["fallbacks"]) == ((1, 0) if shadow == "i8" else (0, 1))
+    assert (st3["bounded"], st3["fallbacks"]) == (0, 0) and st3["second_chances"] >= 1
+    # 9000 identical rows overflow the candidate buffer itself: the ladder decides — the bounded exact pass where the int8 shadow
+    # is kept, the exact pass over all rows otherwise —, same answer
+    rows4 = np.concatenate([base, np.repeat(base[11:12], 9000, axis=0)])
+    ids4 = np.arange(1, len(rows4) + 1, dtype=np.uint64)
+    idx4 = dawn.VectorIndex(0)
+    idx4.add_batch(ids4, rows4)
+    l4, d4, f4 = idx4.search_batch(Q, 20)
+    for b in (0, 3, 15):
+        _assert_same(l4[b], d4[b], *oracle.scan_topk(rows4, ids4, Q[b], 20))
+    st4 = idx4.stats()
+    assert (st4["bounded"], st4["fallbacks"]) == ((1, 0) if shadow == "i8" else (0, 1))
 
 
 def test_batched_clustered_index_overflow_falls_back(dawn, oracle, shadow):
