@@ -402,7 +402,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
                        idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->stream_dyn_tail ? idx->d_i6_pool : nullptr,
                        g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                       idx->force_fallback, true, stream, e0, e1, idx->d_stats);
+                       idx->force_fallback, true, stream, e0, e1, idx->d_stats, idx->i6_central_tail != 0);
     } else if (idx->shadow_small_batches && i8_live(idx)) {
         // 1..8 queries on the int8 shadow (384 B/row): the filter scores are upper bounds of the exact ones
         const ScanGeom& gh = idx->i8_geom();
@@ -806,6 +806,21 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_min_batch") {
         if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (n == "i6_dyn_chunk") {  // sub-tiles per chunk of the packed stream's dynamically assigned tail (default 16)
+        if (value < 1 || value > 256) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_chunk must be 1..256");
+        idx->geom_i6.chunk = idx->geom_i6_small.chunk = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "i6_dyn_share") {  // sixteenths of the index the packed stream hands out dynamically (default 2)
+        if (value < 1 || value > 15) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_share must be 1..15");
+        idx->geom_i6.dyn_share = idx->geom_i6_small.dyn_share = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "i6_central_tail") {  // 1: the packed stream's workgroups do not rescore their own 64 rows exactly; one merge_rescore_kernel
+                                   // rescores the index's 64 best by the refined score (deeper rounds, second chance behind it)
+        idx->i6_central_tail = value != 0;
         return DAWN_OK;
     }
     if (n == "stream_dynamic_tail") {  // 0: the single-query streams assign every sub-tile statically (A/B of the dynamic tails)

@@ -103,14 +103,19 @@ struct dawn_index {
     // / a whole one ahead; profiles/r03/stream_i5_ab_*.log): 100 M rows 8 waves x 4 loads 3551 us, 4 x 8 3523 (but half the waves
     // = half the depth of the coarse lists), 8 x 8 3622, 6 x 8 3670, int8 stream 5607; 12.5 M: 8 x 8 511, 8 x 4 516, int8 714;
     // 3 M: 159 / 174 / 186; 1 M: 90 / 95 / 75.
-    dawn::ScanGeom geom_i6{256, 512, 4};
-    dawn::ScanGeom geom_i6_small{256, 512, 12};
+    // The dynamically assigned tail (scan_i6.hip): chunks of 16 sub-tiles over the last 2/16 of a long stream; below kI6SmallRows
+    // chunks of 8 over the last 3/16 (12.5 M rows: stream kernel 496 -> 485 us; 100 M rows: +0.3 %).  Smaller chunks LOSE: a
+    // chunk costs a same-address scalar atomic, which this chip retires at ~8 M/s per address — 12.5 M rows with chunks of 4 / 2 / 1:
+    // +1 / +12 / +37 %, 100 M rows: +5 / +20 / +50 % (tools/stream_chunk_ab.py, profiles/r04/stream_dyn_chunk_ab.log).
+    dawn::ScanGeom geom_i6{256, 512, 4, 0, 16, 2};
+    dawn::ScanGeom geom_i6_small{256, 512, 12, 0, 8, 3};
     bool geom_i6_pinned = false;
     const dawn::ScanGeom& i6_geom() const { return (!geom_i6_pinned && size < dawn::kI6SmallRows) ? geom_i6_small : geom_i6; }
     float* d_cand_es = nullptr;
     float* d_cand_tb = nullptr;   // [blocks] the workgroups' bounds on their unlisted rows
     uint32_t* d_i6_pool = nullptr;  // [32] chunk counters of the dynamically assigned tail of the packed and the f32-row streams
     int stream_dyn_tail = 1;        // option "stream_dynamic_tail"
+    int i6_central_tail = 0;        // option "i6_central_tail": the packed stream hands its refined lists to merge_rescore_kernel
     uint32_t* d_cand_ep = nullptr;
     int debug_fail_alloc = 0;    // option "debug_fail_alloc" (tests): bit 0 / 1 / 2 = the int8 / f16 / 6-bit shadow allocation fails
     float* d_stage = nullptr;    // device staging ([stage_bytes]): bf16 adds / get_rows / fill, PageEntry records

@@ -108,6 +108,8 @@ struct ScanGeom {
     int threads;          // 1024 / 512 / 256
     int unroll = 2;       // row pairs per wave iteration (batch-1 kernel)
     int refine = 0;       // packed-shadow stream only: entries of its list a wave keeps and refines (0: chosen from N and k)
+    int chunk = 16;       // packed-shadow stream only: sub-tiles per chunk of the dynamically assigned tail ...
+    int dyn_share = 2;    // ... and the sixteenths of the index that tail covers
 };
 
 // Filter pass: approximate scores for all rows, per-block top-64 lists.
@@ -138,13 +140,17 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
-                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats = nullptr);
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats = nullptr,
+                    bool central_tail = false);
 void launch_prep_queries(const float* d_q, int B, const BatchWorkspace& ws, hipStream_t stream);
-// Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.
+// Merge the lists, rescore the 64 survivors exactly (reference order), certify, write results.  list_bounds [n_lists] (B == 1
+// only; the packed stream's tail): list l's own bound on the rows it does not hold, where that is not its 64th entry;
+// d_stats_packed: counters whose [STAT_PACKED_FAIL] is bumped when the query ends flagged for the ladder.
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k,
                           uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
-                          int force_fallback, float eps, hipStream_t stream, uint32_t* pool = nullptr);
+                          int force_fallback, float eps, hipStream_t stream, uint32_t* pool = nullptr,
+                          const float* list_bounds = nullptr, uint32_t* d_stats_packed = nullptr);
 // Batched search on the matrix cores (mfma_min_batch <= B <= BATCH_QT) over 16-bit rows: f16 / bf16 MFMA filter with sampled thresholds,
 // candidate append, exact rescore + certificate (scan_batched.hip).  ev0/ev1 bracket the full pass.
 struct BatchPlan {

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
                                                                const float2* __restrict__ meta8, float* __restrict__ out_s,
                                                                uint32_t* __restrict__ out_p, float* __restrict__ out_es,
                                                                uint32_t* __restrict__ out_ep, float* __restrict__ out_t,
-                                                               int n_refine_arg, uint32_t* __restrict__ pool) {
+                                                               int n_refine_arg, uint32_t* __restrict__ pool, int exact_epilogue,
+                                                               uint32_t chunk_arg) {
     static_assert(BITS == 6 ? 12 % PD == 0 : (PD == 8 || PD == 4), "ring depth");
     typedef PackedShadow<BITS> PS;
     __shared__ float sh_s[8][LIST];
@@ -296,7 +297,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     //   * a rotated static interleave (round i of wave w = sub-tile i W + ((w + 37 i) mod W)) changes nothing: the speed
     //     differences belong to the waves' places on the chip, not to their addresses (..._rotated_interleave_experiment.log).
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    constexpr uint32_t CHUNK = 16, POOLS = 32;
+    constexpr uint32_t POOLS = 32;
+    const uint32_t CHUNK = chunk_arg & 0xFFFFu;  // sub-tiles per chunk of the dynamic tail (16; option "i6_dyn_chunk")
+    const uint32_t SHARE16 = chunk_arg >> 16;     // sixteenths of the index handed out dynamically (2; option "i6_dyn_share")
     uint32_t static_left = NONE;  // further static sub-tiles of this wave (NONE: static to the end)
     uint32_t dyn0 = 0, n_chunks = 0, chunk_base = 0, chunk_i = CHUNK;
     // counters in use: one per group of eight workgroups, at most POOLS (a counter nobody reads would strand its chunks)
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
     uint32_t* my_pool = nullptr;
     if (pool != nullptr && n_sub / t_stride >= 16u) {
-        const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds / 8u;
+        const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds * SHARE16 / 16u;
         dyn0 = t_stride * i_static;
         n_chunks = (n_sub - dyn0 + CHUNK - 1u) / CHUNK;
         my_pool = pool + pool_id;
@@ -712,6 +715,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
             out_t[blockIdx.x] = tb;
         }
     }
+    // (central tail — option "i6_central_tail": the lists and the bound go to merge_rescore_kernel, which rescores the 64 best
+    // rows of the whole index exactly instead of every workgroup its own 64)
+    if (!exact_epilogue) return;
     __syncthreads();
     for (int i = threadIdx.x; i < LIST * S::CH; i += blockDim.x) {
         const int r = i / S::CH, chn = i % S::CH;
@@ -875,7 +881,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,
                     uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
-                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats) {
+                    bool merge, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, bool central_tail) {
     static OncePerDevice attr_once;
     const uint32_t* x = reinterpret_cast<const uint32_t*>(d_i6);
     const float2* mt = reinterpret_cast<const float2*>(d_meta);
@@ -901,14 +907,19 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
 #define DAWN_I6_LAUNCH(RT_, BITS_, PD_)                                                                                  \
     if (rt == RT_ && bits == BITS_ && pd == PD_)                                                                         \
         hipLaunchKernelGGL((scan_filter_i6s_kernel<RT_, BITS_, PD_>), dim3(g.blocks), dim3(g.threads),                  \
-                           RescoreStage<RT_>::BYTES, stream, x, mt, n_rows, d_q, d_rows,                                 \
+                           central_tail ? 0 : RescoreStage<RT_>::BYTES, stream, x, mt, n_rows, d_q, d_rows,              \
                            reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_i8meta), ub_s, ub_p,  \
-                           ex_s, ex_p, tb, n_refine, pool);
+                           ex_s, ex_p, tb, n_refine, pool, central_tail ? 0 : 1, (uint32_t)(g.chunk > 0 ? g.chunk : 16) | ((uint32_t)(g.dyn_share > 0 ? g.dyn_share : 2) << 16));
     DAWN_I6_EACH(DAWN_I6_LAUNCH)
 #undef DAWN_I6_LAUNCH
 #undef DAWN_I6_EACH
     if (ev1) (void)hipEventRecord(ev1, stream);
-    if (merge)
+    if (merge && central_tail)
+        // the tail of the other streams on the refined lists: the 64 best rows of the index by the tight score rescored exactly, the
+        // certificate against T = the largest of the workgroups' bounds (tb), deeper rounds and the 1024-row second chance behind it
+        launch_merge_rescore(d_rows, dtype, d_ids, n_rows, d_q, 1, ub_s, ub_p, g.blocks, k, d_labels, d_dist, d_found, d_flags,
+                             force_fallback, FILTER_EPS_I8, stream, pool, tb, d_stats);
+    else if (merge)
         hipLaunchKernelGGL(merge_exact_kernel, dim3(1), dim3(1024), 0, stream, d_ids, n_rows, tb, ex_s, ex_p, g.blocks, k,
                            d_labels, d_dist, d_found, d_flags, force_fallback, FILTER_EPS_I8, pool, d_stats);
     else if (pool != nullptr)

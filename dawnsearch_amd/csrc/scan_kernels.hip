@@ -444,7 +444,8 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     const void* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_p, int n_lists, uint32_t k,
     uint64_t* __restrict__ out_labels, float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
-    uint32_t* __restrict__ out_flags, int force_fallback, float eps, uint32_t* __restrict__ pool) {
+    uint32_t* __restrict__ out_flags, int force_fallback, float eps, uint32_t* __restrict__ pool,
+    const float* __restrict__ list_bounds, uint32_t* __restrict__ stats_packed) {
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ uint32_t sh_rows[LIST];
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
             for (int j = 0; j < INF; ++j) {
                 if (l0 + j * nwaves >= n_lists) continue;  // wave-uniform
                 if (first) t0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, os[j]))));
+                if (first && list_bounds) t0 = fmaxf(t0, list_bounds[l0 + j * nwaves]);
                 if (!first) {
                     // entries down to the last one already rescored drop out: they are a prefix of the (descending) list,
                     // so the survivors are sorted again with the fillers moved behind them
@@ -512,10 +514,14 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
     bool heavy;
     const uint32_t flag = certify_rounds<RT>(select, T, true, n_rows, found, eps, force_fallback, q_val, x,
                                              rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
+    // (the ladder feedback of an index watches how often the packed stream's queries end up flagged: dawn_index.cpp; a forced
+    // flag is not a failure; a flag the second chance lifts below is taken back there)
+    if (stats_packed && threadIdx.x == 0 && flag == FLAG_FALLBACK && !force_fallback) atomicAdd(&stats_packed[STAT_PACKED_FAIL], 1u);
     if (wave == 0) {
-        if ((uint32_t)lane < found && bp != NO_POS) {
-            out_labels[(size_t)b * k + lane] = ids[bp];
-            out_dist[(size_t)b * k + lane] = -bs;
+        if ((uint32_t)lane < found) {
+            // (slots without a candidate read as "no threshold" to the ladder behind a flag: scan_bounded.hip)
+            out_labels[(size_t)b * k + lane] = bp != NO_POS ? ids[bp] : 0ull;
+            out_dist[(size_t)b * k + lane] = bp != NO_POS ? -bs : POS_INF;
         }
         if (lane == 0) {
             out_found[b] = found;
@@ -542,14 +548,17 @@ __global__ __launch_bounds__(1024) void merge_rescore_kernel(
             out_labels[(size_t)b * k + lane] = ids[p2];
             out_dist[(size_t)b * k + lane] = -s2;
         }
-        if (lane == 0) out_flags[b] = FLAG_SECOND;
+        if (lane == 0) {
+            out_flags[b] = FLAG_SECOND;
+            if (stats_packed && !force_fallback) atomicSub(&stats_packed[STAT_PACKED_FAIL], 1u);
+        }
     }
 }
 
 void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B,
                           const float* cand_s, const uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels,
                           float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps,
-                          hipStream_t stream, uint32_t* pool) {
+                          hipStream_t stream, uint32_t* pool, const float* list_bounds, uint32_t* d_stats_packed) {
     static OncePerDevice attr_once;  // the f32 stage (97 KiB) is above the default dynamic-LDS limit
     once_per_device(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_rescore_kernel<0>),
@@ -559,10 +568,12 @@ void launch_merge_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uin
     });
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL(merge_rescore_kernel<1>, dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x, d_ids, n_rows,
-                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool);
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool,
+                           list_bounds, d_stats_packed);
     else
         hipLaunchKernelGGL(merge_rescore_kernel<0>, dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x, d_ids, n_rows,
-                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool);
+                           d_q, cand_s, cand_p, n_lists, k, d_labels, d_dist, d_found, d_flags, force_fallback, eps, pool,
+                           list_bounds, d_stats_packed);
 }
 
 // ------------------------------------------------------------------------------------------------

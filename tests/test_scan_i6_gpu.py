@@ -481,3 +481,24 @@ def test_k2_covers_the_worst_sub_tile(dawn, oracle, bits):
     # ... and the search itself: exact, as always
     idx.set_option("i6_refine", 0)
     _assert_same(*idx.search(q, 10), *oracle.scan_topk(rows, np.arange(1, 33, dtype=np.uint64), q, 10))
+
+
+@pytest.mark.parametrize("n", [65, 4097, 300_001])
+def test_i6_central_tail_and_tail_geometry_options_agree(dawn, oracle, n):
+    """Two measured-and-not-adopted variants stay selectable and exact: the central tail (option i6_central_tail: the refined
+    lists go to merge_rescore_kernel instead of every workgroup rescoring its own 64 rows — a wash, profiles/r04/
+    stream_central_tail_ab.log) and other chunk sizes / shares of the dynamically assigned tail."""
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 3), synth.planted_queries(1, [n // 2], 4)])
+    for opts in ({"i6_central_tail": 1}, {"i6_dyn_chunk": 2, "i6_dyn_share": 6}, {"i6_dyn_chunk": 64, "i6_dyn_share": 15},
+                 {"i6_central_tail": 1, "i6_dyn_chunk": 1}):
+        for o, v in opts.items():
+            idx.set_option(o, v)
+        for k in (10, 64):
+            for q in Q:
+                _assert_same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
+        idx.set_option("i6_central_tail", 0)
+    st = idx.stats()
+    assert st["fallbacks"] == 0
