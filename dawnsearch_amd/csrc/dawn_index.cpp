@@ -382,16 +382,15 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             } else {
                 ++fb.issued;
             }
+            if (idx->ladder_feedback == 2) demoted = true;  // (tests / A-B: the bounded pass is the whole search of every single query)
         }
         if (demoted) {
             // a demoted index: the bounded exact pass is the whole search (384 B/row, no certificate to fail)
             ++idx->n_demoted;
             launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
                                        idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
-                                       d_labels, d_dist, d_found, stream, e0, e1);
-            launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, 1, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
-                              idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream,
-                              idx->h_stats);
+                                       d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats,
+                                       idx->debug_bad_threshold ? -1.0f : __builtin_inff());
             DAWN_HIP_TRY(hipGetLastError());
             return DAWN_OK;
         }
@@ -427,15 +426,18 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                              (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags, idx->force_fallback, FILTER_EPS_F32, stream,
                              pool);
     }
-    // The ladder behind a failed certificate (both predicated on the query's flag, launch-only): the bounded exact pass on the
-    // int8 shadow (scan_bounded.hip: 384 B per row + the rows that can still matter), then — only if that did not answer — the
-    // exact pass over all rows.  force_fallback = 1 (tests of the exact pass) skips the first rung; 2 forces the flags only.
+    // The ladder behind a failed certificate, predicated on the query's flag (launch-only): an index that keeps an int8 shadow
+    // closes every search with the bounded exact pass (scan_bounded.hip: 384 B per row + the rows that can still matter; it
+    // cannot fail, keeps the certificate counters and mirrors them to the host), the others with the exact pass over all rows.
+    // force_fallback = 1 (tests of the exact pass) takes the second form; 2 forces the flags only.
     if (idx->bounded_pass && idx->force_fallback != 1 && i8_live(idx) && n > 0)
         launch_scan_bounded(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags,
                             idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
-                            d_dist, d_found, stream);
-    launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
-                      idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream, idx->h_stats);
+                            d_dist, d_found, stream, idx->d_stats, idx->h_stats);
+    else
+        launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
+                          idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream,
+                          idx->h_stats);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
 }
@@ -783,10 +785,17 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->force_fallback = (int)value;
         return DAWN_OK;
     }
-    if (n == "ladder_feedback") {  // 0: single queries of a large index always try the packed stream first (A/B, tests)
-        idx->ladder_feedback = value != 0;
+    if (n == "ladder_feedback") {  // 0: single queries of a large index always try the packed stream first (A/B, tests);
+                                   // 2: never — the bounded pass is their whole search (what a demoted index does)
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "ladder_feedback must be 0, 1 or 2");
+        idx->ladder_feedback = (int)value;
         idx->fb = dawn_index::LadderFeedback{};
         if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
+        return DAWN_OK;
+    }
+    if (n == "debug_bad_threshold") {  // test hook: a demoted search starts its bounded pass from an impossible threshold (-1): the
+                                       // pass must notice and its last workgroup scan all rows exactly instead
+        idx->debug_bad_threshold = value != 0;
         return DAWN_OK;
     }
     if (n == "bounded_pass") {  // 0: a failed certificate goes straight to the exact pass over all rows (round 3; A/B)

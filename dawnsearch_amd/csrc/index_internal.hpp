@@ -168,7 +168,8 @@ struct dawn_index {
     // demote_len single queries go to the bounded pass directly (doubling while the next probe window fails again, back to
     // kFbDemoteMin once one passes).  Results never depend on it.  Reset by every mutation and option (index_prepare_search).
     uint32_t* h_stats = nullptr;   // [N_STAT_SLOTS] pinned, device-visible
-    int ladder_feedback = 1;       // option "ladder_feedback"
+    int ladder_feedback = 1;       // option "ladder_feedback": 0 off, 1 adaptive, 2 every single query goes to the bounded pass directly
+    int debug_bad_threshold = 0;   // option "debug_bad_threshold" (tests)
     struct LadderFeedback {
         uint64_t issued = 0, win_issued0 = 0;  // packed single-query searches issued / at the start of the window
         uint32_t win_fail0 = 0;                // h_stats[STAT_PACKED_FAIL] at the start of the window

@@ -194,18 +194,21 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
                        int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
                        uint32_t* stats_mirror = nullptr);
 
-// Bounded exact pass (scan_bounded.hip; predicated per query on d_flags[b] == FLAG_FALLBACK, in front of the exact pass): streams
+// Bounded exact pass (scan_bounded.hip; predicated per query on d_flags[b] == FLAG_FALLBACK): streams
 // the int8 shadow, scores exactly every row whose upper bound can still reach the k-th best distance known so far (d_dist of
 // the failed stage), sets FLAG_BOUNDED.  cand_s / cand_p [B][n_lists][64]; d_done [B] arrival counters (zero before and after).
+// It is the LAST launch of a search (no exact pass behind it): d_stats / stats_mirror as for launch_scan_exact.
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
-                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream);
+                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
+                         uint32_t* d_stats, uint32_t* stats_mirror);
 // ... as the WHOLE search of one query (a demoted index, dawn_index.cpp: ladder feedback): the flag is raised and the threshold
 // starts at +inf — the waves' own k-th best distances are the thresholds.  ev0 / ev1 bracket the pass.
 void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids,
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
-                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
+                                float first_threshold = __builtin_inff());
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.

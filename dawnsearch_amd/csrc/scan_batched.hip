@@ -1135,9 +1135,10 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     const uint32_t flag = certify_rounds<RT>(select, base, !overflow, n_rows, found, eps, force_fallback, q_val, x,
                                              rescore_stage, sh_rows, sh_ctl, wave, lane, bs, bp, heavy);
     if (wave == 0) {
-        if ((uint32_t)lane < found && bp != NO_POS) {
-            out_labels[(size_t)b * k + lane] = ids[bp];
-            out_dist[(size_t)b * k + lane] = -bs;
+        if ((uint32_t)lane < found) {
+            // (slots without a candidate read as "no threshold" to the ladder behind a flag: scan_bounded.hip)
+            out_labels[(size_t)b * k + lane] = bp != NO_POS ? ids[bp] : 0ull;
+            out_dist[(size_t)b * k + lane] = bp != NO_POS ? -bs : POS_INF;
         }
         if (lane == 0) {
             out_found[b] = found;

@@ -19,8 +19,11 @@
 //     rows per wave at a time, and enters the wave's exact top-64;
 //   * D tightens as the wave finds better rows (its own k-th best distance is an upper bound of the final one too);
 //   * the last workgroup to finish merges the exact lists and checks the ONE assumption it made: that the threshold it was given
-//     was a valid upper bound — its own k-th distance must not exceed it.  (It cannot, unless the failed stage's result was not
-//     k distinct rows; then the flag stays FLAG_FALLBACK and the exact pass answers.)
+//     was a valid upper bound — its own k-th distance must not exceed it.  It cannot, unless the failed stage's result was not
+//     k distinct rows (no producer of this library writes such a result); should it happen all the same, that workgroup scans
+//     all rows exactly by itself (block_exact_scan: slow, correct) and the query counts as a fallback.
+//   * this pass is the LAST launch of a search on an index that keeps an int8 shadow (the exact pass over all rows closes the
+//     searches of the others): it keeps the index's certificate counters and mirrors them to the host (see scan_exact_kernel).
 // Cost: one int8 stream (100 M rows: 5.5 ms) + 1536 B for every row within the int8 slack of the k-th score — a few hundred rows on
 // isotropic data, the dense part of a cluster on topical data — read at the exact pass's rate (lane-per-row walks, 4.6 TB/s with
 // every wave of the chip at it): it degrades towards the exact pass's cost as the data gets denser, never beyond it + 5.5 ms.
@@ -36,6 +39,50 @@ namespace dawn {
 constexpr float BOUNDED_MARGIN = 1.0e-4f;
 constexpr int kBoundedMaxFlags = 256;
 
+// The safety net of the bounded pass: exact top-64 of query qv over ALL rows by ONE workgroup (scan_exact_kernel's loop with the
+// workgroup's own waves as the whole grid).  Result in wave 0.  ~N / 256 row walks per lane: seconds on 100 M rows — it exists so
+// that an impossible threshold can never become a wrong answer, not to be fast.
+template <int RT>
+__device__ __noinline__ void block_exact_scan(const float* __restrict__ qv, const void* __restrict__ rows, uint32_t n_rows,
+                                              float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], float& s, uint32_t& p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    float ls = NEG_INF, tau = NEG_INF;
+    uint32_t lp = NO_POS;
+    const uint32_t n_groups = (n_rows + 63u) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64u + lane;
+        float key = NEG_INF;
+        if (r < n_rows) {
+            const float d = __fsub_rn(1.0f, exact_dot_row<RT>(qv, rows, r));
+            key = (d == d) ? -d : NEG_INF;
+        }
+        unsigned long long hits = __ballot(key > tau);  // (rows arrive in ascending order)
+        while (hits) {
+            const int src = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), src));
+            if (ks > tau) {
+                wave_insert(ls, lp, ks, g * 64u + (uint32_t)src, lane);
+                tau = read_lane63(ls);
+            }
+        }
+    }
+    block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
+    s = ls;
+    p = lp;
+}
+
+// What scan_exact_kernel does for the searches it closes: the queries' final flags into the index's counters (the flagged ones
+// are counted when this pass has answered them), and a copy of the counters to the host.  Block 0, after the flags were read.
+__device__ __forceinline__ void bounded_count_and_mirror(uint32_t myflag, uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
+    if (!stats || blockIdx.x != 0) return;
+    if (myflag != FLAG_OK && myflag != FLAG_FALLBACK) atomicAdd(&stats[myflag], 1u);
+    __syncthreads();
+    if (mirror && threadIdx.x < (unsigned)N_STAT_SLOTS) mirror[threadIdx.x] = atomicAdd(&stats[threadIdx.x], 0u);
+}
+
 template <int RT, int PD>
 __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
                                                                const void* __restrict__ rows, const uint64_t* __restrict__ ids,
@@ -43,7 +90,8 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                                                                uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
                                                                float* __restrict__ out_s, uint32_t* __restrict__ out_p,
                                                                uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
-                                                               float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
+                                                               float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
+                                                               uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
     static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
     __shared__ float sh_s[4][LIST];
     __shared__ uint32_t sh_p[4][LIST];
@@ -64,6 +112,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
         const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
         const unsigned long long m = __ballot(myflag == FLAG_FALLBACK);
         if (lane == 0) sh_mask[wave] = m;
+        bounded_count_and_mirror(myflag, stats, mirror);
     }
     __syncthreads();
     for (int w = 0; w < kBoundedMaxFlags / 64; ++w) {
@@ -297,17 +346,22 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                     const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)found - 1));
                     valid = dk <= d_in;  // the threshold this pass started from was an upper bound of the k-th distance
                 }
-                if (valid) {
-                    if ((uint32_t)lane < found) {
-                        out_labels[(size_t)b * k + lane] = ids[pp];
-                        out_dist[(size_t)b * k + lane] = -s;
-                    }
-                    if (lane == 0) {
-                        out_found[b] = found;
-                        flags[b] = FLAG_BOUNDED;
-                    }
+                if (lane == 0) sh_last = valid ? 1u : 2u;
+            }
+            __syncthreads();
+            const bool valid = sh_last == 1u;
+            if (!valid) block_exact_scan<RT>(qv, rows, n_rows, sh_s, sh_p, s, pp);  // (never, see the header)
+            if (wave == 0) {
+                if ((uint32_t)lane < found) {
+                    out_labels[(size_t)b * k + lane] = ids[pp];
+                    out_dist[(size_t)b * k + lane] = -s;
                 }
-                if (lane == 0) done[b] = 0u;
+                if (lane == 0) {
+                    out_found[b] = found;
+                    if (valid) flags[b] = FLAG_BOUNDED;
+                    if (stats) atomicAdd(&stats[valid ? FLAG_BOUNDED : FLAG_FALLBACK], 1u);
+                    done[b] = 0u;
+                }
             }
         }
         __syncthreads();  // the shared state is reused by the next query
@@ -348,7 +402,8 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
                                                                      uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
                                                                      float* __restrict__ out_s, uint32_t* __restrict__ out_p,
                                                                      uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
-                                                                     float* __restrict__ out_dist, uint32_t* __restrict__ out_found) {
+                                                                     float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
+                                                                     uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
     static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char bounded_lds[];
     BoundedMultiLds& S = *reinterpret_cast<BoundedMultiLds*>(bounded_lds);
@@ -362,9 +417,11 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
     // the flagged queries, in order (every workgroup reads the flags before any of them is rewritten: a query is finished by
     // the last workgroup to arrive, after all of them have been here)
     {
-        const bool fl = (int)threadIdx.x < n_q && flags[threadIdx.x] == FLAG_FALLBACK;
+        const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
+        const bool fl = myflag == FLAG_FALLBACK;
         const unsigned long long m = __ballot(fl);
         if (lane == 0) S.mask[wave] = m;
+        bounded_count_and_mirror(myflag, stats, mirror);
         __syncthreads();
         uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(S.mask[w]);
@@ -623,17 +680,23 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
                         const float dk = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (int)found - 1));
                         valid = dk <= S.d_in[sidx];
                     }
-                    if (valid) {
-                        if ((uint32_t)lane < found) {
-                            out_labels[(size_t)b * k + lane] = ids[pp];
-                            out_dist[(size_t)b * k + lane] = -s;
-                        }
-                        if (lane == 0) {
-                            out_found[b] = found;
-                            flags[b] = FLAG_BOUNDED;
-                        }
+                    if (lane == 0) S.last = valid ? 1u : 2u;
+                }
+                __syncthreads();
+                const bool valid = S.last == 1u;
+                if (!valid) block_exact_scan<RT>(q + (size_t)b * EM, rows, n_rows, S.merge_s, S.merge_p, s, pp);  // (never)
+                if (wave == 0) {
+                    if ((uint32_t)lane < found) {
+                        out_labels[(size_t)b * k + lane] = ids[pp];
+                        out_dist[(size_t)b * k + lane] = -s;
+                    }
+                    if (lane == 0) {
+                        out_found[b] = found;
+                        if (valid) flags[b] = FLAG_BOUNDED;
+                        if (stats) atomicAdd(&stats[valid ? FLAG_BOUNDED : FLAG_FALLBACK], 1u);
                     }
                 }
+                __syncthreads();  // (S.last is rewritten for the next query)
             }
             if (threadIdx.x == 0) done[b_first] = 0u;
         }
@@ -646,7 +709,8 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
 // (the filter's own, free by now); d_done [B]: arrival counters, zero before and after.  B <= 256 per launch.
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
-                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream) {
+                         int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
+                         uint32_t* d_stats, uint32_t* stats_mirror) {
     static OncePerDevice attr_once;
     once_per_device(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 6>),
@@ -660,7 +724,8 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
         const int nb = B - b0 < kBoundedMaxFlags ? B - b0 : kBoundedMaxFlags;
 #define DAWN_BOUNDED_ARGS                                                                                                      \
     x8, mt, d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,       \
-        cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0
+        cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0,   \
+        d_stats, stats_mirror
         if (B == 1) {  // one query: its list stays in registers
             if (dtype == ROW_BF16)
                 hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
@@ -678,23 +743,23 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     }
 }
 
-__global__ void bounded_prime_kernel(uint32_t* __restrict__ flags, float* __restrict__ out_dist, uint32_t k, uint32_t found) {
+__global__ void bounded_prime_kernel(uint32_t* __restrict__ flags, float* __restrict__ out_dist, uint32_t found, float threshold) {
     if (threadIdx.x == 0) {
         flags[0] = FLAG_FALLBACK;
-        if (found > 0) out_dist[found - 1] = POS_INF;
+        if (found > 0) out_dist[found - 1] = threshold;
     }
-    (void)k;
 }
 
 void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids,
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
-                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
+                                float first_threshold) {
     const uint32_t found = n_rows < k ? n_rows : k;
-    hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, k, found);
+    hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, found, first_threshold);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_scan_bounded(d_i8, d_i8meta, d_x, dtype, d_ids, n_rows, d_q, 1, d_flags, d_done, cand_s, cand_p, n_lists, k, d_labels,
-                        d_dist, d_found, stream);
+                        d_dist, d_found, stream, d_stats, stats_mirror);
     if (ev1) (void)hipEventRecord(ev1, stream);
 }
 

@@ -74,7 +74,14 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      behind it answers (bounded exact pass first)
  *   "bounded_pass"     0: a failed certificate goes straight to the exact pass over all rows (A/B of the ladder); default 1
  *   "ladder_feedback"  0: single queries of a large index always try the packed stream first, however often its certificate
- *                      fails (default 1: full refinement lists above 5 % failures, the bounded pass directly above 35 %)
+ *                      fails (default 1: full refinement lists above 5 % failures, the bounded pass directly above 35 %);
+ *                      2: never — the bounded pass is their whole search (what a demoted index does; A/B, tests)
+ *   "debug_bad_threshold" test hook: a demoted search starts its bounded pass from an impossible threshold; the pass notices and
+ *                      its last workgroup scans all rows exactly (counted as a fallback)
+ *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
+ *                      the index's 64 best by the refined score (measured: a wash; default 0)
+ *   "i6_dyn_chunk" / "i6_dyn_share"   the packed stream's dynamically assigned tail: sub-tiles per chunk (default 16; 8 below 32 Mi
+ *                      rows) and sixteenths of the index it covers (2; 3)
  *   "debug_i8_levels"  experiment hook (process-wide): quantise the int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
  *                      what a coarser shadow would cost the certificates (tools/coarse_shadow_probe.py); results stay exact
  *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (6-bit shadow -> int8 shadow -> f16 shadow -> the

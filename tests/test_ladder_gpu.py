@@ -242,3 +242,26 @@ def test_ladder_feedback_demotes_and_recovers(dawn, oracle):
             idx2.search(q, 10)
     st = idx2.stats()
     assert st["demoted"] == 0 and st["packed_failures"] == 0 and st["bounded"] == 0 and st["fallbacks"] == 0
+
+
+def test_bounded_pass_notices_an_impossible_threshold(dawn, oracle):
+    """The one assumption of the bounded pass — the threshold it starts from bounds the final k-th distance from above — is
+    checked by its last workgroup; no producer of the library hands over a threshold that fails it, so a test hook does: the
+    workgroup then scans all rows exactly by itself (slow, correct) and the query counts as a fallback."""
+    n = 60_000
+    idx = dawn.VectorIndex(0)
+    idx.set_option("i6_min_rows", 0)
+    idx.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 2), synth.planted_queries(1, [n // 3], 4)])
+    idx.set_option("ladder_feedback", 2)  # every single query: the bounded pass alone, started without a threshold
+    for q in Q:
+        _same(*idx.search(q, 10), *oracle.scan_topk(x, ids, q, 10))
+    st = idx.stats()
+    assert st["demoted"] == 3 and st["bounded"] == 3 and st["fallbacks"] == 0 and st["packed_failures"] == 0, st
+    idx.set_option("debug_bad_threshold", 1)
+    for q in Q:
+        _same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20))
+    st = idx.stats()
+    assert st["demoted"] == 6 and st["bounded"] == 3 and st["fallbacks"] == 3, st
