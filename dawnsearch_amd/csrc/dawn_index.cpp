@@ -270,6 +270,73 @@ bool i6_shadow_sync(dawn_index* idx) {
     return true;
 }
 
+// The FP6 shadow of batches (scan_f6.hip) and its workspaces; released when switched off.  false: not live.
+void f6_release(dawn_index* idx) {
+    if (!idx->d_f6 && !idx->d_f6meta && !idx->f6ws.cand_big) return;
+    (void)hipDeviceSynchronize();
+    void* p[] = {idx->d_f6, idx->d_f6meta, idx->f6ws.qf6, idx->f6ws.qmeta, idx->f6ws.tau6, idx->f6ws.cand_big, idx->f6ws.cnt_big};
+    for (void* q : p)
+        if (q) (void)hipFree(q);
+    idx->d_f6 = nullptr;
+    idx->d_f6meta = nullptr;
+    const int target = idx->f6ws.target;
+    idx->f6ws = dawn::F6Workspace{};
+    idx->f6ws.target = target;
+    idx->f6_cap = idx->f6_rows = 0;
+}
+bool f6_shadow_sync(dawn_index* idx) {
+    hipStream_t stream = idx->stream;
+    const bool wanted = idx->use_f6 && idx->use_i8 && idx->i8_batched && !idx->f6_failed && idx->size >= idx->f6_min_rows && idx->size > 0;
+    if (!wanted) {
+        f6_release(idx);
+        return false;
+    }
+    if (!idx->f6ws.cand_big) {
+        const size_t big = (size_t)dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * idx->f6ws.seg_cap_big * 8;
+        if (hipMalloc(&idx->f6ws.qf6, 16 * 3 * 64 * 6 * 4) != hipSuccess || hipMalloc(&idx->f6ws.qmeta, dawn::BATCH_QT * 8) != hipSuccess ||
+            hipMalloc((void**)&idx->f6ws.tau6, dawn::BATCH_QT * 4) != hipSuccess || hipMalloc(&idx->f6ws.cand_big, big) != hipSuccess ||
+            hipMalloc((void**)&idx->f6ws.cnt_big, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->f6_failed = true;
+            f6_release(idx);
+            return false;
+        }
+        (void)hipMemsetAsync(idx->f6ws.cnt_big, 0, dawn::BATCH_QT * dawn::BATCH_CAND_SEGS * 4, stream);
+    }
+    if (idx->f6_cap < idx->cap_phys) {
+        const size_t prow = padded_rows(idx->cap_phys) + 128;
+        const size_t bytes = prow * 288, mbytes = (prow / 16 + 1) * 8;
+        (void)hipDeviceSynchronize();
+        if (idx->d_f6) (void)hipFree(idx->d_f6);
+        if (idx->d_f6meta) (void)hipFree(idx->d_f6meta);
+        idx->d_f6 = nullptr;
+        idx->d_f6meta = nullptr;
+        idx->f6_cap = idx->f6_rows = 0;
+        char* ns = nullptr;
+        float* nm = nullptr;
+        if (!enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess || hipMalloc((void**)&nm, mbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ns) (void)hipFree(ns);
+            idx->f6_failed = true;
+            f6_release(idx);
+            return false;
+        }
+        (void)hipMemsetAsync(ns, 0, bytes, stream);
+        (void)hipMemsetAsync(nm, 0, mbytes, stream);
+        idx->d_f6 = ns;
+        idx->d_f6meta = nm;
+        idx->f6_cap = idx->cap_phys;
+    }
+    if (idx->f6_rows < idx->size) {
+        dawn::launch_rows_to_f6s(idx->d_x, idx->dtype, idx->d_f6, idx->d_f6meta, idx->f6_rows, idx->size, stream);
+        idx->f6_rows = idx->size;
+    }
+    return true;
+}
+bool f6_live(const dawn_index* idx) {
+    return idx->use_f6 && idx->d_f6 && idx->f6_rows == idx->size && idx->size >= idx->f6_min_rows && idx->f6ws.cand_big;
+}
+
 bool i8_live(const dawn_index* idx);
 // (its stream refines the listed rows on the int8 shadow: no int8 shadow, no packed stream)
 bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size && i8_live(idx); }
@@ -315,6 +382,7 @@ int index_prepare_search(dawn_index* idx) {
     }
     if (!f16_needed) f16_shadow_release(idx);
     (void)i6_shadow_sync(idx);  // single queries stream the 6-bit shadow (released when not wanted)
+    (void)f6_shadow_sync(idx);  // batches of a large index filter on the FP6 shadow first (option "f6_shadow")
     if (f16_needed) f16_shadow_sync(idx);
     DAWN_HIP_TRY(hipGetLastError());
     return DAWN_OK;
@@ -332,7 +400,16 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     }
     const uint32_t n = (uint32_t)idx->size;
     const bool batched = (int)B >= idx->mfma_min_batch;
-    if (batched && idx->i8_batched && i8_live(idx)) {
+    if (batched && idx->i8_batched && i8_live(idx) && f6_live(idx) && n > (uint32_t)BATCH_CAP) {
+        // matrix-core path with the FP6 shadow as first filter (scan_f6.hip), its survivors re-scored on the int8 shadow
+        for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
+            const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
+            launch_scan_batched_f6(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_f6, idx->d_f6meta, idx->d_ids, n,
+                                   d_q + b0 * EM, (int)nb, (uint32_t)k, idx->bws, idx->f6ws, idx->mfma_blocks, d_labels + b0 * k,
+                                   d_dist + b0 * k, d_found + b0, idx->d_flags + b0, idx->force_fallback, stream,
+                                   b0 == 0 ? e0 : nullptr, b0 == 0 ? e1 : nullptr);
+        }
+    } else if (batched && idx->i8_batched && i8_live(idx)) {
         // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
         for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
             const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
@@ -508,6 +585,7 @@ void index_destroy_single(dawn_index* idx) {
         if (p) (void)hipFree(p);
     if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
     if (idx->h_stats) (void)hipHostFree(idx->h_stats);
+    f6_release(idx);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
 }
@@ -638,6 +716,7 @@ int index_clear(dawn_index* idx) {
     idx->shadow_rows = 0;
     idx->i8_rows = 0;
     idx->i6_rows = 0;
+    idx->f6_rows = 0;
     return DAWN_OK;
 }
 
@@ -761,6 +840,10 @@ int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_
         const uint64_t prow = padded_rows(idx->i6_cap) + 128;
         shadows += prow * idx->i6_row_bytes() + (prow / 32 + 1) * 8;
     }
+    if (idx->d_f6) {
+        const uint64_t prow = padded_rows(idx->f6_cap) + 128;
+        shadows += prow * 288 + (prow / 16 + 1) * 8;
+    }
     uint64_t other = (uint64_t)std::max<size_t>(idx->cap_phys, idx->d_ids ? 1 : 0) * sizeof(uint64_t);  // ids
     if (idx->d_cand_s) other += (uint64_t)idx->ws_B * idx->ws_lists * LIST * 8 + 2 * idx->ws_B * 4 + 16;
     if (idx->bws.cand) other += (uint64_t)BATCH_QT * (EM * 2 + 4 + BATCH_CAND_SEGS * 4 + (uint64_t)BATCH_CAP * 8);
@@ -815,6 +898,21 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "mfma_min_batch") {
         if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
+        return DAWN_OK;
+    }
+    if (n == "f6_shadow") {  // 1: batches of an index of >= f6_min_rows rows filter on the FP6 shadow first (scan_f6.hip)
+        idx->use_f6 = value != 0;
+        if (value) idx->f6_failed = false;
+        return reprepare();
+    }
+    if (n == "f6_min_rows") {
+        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "f6_min_rows must be >= 0");
+        idx->f6_min_rows = (size_t)value;
+        return reprepare();
+    }
+    if (n == "f6_target") {  // survivors per query the FP6 threshold aims for (twice that for count > 32)
+        if (value < 256 || value > 24576) return fail(DAWN_ERR_INVALID_ARG, "f6_target must be 256..24576");
+        idx->f6ws.target = (int)value;
         return DAWN_OK;
     }
     if (n == "i6_dyn_chunk") {  // sub-tiles per chunk of the packed stream's dynamically assigned tail (default 16)
@@ -1494,6 +1592,28 @@ int dawn_index_debug_filter_scores(dawn_index* idx, const float* queries, size_t
     DAWN_HIP_TRY(hipGetLastError());
     DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float),
                                   n * sizeof(float), B, hipMemcpyDeviceToHost, idx->stream));
+    DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return DAWN_OK;
+}
+
+// Test hook: the FP6 shadow's upper-bound scores (scan_f6.hip) of B <= 256 queries against rows [0, n), n = min(size, 8192):
+// out [B][n].  Needs option "f6_shadow" = 1 (and "f6_min_rows" <= size).
+int dawn_index_debug_f6_scores(dawn_index* idx, const float* queries, size_t B, float* out, size_t* n_out) {
+    if (!idx || !queries || !out || !n_out) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "debug hooks take a single-device index");
+    if (B == 0 || B > (size_t)dawn::BATCH_QT) return fail(DAWN_ERR_INVALID_ARG, "B must be 1..%d", dawn::BATCH_QT);
+    DAWN_TRY(flush_adds(idx));
+    DAWN_TRY(set_device(idx));
+    if (!f6_live(idx)) return fail(DAWN_ERR_UNSUPPORTED, "the index keeps no FP6 shadow (options f6_shadow / f6_min_rows)");
+    const size_t n = std::min<size_t>(idx->size, dawn::BATCH_CAP);
+    *n_out = n;
+    if (n == 0) return DAWN_OK;
+    DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, queries, B * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    dawn::launch_f6_dense_scores(idx->d_f6, idx->d_f6meta, (uint32_t)idx->size, idx->d_q, (int)B, idx->f6ws.qf6, idx->f6ws.qmeta,
+                                 reinterpret_cast<float*>(idx->bws.cand), idx->stream);
+    DAWN_HIP_TRY(hipGetLastError());
+    DAWN_HIP_TRY(hipMemcpy2DAsync(out, n * sizeof(float), idx->bws.cand, dawn::BATCH_CAP * sizeof(float), n * sizeof(float), B,
+                                  hipMemcpyDeviceToHost, idx->stream));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     return DAWN_OK;
 }

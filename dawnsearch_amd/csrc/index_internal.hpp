@@ -111,6 +111,16 @@ struct dawn_index {
     dawn::ScanGeom geom_i6_small{256, 512, 12, 0, 8, 3};
     bool geom_i6_pinned = false;
     const dawn::ScanGeom& i6_geom() const { return (!geom_i6_pinned && size < dawn::kI6SmallRows) ? geom_i6_small : geom_i6; }
+    // FP6 (e2m3) shadow (ROW_F6S, scan_f6.hip: 288 B/row + 8 B per 16 rows): the FIRST filter of batches on a large index —
+    // 1.5 x the int8 matrix rate under the chip's power envelope; its survivors are re-scored on the int8 shadow.  Option
+    // "f6_shadow" (default 0: measured in bench legs, not the default path yet); kept current by the mutations like the others.
+    char* d_f6 = nullptr;
+    float* d_f6meta = nullptr;
+    size_t f6_cap = 0, f6_rows = 0;
+    int use_f6 = 0;              // option "f6_shadow"
+    size_t f6_min_rows = 8u << 20;  // option "f6_min_rows": batches of smaller indexes take the int8 pass
+    bool f6_failed = false;
+    dawn::F6Workspace f6ws{};
     float* d_cand_es = nullptr;
     float* d_cand_tb = nullptr;   // [blocks] the workgroups' bounds on their unlisted rows
     uint32_t* d_i6_pool = nullptr;  // [32] chunk counters of the dynamically assigned tail of the packed and the f32-row streams

@@ -175,6 +175,26 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
                             uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
                             uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,
                             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+// FP6 (e2m3) shadow of the rows and the batched search that uses it as its FIRST filter (scan_f6.hip)
+struct F6Workspace {
+    void* qf6 = nullptr;         // [16 groups][3 k-steps][64 lanes][6 dwords] e2m3 query images (B-operand order)
+    void* qmeta = nullptr;       // [BATCH_QT] float2 {s_q, ||dq||_2}
+    float* tau6 = nullptr;       // [BATCH_QT]
+    void* cand_big = nullptr;    // [BATCH_QT][BATCH_CAND_SEGS][seg_cap_big] uint2 (bound bits, row): survivors of the FP6 pass
+    uint32_t* cnt_big = nullptr; // [BATCH_QT][BATCH_CAND_SEGS], zero between searches
+    uint32_t seg_cap_big = 2048;
+    int target = 12288;          // survivors per query the FP6 threshold aims for (twice that for k > 32); option "f6_target"
+};
+void launch_rows_to_f6s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid, hipStream_t stream);
+void launch_f6_dense_scores(const void* d_f6, const void* d_meta, uint32_t n_rows, const float* d_q, int B, void* d_qf6, void* d_qmeta,
+                            float* d_out, hipStream_t stream);
+void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const void* d_i8meta, const void* d_f6, const void* d_f6meta,
+                            const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws,
+                            const F6Workspace& f6, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
+                            int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+// the int8 batched path's sampling passes alone: queries -> int8 images, ws.tau = its sampled thresholds, counters at zero
+void launch_i8_sample_thresholds(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B, uint32_t k,
+                                 const BatchWorkspace& ws, int grid, hipStream_t stream);
 // Test hook: dense filter scores of rows [0, min(n_rows, BATCH_CAP)) -> ws.cand viewed as float [BATCH_QT][BATCH_CAP].
 void launch_batched_dense_scores(const void* d_x, int dtype, uint32_t n_rows, const float* d_q, int B,
                                  const BatchWorkspace& ws, int grid, hipStream_t stream);

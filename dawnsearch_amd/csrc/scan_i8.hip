@@ -1608,6 +1608,26 @@ void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32
                     reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, n_tiles < (uint32_t)grid ? n_tiles : (uint32_t)grid, stream);
 }
 
+// The sampling passes of the batched int8 search alone (scan_f6.hip runs its own full pass behind them): queries -> int8 images,
+// ws.tau = the sampled thresholds (rank ~ws.target), segment counters left at zero.  n_rows > BATCH_CAP.
+void launch_i8_sample_thresholds(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B, uint32_t k,
+                                 const BatchWorkspace& ws, int grid, hipStream_t stream) {
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target, k);
+    signed char* qi = reinterpret_cast<signed char*>(ws.qh);
+    float2* qm = reinterpret_cast<float2*>(qi + (size_t)BATCH_QT * EM);
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(BATCH_QT), dim3(64), 0, stream, d_q, B, qi, qm);
+    const unsigned char* xs = reinterpret_cast<const unsigned char*>(d_i8);
+    const float2* mt = reinterpret_cast<const float2*>(d_meta);
+    const uint32_t b1 = pl.s1_tiles < (uint32_t)grid ? pl.s1_tiles : (uint32_t)grid;
+    launch_i8_dense(xs, mt, n_rows, pl.s1_stride, pl.s1_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, b1, stream);
+    launch_tau_select(true, B, ws, pl.s1_tiles * I8_TILE_ROWS, pl.m1, stream);
+    if (pl.s2_tiles) {
+        const uint32_t b2 = pl.s2_tiles < (uint32_t)grid ? pl.s2_tiles : (uint32_t)grid;
+        launch_i8_append(xs, mt, n_rows, pl.s2_stride, pl.s2_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, b2, stream);
+        launch_tau_select(false, B, ws, 0u, pl.m2, stream);
+    }
+}
+
 void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids,
                             uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid,
                             uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags, int force_fallback,

@@ -166,6 +166,14 @@ class VectorIndex:
         return tmp[:, :n.value]
 
 
+    def debug_f6_scores(self, queries: np.ndarray) -> np.ndarray:
+        """Test hook: the FP6 shadow's upper-bound scores of the queries against rows [0, min(size, 8192)) (option f6_shadow)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, EM_LEN)
+        n = C.c_size_t(0)
+        tmp = np.zeros((q.shape[0], min(self.size(), 8192)), dtype=np.float32)
+        check(lib.dawn_index_debug_f6_scores(self._h, _ptr(q), q.shape[0], _ptr(tmp), C.byref(n)))
+        return tmp[:, :n.value]
+
     def debug_time_full_pass(self, B: int, iters: int = 5) -> float:
         """Timing hook: mean ms of the matrix-core full pass alone (after a batched search set the thresholds)."""
         ms = C.c_double(0.0)

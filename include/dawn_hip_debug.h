@@ -25,6 +25,8 @@ int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_m
 /* Test hook: the matrix-core FILTER scores (f16 MFMA, before the exact rescore) of B <= 256 queries against
  * rows [0, n), n = min(size, 8192): out [B][n].  Lets a test check the bound the certificate relies on. */
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
+/* Test hook: the same for the FP6 (e2m3) shadow of the rows (scan_f6.hip; options "f6_shadow" = 1, "f6_min_rows"): upper bounds. */
+int dawn_index_debug_f6_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
@@ -78,6 +80,10 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      2: never — the bounded pass is their whole search (what a demoted index does; A/B, tests)
  *   "debug_bad_threshold" test hook: a demoted search starts its bounded pass from an impossible threshold; the pass notices and
  *                      its last workgroup scans all rows exactly (counted as a fallback)
+ *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 8 Mi) filter on an FP6 (e2m3) shadow of the rows
+ *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
+ *                      envelope), its survivors are re-scored on the int8 shadow; "f6_target" = survivors per query its threshold
+ *                      aims for (12288; twice that for count > 32).  Default 0
  *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
  *                      the index's 64 best by the refined score (measured: a wash; default 0)
  *   "i6_dyn_chunk" / "i6_dyn_share"   the packed stream's dynamically assigned tail: sub-tiles per chunk (default 16; 8 below 32 Mi

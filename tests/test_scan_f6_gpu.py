@@ -1,0 +1,130 @@
+"""GPU parity tests of the FP6 (e2m3) first filter of batched searches (dawnsearch_amd/csrc/scan_f6.hip; option "f6_shadow").
+
+A batch on a large index can filter on a 6-bit floating-point copy of the rows first — v_mfma_scale_f32_16x16x128_f8f6f4 runs at
+1.5 x the int8 matrix rate under the chip's power envelope — and re-score the survivors on the int8 shadow; the common tail and its
+certificates take over from there.  Held here, forced on small indexes (option "f6_min_rows" = 0): the FP6 scores are UPPER BOUNDS
+of the exact scores on every kind of row, and the search results equal the CPU oracle's (oracle/dawn_oracle.c:
+src/search/vector.rs:128-134 + exact top-k) bit for bit, like every other path.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from dawnsearch_amd import synth  # noqa: E402
+
+from test_scan_gpu import _adversarial_rows, _assert_same  # noqa: E402
+
+
+def _mk(dawn, n, dtype="f32", dist=0):
+    idx = dawn.VectorIndex(0, dtype=dtype)
+    idx.set_option("f6_min_rows", 0)
+    idx.set_option("f6_shadow", 1)
+    if dist:
+        idx.set_option("synth_dist", dist)
+    idx.fill_synthetic(1, 0, n, 1)
+    return idx
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 33, 1000, 8192])
+def test_f6_scores_are_upper_bounds(dawn, n):
+    """ub = s s_q acc + E + K2 >= x.q for every row and query (exact integer-like accumulation, measured E and ||dq||), and not
+    absurdly loose (< 0.16 on unit vectors)."""
+    idx = _mk(dawn, n)
+    x = synth.unit_rows(1, 0, n)
+    Q = np.concatenate([synth.unit_rows(2, 0, 20), synth.planted_queries(1, [n // 2], 4)])
+    onehot = np.zeros((1, 384), np.float32)
+    onehot[0, 5] = 1.0
+    Q = np.concatenate([Q, onehot, -x[:1]])
+    ub = idx.debug_f6_scores(Q)
+    assert ub.shape == (len(Q), n)
+    exact = Q.astype(np.float64) @ x.astype(np.float64).T
+    slack = ub.astype(np.float64) - exact
+    assert slack.min() > -4e-6, slack.min()
+    assert slack.max() < 0.16, slack.max()
+
+
+def test_f6_bounds_on_adversarial_and_topical_rows(dawn):
+    rows, base, extra = _adversarial_rows(3000)
+    rows = rows[:8192]
+    idx = dawn.VectorIndex(0)
+    idx.set_option("f6_min_rows", 0)
+    idx.set_option("f6_shadow", 1)
+    idx.add_batch(np.arange(1, len(rows) + 1, dtype=np.uint64), rows)
+    Q = np.stack([synth.unit_rows(2, 0, 1)[0], extra[7], base[9], -base[9]])
+    ub = idx.debug_f6_scores(Q)
+    exact = Q.astype(np.float64) @ rows.astype(np.float64).T
+    assert (ub.astype(np.float64) - exact).min() > -4e-6
+    idx2 = _mk(dawn, 8192, dist=4)
+    x2 = synth.unit_rows_topical(1, 0, 8192)
+    Q2 = synth.unit_rows_topical(1, 1 << 40, 8)
+    ub2 = idx2.debug_f6_scores(Q2)
+    assert (ub2.astype(np.float64) - Q2.astype(np.float64) @ x2.astype(np.float64).T).min() > -4e-6
+
+
+@pytest.mark.parametrize("n", [8193, 20_000, 300_001])
+@pytest.mark.parametrize("k", [10, 20, 64])
+def test_f6_batched_search_matches_oracle(dawn, oracle, n, k):
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(2, 0, 30), synth.planted_queries(1, [0, n // 2, n - 1], 9)])
+    lab, dist, found = idx.search_batch(Q, k)
+    for b, q in enumerate(Q):
+        assert found[b] == k
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(x, ids, q, k, threads=8))
+    # identical to the int8 pass's answers, and the shadow's memory goes back when it is switched off
+    m1 = idx.memory()["shadows"]
+    idx.set_option("f6_shadow", 0)
+    assert m1 - idx.memory()["shadows"] >= n * 288
+    lab0, dist0, _ = idx.search_batch(Q, k)
+    assert np.array_equal(lab, lab0) and np.array_equal(dist.view(np.uint32), dist0.view(np.uint32))
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_f6_batch_of_256_on_1m_rows_and_adds(dawn, oracle):
+    n = 1_000_000
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(3, 0, 256)
+    Q[7] = synth.planted_queries(1, [4242], 5)[0]
+    lab, dist, found = idx.search_batch(Q, 10)
+    for b in list(range(0, 256, 17)) + [7, 255]:
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10, threads=8))
+    assert lab[7][0] == 4243
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["bounded"] <= 2, st
+    # rows added afterwards are in the FP6 shadow too (the last partial tile is re-quantised)
+    extra = synth.unit_rows(9, 0, 37)
+    idx.add_batch(np.arange(n + 1, n + 38, dtype=np.uint64), extra)
+    Q2 = np.stack([extra[3], extra[36], Q[0]])
+    lab2, dist2, _ = idx.search_batch(Q2, 10)
+    xx = np.concatenate([x, extra])
+    ii = np.arange(1, n + 38, dtype=np.uint64)
+    for b in range(3):
+        _assert_same(lab2[b], dist2[b], *oracle.scan_topk(xx, ii, Q2[b], 10, threads=8))
+    assert lab2[0][0] == n + 4 and lab2[1][0] == n + 37
+
+
+def test_f6_on_topical_rows_and_a_bf16_index(dawn, oracle):
+    n = 200_000
+    idx = _mk(dawn, n, dist=4)
+    Q = np.concatenate([synth.unit_rows_topical(1, (1 << 40) + 256 * i, 1) for i in range(24)])
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, 10, dist=4)
+    lab, dist, found = idx.search_batch(Q, 10)
+    for b in range(len(Q)):
+        _assert_same(lab[b], dist[b], want[0][b], want[1][b])
+    assert idx.stats()["fallbacks"] == 0
+    idh = _mk(dawn, 50_000, dtype="bf16")
+    xh = synth.round_bf16(oracle.unit_rows(1, 0, 50_000))
+    ids = np.arange(1, 50_001, dtype=np.uint64)
+    Qh = synth.unit_rows(2, 0, 12)
+    lab, dist, found = idh.search_batch(Qh, 20)
+    for b in range(12):
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(xh, ids, Qh[b], 20))
