@@ -637,6 +637,10 @@ def main():
         try:
             tj = json.load(open(traffic_file))
             key = f"{rows_local}x{B}"
+            if "mfma_busy_frac_12500000x256" in tj:
+                # matrix-pipe utilisation of the batched pass (north_star: "MFMA utilisation ... vs chip peak"): from the committed PMC run
+                out["mfma_busy_frac"] = {"value": tj["mfma_busy_frac_12500000x256"], "kernel": "scan_i8_pipe16_kernel<false>",
+                                         "workload": "12.5 M rows x 256 queries", "source": tj.get("_note_mfma_busy")}
             if key in tj:
                 out["roofline"]["traffic"] = tj[key]
                 out["roofline"]["traffic_source"] = ("HBM bytes per launch from the committed PMC pass (profiles/traffic.json: "

@@ -279,9 +279,10 @@ void f6_release(dawn_index* idx) {
         if (q) (void)hipFree(q);
     idx->d_f6 = nullptr;
     idx->d_f6meta = nullptr;
-    const int target = idx->f6ws.target;
+    const int target = idx->f6ws.target, stagger = idx->f6ws.stagger;
     idx->f6ws = dawn::F6Workspace{};
     idx->f6ws.target = target;
+    idx->f6ws.stagger = stagger;
     idx->f6_cap = idx->f6_rows = 0;
 }
 bool f6_shadow_sync(dawn_index* idx) {
@@ -909,6 +910,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "f6_min_rows must be >= 0");
         idx->f6_min_rows = (size_t)value;
         return reprepare();
+    }
+    if (n == "f6_stagger") {  // tiles the waves of the FP6 pass start apart (0: all four waves on the same tile)
+        if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be 0..4096");
+        idx->f6ws.stagger = (int)value;
+        return DAWN_OK;
     }
     if (n == "f6_target") {  // survivors per query the FP6 threshold aims for (twice that for count > 32)
         if (value < 256 || value > 24576) return fail(DAWN_ERR_INVALID_ARG, "f6_target must be 256..24576");

@@ -298,32 +298,76 @@ void launch_f6_dense_scores(const void* d_f6, const void* d_meta, uint32_t n_row
 //   else:  (bound, row) of every pair above tau[query] -> the query's candidate buffer (segment blockIdx % 16), staged per wave in LDS
 // ------------------------------------------------------------------------------------------------
 constexpr int F6_RING = 4;
-constexpr uint32_t F6_STAGE = 320;  // staged hits per wave (a (group, register) step adds at most 64)
+constexpr uint32_t F6_STAGE = 1344;  // staged hits per wave (a tile adds at most 16 x 64 = 1024: one flush check per tile)
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __restrict__ x, const float2* __restrict__ meta, uint32_t n_rows,
                                                             uint32_t stride, uint32_t n_visits, const uint32_t* __restrict__ qf6,
                                                             const float2* __restrict__ qmeta, int n_q, const float* __restrict__ tau,
                                                             uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t seg_cap,
-                                                            float* __restrict__ dense) {
+                                                            float* __restrict__ dense, uint32_t stagger) {
     __shared__ uint32_t stage[4][F6_STAGE][3];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t G = gridDim.x;
-    uint32_t vis = blockIdx.x;  // this workgroup's visits: vis, vis + G, ...
-    // the rows first
+    // This workgroup's visits: blockIdx.x, + G, ... (n_mine of them); wave w walks them starting `stagger` x w positions in, so
+    // that the four waves have DIFFERENT tiles in flight (four waves on one tile at a time keep 18 KB in flight per CU: the pass is
+    // then bound by memory latency, 15 ms per 100 M x 256) while a tile still comes from HBM once and from L2 / MALL three times.
+    const uint32_t n_mine = n_visits > blockIdx.x ? (n_visits - blockIdx.x + G - 1u) / G : 0u;
+    const uint32_t p0 = n_mine ? ((uint32_t)wave * stagger) % n_mine : 0u;
+    auto visit_of = [&](uint32_t pos) __attribute__((always_inline)) -> uint32_t {  // pos may run past n_mine: wraps (valid memory)
+        if (n_mine == 0u) return 0u;
+        uint32_t q = p0 + pos;
+        q = q >= n_mine ? q - n_mine : q;
+        q = q >= n_mine ? q % n_mine : q;
+        return blockIdx.x + q * G;
+    };
+    uint32_t vis = 0;  // position in the walk
+    // The rows first: a ring of F6_RING tiles (3 x (16 + 8) B per lane each), asm loads under a hand-counted vmcnt.  hipcc cannot
+    // count this ring itself: at the head of the unrolled loop its waitcnt pass merges the states of the two ways in and waits for
+    // EVERYTHING (vmcnt(0)) before the first tile of every iteration — the ring drained every four tiles and a pass over 100 M
+    // rows took 14-16 ms against the 5.1 ms its mix sustains bare (profiles/r04/f6_ab_*.log).  The MFMA's A operand is SIX
+    // consecutive registers filled by two loads; the slot's registers are therefore moved into the operand by the same asm
+    // statement that waits for them (six v_mov in the shadow of the MFMAs) — with the wait as a separate statement, hipcc copied the
+    // slot in FRONT of it (stale data, wrong answers).  Loads return in order: when tile v is consumed, the 3 x 6 loads of the tiles
+    // v + 1 .. v + 3 may still be in flight.
     u32x4 alo[F6_RING][3];
     u32x2 ahi[F6_RING][3];
+    // (plain loads, not nt: the four waves of a workgroup read the same lines one after the other — the first from HBM, the others
+    // should find them in L2)
+#define DAWN_F6_LD4(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
+#define DAWN_F6_LD2(DST, PTR, OFF) asm volatile("global_load_dwordx2 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
     auto load_tile = [&](int slot, uint32_t v) __attribute__((always_inline)) {
         const uint32_t* t = x + (size_t)(v < n_visits ? v * stride : 0u) * F6_TILE_DW;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            alo[slot][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(t + ks * F6_KS_DW) + lane);
-            ahi[slot][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(t + ks * F6_KS_DW + 256) + lane);
-        }
+        const uint32_t* p4 = t + lane * 4;        // [64 lanes x 16 B] of k-step 0
+        const uint32_t* p2 = t + 256 + lane * 2;  // [64 lanes x 8 B]
+        DAWN_F6_LD4(alo[slot][0], p4, 0);
+        DAWN_F6_LD2(ahi[slot][0], p2, 0);
+        DAWN_F6_LD4(alo[slot][1], p4, 1536);
+        DAWN_F6_LD2(ahi[slot][1], p2, 1536);
+        DAWN_F6_LD4(alo[slot][2], p4, 3072);
+        DAWN_F6_LD2(ahi[slot][2], p2, 3072);
+    };
+    // wait for the slot's loads (N younger loads may stay in flight) and move fragment ks into six registers of their own
+    auto take = [&](int slot, int ks, auto n_tag) __attribute__((always_inline)) -> i32x8_t {
+        constexpr int N = decltype(n_tag)::value;
+        int o0, o1, o2, o3, o4, o5;
+        if constexpr (N >= 0)
+            asm volatile("s_waitcnt vmcnt(%12)\n\tv_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\t"
+                         "v_mov_b32 %4, %10\n\tv_mov_b32 %5, %11"
+                         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5)
+                         : "v"(alo[slot][ks].x), "v"(alo[slot][ks].y), "v"(alo[slot][ks].z), "v"(alo[slot][ks].w), "v"(ahi[slot][ks].x),
+                           "v"(ahi[slot][ks].y), "n"(N));
+        else
+            asm volatile("v_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\tv_mov_b32 %4, %10\n\t"
+                         "v_mov_b32 %5, %11"
+                         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5)
+                         : "v"(alo[slot][ks].x), "v"(alo[slot][ks].y), "v"(alo[slot][ks].z), "v"(alo[slot][ks].w), "v"(ahi[slot][ks].x),
+                           "v"(ahi[slot][ks].y));
+        return i32x8_t{o0, o1, o2, o3, o4, o5, 0, 0};
     };
 #pragma unroll
-    for (int d = 0; d < F6_RING; ++d) load_tile(d, vis + (uint32_t)d * G);
+    for (int d = 0; d < F6_RING; ++d) load_tile(d, visit_of((uint32_t)d));
     // the wave's query images and per-lane constants
     i32x8_t bq[4][3];
     float thrA[4], thrB[4], thrC[4], sq_l[4], dqn_l[4], tau_l[4];
@@ -359,19 +403,25 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
         n_stage = 0;
     };
 
-    for (; vis < n_visits; vis += (uint32_t)F6_RING * G) {
+    // Two loops.  The INNER one — up to 16 x F6_RING tiles — touches no memory but the ring's loads and the wave's LDS stage, so
+    // that hipcc can count its waits (a global atomic anywhere in a loop makes its waitcnt pass drain the ring, vmcnt(0), at
+    // every tile of that loop); the stage is flushed between two runs of it.  A tile whose hits do not fit the stage any more
+    // (> 1000 pairs within a few tiles: no data does that) drops them and marks the wave's queries as overflowed — the tail then
+    // sends them to the ladder.
+    bool lost = false;
+    while (vis < n_mine) {
+      for (int it = 0; it < 16 && vis < n_mine && (DENSE || n_stage <= F6_STAGE - 1024u); ++it, vis += (uint32_t)F6_RING) {
 #pragma unroll
         for (int d = 0; d < F6_RING; ++d) {
-            const uint32_t v = vis + (uint32_t)d * G;
-            if (v >= n_visits) break;  // (workgroup-uniform)
+            if (vis + (uint32_t)d >= n_mine) break;  // (workgroup-uniform)
+            const uint32_t v = visit_of(vis + (uint32_t)d);
             const uint32_t tile = v * stride;
             const float2 mt = meta[tile];
             i32x8_t av[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-                av[ks] = i32x8_t{(int)alo[d][ks].x, (int)alo[d][ks].y, (int)alo[d][ks].z, (int)alo[d][ks].w, (int)ahi[d][ks].x,
-                                 (int)ahi[d][ks].y, 0, 0};
-            load_tile(d, v + (uint32_t)F6_RING * G);
+            av[0] = take(d, 0, std::integral_constant<int, 6 * (F6_RING - 1)>());  // (in-order returns: the whole tile has landed)
+            av[1] = take(d, 1, std::integral_constant<int, -1>());
+            av[2] = take(d, 2, std::integral_constant<int, -1>());
+            load_tile(d, visit_of(vis + (uint32_t)d + (uint32_t)F6_RING));
             f32x4 acc[4];
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
@@ -417,22 +467,34 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
                             const bool hit = acc[gg][r] > thr[gg] && ub > tau_l[gg] && row0 + (uint32_t)r < n_rows;
                             const unsigned long long m = __ballot(hit);
                             if (m) {
-                                if (n_stage + 64u > F6_STAGE) flush();
                                 if (hit) {
                                     const uint32_t slot = n_stage + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                                    st[slot][0] = __builtin_bit_cast(uint32_t, ub);
-                                    st[slot][1] = row0 + (uint32_t)r;
-                                    st[slot][2] = qi;
+                                    if (slot < F6_STAGE) {
+                                        st[slot][0] = __builtin_bit_cast(uint32_t, ub);
+                                        st[slot][1] = row0 + (uint32_t)r;
+                                        st[slot][2] = qi;
+                                    } else {
+                                        lost = true;
+                                    }
                                 }
                                 n_stage += (uint32_t)__popcll(m);
+                                if (n_stage > F6_STAGE) n_stage = F6_STAGE;
                             }
                         }
                     }
                 }
             }
         }
+      }
+      if (!DENSE && n_stage > 0u) flush();
     }
-    if (!DENSE && n_stage > 0u) flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's last loads: nothing may be in flight when the wave ends)
+#undef DAWN_F6_LD4
+#undef DAWN_F6_LD2
+    if (!DENSE && __any(lost)) {  // (never on real data: see above)
+        const uint32_t qi = (uint32_t)(64 * wave + lane);
+        if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,13 +623,13 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     {
         const uint32_t blocks = pl.s1_tiles < (uint32_t)grid ? pl.s1_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, pl.s1_stride, pl.s1_tiles, qf6,
-                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand));
+                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u);
         launch_tau_select(true, B, w6, pl.s1_tiles * 16u, pl.m1, stream);
     }
     {
         const uint32_t blocks = pl.s2_tiles < (uint32_t)grid ? pl.s2_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, pl.s2_stride, pl.s2_tiles, qf6,
-                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand));
+                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u);
         launch_tau_select(false, B, w6, 0u, pl.m2, stream);
     }
     hipLaunchKernelGGL(f6_merge_tau_kernel, dim3(1), dim3(256), 0, stream, ws.tau, f6.tau6, B);
@@ -576,7 +638,7 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     {
         const uint32_t blocks = pl.n_tiles < (uint32_t)grid ? pl.n_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 1u, pl.n_tiles, qf6, qm6, B,
-                           f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big, nullptr);
+                           f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big, nullptr, (uint32_t)f6.stagger);
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
     // 4. survivors -> int8 bound -> the ordinary candidate buffers

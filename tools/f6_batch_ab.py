@@ -18,6 +18,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 targets = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [12288]
 dist = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+staggers = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 else [8]
 dev = torch.device("cuda", 0)
 idx = dawn.VectorIndex(0)
 if dist:
@@ -45,16 +46,17 @@ for k in (10, 20):
     nb = dawn.result_blob_bytes(B, k)
     blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
     p = blob.data_ptr()
-    cfgs = [("int8 pass", 0, 0)] + [(f"FP6 first filter, target {t}", 1, t) for t in targets]
+    cfgs = [("int8 pass", 0, 0, 0)] + [(f"FP6 first filter, target {t}, stagger {sg}", 1, t, sg) for t in targets for sg in staggers]
     res = {c[0]: [] for c in cfgs}
     ker = {c[0]: [] for c in cfgs}
     st = {}
     ans = {}
     for r in range(rounds):
-        for name, f6, tgt in cfgs:
+        for name, f6, tgt, sg in cfgs:
             idx.set_option("f6_shadow", f6)
             if f6:
                 idx.set_option("f6_target", tgt)
+                idx.set_option("f6_stagger", sg)
             for _ in range(2):
                 idx.search_device(d_q.data_ptr(), B, k, p, p + B * k * 8, p + B * k * 12, stream)
             torch.cuda.synchronize()
@@ -74,7 +76,7 @@ for k in (10, 20):
             raw = blob.cpu().numpy()
             ans[name] = (raw[:B * k * 8].copy(), raw[B * k * 8:B * k * 12].copy())
     base = ans["int8 pass"]
-    for name, _, _ in cfgs:
+    for name, _, _, _ in cfgs:
         same = np.array_equal(ans[name][0], base[0]) and np.array_equal(ans[name][1], base[1])
-        print(f"rows={rows} B={B} k={k} {name:34s}: ms per batch {[round(v, 3) for v in res[name]]} best {min(res[name]):.3f}; pass kernel ms "
+        print(f"rows={rows} B={B} k={k} {name:46s}: ms per batch {[round(v, 3) for v in res[name]]} best {min(res[name]):.3f}; pass kernel ms "
               f"{[round(v, 3) for v in ker[name]]}; rates {st[name]}; identical to the int8 pass: {same}", flush=True)
