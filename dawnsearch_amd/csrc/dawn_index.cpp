@@ -911,8 +911,8 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->f6_min_rows = (size_t)value;
         return reprepare();
     }
-    if (n == "f6_stagger") {  // tiles the waves of the FP6 pass start apart (0: all four waves on the same tile)
-        if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be 0..4096");
+    if (n == "f6_stagger") {  // -1: the LDS-staged FP6 pass (default); >= 0: the register-ring pass, its waves this many tiles apart
+        if (value < -1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -1..4096");
         idx->f6ws.stagger = (int)value;
         return DAWN_OK;
     }

@@ -297,7 +297,7 @@ void launch_f6_dense_scores(const void* d_f6, const void* d_meta, uint32_t n_row
 //   DENSE: every bound of the visited tiles -> dense[query][visit * 16 + row]  (the strided sample)
 //   else:  (bound, row) of every pair above tau[query] -> the query's candidate buffer (segment blockIdx % 16), staged per wave in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int F6_RING = 4;
+constexpr int F6_RING = 3;
 constexpr uint32_t F6_STAGE = 1344;  // staged hits per wave (a tile adds at most 16 x 64 = 1024: one flush check per tile)
 
 template <bool DENSE>
@@ -335,12 +335,13 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
     u32x2 ahi[F6_RING][3];
     // (plain loads, not nt: the four waves of a workgroup read the same lines one after the other — the first from HBM, the others
     // should find them in L2)
-#define DAWN_F6_LD4(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
-#define DAWN_F6_LD2(DST, PTR, OFF) asm volatile("global_load_dwordx2 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
+    // (scalar base + per-lane 32-bit offset: the tile's address costs no vector instruction)
+#define DAWN_F6_LD4(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(off4), "s"(PTR))
+#define DAWN_F6_LD2(DST, PTR, OFF) asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(off2), "s"(PTR))
+    const uint32_t off4 = (uint32_t)lane * 16u, off2 = 1024u + (uint32_t)lane * 8u;  // byte offsets inside k-step 0
     auto load_tile = [&](int slot, uint32_t v) __attribute__((always_inline)) {
-        const uint32_t* t = x + (size_t)(v < n_visits ? v * stride : 0u) * F6_TILE_DW;
-        const uint32_t* p4 = t + lane * 4;        // [64 lanes x 16 B] of k-step 0
-        const uint32_t* p2 = t + 256 + lane * 2;  // [64 lanes x 8 B]
+        const uint32_t* p4 = x + (size_t)(v < n_visits ? v * stride : 0u) * F6_TILE_DW;  // (wave-uniform)
+        const uint32_t* p2 = p4;
         DAWN_F6_LD4(alo[slot][0], p4, 0);
         DAWN_F6_LD2(ahi[slot][0], p2, 0);
         DAWN_F6_LD4(alo[slot][1], p4, 1536);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
         tau_l[gg] = (!DENSE && qi < n_q) ? tau[qi] : POS_INF;
         thrA[gg] = 1.0f / qm.x;
         thrB[gg] = tau_l[gg] - 1.015f * qm.y;
-        thrC[gg] = 1.0f + qm.y;
+        thrC[gg] = -(1.0f + qm.y);
     }
     uint32_t n_stage = 0;  // wave-uniform
     uint32_t(*st)[3] = stage[wave];
@@ -452,8 +453,8 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
                 float thr[4];
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
-                    const float u = __builtin_fmaf(-mt.y, thrC[gg], thrB[gg]) * (mt.x * thrA[gg]);
-                    thr[gg] = u - fabsf(u) * 4e-6f - 1e-3f;
+                    // (acc is a multiple of 1/64; the f32 rounding of this expression is < 1e-4 at |thr| < 1000: 0.02 below is safe)
+                    thr[gg] = __builtin_fmaf(__builtin_fmaf(mt.y, thrC[gg], thrB[gg]), mt.x * thrA[gg], -0.02f);
                     any = any || fmaxf(fmaxf(acc[gg][0], acc[gg][1]), fmaxf(acc[gg][2], acc[gg][3])) > thr[gg];
                 }
                 if (__any(any)) {
@@ -493,6 +494,171 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
 #undef DAWN_F6_LD2
     if (!DENSE && __any(lost)) {  // (never on real data: see above)
         const uint32_t qi = (uint32_t)(64 * wave + lane);
+        if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The full pass, staged through LDS.  The kernel above has each of its four waves load every tile itself: the rows then cross
+// L2 -> L1 -> registers four times (115 GB per 100 M rows) with one wave per SIMD and nothing to hide a stall behind — 16-17 ms per
+// 100 M x 256 whatever the ring, the load form or the hit rate (profiles/r04/f6_ab_*.log).  Here a workgroup of EIGHT waves takes
+// groups of 8 consecutive tiles (36864 B, contiguous): every thread copies 4 x 16 B + 8 B of the NEXT group global -> registers
+// while the current group is worked on, registers -> LDS (double buffer, one barrier per group), and a tile's fragments are read
+// from LDS by the four waves that hold the four quarters of the batch: waves 0-3 take the even tiles of a group, waves 4-7 the odd
+// ones, so that each SIMD has two waves to overlap.  Every byte of the shadow is read from HBM once and crosses L2 once.
+// ------------------------------------------------------------------------------------------------
+constexpr int F6L_GROUP = 8;                                       // tiles per group
+constexpr uint32_t F6L_GROUP_BYTES = F6L_GROUP * F6_TILE_DW * 4u;  // 36864
+constexpr uint32_t F6L_STAGE = 448;                                // staged hits per wave
+constexpr uint32_t F6L_FLUSH_AT = 192;                             // flush between groups above this
+struct F6PassLds {
+    uint32_t tiles[2][F6L_GROUP_BYTES / 4];
+    uint32_t stage[8][F6L_STAGE][3];
+};
+
+__global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* __restrict__ x, const float2* __restrict__ meta,
+                                                                uint32_t n_rows, uint32_t n_tiles, const uint32_t* __restrict__ qf6,
+                                                                const float2* __restrict__ qmeta, int n_q, const float* __restrict__ tau,
+                                                                uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t seg_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char f6l_raw[];
+    F6PassLds& L = *reinterpret_cast<F6PassLds*>(f6l_raw);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qw = wave & 3, half = wave >> 2;
+    const uint32_t G = gridDim.x;
+    const uint32_t n_groups = (n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
+    // the wave's query images and per-lane constants
+    i32x8_t bq[4][3];
+    float thrA[4], thrB[4], thrC[4], sq_l[4], dqn_l[4], tau_l[4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        const int g = 4 * qw + gg;
+        const int qi = 16 * g + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const uint32_t* bp = qf6 + (((size_t)g * 3 + ks) * 64 + lane) * 6;
+            const u32x2 b01 = *reinterpret_cast<const u32x2*>(bp), b23 = *reinterpret_cast<const u32x2*>(bp + 2),
+                        b45 = *reinterpret_cast<const u32x2*>(bp + 4);
+            bq[gg][ks] = i32x8_t{(int)b01.x, (int)b01.y, (int)b23.x, (int)b23.y, (int)b45.x, (int)b45.y, 0, 0};
+        }
+        const float2 qm = qmeta[qi];
+        sq_l[gg] = qm.x;
+        dqn_l[gg] = qm.y;
+        tau_l[gg] = qi < n_q ? tau[qi] : POS_INF;
+        thrA[gg] = 1.0f / qm.x;
+        thrB[gg] = tau_l[gg] - 1.015f * qm.y;
+        thrC[gg] = -(1.0f + qm.y);
+    }
+    uint32_t n_stage = 0;  // wave-uniform
+    uint32_t(*st)[3] = L.stage[wave];
+    const uint32_t seg = blockIdx.x % (uint32_t)BATCH_CAND_SEGS;
+    bool lost = false;
+
+    // the copy of one group: thread t moves the 16-B pieces t, t + 512, t + 1024, t + 1536 and the 8-B piece 4096 + t / 2 ...
+    // (the shadow is padded by 8 tiles of zeros: a group that starts inside the index never reads outside the allocation)
+    u32x4 pre4[4];
+    u32x2 pre2;
+    float2 pre_m = float2{0.f, 0.f};
+    auto prefetch = [&](uint32_t grp) __attribute__((always_inline)) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + (size_t)grp * F6L_GROUP_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            pre4[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + ((uint32_t)threadIdx.x + 512u * (uint32_t)r) * 16u));
+        pre2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(base + 32768u + (uint32_t)threadIdx.x * 8u));
+        if (lane < F6L_GROUP) pre_m = meta[(size_t)grp * F6L_GROUP + (uint32_t)lane];
+    };
+    uint32_t grp = blockIdx.x;
+    if (grp < n_groups) prefetch(grp);
+    int buf = 0;
+    for (; grp < n_groups; grp += G, buf ^= 1) {
+        unsigned char* tb = reinterpret_cast<unsigned char*>(L.tiles[buf]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<u32x4*>(tb + ((uint32_t)threadIdx.x + 512u * (uint32_t)r) * 16u) = pre4[r];
+        *reinterpret_cast<u32x2*>(tb + 32768u + (uint32_t)threadIdx.x * 8u) = pre2;
+        const float2 cur_m = pre_m;
+        __syncthreads();  // (one barrier per group: the buffer written now was last read two groups ago, before the previous barrier)
+        if (grp + G < n_groups) prefetch(grp + G);
+        auto read_tile = [&](int t, i32x8_t (&av)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const unsigned char* f = tb + (uint32_t)t * (F6_TILE_DW * 4u) + (uint32_t)ks * (F6_KS_DW * 4u);
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(f + lane * 16);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(f + 1024 + lane * 8);
+                av[ks] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+            }
+        };
+        i32x8_t av[2][3];
+        read_tile(half, av[0]);
+#pragma unroll
+        for (int tt = 0; tt < F6L_GROUP / 2; ++tt) {
+            const int t = half + 2 * tt;
+            if (tt + 1 < F6L_GROUP / 2) read_tile(t + 2, av[(tt + 1) & 1]);
+            const uint32_t tile = grp * (uint32_t)F6L_GROUP + (uint32_t)t;
+            const float2 mt = float2{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_m.x), t)),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_m.y), t))};
+            f32x4 acc[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) acc[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)  // (k-step outside: four independent accumulators back to back)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    acc[gg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av[tt & 1][ks], bq[gg][ks], acc[gg], 2, 2, 0, 0x7F7F7F7F, 0,
+                                                                                0x7F7F7F7F);
+            if (tile >= n_tiles) continue;  // (workgroup-uniform; the padding of the last group)
+            const float s = __builtin_amdgcn_rcpf(mt.x);
+            const uint32_t row0 = tile * 16u + 4u * (uint32_t)(lane >> 4);
+            // acc > thr  <=  ub = acc s s_q + E + (1.015 + E) dqn > tau   (thr a little low: hits are re-tested on ub itself)
+            float thr[4], over = NEG_INF;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                thr[gg] = __builtin_fmaf(__builtin_fmaf(mt.y, thrC[gg], thrB[gg]), mt.x * thrA[gg], -0.02f);
+                over = fmaxf(over, fmaxf(fmaxf(acc[gg][0], acc[gg][1]), fmaxf(acc[gg][2], acc[gg][3])) - thr[gg]);
+            }
+            if (__any(over > 0.f)) {
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const uint32_t qi = (uint32_t)(16 * (4 * qw + gg) + (lane & 15));
+                    const float g1 = s * sq_l[gg], g0 = mt.y + (1.015f + mt.y) * dqn_l[gg];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float ub = __builtin_fmaf(acc[gg][r], g1, g0);
+                        const bool hit = acc[gg][r] > thr[gg] && ub > tau_l[gg] && row0 + (uint32_t)r < n_rows;
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {
+                            if (hit) {
+                                const uint32_t slot = n_stage + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                                if (slot < F6L_STAGE) {
+                                    st[slot][0] = __builtin_bit_cast(uint32_t, ub);
+                                    st[slot][1] = row0 + (uint32_t)r;
+                                    st[slot][2] = qi;
+                                } else {
+                                    lost = true;
+                                }
+                            }
+                            n_stage += (uint32_t)__popcll(m);
+                            if (n_stage > F6L_STAGE) n_stage = F6L_STAGE;
+                        }
+                    }
+                }
+            }
+        }
+        if (n_stage > F6L_FLUSH_AT) {  // (a wave's own decision: no barrier inside)
+            for (uint32_t i = lane; i < n_stage; i += 64u) {
+                const uint32_t ub = st[i][0], row = st[i][1], qi = st[i][2];
+                const uint32_t pos = atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], 1u);
+                if (pos < seg_cap) cand[((size_t)qi * BATCH_CAND_SEGS + seg) * seg_cap + pos] = uint2{ub, row};
+            }
+            n_stage = 0;
+        }
+    }
+    for (uint32_t i = lane; i < n_stage; i += 64u) {
+        const uint32_t ub = st[i][0], row = st[i][1], qi = st[i][2];
+        const uint32_t pos = atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], 1u);
+        if (pos < seg_cap) cand[((size_t)qi * BATCH_CAND_SEGS + seg) * seg_cap + pos] = uint2{ub, row};
+    }
+    if (__any(lost)) {  // (a burst of > 256 pairs within four tiles: the tail sends the wave's queries to the ladder)
+        const uint32_t qi = (uint32_t)(64 * qw + lane);
         if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
     }
 }
@@ -635,7 +801,17 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     hipLaunchKernelGGL(f6_merge_tau_kernel, dim3(1), dim3(256), 0, stream, ws.tau, f6.tau6, B);
     // 3. the pass
     if (ev0) (void)hipEventRecord(ev0, stream);
-    {
+    if (f6.stagger < 0) {  // the LDS-staged pass (the default)
+        static OncePerDevice attr_once;
+        once_per_device(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sizeof(F6PassLds));
+        });
+        const uint32_t n_groups = (pl.n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
+        const uint32_t blocks = n_groups < (uint32_t)grid ? n_groups : (uint32_t)grid;
+        hipLaunchKernelGGL(scan_f6_pass_lds_kernel, dim3(blocks), dim3(512), sizeof(F6PassLds), stream, xs, mt, n_rows, pl.n_tiles, qf6,
+                           qm6, B, f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big);
+    } else {
         const uint32_t blocks = pl.n_tiles < (uint32_t)grid ? pl.n_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 1u, pl.n_tiles, qf6, qm6, B,
                            f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big, nullptr, (uint32_t)f6.stagger);

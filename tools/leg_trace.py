@@ -58,7 +58,8 @@ def summary(db):
     starts = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         seg = seq[a + 1:b]
-        seg = [s for s in seg if not s[0].startswith(("rows_to_", "synth_", "iota", "validate"))]
+        # (torch's own kernels — the fills behind torch.zeros, copies — are not part of a search)
+        seg = [s for s in seg if not s[0].startswith(("rows_to_", "synth_", "iota", "validate", "__amd_rocclr", "void at::", "at::"))]
         if not seg:
             continue
         # split into the batch-1 part and the batch-256 part: the latter starts at the first prep_queries_i8 launch
