@@ -279,10 +279,11 @@ void f6_release(dawn_index* idx) {
         if (q) (void)hipFree(q);
     idx->d_f6 = nullptr;
     idx->d_f6meta = nullptr;
-    const int target = idx->f6ws.target, stagger = idx->f6ws.stagger;
+    const int target = idx->f6ws.target, stagger = idx->f6ws.stagger, refine_rows = idx->f6ws.refine_rows;
     idx->f6ws = dawn::F6Workspace{};
     idx->f6ws.target = target;
     idx->f6ws.stagger = stagger;
+    idx->f6ws.refine_rows = refine_rows;
     idx->f6_cap = idx->f6_rows = 0;
 }
 bool f6_shadow_sync(dawn_index* idx) {
@@ -912,8 +913,13 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         return reprepare();
     }
     if (n == "f6_stagger") {  // -1: the LDS-staged FP6 pass (default); >= 0: the register-ring pass, its waves this many tiles apart
-        if (value < -1 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -1..4096");
+        if (value < -3 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -3..4096");
         idx->f6ws.stagger = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "f6_refine_rows") {  // f32 index: re-score the FP6 survivors on the rows themselves (1, default) or on the int8 shadow (0)
+        if (value != 0 && value != 1) return fail(DAWN_ERR_INVALID_ARG, "f6_refine_rows must be 0 or 1");
+        idx->f6ws.refine_rows = (int)value;
         return DAWN_OK;
     }
     if (n == "f6_target") {  // survivors per query the FP6 threshold aims for (twice that for count > 32)

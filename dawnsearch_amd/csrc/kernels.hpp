@@ -184,6 +184,7 @@ struct F6Workspace {
     uint32_t* cnt_big = nullptr; // [BATCH_QT][BATCH_CAND_SEGS], zero between searches
     uint32_t seg_cap_big = 2048;
     int target = 12288;          // survivors per query the FP6 threshold aims for (twice that for k > 32); option "f6_target"
+    int refine_rows = 1;         // f32 index: survivors are re-scored on the rows themselves (0: on the int8 shadow); option "f6_refine_rows"
     int stagger = -1;            // < 0: the LDS-staged pass; >= 0: the register-ring pass, its waves this many tiles apart; option "f6_stagger"
 };
 void launch_rows_to_f6s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid, hipStream_t stream);

@@ -516,6 +516,7 @@ struct F6PassLds {
     uint32_t stage[8][F6L_STAGE][3];
 };
 
+template <int MODE>  // 0: the pass; 1, 2: timing experiments (1: no threshold tests, 2: one tile of a group read four times) — wrong results
 __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* __restrict__ x, const float2* __restrict__ meta,
                                                                 uint32_t n_rows, uint32_t n_tiles, const uint32_t* __restrict__ qf6,
                                                                 const float2* __restrict__ qmeta, int n_q, const float* __restrict__ tau,
@@ -554,30 +555,44 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
     const uint32_t seg = blockIdx.x % (uint32_t)BATCH_CAND_SEGS;
     bool lost = false;
 
-    // the copy of one group: thread t moves the 16-B pieces t, t + 512, t + 1024, t + 1536 and the 8-B piece 4096 + t / 2 ...
-    // (the shadow is padded by 8 tiles of zeros: a group that starts inside the index never reads outside the allocation)
-    u32x4 pre4[4];
-    u32x2 pre2;
-    float2 pre_m = float2{0.f, 0.f};
-    auto prefetch = [&](uint32_t grp) __attribute__((always_inline)) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + (size_t)grp * F6L_GROUP_BYTES;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            pre4[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + ((uint32_t)threadIdx.x + 512u * (uint32_t)r) * 16u));
-        pre2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(base + 32768u + (uint32_t)threadIdx.x * 8u));
-        if (lane < F6L_GROUP) pre_m = meta[(size_t)grp * F6L_GROUP + (uint32_t)lane];
-    };
-    uint32_t grp = blockIdx.x;
-    if (grp < n_groups) prefetch(grp);
-    int buf = 0;
-    for (; grp < n_groups; grp += G, buf ^= 1) {
-        unsigned char* tb = reinterpret_cast<unsigned char*>(L.tiles[buf]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<u32x4*>(tb + ((uint32_t)threadIdx.x + 512u * (uint32_t)r) * 16u) = pre4[r];
-        *reinterpret_cast<u32x2*>(tb + 32768u + (uint32_t)threadIdx.x * 8u) = pre2;
-        const float2 cur_m = pre_m;
-        __syncthreads();  // (one barrier per group: the buffer written now was last read two groups ago, before the previous barrier)
-        if (grp + G < n_groups) prefetch(grp + G);
+    // The copy of a group: thread t moves the 16-B pieces t, t + 512, t + 1024, t + 1536 and the 8-B piece 4096 + t / 2 (the shadow
+    // is padded by 8 tiles of zeros: a group that starts inside the index never reads outside the allocation), and lane l of every
+    // wave the metadata of tile l & 7.  TWO groups are in flight per workgroup (72 KB per CU, 18 MB on the chip: with one group the
+    // pass waits for memory latency, 9.8 ms per 100 M x 256): two register sets, asm loads under a hand-counted vmcnt — hipcc's
+    // waitcnt pass drains a ring like this at the loop header (see the kernel above).  The asm statement that waits for a set also
+    // writes it to LDS and copies the metadata out, so nothing the compiler schedules can read a register before its data is there.
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)f6l_raw;
+    const uint32_t o4 = (uint32_t)threadIdx.x * 16u, o2 = 32768u + (uint32_t)threadIdx.x * 8u, om = (uint32_t)(lane & 7) * 8u;
+    const uint32_t o4b = o4 + 8192u, o4c = o4 + 16384u, o4d = o4 + 24576u;
+    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+    u32x2 pa4, pb4, pam, pbm;
+#define DAWN_F6L_PREFETCH(P0, P1, P2, P3, P4, PM, GRP)                                                                         \
+    do {                                                                                                                      \
+        const uint32_t g_ = (GRP) < n_groups ? (GRP) : n_groups - 1u; /* (past the end: any valid group, never used) */        \
+        const unsigned char* xb_ = reinterpret_cast<const unsigned char*>(x) + (size_t)g_ * F6L_GROUP_BYTES;                  \
+        const float2* mb_ = meta + (size_t)g_ * F6L_GROUP;                                                                    \
+        asm volatile("global_load_dwordx4 %0, %6, %11 nt\n\tglobal_load_dwordx4 %1, %7, %11 nt\n\t"                           \
+                     "global_load_dwordx4 %2, %8, %11 nt\n\tglobal_load_dwordx4 %3, %9, %11 nt\n\t"                           \
+                     "global_load_dwordx2 %4, %10, %11 nt\n\tglobal_load_dwordx2 %5, %12, %13"                                \
+                     : "=&v"(P0), "=&v"(P1), "=&v"(P2), "=&v"(P3), "=&v"(P4), "=&v"(PM)                                       \
+                     : "v"(o4), "v"(o4b), "v"(o4c), "v"(o4d), "v"(o2), "s"(xb_), "v"(om), "s"(mb_)                            \
+                     : "memory");                                                                                             \
+    } while (0)
+    // wait until only the OTHER set's six loads are in flight, set -> LDS buffer at byte offset BUF, metadata -> (MX, MY), and the
+    // workgroup's barrier (one per group: the buffer written now was last read two groups ago, before the previous barrier)
+#define DAWN_F6L_LAND(P0, P1, P2, P3, P4, PM, BUF, MX, MY)                                                                     \
+    do {                                                                                                                      \
+        const uint32_t a4_ = lds0 + (BUF) + o4, a2_ = lds0 + (BUF) + (uint32_t)threadIdx.x * 8u;                              \
+        asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %2, %4\n\tds_write_b128 %2, %5 offset:8192\n\t"                    \
+                     "ds_write_b128 %2, %6 offset:16384\n\tds_write_b128 %2, %7 offset:24576\n\t"                            \
+                     "ds_write_b64 %3, %8 offset:32768\n\tv_mov_b32 %0, %9\n\tv_mov_b32 %1, %10\n\t"                        \
+                     "s_waitcnt lgkmcnt(0)\n\ts_barrier"                                                                     \
+                     : "=&v"(MX), "=&v"(MY)                                                                                   \
+                     : "v"(a4_), "v"(a2_), "v"(P0), "v"(P1), "v"(P2), "v"(P3), "v"(P4), "v"(PM.x), "v"(PM.y)                  \
+                     : "memory");                                                                                             \
+    } while (0)
+
+    auto compute = [&](const unsigned char* tb, uint32_t grp, int cmx, int cmy) __attribute__((always_inline)) {
         auto read_tile = [&](int t, i32x8_t (&av)[3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
@@ -592,10 +607,10 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
 #pragma unroll
         for (int tt = 0; tt < F6L_GROUP / 2; ++tt) {
             const int t = half + 2 * tt;
-            if (tt + 1 < F6L_GROUP / 2) read_tile(t + 2, av[(tt + 1) & 1]);
+            if (tt + 1 < F6L_GROUP / 2) read_tile(MODE == 2 ? half : t + 2, av[MODE == 2 ? 0 : (tt + 1) & 1]);
             const uint32_t tile = grp * (uint32_t)F6L_GROUP + (uint32_t)t;
-            const float2 mt = float2{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_m.x), t)),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_m.y), t))};
+            const float2 mt = float2{__builtin_bit_cast(float, __builtin_amdgcn_readlane(cmx, t)),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(cmy, t))};
             f32x4 acc[4];
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) acc[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -603,21 +618,28 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
             for (int ks = 0; ks < 3; ++ks)  // (k-step outside: four independent accumulators back to back)
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg)
-                    acc[gg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av[tt & 1][ks], bq[gg][ks], acc[gg], 2, 2, 0, 0x7F7F7F7F, 0,
-                                                                                0x7F7F7F7F);
+                    acc[gg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av[MODE == 2 ? 0 : tt & 1][ks], bq[gg][ks], acc[gg], 2, 2, 0,
+                                                                                0x7F7F7F7F, 0, 0x7F7F7F7F);
             if (tile >= n_tiles) continue;  // (workgroup-uniform; the padding of the last group)
+            if constexpr (MODE == 1) {
+                const float sum = (acc[0][0] + acc[1][1]) + (acc[2][2] + acc[3][3]);
+                if (sum == 1.2345e30f) lost = true;
+                continue;
+            }
             const float s = __builtin_amdgcn_rcpf(mt.x);
             const uint32_t row0 = tile * 16u + 4u * (uint32_t)(lane >> 4);
             // acc > thr  <=  ub = acc s s_q + E + (1.015 + E) dqn > tau   (thr a little low: hits are re-tested on ub itself)
-            float thr[4], over = NEG_INF;
+            float thr[4], og[4], over = NEG_INF;
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 thr[gg] = __builtin_fmaf(__builtin_fmaf(mt.y, thrC[gg], thrB[gg]), mt.x * thrA[gg], -0.02f);
-                over = fmaxf(over, fmaxf(fmaxf(acc[gg][0], acc[gg][1]), fmaxf(acc[gg][2], acc[gg][3])) - thr[gg]);
+                og[gg] = fmaxf(fmaxf(acc[gg][0], acc[gg][1]), fmaxf(acc[gg][2], acc[gg][3])) - thr[gg];
+                over = fmaxf(over, og[gg]);
             }
-            if (__any(over > 0.f)) {
+            if (__any(over > 0.f)) {  // (one tile in a few: ~0.1-0.5 pairs per tile and wave at the default target)
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
+                    if (!__any(og[gg] > 0.f)) continue;
                     const uint32_t qi = (uint32_t)(16 * (4 * qw + gg) + (lane & 15));
                     const float g1 = s * sq_l[gg], g0 = mt.y + (1.015f + mt.y) * dqn_l[gg];
 #pragma unroll
@@ -643,20 +665,43 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
                 }
             }
         }
-        if (n_stage > F6L_FLUSH_AT) {  // (a wave's own decision: no barrier inside)
-            for (uint32_t i = lane; i < n_stage; i += 64u) {
-                const uint32_t ub = st[i][0], row = st[i][1], qi = st[i][2];
-                const uint32_t pos = atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], 1u);
-                if (pos < seg_cap) cand[((size_t)qi * BATCH_CAND_SEGS + seg) * seg_cap + pos] = uint2{ub, row};
-            }
-            n_stage = 0;
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (uint32_t i = lane; i < n_stage; i += 64u) {
+            const uint32_t ub = st[i][0], row = st[i][1], qi = st[i][2];
+            const uint32_t pos = atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], 1u);
+            if (pos < seg_cap) cand[((size_t)qi * BATCH_CAND_SEGS + seg) * seg_cap + pos] = uint2{ub, row};
         }
+        n_stage = 0;
+        // (stores and atomics share the loads' counter and return out of order with them: start the hand count from zero again)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    uint32_t grp = blockIdx.x;
+    if (grp < n_groups) {  // (workgroup-uniform)
+        const unsigned char* tb0 = reinterpret_cast<const unsigned char*>(L.tiles[0]);
+        const unsigned char* tb1 = reinterpret_cast<const unsigned char*>(L.tiles[1]);
+        DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp);
+        DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + G);
+        while (true) {
+            int mx, my;
+            DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx, my);
+            DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 2u * G);
+            compute(tb0, grp, mx, my);
+            grp += G;
+            if (grp >= n_groups) break;
+            DAWN_F6L_LAND(pb0, pb1, pb2, pb3, pb4, pbm, F6L_GROUP_BYTES, mx, my);
+            DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + 2u * G);
+            compute(tb1, grp, mx, my);
+            grp += G;
+            if (grp >= n_groups) break;
+            if (n_stage > F6L_FLUSH_AT) flush();  // (a wave's own decision: no barrier inside)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's last loads: nothing may be in flight when the wave ends)
+        if (n_stage > 0u) flush();
     }
-    for (uint32_t i = lane; i < n_stage; i += 64u) {
-        const uint32_t ub = st[i][0], row = st[i][1], qi = st[i][2];
-        const uint32_t pos = atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], 1u);
-        if (pos < seg_cap) cand[((size_t)qi * BATCH_CAND_SEGS + seg) * seg_cap + pos] = uint2{ub, row};
-    }
+#undef DAWN_F6L_PREFETCH
+#undef DAWN_F6L_LAND
     if (__any(lost)) {  // (a burst of > 256 pairs within four tiles: the tail sends the wave's queries to the ladder)
         const uint32_t qi = (uint32_t)(64 * qw + lane);
         if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
@@ -722,6 +767,72 @@ __global__ __launch_bounds__(256) void f6_refine_kernel(const uint2* __restrict_
         // a big segment that overflowed lost candidates: make the query's ordinary counter say so
         if (cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] > seg_cap_big)
             atomicAdd(&cnt[(size_t)b * BATCH_CAND_SEGS + seg], (uint32_t)BATCH_CAP);
+        cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] = 0u;
+    }
+}
+
+// The same on an f32 index, from the rows themselves.  A survivor's int8 image is 24 pieces of 16 B in 24 different 128-B lines
+// (3 KB of traffic per candidate: 1.4-2 ms per 100 M x 256 at ~12 k survivors per query); its f32 row is 1536 contiguous bytes.
+// Sixteen lanes per candidate, six 16-B pieces each against the query's in registers, a butterfly over the sixteen lanes; the
+// f32 dot product is within gamma_384 x 1.0201 = 2.34e-5 of the real one whatever the order of the sum: + 3e-5 makes it a bound.
+__global__ __launch_bounds__(256) void f6_refine_rows_kernel(const uint2* __restrict__ big, uint32_t* __restrict__ cnt_big,
+                                                              uint32_t seg_cap_big, const f32x4* __restrict__ x,
+                                                              const float* __restrict__ q, const float* __restrict__ tau,
+                                                              uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
+    const int b = blockIdx.x, seg = blockIdx.y;
+    const int part = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    f32x4 qv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) qv[j] = reinterpret_cast<const f32x4*>(q + (size_t)b * EM)[part + 16 * j];
+    const uint32_t c0 = cnt_big[(size_t)b * BATCH_CAND_SEGS + seg];
+    const uint32_t n = c0 < seg_cap_big ? c0 : seg_cap_big;
+    const float t = tau[b];
+    const uint2* src = big + ((size_t)b * BATCH_CAND_SEGS + seg) * seg_cap_big;
+    constexpr uint32_t seg_small = (uint32_t)BATCH_CAP / (uint32_t)BATCH_CAND_SEGS;
+    for (uint32_t e0 = 0; e0 < n; e0 += 32u) {  // two candidates per 16 lanes and step: 12 loads in flight per lane
+        const uint32_t ea = e0 + (uint32_t)grp, eb = ea + 16u;
+        const uint2 va = ea < n ? src[ea] : uint2{0u, 0u}, vb = eb < n ? src[eb] : uint2{0u, 0u};
+        const f32x4* ra = x + (size_t)va.y * ROW_F4 + part;
+        const f32x4* rb = x + (size_t)vb.y * ROW_F4 + part;
+        f32x4 xa[6], xb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            xa[j] = __builtin_nontemporal_load(ra + 16 * j);
+            xb[j] = __builtin_nontemporal_load(rb + 16 * j);
+        }
+        float da = 0.f, db = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            da = __builtin_fmaf(xa[j].x, qv[j].x, da);
+            da = __builtin_fmaf(xa[j].y, qv[j].y, da);
+            da = __builtin_fmaf(xa[j].z, qv[j].z, da);
+            da = __builtin_fmaf(xa[j].w, qv[j].w, da);
+            db = __builtin_fmaf(xb[j].x, qv[j].x, db);
+            db = __builtin_fmaf(xb[j].y, qv[j].y, db);
+            db = __builtin_fmaf(xb[j].z, qv[j].z, db);
+            db = __builtin_fmaf(xb[j].w, qv[j].w, db);
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            da += __shfl_xor(da, o);
+            db += __shfl_xor(db, o);
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t e = h ? eb : ea;
+                const uint2 v = h ? vb : va;
+                const float ub = fminf(__builtin_bit_cast(float, v.x), (h ? db : da) + 3e-5f);
+                if (e < n && ub > t) {
+                    const uint32_t pos = atomicAdd(&cnt[(size_t)b * BATCH_CAND_SEGS + seg], 1u);
+                    if (pos < seg_small) cand[((size_t)b * BATCH_CAND_SEGS + seg) * seg_small + pos] = uint2{__builtin_bit_cast(uint32_t, ub), v.y};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (c0 > seg_cap_big) atomicAdd(&cnt[(size_t)b * BATCH_CAND_SEGS + seg], (uint32_t)BATCH_CAP);
         cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] = 0u;
     }
 }
@@ -804,13 +915,18 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     if (f6.stagger < 0) {  // the LDS-staged pass (the default)
         static OncePerDevice attr_once;
         once_per_device(attr_once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sizeof(F6PassLds));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sizeof(F6PassLds));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
         });
         const uint32_t n_groups = (pl.n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
         const uint32_t blocks = n_groups < (uint32_t)grid ? n_groups : (uint32_t)grid;
-        hipLaunchKernelGGL(scan_f6_pass_lds_kernel, dim3(blocks), dim3(512), sizeof(F6PassLds), stream, xs, mt, n_rows, pl.n_tiles, qf6,
-                           qm6, B, f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big);
+        auto kern = f6.stagger == -2 ? scan_f6_pass_lds_kernel<1> : f6.stagger == -3 ? scan_f6_pass_lds_kernel<2> : scan_f6_pass_lds_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), sizeof(F6PassLds), stream, xs, mt, n_rows, pl.n_tiles, qf6, qm6, B, f6.tau6,
+                           f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big);
     } else {
         const uint32_t blocks = pl.n_tiles < (uint32_t)grid ? pl.n_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 1u, pl.n_tiles, qf6, qm6, B,
@@ -820,9 +936,14 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     // 4. survivors -> int8 bound -> the ordinary candidate buffers
     const signed char* qi8 = reinterpret_cast<const signed char*>(ws.qh);
     const float2* qm8 = reinterpret_cast<const float2*>(qi8 + (size_t)BATCH_QT * EM);
-    hipLaunchKernelGGL(f6_refine_kernel, dim3(B, BATCH_CAND_SEGS), dim3(256), 0, stream, reinterpret_cast<const uint2*>(f6.cand_big),
-                       f6.cnt_big, f6.seg_cap_big, reinterpret_cast<const unsigned char*>(d_i8),
-                       reinterpret_cast<const float2*>(d_i8meta), qi8, qm8, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand));
+    if (dtype == ROW_F32 && f6.refine_rows)
+        hipLaunchKernelGGL(f6_refine_rows_kernel, dim3(B, BATCH_CAND_SEGS), dim3(256), 0, stream,
+                           reinterpret_cast<const uint2*>(f6.cand_big), f6.cnt_big, f6.seg_cap_big, reinterpret_cast<const f32x4*>(d_x),
+                           d_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand));
+    else
+        hipLaunchKernelGGL(f6_refine_kernel, dim3(B, BATCH_CAND_SEGS), dim3(256), 0, stream, reinterpret_cast<const uint2*>(f6.cand_big),
+                           f6.cnt_big, f6.seg_cap_big, reinterpret_cast<const unsigned char*>(d_i8),
+                           reinterpret_cast<const float2*>(d_i8meta), qi8, qm8, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand));
     // 5. the common tail
     launch_select_rescore_eps(false, d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, force_fallback,
                               FILTER_EPS_I8, stream);

@@ -82,8 +82,10 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      its last workgroup scans all rows exactly (counted as a fallback)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 8 Mi) filter on an FP6 (e2m3) shadow of the rows
  *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
- *                      envelope), its survivors are re-scored on the int8 shadow; "f6_target" = survivors per query its threshold
- *                      aims for (12288; twice that for count > 32).  Default 0
+ *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow
+ *                      (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
+ *                      that for count > 32); "f6_stagger" -1 (default): the pass staged through LDS, >= 0: the register-ring pass
+ *                      with its waves that many tiles apart (A/B).  Default 0
  *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
  *                      the index's 64 best by the refined score (measured: a wash; default 0)
  *   "i6_dyn_chunk" / "i6_dyn_share"   the packed stream's dynamically assigned tail: sub-tiles per chunk (default 16; 8 below 32 Mi
