@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
     const uint32_t n_groups = (n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
     // the wave's query images and per-lane constants
     i32x8_t bq[4][3];
-    float thrA[4], thrB[4], thrC[4], sq_l[4], dqn_l[4], tau_l[4];
+    float thrP[4], thrQ[4], sq_l[4], dqn_l[4];
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
         const int g = 4 * qw + gg;
@@ -545,10 +545,9 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
         const float2 qm = qmeta[qi];
         sq_l[gg] = qm.x;
         dqn_l[gg] = qm.y;
-        tau_l[gg] = qi < n_q ? tau[qi] : POS_INF;
-        thrA[gg] = 1.0f / qm.x;
-        thrB[gg] = tau_l[gg] - 1.015f * qm.y;
-        thrC[gg] = -(1.0f + qm.y);
+        const float tau_q = qi < n_q ? tau[qi] : POS_INF;
+        thrP[gg] = (tau_q - 1.015f * qm.y) / qm.x;
+        thrQ[gg] = -(1.0f + qm.y) / qm.x;
     }
     uint32_t n_stage = 0;  // wave-uniform
     uint32_t(*st)[3] = L.stage[wave];
@@ -578,21 +577,27 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
                      : "v"(o4), "v"(o4b), "v"(o4c), "v"(o4d), "v"(o2), "s"(xb_), "v"(om), "s"(mb_)                            \
                      : "memory");                                                                                             \
     } while (0)
-    // wait until only the OTHER set's six loads are in flight, set -> LDS buffer at byte offset BUF, metadata -> (MX, MY), and the
-    // workgroup's barrier (one per group: the buffer written now was last read two groups ago, before the previous barrier)
+    // wait until only the OTHER set's six loads are in flight, set -> LDS buffer at byte offset BUF, metadata -> (MX, MY)
 #define DAWN_F6L_LAND(P0, P1, P2, P3, P4, PM, BUF, MX, MY)                                                                     \
     do {                                                                                                                      \
         const uint32_t a4_ = lds0 + (BUF) + o4, a2_ = lds0 + (BUF) + (uint32_t)threadIdx.x * 8u;                              \
         asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %2, %4\n\tds_write_b128 %2, %5 offset:8192\n\t"                    \
                      "ds_write_b128 %2, %6 offset:16384\n\tds_write_b128 %2, %7 offset:24576\n\t"                            \
-                     "ds_write_b64 %3, %8 offset:32768\n\tv_mov_b32 %0, %9\n\tv_mov_b32 %1, %10\n\t"                        \
-                     "s_waitcnt lgkmcnt(0)\n\ts_barrier"                                                                     \
+                     "ds_write_b64 %3, %8 offset:32768\n\tv_mov_b32 %0, %9\n\tv_mov_b32 %1, %10"                             \
                      : "=&v"(MX), "=&v"(MY)                                                                                   \
                      : "v"(a4_), "v"(a2_), "v"(P0), "v"(P1), "v"(P2), "v"(P3), "v"(P4), "v"(PM.x), "v"(PM.y)                  \
                      : "memory");                                                                                             \
     } while (0)
+    // the workgroup's barrier, one per group: every wave has written its share of the NEXT group (in the middle of its work on the
+    // current one, where the wait for the data and the LDS writes cost nothing) and is done reading the current one
+#define DAWN_F6L_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-    auto compute = [&](const unsigned char* tb, uint32_t grp, int cmx, int cmy) __attribute__((always_inline)) {
+    // A group's work for this wave: its four tiles, software-pipelined — the fragments of tile k + 1 are read from LDS and the
+    // thresholds of tile k - 1 tested while the 12 MFMAs of tile k run (the matrix pipe takes one every 16 cycles: three or four
+    // vector instructions fit between two of them; in program order tests-after-MFMAs a wave leaves the pipe idle for the ~180
+    // cycles of its tests, and with two waves per SIMD nothing else fills them).  `mid` runs after the second tile: the landing of
+    // the next group.
+    auto compute = [&](const unsigned char* tb, uint32_t grp, int cmx, int cmy, auto mid) __attribute__((always_inline)) {
         auto read_tile = [&](int t, i32x8_t (&av)[3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
@@ -602,56 +607,72 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
                 av[ks] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
             }
         };
+        constexpr int NT = F6L_GROUP / 2;
         i32x8_t av[2][3];
+        f32x4 acc[2][4];
         read_tile(half, av[0]);
 #pragma unroll
-        for (int tt = 0; tt < F6L_GROUP / 2; ++tt) {
-            const int t = half + 2 * tt;
-            if (tt + 1 < F6L_GROUP / 2) read_tile(MODE == 2 ? half : t + 2, av[MODE == 2 ? 0 : (tt + 1) & 1]);
-            const uint32_t tile = grp * (uint32_t)F6L_GROUP + (uint32_t)t;
-            const float2 mt = float2{__builtin_bit_cast(float, __builtin_amdgcn_readlane(cmx, t)),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(cmy, t))};
-            f32x4 acc[4];
+        for (int k = 0; k <= NT; ++k) {
+            if (k + 1 < NT) read_tile(half + 2 * (k + 1), av[(k + 1) & 1]);
+            if (k < NT) {
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) acc[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int gg = 0; gg < 4; ++gg) acc[k & 1][gg] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks)  // (k-step outside: four independent accumulators back to back)
+                for (int ks = 0; ks < 3; ++ks)  // (k-step outside: four independent accumulators back to back)
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg)
-                    acc[gg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av[MODE == 2 ? 0 : tt & 1][ks], bq[gg][ks], acc[gg], 2, 2, 0,
-                                                                                0x7F7F7F7F, 0, 0x7F7F7F7F);
-            if (tile >= n_tiles) continue;  // (workgroup-uniform; the padding of the last group)
-            if constexpr (MODE == 1) {
-                const float sum = (acc[0][0] + acc[1][1]) + (acc[2][2] + acc[3][3]);
-                if (sum == 1.2345e30f) lost = true;
-                continue;
+                    for (int gg = 0; gg < 4; ++gg)
+                        acc[k & 1][gg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av[k & 1][ks], bq[gg][ks], acc[k & 1][gg], 2, 2, 0,
+                                                                                           0x7F7F7F7F, 0, 0x7F7F7F7F);
             }
-            const float s = __builtin_amdgcn_rcpf(mt.x);
-            const uint32_t row0 = tile * 16u + 4u * (uint32_t)(lane >> 4);
-            // acc > thr  <=  ub = acc s s_q + E + (1.015 + E) dqn > tau   (thr a little low: hits are re-tested on ub itself)
-            float thr[4], og[4], over = NEG_INF;
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                thr[gg] = __builtin_fmaf(__builtin_fmaf(mt.y, thrC[gg], thrB[gg]), mt.x * thrA[gg], -0.02f);
-                og[gg] = fmaxf(fmaxf(acc[gg][0], acc[gg][1]), fmaxf(acc[gg][2], acc[gg][3])) - thr[gg];
-                over = fmaxf(over, og[gg]);
-            }
-            if (__any(over > 0.f)) {  // (one tile in a few: ~0.1-0.5 pairs per tile and wave at the default target)
+            if (k >= 1) {
+                const int t = half + 2 * (k - 1);
+                const f32x4(&ac)[4] = acc[(k - 1) & 1];
+                const uint32_t tile = grp * (uint32_t)F6L_GROUP + (uint32_t)t;
+                const float2 mt = float2{__builtin_bit_cast(float, __builtin_amdgcn_readlane(cmx, t)),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(cmy, t))};
+                // acc > thr  <=>  ub = acc s s_q + E + (1.015 + E) dqn > tau:  thr = (tau - E - (1.015 + E) dqn) / (s s_q) - 0.02
+                //   = (1 / s) P + (E / s) Q - 0.02 with P, Q per query (acc is a multiple of 1/64 and |thr| < 1e4: the f32 rounding of
+                // this expression is < 1e-3, 0.02 is safe).  Sixteen compares straight into scalar masks — no maxima, no ballots:
+                // the fast path is 8 + 16 vector instructions per tile.  (The zero padding behind the last tile has thr = -0.02 <
+                // acc = 0: its rows fail the row < n_rows test below.)
+                const float sx = mt.x, sxy = mt.x * mt.y;
+                unsigned long long mk[4][4], any_m = 0ull;
+                float thr[4];
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
-                    if (!__any(og[gg] > 0.f)) continue;
-                    const uint32_t qi = (uint32_t)(16 * (4 * qw + gg) + (lane & 15));
-                    const float g1 = s * sq_l[gg], g0 = mt.y + (1.015f + mt.y) * dqn_l[gg];
+                    thr[gg] = __builtin_fmaf(sx, thrP[gg], __builtin_fmaf(sxy, thrQ[gg], -0.02f));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float ub = __builtin_fmaf(acc[gg][r], g1, g0);
-                        const bool hit = acc[gg][r] > thr[gg] && ub > tau_l[gg] && row0 + (uint32_t)r < n_rows;
-                        const unsigned long long m = __ballot(hit);
-                        if (m) {
+                        mk[gg][r] = __ballot(ac[gg][r] > thr[gg]);
+                        any_m |= mk[gg][r];
+                    }
+                }
+                if (k < NT) {
+                    if constexpr (MODE != 2) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two vector instructions
+                        }
+                    }
+                }
+                if (MODE != 1 && any_m != 0ull) {  // (one tile in four or five: ~0.25 pairs per tile and wave at the default target)
+                    const float s = __builtin_amdgcn_rcpf(mt.x);
+                    const uint32_t row0 = tile * 16u + 4u * (uint32_t)(lane >> 4);
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        if ((mk[gg][0] | mk[gg][1] | mk[gg][2] | mk[gg][3]) == 0ull) continue;
+                        const uint32_t qi = (uint32_t)(16 * (4 * qw + gg) + (lane & 15));
+                        const float g1 = s * sq_l[gg], g0 = mt.y + (1.015f + mt.y) * dqn_l[gg];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (mk[gg][r] == 0ull) continue;
+                            const bool hit = ac[gg][r] > thr[gg] && row0 + (uint32_t)r < n_rows;
+                            const unsigned long long m = __ballot(hit);
                             if (hit) {
                                 const uint32_t slot = n_stage + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                                 if (slot < F6L_STAGE) {
-                                    st[slot][0] = __builtin_bit_cast(uint32_t, ub);
+                                    st[slot][0] = __builtin_bit_cast(uint32_t, __builtin_fmaf(ac[gg][r], g1, g0));
                                     st[slot][1] = row0 + (uint32_t)r;
                                     st[slot][2] = qi;
                                 } else {
@@ -663,7 +684,12 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
                         }
                     }
                 }
+                if constexpr (MODE == 1) {
+                    const float sum = (ac[0][0] + ac[1][1]) + (ac[2][2] + ac[3][3]);
+                    if (sum == 1.2345e30f) lost = true;
+                }
             }
+            if (k == 1) mid();
         }
     };
     auto flush = [&]() __attribute__((always_inline)) {
@@ -681,18 +707,25 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
     if (grp < n_groups) {  // (workgroup-uniform)
         const unsigned char* tb0 = reinterpret_cast<const unsigned char*>(L.tiles[0]);
         const unsigned char* tb1 = reinterpret_cast<const unsigned char*>(L.tiles[1]);
+        int mx0, my0, mx1, my1;  // metadata of the group in buffer 0 / 1
         DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp);
         DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + G);
+        DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx0, my0);
+        DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 2u * G);
+        DAWN_F6L_BARRIER();
         while (true) {
-            int mx, my;
-            DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx, my);
-            DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 2u * G);
-            compute(tb0, grp, mx, my);
+            compute(tb0, grp, mx0, my0, [&]() __attribute__((always_inline)) {
+                DAWN_F6L_LAND(pb0, pb1, pb2, pb3, pb4, pbm, F6L_GROUP_BYTES, mx1, my1);
+                DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + 3u * G);
+            });
+            DAWN_F6L_BARRIER();
             grp += G;
             if (grp >= n_groups) break;
-            DAWN_F6L_LAND(pb0, pb1, pb2, pb3, pb4, pbm, F6L_GROUP_BYTES, mx, my);
-            DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + 2u * G);
-            compute(tb1, grp, mx, my);
+            compute(tb1, grp, mx1, my1, [&]() __attribute__((always_inline)) {
+                DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx0, my0);
+                DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 3u * G);
+            });
+            DAWN_F6L_BARRIER();
             grp += G;
             if (grp >= n_groups) break;
             if (n_stage > F6L_FLUSH_AT) flush();  // (a wave's own decision: no barrier inside)
@@ -702,6 +735,7 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
     }
 #undef DAWN_F6L_PREFETCH
 #undef DAWN_F6L_LAND
+#undef DAWN_F6L_BARRIER
     if (__any(lost)) {  // (a burst of > 256 pairs within four tiles: the tail sends the wave's queries to the ladder)
         const uint32_t qi = (uint32_t)(64 * qw + lane);
         if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
@@ -838,10 +872,10 @@ __global__ __launch_bounds__(256) void f6_refine_rows_kernel(const uint2* __rest
 }
 
 // tau <- max(tau, tau6): one threshold for both filters (a row dropped by either scores <= it)
-__global__ void f6_merge_tau_kernel(float* __restrict__ tau, float* __restrict__ tau6, int n) {
+__global__ void f6_merge_tau_kernel(float* __restrict__ tau, float* __restrict__ tau6, int n, int have_tau8) {
     const int i = threadIdx.x;
     if (i < n) {
-        const float t = fmaxf(tau[i], tau6[i]);
+        const float t = have_tau8 ? fmaxf(tau[i], tau6[i]) : tau6[i];
         tau[i] = t;
         tau6[i] = t;
     }
@@ -884,8 +918,10 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
                             const uint64_t* d_ids, uint32_t n_rows, const float* d_q, int B, uint32_t k, const BatchWorkspace& ws,
                             const F6Workspace& f6, int grid, uint64_t* d_labels, float* d_dist, uint32_t* d_found, uint32_t* d_flags,
                             int force_fallback, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    // 1. the int8 path's thresholds (tau8 at rank ~1024) — its sampling passes, not its full pass
-    launch_i8_sample_thresholds(d_i8, d_i8meta, n_rows, d_q, B, k, ws, grid, stream);
+    // 1. survivors re-scored on the int8 shadow: the int8 path's query images and thresholds (tau8 at rank ~1024) — its sampling
+    //    passes, not its full pass (0.41 ms per 100 M rows).  Re-scored on the f32 rows themselves, nothing of the int8 path is needed.
+    const bool rows_refine = dtype == ROW_F32 && f6.refine_rows;
+    if (!rows_refine) launch_i8_sample_thresholds(d_i8, d_i8meta, n_rows, d_q, B, k, ws, grid, stream);
     // 2. the FP6 thresholds
     const uint32_t target = (uint32_t)f6.target * (k > 32 ? 2u : 1u);
     const F6Plan pl = plan_f6(n_rows, target);
@@ -904,12 +940,13 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
         launch_tau_select(true, B, w6, pl.s1_tiles * 16u, pl.m1, stream);
     }
     {
-        const uint32_t blocks = pl.s2_tiles < (uint32_t)grid ? pl.s2_tiles : (uint32_t)grid;
+        // (two workgroups per CU: the strided sample is bound by memory latency, 0.36 -> 0.2 ms per 100 M rows)
+        const uint32_t blocks = pl.s2_tiles < 2u * (uint32_t)grid ? pl.s2_tiles : 2u * (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, pl.s2_stride, pl.s2_tiles, qf6,
                            qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u);
         launch_tau_select(false, B, w6, 0u, pl.m2, stream);
     }
-    hipLaunchKernelGGL(f6_merge_tau_kernel, dim3(1), dim3(256), 0, stream, ws.tau, f6.tau6, B);
+    hipLaunchKernelGGL(f6_merge_tau_kernel, dim3(1), dim3(256), 0, stream, ws.tau, f6.tau6, B, rows_refine ? 0 : 1);
     // 3. the pass
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (f6.stagger < 0) {  // the LDS-staged pass (the default)
@@ -936,7 +973,7 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     // 4. survivors -> int8 bound -> the ordinary candidate buffers
     const signed char* qi8 = reinterpret_cast<const signed char*>(ws.qh);
     const float2* qm8 = reinterpret_cast<const float2*>(qi8 + (size_t)BATCH_QT * EM);
-    if (dtype == ROW_F32 && f6.refine_rows)
+    if (rows_refine)
         hipLaunchKernelGGL(f6_refine_rows_kernel, dim3(B, BATCH_CAND_SEGS), dim3(256), 0, stream,
                            reinterpret_cast<const uint2*>(f6.cand_big), f6.cnt_big, f6.seg_cap_big, reinterpret_cast<const f32x4*>(d_x),
                            d_q, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand));
