@@ -379,7 +379,9 @@ def main():
         #         (scan_i6.hip; "i6" 288.25: its 6-bit form, option i6_bits = 6)
         if rows_read == "default":
             rows_read = "i5" if (Bq == 1 and rows_here >= I6_MIN_ROWS) else "i8"
-        row_bytes = {"i5": 240.25, "i6": 288.25, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2, "f32": ROW_BYTES}[rows_read]
+        #   "f6"  288.5: the FP6 shadow (+ 8 B of scale/bound per 16 rows)
+        row_bytes = {"i5": 240.25, "i6": 288.25, "f6": 288.5, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2,
+                     "f32": ROW_BYTES}[rows_read]
         leg["row_bytes_streamed"] = row_bytes
         algo = int(rows_here * row_bytes) * scan_passes(Bq)
         if leg["scan_kernel_ms"] > 0:
@@ -389,7 +391,9 @@ def main():
                 # 256 query columns are multiplied whatever Bq is; dense peaks: 2.5 PFLOP/s f16/bf16, int8 twice that
                 # (MI355X_MICROARCH.md: the i8 MFMA has the cycles of the bf16 form at 2x the K)
                 leg["mfma_TFLOPs"] = 2.0 * 256 * rows_here * 384 / (leg["scan_kernel_ms"] * 1e-3) / 1e12
-                if rows_read == "i8":
+                if rows_read == "f6":  # (16 cycles per 16x16x128: 10 Pflop/s at 2.4 GHz)
+                    leg["mfma_frac_f6_dense_peak"] = leg["mfma_TFLOPs"] / 10000.0
+                elif rows_read == "i8":
                     leg["mfma_frac_i8_dense_peak"] = leg["mfma_TFLOPs"] / 5000.0
                 else:
                     leg["mfma_frac_f16_dense_peak"] = leg["mfma_TFLOPs"] / 2500.0
@@ -677,6 +681,16 @@ def main():
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
         leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)
         extra["batch256"] = leg
+        # ... with the optional FP6 (e2m3) first filter (option "f6_shadow": + 288 B per row; scan_f6.hip): the 6-bit floating-point
+        # shadow through v_mfma_scale_f32_16x16x128_f8f6f4, survivors re-scored on the f32 rows, the same tail and certificates
+        if world == 1 and rows_local >= (8 << 20):
+            sh0 = idx.memory()["shadows"]
+            idx.set_option("f6_shadow", 1)
+            legf6, _ = run_leg(idx, 256, b256_steps, 2, seed=3, rows_read="f6")
+            legf6["f6_shadow_bytes"] = int(idx.memory()["shadows"] - sh0)  # (0: not enough free HBM — the int8 pass answered)
+            legf6["vs_int8_pass"] = legf6["queries_per_s"] / leg["queries_per_s"]
+            idx.set_option("f6_shadow", 0)
+            extra["batch256_f6_first_filter"] = legf6
         # ... and on the f16 shadow (scan_f16_pipe_kernel; int8 shadow off)
         idx.set_option("i8_shadow", 0)
         leg, _ = run_leg(idx, 256, max(3, b256_steps // 2), 1, seed=3, rows_read="f16")

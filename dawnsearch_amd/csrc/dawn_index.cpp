@@ -370,6 +370,7 @@ namespace dawn {
 int index_prepare_search(dawn_index* idx) {
     DAWN_TRY(ensure_workspace(idx, std::max(idx->ws_B, kMaxBatch)));
     idx->fb = dawn_index::LadderFeedback{};  // the rows (or the options) changed: what the certificates did before says nothing
+    idx->f6fb = dawn_index::F6Feedback{};
     if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
@@ -402,8 +403,33 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     }
     const uint32_t n = (uint32_t)idx->size;
     const bool batched = (int)B >= idx->mfma_min_batch;
-    if (batched && idx->i8_batched && i8_live(idx) && f6_live(idx) && n > (uint32_t)BATCH_CAP) {
-        // matrix-core path with the FP6 shadow as first filter (scan_f6.hip), its survivors re-scored on the int8 shadow
+    bool use_f6 = batched && idx->i8_batched && i8_live(idx) && f6_live(idx) && n > (uint32_t)BATCH_CAP;
+    if (use_f6 && idx->ladder_feedback && idx->h_stats && !idx->force_fallback) {
+        // FP6 feedback (index_internal.hpp): does this index send too many of its FP6-filtered queries to the ladder?
+        auto& fb = idx->f6fb;
+        const volatile uint32_t* hs = reinterpret_cast<volatile uint32_t*>(idx->h_stats);
+        if (fb.suspend_left == 0 && fb.issued >= kF6FbWindow) {
+            const uint32_t now = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
+            if ((double)(now - fb.ladder0) > kF6FbSuspend * (double)fb.issued) {
+                fb.suspend_left = fb.suspend_len;
+                fb.suspend_len = std::min(fb.suspend_len * 2u, kF6FbSuspendMax);
+            } else {
+                fb.suspend_len = kF6FbSuspendMin;
+            }
+            fb.issued = 0;
+        }
+        if (fb.suspend_left > 0) {
+            --fb.suspend_left;
+            ++idx->n_f6_suspended;
+            use_f6 = false;
+        } else {
+            if (fb.issued == 0) fb.ladder0 = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
+            fb.issued += B;
+        }
+    }
+    if (use_f6) {
+        // matrix-core path with the FP6 shadow as first filter (scan_f6.hip), its survivors re-scored on the f32 rows / the int8 shadow
+        idx->n_f6_batches += (B + BATCH_QT - 1) / BATCH_QT;
         for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
             const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
             launch_scan_batched_f6(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_f6, idx->d_f6meta, idx->d_ids, n,
@@ -875,6 +901,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "ladder_feedback must be 0, 1 or 2");
         idx->ladder_feedback = (int)value;
         idx->fb = dawn_index::LadderFeedback{};
+        idx->f6fb = dawn_index::F6Feedback{};
         if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
         return DAWN_OK;
     }
@@ -913,7 +940,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         return reprepare();
     }
     if (n == "f6_stagger") {  // -1: the LDS-staged FP6 pass (default); >= 0: the register-ring pass, its waves this many tiles apart
-        if (value < -3 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -3..4096");
+        if (value < -4 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -4..4096");
         idx->f6ws.stagger = (int)value;
         return DAWN_OK;
     }
@@ -1558,6 +1585,15 @@ int dawn_index_stats_ladder(dawn_index* idx, uint64_t* bounded, uint64_t* packed
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     return idx->shards ? dawn::sharded_stats(idx, nullptr, nullptr, nullptr, nullptr, bounded, packed_failures, demoted)
                        : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, nullptr, bounded, packed_failures, demoted);
+}
+
+// ... batches (of <= 256 queries) the FP6 first filter took, and batches its feedback handed to the int8 pass instead (debug header)
+int dawn_index_stats_f6(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended) {
+    if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "per-shard counters: ask the shards");
+    if (f6_batches) *f6_batches = idx->n_f6_batches;
+    if (f6_suspended) *f6_suspended = idx->n_f6_suspended;
+    return DAWN_OK;
 }
 
 // ... and, of the second chances, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled

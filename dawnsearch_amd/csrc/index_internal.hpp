@@ -26,6 +26,9 @@ constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf1
 constexpr uint32_t kFbWindow = 32;        // ladder feedback: packed single-query searches per window
 constexpr double kFbBoost = 0.05, kFbDemote = 0.35;  // failure rates that make the waves refine full lists / demote the index
 constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
+constexpr uint32_t kF6FbWindow = 1024;  // FP6 feedback: queries per window
+constexpr double kF6FbSuspend = 0.30;
+constexpr uint32_t kF6FbSuspendMin = 16, kF6FbSuspendMax = 1024;
 }  // namespace dawn
 
 struct dawn_index {
@@ -187,6 +190,17 @@ struct dawn_index {
         bool boosted = false;
     } fb;
     uint64_t n_demoted = 0;        // single queries answered by the bounded pass directly
+    // The same for the FP6 first filter of batches ("f6_shadow"): its looser bound sends MORE queries of a batch to the ladder than
+    // the int8 pass on topical rows (81-90 % against 53-68 % at 100 M rows: 133 against 80 ms per batch, profiles/r04/
+    // f6_ab_100M_v7_topical*.log) while it wins 10 % where certificates hold.  Over windows of kF6FbWindow queries filtered that way:
+    // above kF6FbSuspend of them ended in the ladder (h_stats, the mirrored counters: an over-estimate when single queries run in
+    // between) the next suspend_len batches take the int8 pass (doubling up to kF6FbSuspendMax while the probes keep failing).
+    struct F6Feedback {
+        uint64_t issued = 0;      // queries filtered through the FP6 pass in this window
+        uint32_t ladder0 = 0;     // h_stats[FLAG_BOUNDED] + h_stats[FLAG_FALLBACK] at its start
+        uint32_t suspend_left = 0, suspend_len = 16;
+    } f6fb;
+    uint64_t n_f6_batches = 0, n_f6_suspended = 0;  // batches (of <= 256 queries) the FP6 filter took / handed to the int8 pass
     int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)
 
     // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,

@@ -501,11 +501,21 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
 // ------------------------------------------------------------------------------------------------
 // The full pass, staged through LDS.  The kernel above has each of its four waves load every tile itself: the rows then cross
 // L2 -> L1 -> registers four times (115 GB per 100 M rows) with one wave per SIMD and nothing to hide a stall behind — 16-17 ms per
-// 100 M x 256 whatever the ring, the load form or the hit rate (profiles/r04/f6_ab_*.log).  Here a workgroup of EIGHT waves takes
-// groups of 8 consecutive tiles (36864 B, contiguous): every thread copies 4 x 16 B + 8 B of the NEXT group global -> registers
-// while the current group is worked on, registers -> LDS (double buffer, one barrier per group), and a tile's fragments are read
-// from LDS by the four waves that hold the four quarters of the batch: waves 0-3 take the even tiles of a group, waves 4-7 the odd
-// ones, so that each SIMD has two waves to overlap.  Every byte of the shadow is read from HBM once and crosses L2 once.
+// 100 M x 256 whatever the ring, the load form or the hit rate (profiles/r04/f6_ab_*.log); it stays for the strided samples.
+// Here a workgroup of EIGHT waves takes groups of 8 consecutive tiles (36864 B, contiguous): every thread copies 4 x 16 B + 8 B of
+// a group global -> registers two groups ahead, registers -> LDS (double buffer) in the MIDDLE of the work on the group before it,
+// one barrier per group; a tile's fragments are read from LDS by the four waves that hold the four quarters of the batch: waves
+// 0-3 take the even tiles of a group, waves 4-7 the odd ones, two waves per SIMD.  Every byte of the shadow is read from HBM once
+// and crosses L2 once.  What each step was worth, per 100 M rows x 256 queries (profiles/r04/f6_ab_*_v5..v7*.log):
+//     16.0 ms  the register-ring kernel above
+//      9.8     through LDS, one group in flight
+//      9.1     two groups in flight (hand-counted vmcnt)
+//      8.0     per-query-group ballots in the hit path
+//      7.45    tiles software-pipelined inside a wave, landing moved into the middle of a group, compares into scalar masks
+// against 8.9-9.3 ms of the int8 pass on the same index.  The copy alone (no MFMA, no tests) runs at 7 TB/s (4.1 ms); with the
+// MFMAs 6.5 ms; a wave's cycles (MODE 4): 5-6 % waiting for its loads, 13-23 % at the barrier (the older wave of a SIMD gets there
+// first), the rest ~470 cycles per tile and wave for 12 MFMAs (192 cycles of matrix pipe) and ~46 vector instructions — two waves
+// per SIMD do not cover each other's dependency stalls completely, and 226 VGPRs do not leave room for a third.
 // ------------------------------------------------------------------------------------------------
 constexpr int F6L_GROUP = 8;                                       // tiles per group
 constexpr uint32_t F6L_GROUP_BYTES = F6L_GROUP * F6_TILE_DW * 4u;  // 36864
@@ -516,7 +526,7 @@ struct F6PassLds {
     uint32_t stage[8][F6L_STAGE][3];
 };
 
-template <int MODE>  // 0: the pass; 1, 2: timing experiments (1: no threshold tests, 2: one tile of a group read four times) — wrong results
+template <int MODE>  // 0: the pass; timing experiments: 1: no threshold tests (wrong results), 4: a few waves print where their cycles went
 __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* __restrict__ x, const float2* __restrict__ meta,
                                                                 uint32_t n_rows, uint32_t n_tiles, const uint32_t* __restrict__ qf6,
                                                                 const float2* __restrict__ qmeta, int n_q, const float* __restrict__ tau,
@@ -647,15 +657,6 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
                         any_m |= mk[gg][r];
                     }
                 }
-                if (k < NT) {
-                    if constexpr (MODE != 2) {
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two vector instructions
-                        }
-                    }
-                }
                 if (MODE != 1 && any_m != 0ull) {  // (one tile in four or five: ~0.25 pairs per tile and wave at the default target)
                     const float s = __builtin_amdgcn_rcpf(mt.x);
                     const uint32_t row0 = tile * 16u + 4u * (uint32_t)(lane >> 4);
@@ -713,24 +714,45 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
         DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx0, my0);
         DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 2u * G);
         DAWN_F6L_BARRIER();
+        // MODE 4 (timing experiment): cycles this wave spends waiting for its loads (the landing) and at the barrier
+        unsigned long long t_land = 0, t_bar = 0, t_all = 0, t0 = 0, n_it = 0;
+#define DAWN_F6L_T() (MODE == 4 ? __builtin_readcyclecounter() : 0ull)
+        t_all = DAWN_F6L_T();
         while (true) {
             compute(tb0, grp, mx0, my0, [&]() __attribute__((always_inline)) {
+                t0 = DAWN_F6L_T();
                 DAWN_F6L_LAND(pb0, pb1, pb2, pb3, pb4, pbm, F6L_GROUP_BYTES, mx1, my1);
+                t_land += DAWN_F6L_T() - t0;
                 DAWN_F6L_PREFETCH(pb0, pb1, pb2, pb3, pb4, pbm, grp + 3u * G);
             });
+            t0 = DAWN_F6L_T();
             DAWN_F6L_BARRIER();
+            t_bar += DAWN_F6L_T() - t0;
+            ++n_it;
             grp += G;
             if (grp >= n_groups) break;
             compute(tb1, grp, mx1, my1, [&]() __attribute__((always_inline)) {
+                t0 = DAWN_F6L_T();
                 DAWN_F6L_LAND(pa0, pa1, pa2, pa3, pa4, pam, 0u, mx0, my0);
+                t_land += DAWN_F6L_T() - t0;
                 DAWN_F6L_PREFETCH(pa0, pa1, pa2, pa3, pa4, pam, grp + 3u * G);
             });
+            t0 = DAWN_F6L_T();
             DAWN_F6L_BARRIER();
+            t_bar += DAWN_F6L_T() - t0;
+            ++n_it;
             grp += G;
             if (grp >= n_groups) break;
             if (n_stage > F6L_FLUSH_AT) flush();  // (a wave's own decision: no barrier inside)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's last loads: nothing may be in flight when the wave ends)
+        if constexpr (MODE == 4) {
+            t_all = DAWN_F6L_T() - t_all;
+            if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5))
+                printf("f6 pass timing: block %d wave %d: %llu groups, shader cycles total %llu, landing %llu, barrier %llu\n",
+                       (int)blockIdx.x, wave, n_it, t_all, t_land, t_bar);
+        }
+#undef DAWN_F6L_T
         if (n_stage > 0u) flush();
     }
 #undef DAWN_F6L_PREFETCH
@@ -956,12 +978,12 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
                                       (int)sizeof(F6PassLds));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
         });
         const uint32_t n_groups = (pl.n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
         const uint32_t blocks = n_groups < (uint32_t)grid ? n_groups : (uint32_t)grid;
-        auto kern = f6.stagger == -2 ? scan_f6_pass_lds_kernel<1> : f6.stagger == -3 ? scan_f6_pass_lds_kernel<2> : scan_f6_pass_lds_kernel<0>;
+        auto kern = f6.stagger == -2 ? scan_f6_pass_lds_kernel<1> : f6.stagger == -4 ? scan_f6_pass_lds_kernel<4> : scan_f6_pass_lds_kernel<0>;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), sizeof(F6PassLds), stream, xs, mt, n_rows, pl.n_tiles, qf6, qm6, B, f6.tau6,
                            f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big);
     } else {

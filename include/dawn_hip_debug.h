@@ -27,6 +27,10 @@ int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_m
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
 /* Test hook: the same for the FP6 (e2m3) shadow of the rows (scan_f6.hip; options "f6_shadow" = 1, "f6_min_rows"): upper bounds. */
 int dawn_index_debug_f6_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
+/* Counters of the FP6 first filter: batches (of <= 256 queries) it took, and batches its feedback handed to the int8 pass instead
+ * (an index whose FP6-filtered queries end in the ladder more than 30 % of the time — topical rows — suspends it for 16 .. 1024
+ * batches at a time; option "ladder_feedback" = 0 switches that off).  Not on a sharded handle. */
+int dawn_index_stats_f6(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
@@ -85,7 +89,9 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow
  *                      (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
  *                      that for count > 32); "f6_stagger" -1 (default): the pass staged through LDS, >= 0: the register-ring pass
- *                      with its waves that many tiles apart (A/B).  Default 0
+ *                      with its waves that many tiles apart (A/B), -2 / -4: timing experiments of the LDS-staged pass (no threshold
+ *                      tests: wrong results / a few waves print their cycle counts).  Default 0: 8.55 against 9.55 ms per batch of
+ *                      256 on 100 M rows with it (profiles/r04/f6_ab_100M_v7_*.log) for 28.8 GB more HBM
  *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
  *                      the index's 64 best by the refined score (measured: a wash; default 0)
  *   "i6_dyn_chunk" / "i6_dyn_share"   the packed stream's dynamically assigned tail: sub-tiles per chunk (default 16; 8 below 32 Mi

@@ -116,8 +116,8 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
 
 def test_100m_batch256_all_paths_agree(dawn, big):
     """configs[3]'s per-shard workload at B = 256, k = 20 (the service's count): ALL 256 queries over 100 M rows through
-    the int8 matrix-core pass (default), the f16-shadow matrix-core pass and the int8 streaming filter (8 queries per pass)
-    — three kernels, two shadows — bit-identical; a sample also against the f32-row stream; no exact pass anywhere."""
+    the int8 matrix-core pass (default), the FP6 first filter, the f16-shadow matrix-core pass and the int8 streaming filter
+    (8 queries per pass) — four kernels, three shadows — bit-identical; a sample also against the f32-row stream; no exact pass anywhere."""
     idx = big
     k = 20
     Q = synth.unit_rows(3, 0, 256)
@@ -126,6 +126,14 @@ def test_100m_batch256_all_paths_agree(dawn, big):
     labels, dist, found = idx.search_batch(Q, k)
     assert np.all(found == k) and np.all(np.diff(dist, axis=1) >= 0) and labels.min() >= 1 and labels.max() <= N
     assert np.array_equal(labels[:10, 0], _queries()[1] + 1)
+    idx.set_option("f6_shadow", 1)  # the FP6 (e2m3) first filter in front of the same tail (+ 28.8 GB; scan_f6.hip)
+    try:
+        f6_before = idx.stats_f6()["f6_batches"]
+        l6, d6, _ = idx.search_batch(Q, k)
+        assert idx.stats_f6()["f6_batches"] == f6_before + 1  # (it did run: the shadow found its memory)
+    finally:
+        idx.set_option("f6_shadow", 0)
+    assert np.array_equal(l6, labels) and np.array_equal(d6.view(np.uint32), dist.view(np.uint32))
     idx.set_option("mfma_min_batch", 100000)  # the streaming filter, 8 queries per pass over the int8 shadow
     try:
         ls, ds, fs = idx.search_batch(Q, k)
@@ -149,6 +157,7 @@ def test_100m_batch256_all_paths_agree(dawn, big):
     assert after["fallbacks"] == before["fallbacks"]
     # the first certificate's misses were all settled by a deeper round of the same certificate
     assert after["second_chances"] - before["second_chances"] == after["deepened"] - before["deepened"]
+    assert after["bounded"] == before["bounded"]
 
 
 def test_100m_default_path_equals_the_oracle_scan_of_all_rows(dawn, oracle, big):

@@ -128,3 +128,53 @@ def test_f6_on_topical_rows_and_a_bf16_index(dawn, oracle):
     lab, dist, found = idh.search_batch(Qh, 20)
     for b in range(12):
         _assert_same(lab[b], dist[b], *oracle.scan_topk(xh, ids, Qh[b], 20))
+
+
+@pytest.mark.parametrize("opts", [{"f6_refine_rows": 0}, {"f6_stagger": 8}, {"f6_stagger": 0, "f6_refine_rows": 0}, {"f6_target": 256}])
+def test_f6_variants_answer_alike(dawn, oracle, opts):
+    """The other forms of the filter — survivors re-scored on the int8 shadow instead of the f32 rows, the register-ring pass instead
+    of the LDS-staged one, a threshold that is far too tight (most searches end in the ladder) — give the oracle's answers too."""
+    n = 150_001  # (9376 tiles: the last group of 8 is ragged, the last tile holds one row)
+    idx = _mk(dawn, n)
+    for name, v in opts.items():
+        idx.set_option(name, v)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(5, 0, 61), synth.planted_queries(1, [0, n - 1], 9)])
+    lab, dist, found = idx.search_batch(Q, 10)
+    for b, q in enumerate(Q):
+        assert found[b] == 10
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(x, ids, q, 10, threads=8))
+    assert lab[61][0] == 1 and lab[62][0] == n
+    assert idx.stats()["fallbacks"] == 0
+
+
+def test_f6_feedback_suspends_the_filter_where_it_loses(dawn, oracle):
+    """An index whose FP6-filtered queries mostly end in the ladder (here: a threshold that is far too tight; in the field: topical
+    rows at 100 M) hands its batches back to the int8 pass after one window of 1024 queries, probes again later, and answers alike
+    throughout; with "ladder_feedback" = 0 it never does."""
+    n = 120_000
+    idx = _mk(dawn, n)
+    idx.set_option("f6_target", 256)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(6, 0, 256)
+    first = idx.search_batch(Q, 10)
+    for b in (0, 100, 255):
+        _assert_same(first[0][b], first[1][b], *oracle.scan_topk(x, ids, Q[b], 10, threads=8))
+    for _ in range(9):
+        lab, dist, _ = idx.search_batch(Q, 10)
+        assert np.array_equal(lab, first[0]) and np.array_equal(dist.view(np.uint32), first[1].view(np.uint32))
+    s = idx.stats_f6()
+    assert s["f6_batches"] >= 4 and s["f6_suspended"] >= 4 and s["f6_batches"] + s["f6_suspended"] == 10, s
+    assert idx.stats()["bounded"] >= 512
+    idx.set_option("ladder_feedback", 0)
+    for _ in range(8):
+        idx.search_batch(Q, 10)
+    s2 = idx.stats_f6()
+    assert s2["f6_suspended"] == s["f6_suspended"] and s2["f6_batches"] == s["f6_batches"] + 8, (s, s2)
+    # where the certificates hold it stays on
+    idy = _mk(dawn, n)
+    for _ in range(10):
+        idy.search_batch(Q, 10)
+    assert idy.stats_f6() == {"f6_batches": 10, "f6_suspended": 0}
