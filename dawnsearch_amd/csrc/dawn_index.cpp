@@ -371,6 +371,7 @@ int index_prepare_search(dawn_index* idx) {
     DAWN_TRY(ensure_workspace(idx, std::max(idx->ws_B, kMaxBatch)));
     idx->fb = dawn_index::LadderFeedback{};  // the rows (or the options) changed: what the certificates did before says nothing
     idx->f6fb = dawn_index::F6Feedback{};
+    idx->bfb = dawn_index::BatchFeedback{};
     if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
@@ -439,10 +440,27 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         }
     } else if (batched && idx->i8_batched && i8_live(idx)) {
         // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
+        dawn::BatchWorkspace bw = idx->bws;
+        if (idx->ladder_feedback && idx->h_stats && !idx->force_fallback && n > (uint32_t)BATCH_CAP) {
+            // batch feedback (index_internal.hpp): too many of this index's batched queries in the ladder -> deeper thresholds
+            auto& fb = idx->bfb;
+            const volatile uint32_t* hs = reinterpret_cast<volatile uint32_t*>(idx->h_stats);
+            if (!fb.boosted && fb.issued >= kBatchFbWindow) {
+                const uint32_t now = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
+                if ((double)(now - fb.ladder0) > kBatchFbBoost * (double)fb.issued) fb.boosted = true;
+                fb.issued = 0;
+            }
+            if (fb.issued == 0) fb.ladder0 = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
+            fb.issued += B;
+            if (fb.boosted) {
+                bw.target = std::max(bw.target, k > 32 ? kBatchBoostTargetWide : kBatchBoostTarget);
+                idx->n_deepened_batches += (B + BATCH_QT - 1) / BATCH_QT;
+            }
+        }
         for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
             const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
             launch_scan_batched_i8(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * EM, (int)nb,
-                                   (uint32_t)k, idx->bws, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
+                                   (uint32_t)k, bw, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
                                    idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                    b0 == 0 ? e1 : nullptr);
         }
@@ -902,6 +920,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->ladder_feedback = (int)value;
         idx->fb = dawn_index::LadderFeedback{};
         idx->f6fb = dawn_index::F6Feedback{};
+        idx->bfb = dawn_index::BatchFeedback{};
         if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
         return DAWN_OK;
     }
@@ -942,6 +961,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "f6_stagger") {  // -1: the LDS-staged FP6 pass (default); >= 0: the register-ring pass, its waves this many tiles apart
         if (value < -4 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -4..4096");
         idx->f6ws.stagger = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_ring") {  // process-wide: 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)
+        if (value != 6 && value != 12) return fail(DAWN_ERR_INVALID_ARG, "bounded_ring must be 6 or 12");
+        dawn::set_bounded_ring((int)value);
         return DAWN_OK;
     }
     if (n == "f6_refine_rows") {  // f32 index: re-score the FP6 survivors on the rows themselves (1, default) or on the int8 shadow (0)
@@ -1587,12 +1611,14 @@ int dawn_index_stats_ladder(dawn_index* idx, uint64_t* bounded, uint64_t* packed
                        : dawn::index_stats_single(idx, nullptr, nullptr, nullptr, nullptr, bounded, packed_failures, demoted);
 }
 
-// ... batches (of <= 256 queries) the FP6 first filter took, and batches its feedback handed to the int8 pass instead (debug header)
-int dawn_index_stats_f6(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended) {
+// ... what the feedback of the batched paths did (debug header): batches (of <= 256 queries) the FP6 first filter took, batches
+// its feedback handed to the int8 pass instead, batches the int8 pass ran with the deeper thresholds of a ladder-heavy index
+int dawn_index_stats_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "per-shard counters: ask the shards");
     if (f6_batches) *f6_batches = idx->n_f6_batches;
     if (f6_suspended) *f6_suspended = idx->n_f6_suspended;
+    if (deepened_batches) *deepened_batches = idx->n_deepened_batches;
     return DAWN_OK;
 }
 

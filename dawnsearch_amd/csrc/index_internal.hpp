@@ -26,6 +26,9 @@ constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf1
 constexpr uint32_t kFbWindow = 32;        // ladder feedback: packed single-query searches per window
 constexpr double kFbBoost = 0.05, kFbDemote = 0.35;  // failure rates that make the waves refine full lists / demote the index
 constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
+constexpr uint32_t kBatchFbWindow = 1024;  // int8 batched pass: queries per feedback window
+constexpr double kBatchFbBoost = 0.10;
+constexpr int kBatchBoostTarget = 4096, kBatchBoostTargetWide = 3072;  // (k > 32 doubles the target: 2 x 3072 stays inside the 8192 slots)
 constexpr uint32_t kF6FbWindow = 1024;  // FP6 feedback: queries per window
 constexpr double kF6FbSuspend = 0.30;
 constexpr uint32_t kF6FbSuspendMin = 16, kF6FbSuspendMax = 1024;
@@ -200,7 +203,17 @@ struct dawn_index {
         uint32_t ladder0 = 0;     // h_stats[FLAG_BOUNDED] + h_stats[FLAG_FALLBACK] at its start
         uint32_t suspend_left = 0, suspend_len = 16;
     } f6fb;
-    uint64_t n_f6_batches = 0, n_f6_suspended = 0;  // batches (of <= 256 queries) the FP6 filter took / handed to the int8 pass
+    // ... and for the int8 matrix-core pass of batches: its sampled thresholds aim at ~1024 candidates per query ("mfma_target":
+    // the fastest pass on well-spread rows, 8.82 ms per 100 M x 256 against 9.21 at 4096).  On topical rows a threshold that shallow
+    // often sits ABOVE the k-th score inside a shell of near-ties and no certificate can hold: 53 % of a batch ended in the ladder
+    // at 1024, 39 % at 4096 (79 -> 67 ms per batch at 100 M rows, profiles/r04/topical_target_sweep_100M.log).  Above
+    // kBatchFbBoost of a window's queries in the ladder, the index's batches aim four times as deep until its rows change.
+    struct BatchFeedback {
+        uint64_t issued = 0;
+        uint32_t ladder0 = 0;
+        bool boosted = false;
+    } bfb;
+    uint64_t n_f6_batches = 0, n_f6_suspended = 0, n_deepened_batches = 0;  // batches (of <= 256 queries) the FP6 filter took / handed to the int8 pass
     int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)
 
     // bulk transfers (load / load_page_entries): one event per pinned host buffer of the caller's double buffer,

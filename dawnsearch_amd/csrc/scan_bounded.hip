@@ -707,6 +707,10 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
 // Per query b < B with d_flags[b] == FLAG_FALLBACK: the exact top-k through the int8 shadow, flag -> FLAG_BOUNDED; every other
 // query is left alone (one nearly empty launch when no flag is set).  cand_s / cand_p: the per-workgroup lists [B][n_lists][64]
 // (the filter's own, free by now); d_done [B]: arrival counters, zero before and after.  B <= 256 per launch.
+// fragments a wave keeps in flight ahead of its MFMAs (6: half a sub-tile, 12: a whole one); process-wide, option "bounded_ring"
+static int g_bounded_ring = 6;
+void set_bounded_ring(int pd) { g_bounded_ring = pd == 12 ? 12 : 6; }
+
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
@@ -717,6 +721,10 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 12>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 12>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
     });
     const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
     const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
@@ -726,18 +734,31 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     x8, mt, d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,       \
         cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0,   \
         d_stats, stats_mirror
+        const bool deep = g_bounded_ring == 12;
         if (B == 1) {  // one query: its list stays in registers
-            if (dtype == ROW_BF16)
-                hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
-            else
-                hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+            if (dtype == ROW_BF16) {
+                if (deep) hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 12>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+                else hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+            } else {
+                if (deep) hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 12>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+                else hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
+            }
         } else {       // a batch: its flagged queries, sixteen per stream of the shadow
-            if (dtype == ROW_BF16)
-                hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                   DAWN_BOUNDED_ARGS);
-            else
-                hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                   DAWN_BOUNDED_ARGS);
+            if (dtype == ROW_BF16) {
+                if (deep)
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 12>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                       DAWN_BOUNDED_ARGS);
+                else
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                       DAWN_BOUNDED_ARGS);
+            } else {
+                if (deep)
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 12>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                       DAWN_BOUNDED_ARGS);
+                else
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
+                                       DAWN_BOUNDED_ARGS);
+            }
         }
 #undef DAWN_BOUNDED_ARGS
     }

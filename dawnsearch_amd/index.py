@@ -146,11 +146,16 @@ class VectorIndex:
         return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value,
                 "bounded": bd.value, "packed_failures": pf.value, "demoted": dm.value}
 
+    def stats_batch_feedback(self):
+        """Batches the FP6 first filter took / batches its feedback handed to the int8 pass / batches the int8 pass ran with the
+        deeper thresholds of a ladder-heavy index (dawn_hip_debug.h)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib.dawn_index_stats_batch_feedback(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"f6_batches": a.value, "f6_suspended": b.value, "deepened_batches": c.value}
+
     def stats_f6(self):
-        """Batches the FP6 first filter took / batches its feedback handed to the int8 pass (dawn_hip_debug.h)."""
-        a, b = C.c_uint64(0), C.c_uint64(0)
-        check(lib.dawn_index_stats_f6(self._h, C.byref(a), C.byref(b)))
-        return {"f6_batches": a.value, "f6_suspended": b.value}
+        s = self.stats_batch_feedback()
+        return {"f6_batches": s["f6_batches"], "f6_suspended": s["f6_suspended"]}
 
     def memory(self):
         """HBM bytes held by the index: rows, filter shadows built so far, everything else."""

@@ -27,10 +27,12 @@ int dawn_index_profile_read(dawn_index *idx, uint64_t *launches, double *total_m
 int dawn_index_debug_filter_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
 /* Test hook: the same for the FP6 (e2m3) shadow of the rows (scan_f6.hip; options "f6_shadow" = 1, "f6_min_rows"): upper bounds. */
 int dawn_index_debug_f6_scores(dawn_index *idx, const float *queries, size_t B, float *out, size_t *n_out);
-/* Counters of the FP6 first filter: batches (of <= 256 queries) it took, and batches its feedback handed to the int8 pass instead
- * (an index whose FP6-filtered queries end in the ladder more than 30 % of the time — topical rows — suspends it for 16 .. 1024
- * batches at a time; option "ladder_feedback" = 0 switches that off).  Not on a sharded handle. */
-int dawn_index_stats_f6(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended);
+/* What the feedback of the batched paths did: batches (of <= 256 queries) the FP6 first filter took; batches its feedback handed
+ * to the int8 pass instead (an index whose FP6-filtered queries end in the ladder more than 30 % of the time — topical rows —
+ * suspends it for 16 .. 1024 batches at a time); batches the int8 pass ran with thresholds four times as deep ("mfma_target" 4096
+ * instead of 1024: an index that sent more than 10 % of a window of 1024 batched queries to the ladder keeps them until its rows
+ * change).  Option "ladder_feedback" = 0 switches all of it off.  Not on a sharded handle. */
+int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended, uint64_t *deepened_batches);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);

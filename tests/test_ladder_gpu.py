@@ -265,3 +265,36 @@ def test_bounded_pass_notices_an_impossible_threshold(dawn, oracle):
         _same(*idx.search(q, 20), *oracle.scan_topk(x, ids, q, 20))
     st = idx.stats()
     assert st["demoted"] == 6 and st["bounded"] == 3 and st["fallbacks"] == 3, st
+
+
+def test_batch_feedback_deepens_the_thresholds_of_a_ladder_heavy_index(dawn, oracle):
+    """Batches on topical rows whose queries sit in the largest clusters end in the ladder often; after one window of 1024 batched
+    queries above 10 % the index's batches aim four times as deep ("mfma_target" 4096 instead of 1024) — fewer of them reach the
+    ladder, the answers stay the oracle's; an index of well-spread rows never deepens; "ladder_feedback" = 0 switches it off."""
+    n = 400_000
+    idx = _topical_index(dawn, n, 4, packed=False)
+    Q = np.concatenate([_topical_queries(4, 192, clusters={0, 1, 2}), _topical_queries(4, 64)])
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q[::16], 10, dist=4)
+    rates = []
+    for it in range(8):
+        s0 = idx.stats()
+        lab, dist, found = idx.search_batch(Q, 10)
+        s1 = idx.stats()
+        rates.append((s1["bounded"] - s0["bounded"]) / 256.0)
+        for j, b in enumerate(range(0, 256, 16)):
+            _same(lab[b], dist[b], want[0][j], want[1][j])
+    fbk = idx.stats_batch_feedback()
+    assert rates[0] > 0.10, rates                     # (the premise: this index is ladder-heavy)
+    assert fbk["deepened_batches"] == 4, (fbk, rates)  # batches 5 .. 8, after the window of 4 x 256 queries
+    assert min(rates[4:]) <= max(rates[:4]), rates
+    assert idx.stats()["fallbacks"] == 0
+    idx.set_option("ladder_feedback", 0)
+    for _ in range(6):
+        idx.search_batch(Q, 10)
+    assert idx.stats_batch_feedback()["deepened_batches"] == 4
+    flat = dawn.VectorIndex(0)
+    flat.fill_synthetic(1, 0, 300_000, 1)
+    Qf = synth.unit_rows(2, 0, 256)
+    for _ in range(8):
+        flat.search_batch(Qf, 10)
+    assert flat.stats_batch_feedback()["deepened_batches"] == 0
