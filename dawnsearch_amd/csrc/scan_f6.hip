@@ -515,7 +515,9 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
 // against 8.9-9.3 ms of the int8 pass on the same index.  The copy alone (no MFMA, no tests) runs at 7 TB/s (4.1 ms); with the
 // MFMAs 6.5 ms; a wave's cycles (MODE 4): 5-6 % waiting for its loads, 13-23 % at the barrier (the older wave of a SIMD gets there
 // first), the rest ~470 cycles per tile and wave for 12 MFMAs (192 cycles of matrix pipe) and ~46 vector instructions — two waves
-// per SIMD do not cover each other's dependency stalls completely, and 226 VGPRs do not leave room for a third.
+// per SIMD do not cover each other's dependency stalls completely, and 226 VGPRs do not leave room for a third.  The barrier share
+// is slack, not loss: two workgroups of four waves per CU (groups of four tiles, two barrier domains) take exactly as long
+// (profiles/r04/f6_ab_100M_v9_two_workgroups_per_cu_no_gain.log); so do scheduling hints that interleave MFMAs and tests.
 // ------------------------------------------------------------------------------------------------
 constexpr int F6L_GROUP = 8;                                       // tiles per group
 constexpr uint32_t F6L_GROUP_BYTES = F6L_GROUP * F6_TILE_DW * 4u;  // 36864
