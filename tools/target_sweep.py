@@ -10,7 +10,7 @@ idx = dawn.VectorIndex(0)
 idx.fill_synthetic(1, 0, rows, 1)
 Q = synth.unit_rows(2, 0, B)
 ref = None
-for target in (4096, 3072, 2048, 1536, 1024, 512):
+for target in [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "4096,3072,2048,1536,1024,512".split(","))]:
     idx.set_option("mfma_target", target)
     out = idx.search_batch(Q, 20)
     ref = ref or out
