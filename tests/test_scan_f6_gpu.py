@@ -178,3 +178,28 @@ def test_f6_feedback_suspends_the_filter_where_it_loses(dawn, oracle):
     for _ in range(10):
         idy.search_batch(Q, 10)
     assert idy.stats_f6() == {"f6_batches": 10, "f6_suspended": 0}
+
+
+def test_f6_behind_a_sharded_handle(dawn, oracle):
+    """The option reaches every shard of a sharded handle (three logical shards on one device): each shard's batches filter on its own
+    FP6 shadow, the merged answers are the oracle's, the shadows' memory shows in the handle's total and goes back."""
+    n = 90_000
+    sh = dawn.VectorIndex(devices=[0, 0, 0])
+    sh.set_option("shard_chunk", 4096)
+    sh.fill_synthetic(1, 0, n, 1)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = np.concatenate([synth.unit_rows(7, 0, 40), synth.planted_queries(1, [5, n - 2], 9)])
+    base = sh.search_batch(Q, 10)
+    m0 = sh.memory()["shadows"]
+    sh.set_option("f6_min_rows", 0)
+    sh.set_option("f6_shadow", 1)
+    lab, dist, found = sh.search_batch(Q, 10)
+    assert sh.memory()["shadows"] - m0 >= n * 288
+    for b, q in enumerate(Q):
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(x, ids, q, 10, threads=8))
+    assert np.array_equal(lab, base[0]) and np.array_equal(dist.view(np.uint32), base[1].view(np.uint32))
+    assert lab[40][0] == 6 and lab[41][0] == n - 1
+    sh.set_option("f6_shadow", 0)
+    assert sh.memory()["shadows"] <= m0
+    assert sh.stats()["fallbacks"] == 0
