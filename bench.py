@@ -683,7 +683,7 @@ def main():
         extra["batch256"] = leg
         # ... with the optional FP6 (e2m3) first filter (option "f6_shadow": + 288 B per row; scan_f6.hip): the 6-bit floating-point
         # shadow through v_mfma_scale_f32_16x16x128_f8f6f4, survivors re-scored on the f32 rows, the same tail and certificates
-        if world == 1 and rows_local >= (8 << 20):
+        if world == 1 and rows_local >= (64 << 20):
             sh0 = idx.memory()["shadows"]
             idx.set_option("f6_shadow", 1)
             legf6, _ = run_leg(idx, 256, b256_steps, 2, seed=3, rows_read="f6")

@@ -124,7 +124,10 @@ struct dawn_index {
     float* d_f6meta = nullptr;
     size_t f6_cap = 0, f6_rows = 0;
     int use_f6 = 0;              // option "f6_shadow"
-    size_t f6_min_rows = 8u << 20;  // option "f6_min_rows": batches of smaller indexes take the int8 pass
+    // option "f6_min_rows": batches of smaller indexes take the int8 pass.  The re-scoring of the filter's ~12 k survivors per
+    // query costs 0.8 ms per batch of 256 whatever the index size: a tie at 50 M rows (4.79 ms both), -10 % at 100 M, + 55 % at
+    // 12.5 M (2.00 against 1.29 ms; profiles/r04/f6_ab_12p5M_v8.log)
+    size_t f6_min_rows = 64u << 20;
     bool f6_failed = false;
     dawn::F6Workspace f6ws{};
     float* d_cand_es = nullptr;

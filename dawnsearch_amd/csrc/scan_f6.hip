@@ -935,7 +935,7 @@ static F6Plan plan_f6(uint32_t n_rows, uint32_t target) {
     return pl;
 }
 
-// Batched search with the FP6 first filter (n_rows well above 8 M: below that the int8 pass is as fast).  ws: the int8 path's
+// Batched search with the FP6 first filter (n_rows above ~50 M: below that the re-scoring of its survivors costs more than its pass saves).  ws: the int8 path's
 // workspace (its query images refine the survivors; its sampled threshold tau8 and its candidate buffer feed the common tail);
 // f6: the FP6 path's own buffers.
 void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const void* d_i8meta, const void* d_f6, const void* d_f6meta,

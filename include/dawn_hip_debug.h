@@ -86,7 +86,7 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      2: never — the bounded pass is their whole search (what a demoted index does; A/B, tests)
  *   "debug_bad_threshold" test hook: a demoted search starts its bounded pass from an impossible threshold; the pass notices and
  *                      its last workgroup scans all rows exactly (counted as a fallback)
- *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 8 Mi) filter on an FP6 (e2m3) shadow of the rows
+ *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows
  *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
  *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow
  *                      (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
