@@ -341,6 +341,16 @@ bool f6_live(const dawn_index* idx) {
 
 bool i8_live(const dawn_index* idx);
 // (its stream refines the listed rows on the int8 shadow: no int8 shadow, no packed stream)
+// The bounded pass of a single query on the packed 5-bit shadow instead of the int8 one: 240 instead of 384 B per row, but a bound
+// seven times as loose — more rows reach the exact scores, and a pass that starts without a threshold needs longer to find one.
+// Measured on topical rows (profiles/r04/bounded_packed_ab_*.log; mean ms per query, int8 -> packed): 12.5 M rows 0.89 -> 1.04,
+// 25 M 1.58 -> 1.69, 50 M 3.00 -> 2.80, 100 M 5.80 -> 4.98 (k = 20: 5.86 -> 5.35).  Option "bounded_packed": 0 never, 1 from
+// 40 Mi rows (default), 2 always (tests).
+static bool bounded_packed_wanted(const dawn_index* idx, uint32_t n) {
+    if (idx->i6_bits != 5) return false;
+    return idx->bounded_packed == 2 || (idx->bounded_packed == 1 && n >= (40u << 20));
+}
+
 bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size && i8_live(idx); }
 bool i8_live(const dawn_index* idx) {
     return idx->use_i8 && !idx->i8_failed && idx->i8_rows == idx->size && (idx->d_i8 || idx->size == 0);
@@ -508,12 +518,14 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             if (idx->ladder_feedback == 2) demoted = true;  // (tests / A-B: the bounded pass is the whole search of every single query)
         }
         if (demoted) {
-            // a demoted index: the bounded exact pass is the whole search (384 B/row, no certificate to fail)
+            // a demoted index: the bounded exact pass is the whole search (240 B/row on the packed shadow, no certificate to fail)
             ++idx->n_demoted;
+            const bool p5 = bounded_packed_wanted(idx, n);
             launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
                                        idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
                                        d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats,
-                                       idx->debug_bad_threshold ? -1.0f : __builtin_inff());
+                                       idx->debug_bad_threshold ? -1.0f : __builtin_inff(), p5 ? idx->d_i6 : nullptr,
+                                       p5 ? idx->d_i6meta : nullptr);
             DAWN_HIP_TRY(hipGetLastError());
             return DAWN_OK;
         }
@@ -553,10 +565,13 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     // closes every search with the bounded exact pass (scan_bounded.hip: 384 B per row + the rows that can still matter; it
     // cannot fail, keeps the certificate counters and mirrors them to the host), the others with the exact pass over all rows.
     // force_fallback = 1 (tests of the exact pass) takes the second form; 2 forces the flags only.
+    // (a single query of an index with a live packed 5-bit shadow streams that one: 240 instead of 384 B per row; option "bounded_packed")
+    const bool packed5 = bounded_packed_wanted(idx, n) && B == 1 && i6_live(idx);
     if (idx->bounded_pass && idx->force_fallback != 1 && i8_live(idx) && n > 0)
         launch_scan_bounded(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags,
                             idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
-                            d_dist, d_found, stream, idx->d_stats, idx->h_stats);
+                            d_dist, d_found, stream, idx->d_stats, idx->h_stats, packed5 ? idx->d_i6 : nullptr,
+                            packed5 ? idx->d_i6meta : nullptr);
     else
         launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
                           idx->d_cand_s, idx->d_cand_p, idx->geom.blocks, (uint32_t)k, d_labels, d_dist, d_found, stream,
@@ -961,6 +976,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "f6_stagger") {  // -1: the LDS-staged FP6 pass (default); >= 0: the register-ring pass, its waves this many tiles apart
         if (value < -4 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "f6_stagger must be -4..4096");
         idx->f6ws.stagger = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_packed") {  // the bounded pass of a single query streams the packed 5-bit shadow: 0 never, 1 from 40 Mi rows, 2 always
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_packed must be 0, 1 or 2");
+        idx->bounded_packed = (int)value;
         return DAWN_OK;
     }
     if (n == "bounded_ring") {  // process-wide: 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)

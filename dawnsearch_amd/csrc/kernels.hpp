@@ -224,14 +224,16 @@ void set_bounded_ring(int pd);  // 6 or 12 fragments in flight per wave (process
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
-                         uint32_t* d_stats, uint32_t* stats_mirror);
+                         uint32_t* d_stats, uint32_t* stats_mirror, const void* d_i5 = nullptr, const void* d_i5meta = nullptr);
+// (d_i5 / d_i5meta: the packed 5-bit shadow of the same rows, or NULL — a single query (B = 1) then streams it, 240 B per row,
+// instead of the int8 shadow)
 // ... as the WHOLE search of one query (a demoted index, dawn_index.cpp: ladder feedback): the flag is raised and the threshold
 // starts at +inf — the waves' own k-th best distances are the thresholds.  ev0 / ev1 bracket the pass.
 void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids,
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold = __builtin_inff());
+                                float first_threshold = __builtin_inff(), const void* d_i5 = nullptr, const void* d_i5meta = nullptr);
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.

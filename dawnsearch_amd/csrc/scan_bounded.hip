@@ -28,10 +28,16 @@
 // isotropic data, the dense part of a cluster on topical data — read at the exact pass's rate (lane-per-row walks, 4.6 TB/s with
 // every wave of the chip at it): it degrades towards the exact pass's cost as the data gets denser, never beyond it + 5.5 ms.
 // Predicated per query on d_flags[b] == FLAG_FALLBACK like the exact pass (launch-only searches: no host decision).
+// A SINGLE query of an index of >= 40 Mi rows with a packed 5-bit shadow (scan_i6.hip) streams THAT shadow instead (template
+// parameter SH = 5: 240 B per row, the packed stream's loads and unpacking, its bound E (1 + k2u) + k2c): 4.98 against 5.80 ms per
+// query on 100 M topical rows (k = 20: 5.35 against 5.86); its bound is seven times as loose, so more rows reach the exact scores
+// and a pass that starts without a threshold takes longer to find one — below ~40 M rows the int8 shadow wins
+// (dawn_index.cpp: bounded_packed_wanted; profiles/r04/bounded_packed_ab_*.log).
 #include <type_traits>
 
 #include "kernels.hpp"
 #include "rotate384.hpp"
+#include "packed_shadow.hpp"
 #include "wave_topk.hpp"
 
 namespace dawn {
@@ -83,8 +89,11 @@ __device__ __forceinline__ void bounded_count_and_mirror(uint32_t myflag, uint32
     if (mirror && threadIdx.x < (unsigned)N_STAT_SLOTS) mirror[threadIdx.x] = atomicAdd(&stats[threadIdx.x], 0u);
 }
 
-template <int RT, int PD>
-__global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+// SH = 8: the int8 shadow (384 B per row; PD fragments of 1 KB in flight per wave).  SH = 5: the packed 5-bit shadow of scan_i6.hip
+// (240 B per row; its looser bound — E ~ 0.075 instead of ~ 0.01 — lets more rows through to the exact scores, 1536 B each: worth it
+// while those stay well below the 144 B per row the stream saves; PD = 4 or 8 as there).  One query per launch either way.
+template <int RT, int PD, int SH = 8>
+__global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const void* __restrict__ xv, const float2* __restrict__ meta,
                                                                const void* __restrict__ rows, const uint64_t* __restrict__ ids,
                                                                uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                                uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
@@ -92,7 +101,11 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                                                                uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
                                                                float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
                                                                uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
-    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    static_assert(SH == 5 ? (PD == 4 || PD == 8) : 12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    const u32x4* x = reinterpret_cast<const u32x4*>(xv);        // SH = 8
+    const uint32_t* x5 = reinterpret_cast<const uint32_t*>(xv);  // SH = 5
+    constexpr int NH = SH == 5 ? PD / 4 : 1, NN = SH == 5 ? 3 * PD / 4 : 1, NA = SH == 5 ? 1 : PD;
+    __shared__ int sh_sum[2];
     __shared__ float sh_s[4][LIST];
     __shared__ uint32_t sh_p[4][LIST];
     __shared__ uint32_t sh_queue[4][LIST];  // rows waiting for their exact score, per wave
@@ -127,11 +140,27 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
 
         uint32_t t = blockIdx.x * nwaves + wave;
         const u32x4* p = x + (size_t)(t < n_sub ? t : 0) * (12 * 64) + lane;
-        u32x4 a[PD];
+        const uint32_t* p5 = x5 + (size_t)(t < n_sub ? t : 0) * I5_SUB_DW;
+        [[maybe_unused]] u32x4 a[NA];
+        [[maybe_unused]] u32x3 hq[NH];
+        [[maybe_unused]] u32x4 nq[NN];
+        auto load_h = [&](const uint32_t* sub, int g) __attribute__((always_inline)) { return frag_load(sub + g * I5_HALF_DW + lane * 3); };
+        auto load_n = [&](const uint32_t* sub, int pr) __attribute__((always_inline)) {  // pr = fragment pair 0..5
+            return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sub + (pr / 3) * I5_HALF_DW + 192 + (pr % 3) * 256 + lane * 4));
+        };
         float2 mt = {0.f, 0.f};
         if (t < n_sub) {
+            if constexpr (SH == 5) {
 #pragma unroll
-            for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+                for (int g = 0; g < NH; ++g) {
+                    hq[g] = load_h(p5, g);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) nq[3 * g + m] = load_n(p5, 3 * g + m);
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+            }
             mt = meta[t];
         }
         // the query: f32 copy for the exact scores, two int8 images for the bounds (scan_filter_i8s_kernel)
@@ -147,6 +176,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
             const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+            int sumH = 0, sumL = 0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float tt = v[j] / sq;
@@ -154,8 +184,19 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                 const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
                 sh_img[0][lane + 64 * j] = (signed char)(int)H;
                 sh_img[1][lane + 64 * j] = (signed char)(int)L;
+                sumH += (int)H;
+                sumL += (int)L;
             }
-            if (lane == 0) sh_sq = sq;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {  // (the packed codes are value + 16: the accumulators start from -16 x these sums)
+                sumH += __shfl_xor(sumH, o);
+                sumL += __shfl_xor(sumL, o);
+            }
+            if (lane == 0) {
+                sh_sq = sq;
+                sh_sum[0] = sumH;
+                sh_sum[1] = sumL;
+            }
         }
         __syncthreads();
         i32x4_t qf[12];
@@ -166,7 +207,12 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
             for (int f = 0; f < 12; ++f) qf[f] = col_live ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
         }
         const float sq = sh_sq;
-        const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq, k2 = I8_K2_PER_SQ * sq;
+        // ub = C g1 + g0(E):  int8 shadow: E + K2, K2 = I8_K2_PER_SQ s_q;  packed shadow: E + (I6_XNORM + E) k2u = E emul + k2c (scan_i6.hip)
+        const float sq254 = sq / 254.0f, rsq254 = 254.0f / sq;
+        const float k2u = I6_K2U_PER_SQ * sq;
+        const float k2 = SH == 5 ? I6_XNORM * k2u : I8_K2_PER_SQ * sq;  // the part of the slack that does not depend on the sub-tile
+        const float emul = SH == 5 ? 1.0f + k2u : 1.0f, emul_thr = emul * 1.000001f;
+        const int acc0 = (SH == 5 && col_live) ? -PackedShadow<5>::OFFSET * sh_sum[c == 8 ? 1 : 0] : 0;
         const bool tested = c == 0;
 
         // the wave's exact list (key = -distance, descending) and the score threshold below which a row is skipped
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
             auto slow_path = [&]() __attribute__((always_inline)) {
                 float* strip = &sh_strip[wave][0];
                 if (c == 0) {  // lanes 0 (h = 0) and 32 (h = 1) hold the sub-tile's 32 sums
-                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = pmt.y + k2;
+                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254, g0 = __builtin_fmaf(pmt.y, emul, k2);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const uint32_t roff = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
@@ -258,7 +304,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
             };
             auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
                 if (s == 0) {
-                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                    const float u = __builtin_fmaf(-pmt.y, emul_thr, tau_m);
                     float thr_f = __builtin_fmaf(u, pmt.x * rsq254, -2.0f);
                     thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
                     if (!tested) thr_f = 2.0e9f;
@@ -279,16 +325,51 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                 const uint32_t tn = t + t_stride;
                 more = tn < n_sub;
                 const u32x4* pn = more ? x + (size_t)tn * (12 * 64) + lane : p;
+                const uint32_t* pn5 = more ? x5 + (size_t)tn * I5_SUB_DW : p5;
                 const float2 mtn = meta[more ? tn : t];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0;
+                for (int e = 0; e < 16; ++e) acc[e] = acc0;
+                if constexpr (SH == 5) {
+                    // (scan_filter_i6s_kernel's 5-bit loop: a fragment pair = one 16-B load of nibbles + a third of a 12-B load of
+                    // fifth bits -> two MFMA operands)
 #pragma unroll
-                for (int f = 0; f < 12; ++f) {
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
-                    if (f + PD < 12) a[f % PD] = __builtin_nontemporal_load(p + (f + PD) * 64);
-                    else a[f % PD] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
-                    if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int pr = 0; pr < 6; ++pr) {
+                        const int g = pr / 3, m = pr % 3;
+                        const u32x4 nw = nq[pr % NN];
+                        const u32x3 hw = hq[g % NH];
+                        const uint32_t H = m == 0 ? hw.x : m == 1 ? hw.y : hw.z;
+                        const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z, n3 = nw.w;
+                        i32x4_t av, bv;
+                        av[0] = (int)((n0 & 0x0F0F0F0Fu) | (H & 0x10101010u));
+                        av[1] = (int)(((n0 >> 4) & 0x0F0F0F0Fu) | ((H >> 1) & 0x10101010u));
+                        av[2] = (int)((n1 & 0x0F0F0F0Fu) | ((H >> 2) & 0x10101010u));
+                        av[3] = (int)(((n1 >> 4) & 0x0F0F0F0Fu) | ((H >> 3) & 0x10101010u));
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[2 * pr], acc, 0, 0, 0);
+                        if constexpr (decltype(with_test)::value) test_slice(2 * pr, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bv[0] = (int)((n2 & 0x0F0F0F0Fu) | ((H << 4) & 0x10101010u));
+                        bv[1] = (int)(((n2 >> 4) & 0x0F0F0F0Fu) | ((H << 3) & 0x10101010u));
+                        bv[2] = (int)((n3 & 0x0F0F0F0Fu) | ((H << 2) & 0x10101010u));
+                        bv[3] = (int)(((n3 >> 4) & 0x0F0F0F0Fu) | ((H << 1) & 0x10101010u));
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bv, qf[2 * pr + 1], acc, 0, 0, 0);
+                        if (pr + NN < 6) nq[pr % NN] = load_n(p5, pr + NN);
+                        else nq[pr % NN] = load_n(pn5, pr + NN - 6);
+                        if (m == 2) {
+                            if (g + NH < 2) hq[g % NH] = load_h(p5, g + NH);
+                            else hq[g % NH] = load_h(pn5, g + NH - 2);
+                        }
+                        if constexpr (decltype(with_test)::value) test_slice(2 * pr + 1, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 12; ++f) {
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % NA]), qf[f], acc, 0, 0, 0);
+                        if (f + PD < 12) a[f % NA] = __builtin_nontemporal_load(p + (f + PD) * 64);
+                        else a[f % NA] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
+                        if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if constexpr (decltype(with_test)::value)
                     if (__any(mx > thr)) slow_path();
@@ -296,6 +377,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const u32x4* __res
                 prow = t * 32u;
                 t = tn;
                 p = pn;
+                p5 = pn5;
                 mt = mtn;
             };
             using P0 = std::integral_constant<int, 0>;
@@ -714,7 +796,7 @@ void set_bounded_ring(int pd) { g_bounded_ring = pd == 12 ? 12 : 6; }
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
-                         uint32_t* d_stats, uint32_t* stats_mirror) {
+                         uint32_t* d_stats, uint32_t* stats_mirror, const void* d_i5, const void* d_i5meta) {
     static OncePerDevice attr_once;
     once_per_device(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 6>),
@@ -735,7 +817,17 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
         cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0,   \
         d_stats, stats_mirror
         const bool deep = g_bounded_ring == 12;
-        if (B == 1) {  // one query: its list stays in registers
+        if (B == 1 && d_i5 && d_i5meta) {  // one query, an index with a packed shadow: 240 B per row
+#define DAWN_BOUNDED_ARGS5                                                                                                     \
+    d_i5, reinterpret_cast<const float2*>(d_i5meta), d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0,   \
+        cand_s + (size_t)b0 * n_lists * LIST, cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, \
+        d_dist + (size_t)b0 * k, d_found + b0, d_stats, stats_mirror
+            if (dtype == ROW_BF16)
+                hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 8, 5>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS5);
+            else
+                hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 8, 5>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS5);
+#undef DAWN_BOUNDED_ARGS5
+        } else if (B == 1) {  // one query: its list stays in registers
             if (dtype == ROW_BF16) {
                 if (deep) hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 12>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
                 else hipLaunchKernelGGL((scan_bounded_i8_kernel<1, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
@@ -775,12 +867,12 @@ void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const vo
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold) {
+                                float first_threshold, const void* d_i5, const void* d_i5meta) {
     const uint32_t found = n_rows < k ? n_rows : k;
     hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, found, first_threshold);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_scan_bounded(d_i8, d_i8meta, d_x, dtype, d_ids, n_rows, d_q, 1, d_flags, d_done, cand_s, cand_p, n_lists, k, d_labels,
-                        d_dist, d_found, stream, d_stats, stats_mirror);
+                        d_dist, d_found, stream, d_stats, stats_mirror, d_i5, d_i5meta);
     if (ev1) (void)hipEventRecord(ev1, stream);
 }
 

@@ -34,6 +34,7 @@
 
 #include "kernels.hpp"
 #include "rotate384.hpp"
+#include "packed_shadow.hpp"
 #include "wave_topk.hpp"
 
 // FIVE bits (240 B per row, BITS = 5 below — the default; the 6-bit form stays selectable): the same with 15 levels, codes X + 16.
@@ -64,23 +65,6 @@ static __device__ unsigned long long dawn_ts_i6[2048 * 5];
 #endif
 
 namespace dawn {
-
-typedef int i32x16_t __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-typedef u32x3 u32x3_u __attribute__((aligned(4)));  // (fragments are 12-B lane slots: 4-B aligned)
-
-constexpr uint32_t I6_FRAG_DW = 64 * 3;            // 6-bit form: dwords per fragment
-constexpr uint32_t I6_SUB_DW = 12 * I6_FRAG_DW;    // ... per sub-tile (9216 B)
-constexpr uint32_t I5_SUB_DW = 1920;               // 5-bit form: dwords per sub-tile (7680 B)
-constexpr uint32_t I5_HALF_DW = 960;               // [H (192 dwords) | N N N (256 dwords each)]
-template <int BITS> struct PackedShadow {
-    static constexpr float LEVELS = BITS == 6 ? 31.0f : 15.0f;
-    static constexpr int OFFSET = BITS == 6 ? 32 : 16;  // code = value + OFFSET
-    static constexpr uint32_t SUB_DW = BITS == 6 ? I6_SUB_DW : I5_SUB_DW;
-};
-// K2 of a sub-tile with measured error E and a query of scale s_q: (I6_XNORM + E) * I6_K2U_PER_SQ * s_q  (header)
-constexpr float I6_XNORM = 1.015f;
-constexpr float I6_K2U_PER_SQ = 19.6f * I8_QRES;
 
 // ------------------------------------------------------------------------------------------------
 // conversion: rows -> 6-bit sub-tiles + {1 / s, E} per sub-tile (rows_to_i8s_kernel with the packing above)
@@ -231,9 +215,6 @@ __device__ __forceinline__ float dot4_f(const f32x4& a, const f32x4& b, float ac
     return acc;
 }
 
-__device__ __forceinline__ u32x3 frag_load(const uint32_t* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x3_u*>(p));
-}
 
 // block_merge (wave_topk.hpp) for any number of waves
 __device__ __forceinline__ void block_merge_any(float& s, uint32_t& p, float (*sh_s)[LIST], uint32_t (*sh_p)[LIST], int wave,

@@ -86,6 +86,11 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      2: never — the bounded pass is their whole search (what a demoted index does; A/B, tests)
  *   "debug_bad_threshold" test hook: a demoted search starts its bounded pass from an impossible threshold; the pass notices and
  *                      its last workgroup scans all rows exactly (counted as a fallback)
+ *   "bounded_packed"   the bounded pass of a SINGLE query streams the packed 5-bit shadow (240 B/row) instead of the int8 one: 0 never,
+ *                      1 (default) on indexes of >= 40 Mi rows (100 M topical rows: 4.98 against 5.80 ms per query; 12.5 M: 1.04
+ *                      against 0.89), 2 always (tests)
+ *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
+ *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows
  *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
  *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow

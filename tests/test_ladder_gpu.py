@@ -63,14 +63,18 @@ def test_topical_generator_matches_numpy_and_oracle(dawn, oracle, dist):
 
 @pytest.mark.parametrize("dist", [4, 5])
 @pytest.mark.parametrize("k", [10, 20])
-def test_topical_index_every_rung_equals_the_oracle(dawn, oracle, dist, k):
+@pytest.mark.parametrize("bounded_packed", [0, 2])
+def test_topical_index_every_rung_equals_the_oracle(dawn, oracle, dist, k, bounded_packed):
     """400 k topical rows, queries inside the three largest clusters (33 k, 17 k, 17 k rows) and anywhere.  The lists are sized
     for 100 M rows; here the grids are shrunk until they are as short of this index's clusters as the full grids are of a
     100 M-row index's (tools/clustered_probe.py: 28 % of such queries fail on 12.5 M rows): packed stream 4 workgroups x 8 waves x
     8 entries, int8 stream 2 workgroups, 64 candidates per query in a batch.  Packed stream, int8 stream, a batch — all bit-equal
-    to the oracle's scan of the same rows, no exact pass anywhere, the bounded pass counted where certificates failed."""
+    to the oracle's scan of the same rows, no exact pass anywhere, the bounded pass counted where certificates failed.
+    bounded_packed: the bounded pass of a single query streams the int8 shadow (0) or the packed 5-bit shadow (2: forced; by
+    default from 40 Mi rows)."""
     n = 400_000
     idx = _topical_index(dawn, n, dist)
+    idx.set_option("bounded_packed", bounded_packed)
     idx.set_option("i6_scan_blocks", 4)
     idx.set_option("i6_refine", 8)
     idx.set_option("shadow_scan_blocks", 2)
@@ -298,3 +302,32 @@ def test_batch_feedback_deepens_the_thresholds_of_a_ladder_heavy_index(dawn, ora
     for _ in range(8):
         flat.search_batch(Qf, 10)
     assert flat.stats_batch_feedback()["deepened_batches"] == 0
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 64, 1000, 4097, 100_003])
+@pytest.mark.parametrize("k", [1, 10, 64])
+def test_bounded_pass_on_the_packed_shadow_sizes(dawn, oracle, n, k):
+    """The bounded pass of a single query on the packed 5-bit shadow (option "bounded_packed" = 2: by default only from 40 Mi rows):
+    behind certificates that are made to fail (force_fallback = 2) and as the whole search of a demoted index (ladder_feedback =
+    2: no first threshold), sizes around the sub-tile boundaries, k up to the list length, an f32 and a bf16 index."""
+    for dtype in ("f32", "bf16"):
+        idx = dawn.VectorIndex(0, dtype=dtype)
+        idx.set_option("i6_min_rows", 0)
+        idx.set_option("bounded_packed", 2)
+        idx.fill_synthetic(1, 0, n, 1)
+        x = oracle.unit_rows(1, 0, n)
+        if dtype == "bf16":
+            x = synth.round_bf16(x)
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        Q = np.concatenate([synth.unit_rows(2, 0, 2), synth.planted_queries(1, [n // 2], 4)])
+        idx.set_option("force_fallback", 2)
+        for q in Q:
+            lab, dist = idx.search(q, k)
+            assert len(lab) == min(k, n)
+            _same(lab, dist, *oracle.scan_topk(x, ids, q, k))
+        idx.set_option("force_fallback", 0)
+        idx.set_option("ladder_feedback", 2)
+        for q in Q:
+            _same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
+        st = idx.stats()
+        assert st["bounded"] == 6 and st["fallbacks"] == 0 and st["demoted"] == 3, st
