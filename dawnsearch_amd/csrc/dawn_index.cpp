@@ -521,11 +521,24 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             // a demoted index: the bounded exact pass is the whole search (240 B/row on the packed shadow, no certificate to fail)
             ++idx->n_demoted;
             const bool p5 = bounded_packed_wanted(idx, n);
+            // A pass that starts without a threshold scores rows exactly until its waves have found k good ones each — with the
+            // packed shadow's loose bound that costs ~0.75 ms of a 5-ms pass at 100 M rows (a pass behind a failed packed stream,
+            // which hands over its k-th distance: 4.2 ms).  The packed stream over the first 1/32 of the rows (0.15 ms) finds a
+            // k-th exact distance that bounds the final one from above just as well (option "bounded_seed").
+            const bool seed = p5 && idx->bounded_seed && !idx->debug_bad_threshold &&
+                              n / 32u >= (idx->bounded_seed == 2 ? 1024u : (1u << 20));  // (2: tests, any index of >= 32 Ki rows)
+            if (seed) {
+                ScanGeom g6 = idx->i6_geom();
+                launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
+                               n / 32u, d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
+                               idx->stream_dyn_tail ? idx->d_i6_pool : nullptr, g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
+                               0, true, stream, nullptr, nullptr, nullptr, idx->i6_central_tail != 0);
+            }
             launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
                                        idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
                                        d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats,
                                        idx->debug_bad_threshold ? -1.0f : __builtin_inff(), p5 ? idx->d_i6 : nullptr,
-                                       p5 ? idx->d_i6meta : nullptr);
+                                       p5 ? idx->d_i6meta : nullptr, seed);
             DAWN_HIP_TRY(hipGetLastError());
             return DAWN_OK;
         }
@@ -981,6 +994,12 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "bounded_packed") {  // the bounded pass of a single query streams the packed 5-bit shadow: 0 never, 1 from 40 Mi rows, 2 always
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_packed must be 0, 1 or 2");
         idx->bounded_packed = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_seed") {  // 1 (default): a demoted query's bounded pass on the packed shadow starts from the k-th distance of a
+                                // packed-stream search over the first 1/32 of the rows
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_seed must be 0, 1 or 2");
+        idx->bounded_seed = (int)value;
         return DAWN_OK;
     }
     if (n == "bounded_ring") {  // process-wide: 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)

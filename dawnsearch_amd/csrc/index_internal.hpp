@@ -178,6 +178,7 @@ struct dawn_index {
     size_t events_used = 0;
     uint64_t n_searches = 0;
     int force_fallback = 0;      // option "force_fallback": 1 = every query takes the exact pass, 2 = every certificate fails (ladder)
+    int bounded_seed = 1;        // option "bounded_seed": a demoted query's packed bounded pass is seeded by a search over 1/32 of the rows
     int bounded_packed = 1;      // option "bounded_packed": the bounded pass of a single query streams the packed 5-bit shadow
                                  // (240 B/row): 0 never, 1 from 40 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)
     int bounded_pass = 1;        // option "bounded_pass": a failed certificate is answered from the int8 shadow (scan_bounded.hip)

@@ -233,7 +233,9 @@ void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const vo
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold = __builtin_inff(), const void* d_i5 = nullptr, const void* d_i5meta = nullptr);
+                                float first_threshold = __builtin_inff(), const void* d_i5 = nullptr, const void* d_i5meta = nullptr,
+                                bool seeded = false);
+// (seeded: d_dist[k - 1] already holds the k-th exact distance of a search over PART of the rows — a valid first threshold; it is kept)
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion
 // positions — ties go to the lower position and the winners are translated through the table.

@@ -856,10 +856,13 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     }
 }
 
-__global__ void bounded_prime_kernel(uint32_t* __restrict__ flags, float* __restrict__ out_dist, uint32_t found, float threshold) {
+// keep = 1: out_dist[found - 1] already holds a valid first threshold (the k-th exact distance of a search over a PART of the rows:
+// launch_scan_bounded_direct's seed) — only the flag is raised
+__global__ void bounded_prime_kernel(uint32_t* __restrict__ flags, float* __restrict__ out_dist, uint32_t found, float threshold,
+                                     int keep) {
     if (threadIdx.x == 0) {
         flags[0] = FLAG_FALLBACK;
-        if (found > 0) out_dist[found - 1] = threshold;
+        if (found > 0 && !keep) out_dist[found - 1] = threshold;
     }
 }
 
@@ -867,9 +870,9 @@ void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const vo
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold, const void* d_i5, const void* d_i5meta) {
+                                float first_threshold, const void* d_i5, const void* d_i5meta, bool seeded) {
     const uint32_t found = n_rows < k ? n_rows : k;
-    hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, found, first_threshold);
+    hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, found, first_threshold, seeded ? 1 : 0);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_scan_bounded(d_i8, d_i8meta, d_x, dtype, d_ids, n_rows, d_q, 1, d_flags, d_done, cand_s, cand_p, n_lists, k, d_labels,
                         d_dist, d_found, stream, d_stats, stats_mirror, d_i5, d_i5meta);

@@ -89,6 +89,9 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "bounded_packed"   the bounded pass of a SINGLE query streams the packed 5-bit shadow (240 B/row) instead of the int8 one: 0 never,
  *                      1 (default) on indexes of >= 40 Mi rows (100 M topical rows: 4.98 against 5.80 ms per query; 12.5 M: 1.04
  *                      against 0.89), 2 always (tests)
+ *   "bounded_seed"     1 (default): a demoted single query's bounded pass on the packed shadow (indexes of >= 40 Mi rows) starts from the
+ *                      k-th exact distance of a packed-stream search over the first 1/32 of the rows (100 M topical rows: mean 4.98 ->
+ *                      4.17 ms, p50 4.63 -> 3.71); 0: from no threshold; 2: also on small indexes (tests)
  *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
  *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows

@@ -331,3 +331,31 @@ def test_bounded_pass_on_the_packed_shadow_sizes(dawn, oracle, n, k):
             _same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
         st = idx.stats()
         assert st["bounded"] == 6 and st["fallbacks"] == 0 and st["demoted"] == 3, st
+        if n >= 32 * 1024:
+            # ... seeded: the packed stream over the first 1/32 of the rows hands the pass its first threshold (by default from 32 Mi rows)
+            idx.set_option("bounded_seed", 2)
+            for q in Q:
+                _same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
+            st = idx.stats()
+            assert st["bounded"] == 9 and st["fallbacks"] == 0 and st["demoted"] == 6, st
+
+
+@pytest.mark.parametrize("dist", [4, 5])
+def test_seeded_bounded_pass_on_topical_rows(dawn, oracle, dist):
+    """A demoted index on topical rows, the bounded pass on the packed shadow seeded by a packed-stream search over the first 1/32 of
+    the rows (whose own certificate may fail — with the shrunken lists it does: its k-th distance is a valid threshold all the
+    same): the oracle's answers, no exact pass."""
+    n = 400_000
+    idx = _topical_index(dawn, n, dist)
+    idx.set_option("bounded_packed", 2)
+    idx.set_option("bounded_seed", 2)
+    idx.set_option("ladder_feedback", 2)
+    idx.set_option("i6_scan_blocks", 4)
+    idx.set_option("i6_refine", 8)
+    Q = np.concatenate([_topical_queries(dist, 6, clusters={0, 1, 2}), _topical_queries(dist, 6)])
+    for k in (10, 20):
+        want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=dist)
+        for b, q in enumerate(Q):
+            _same(*idx.search(q, k), want[0][b], want[1][b])
+    st = idx.stats()
+    assert st["fallbacks"] == 0 and st["bounded"] == 24 and st["demoted"] == 24, st

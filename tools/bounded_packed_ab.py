@@ -30,9 +30,11 @@ stream = torch.cuda.current_stream().cuda_stream
 ref = {}
 for k in (10, 20):
     blob = torch.zeros((nq, dawn.result_blob_bytes(1, k)), dtype=torch.uint8, device=dev)
-    for packed in (0, 1, 0, 1):
+    for packed, seed in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 0), (1, 1)):
         idx.set_option("bounded_packed", packed)
-        for name, fb in (("bounded pass directly", 2), ("default ladder (packed stream first, feedback)", 1)):
+        idx.set_option("bounded_seed", seed)
+        for name, fb in (("bounded pass directly", 2), ("default ladder (packed stream first, feedback)", 1),
+                         ("packed stream first, no feedback", 0)):
             idx.set_option("ladder_feedback", fb)
             lat = []
             s0 = idx.stats()
@@ -49,7 +51,7 @@ for k in (10, 20):
             raw = blob.cpu().numpy()[:, :k * 12].copy()
             same = np.array_equal(ref.setdefault(k, raw), raw)
             lat = np.array(lat)
-            print(f"rows={rows} dist={dist} k={k} bounded_packed={packed} {name:48s}: mean {lat.mean():6.3f} p50 {np.percentile(lat, 50):6.3f} "
+            print(f"rows={rows} dist={dist} k={k} bounded_packed={packed} seed={seed} {name:48s}: mean {lat.mean():6.3f} p50 {np.percentile(lat, 50):6.3f} "
                   f"p95 {np.percentile(lat, 95):6.3f} max {lat.max():6.3f} ms; bounded {(s1['bounded'] - s0['bounded']) / (2 * nq):.2f} "
-                  f"demoted {(s1['demoted'] - s0['demoted']) / (2 * nq):.2f} fallbacks {s1['fallbacks'] - s0['fallbacks']}; identical: {same}",
+                  f"demoted {(s1['demoted'] - s0['demoted']) / (2 * nq):.2f} packed failures {(s1['packed_failures'] - s0['packed_failures']) / (2 * nq):.2f} fallbacks {s1['fallbacks'] - s0['fallbacks']}; identical: {same}",
                   flush=True)
