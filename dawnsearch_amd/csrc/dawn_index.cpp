@@ -499,7 +499,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             if (fb.demote_left == 0 && fb.issued - fb.win_issued0 >= kFbWindow) {
                 const uint32_t now = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
                 const double rate = (double)(now - fb.win_fail0) / (double)(fb.issued - fb.win_issued0);
-                if (rate > kFbDemote) {
+                if (rate > (bounded_packed_wanted(idx, n) && idx->bounded_seed ? kFbDemotePacked : kFbDemote)) {
                     fb.demote_left = fb.demote_len;
                     fb.demote_len = std::min(fb.demote_len * 2u, kFbDemoteMax);
                 } else {

@@ -25,6 +25,9 @@ constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host b
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
 constexpr uint32_t kFbWindow = 32;        // ladder feedback: packed single-query searches per window
 constexpr double kFbBoost = 0.05, kFbDemote = 0.35;  // failure rates that make the waves refine full lists / demote the index
+// ... an index whose bounded pass runs on the packed shadow, seeded (>= 40 Mi rows): packed stream 3.5 ms + 4.2 ms behind a failure
+// against 4.17 ms for the seeded pass alone on 100 M rows — break-even at a failure rate of 0.16
+constexpr double kFbDemotePacked = 0.18;
 constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
 constexpr uint32_t kBatchFbWindow = 1024;  // int8 batched pass: queries per feedback window
 constexpr double kBatchFbBoost = 0.10;
