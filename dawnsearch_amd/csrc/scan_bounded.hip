@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
         __syncthreads();
         i32x4_t qf[12];
         const bool tested = (c & 8u) == 0u && slot < ng;
+        const unsigned long long tested_mask = __ballot(tested);
         {
             const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&S.img[(c & 8u) ? 1 : 0][slot][0]);
 #pragma unroll
@@ -651,8 +652,15 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
 
             auto slow_path = [&]() __attribute__((always_inline)) {
                 const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l, g0 = pmt.y + k2_l;
+                // (sixteen compares into scalar masks first: with 16 queries per stream some lane is over its threshold in most
+                // sub-tiles of a topical index, but in one or two of the sixteen accumulator registers only — the rest of the work
+                // is skipped by scalar branches)
+                unsigned long long mk[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mk[e] = __ballot(C[e] > thr) & tested_mask;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
+                    if (mk[e] == 0ull) continue;
                     const uint32_t row = prow + (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
                     const bool hit = tested && C[e] > thr && row < n_rows && __builtin_fmaf((float)C[e], g1, g0) > tau_l;
                     const unsigned long long m = __ballot(hit);

@@ -32,7 +32,7 @@ ref = {}
 for r in range(rounds):
     for ring in (6, 12):
         idx.set_option("bounded_ring", ring)
-        for name, B, fb, iters in (("batch 256", 256, 1, 6), ("single queries, bounded pass directly", 1, 2, 32)):
+        for name, B, fb, iters in (("batch 256", 256, 0, 6), ("single queries, bounded pass directly", 1, 2, 32)):
             idx.set_option("ladder_feedback", fb)
             for _ in range(2):
                 idx.search_device(d_q.data_ptr(), B, k, p, p + B * k * 8, p + B * k * 12, stream)
