@@ -1002,6 +1002,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->bounded_seed = (int)value;
         return DAWN_OK;
     }
+    if (n == "bounded_multi_waves") {  // process-wide: waves per workgroup of the bounded pass of batches (4 or 8)
+        if (value != 4 && value != 8) return fail(DAWN_ERR_INVALID_ARG, "bounded_multi_waves must be 4 or 8");
+        dawn::set_bounded_multi_waves((int)value);
+        return DAWN_OK;
+    }
     if (n == "bounded_ring") {  // process-wide: 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)
         if (value != 6 && value != 12) return fail(DAWN_ERR_INVALID_ARG, "bounded_ring must be 6 or 12");
         dawn::set_bounded_ring((int)value);

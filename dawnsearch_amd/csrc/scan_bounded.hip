@@ -462,14 +462,15 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const void* __rest
 constexpr int BQ = 16;          // queries per stream
 constexpr int BQ_QSTRIDE = 388; // floats per staged query (odd multiple of 4: lanes reading different queries hit different banks)
 constexpr int BQ_QCAP = 640;    // queue entries per wave (< 64 waiting + <= 32 rows x 16 queries of one sub-tile)
+template <int NW>  // waves per workgroup: 4 (93 KB) or 8 (149 KB)
 struct BoundedMultiLds {
     float q[BQ][BQ_QSTRIDE];
     signed char img[2][BQ][EM];
-    float lists_s[4][BQ][LIST];
-    uint32_t lists_p[4][BQ][LIST];
-    uint2 queue[4][BQ_QCAP];
-    float merge_s[4][LIST];
-    uint32_t merge_p[4][LIST];
+    float lists_s[NW][BQ][LIST];
+    uint32_t lists_p[NW][BQ][LIST];
+    uint2 queue[NW][BQ_QCAP];
+    float merge_s[NW][LIST];
+    uint32_t merge_p[NW][LIST];
     float sq[BQ];
     float d_in[BQ];
     uint32_t flagged[kBoundedMaxFlags];
@@ -477,8 +478,8 @@ struct BoundedMultiLds {
     uint32_t last;
 };
 
-template <int RT, int PD>
-__global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+template <int RT, int PD, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
                                                                      const void* __restrict__ rows, const uint64_t* __restrict__ ids,
                                                                      uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                                      uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
@@ -488,10 +489,10 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
                                                                      uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
     static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char bounded_lds[];
-    BoundedMultiLds& S = *reinterpret_cast<BoundedMultiLds*>(bounded_lds);
+    BoundedMultiLds<NW>& S = *reinterpret_cast<BoundedMultiLds<NW>*>(bounded_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;  // 4
+    const int nwaves = NW;
     const uint32_t n_sub = (n_rows + 31u) >> 5;
     const uint32_t c = lane & 31, h = lane >> 5;
     const uint32_t t_stride = gridDim.x * nwaves;
@@ -502,11 +503,11 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
         const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
         const bool fl = myflag == FLAG_FALLBACK;
         const unsigned long long m = __ballot(fl);
-        if (lane == 0) S.mask[wave] = m;
+        if (lane == 0 && wave < kBoundedMaxFlags / 64) S.mask[wave] = m;  // (the flags live in the first four waves)
         bounded_count_and_mirror(myflag, stats, mirror);
         __syncthreads();
         uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(S.mask[w]);
+        for (int w = 0; w < wave && w < kBoundedMaxFlags / 64; ++w) rank += (uint32_t)__popcll(S.mask[w]);
         if (fl) S.flagged[rank] = threadIdx.x;
         __syncthreads();
     }
@@ -800,6 +801,9 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_multi_kernel(const u32x4*
 // fragments a wave keeps in flight ahead of its MFMAs (6: half a sub-tile, 12: a whole one); process-wide, option "bounded_ring"
 static int g_bounded_ring = 6;
 void set_bounded_ring(int pd) { g_bounded_ring = pd == 12 ? 12 : 6; }
+// waves per workgroup of the batch form (one workgroup per CU either way: its LDS); process-wide, option "bounded_multi_waves"
+static int g_bounded_multi_waves = 8;  // (74.0 against 77.4 ms per topical batch of 256 at 100 M rows: profiles/r04/bounded_multi_waves_100M.log)
+void set_bounded_multi_waves(int nw) { g_bounded_multi_waves = nw == 8 ? 8 : 4; }
 
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
@@ -807,14 +811,11 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                          uint32_t* d_stats, uint32_t* stats_mirror, const void* d_i5, const void* d_i5meta) {
     static OncePerDevice attr_once;
     once_per_device(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 6>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 6>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 12>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 12>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds));
+#define DAWN_BM_ATTR(RT_, PD_, NW_)                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<RT_, PD_, NW_>), \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<NW_>));
+        DAWN_BM_ATTR(0, 6, 4) DAWN_BM_ATTR(1, 6, 4) DAWN_BM_ATTR(0, 12, 4) DAWN_BM_ATTR(1, 12, 4) DAWN_BM_ATTR(0, 6, 8) DAWN_BM_ATTR(1, 6, 8)
+#undef DAWN_BM_ATTR
     });
     const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
     const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
@@ -844,21 +845,18 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                 else hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
             }
         } else {       // a batch: its flagged queries, sixteen per stream of the shadow
-            if (dtype == ROW_BF16) {
-                if (deep)
-                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 12>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                       DAWN_BOUNDED_ARGS);
-                else
-                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                       DAWN_BOUNDED_ARGS);
+#define DAWN_BM_LAUNCH(RT_, PD_, NW_)                                                                                                  \
+    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<RT_, PD_, NW_>), dim3(n_lists), dim3(64 * NW_), sizeof(BoundedMultiLds<NW_>), stream, \
+                       DAWN_BOUNDED_ARGS)
+            const int rt = dtype == ROW_BF16 ? 1 : 0;
+            if (g_bounded_multi_waves == 8) {
+                if (rt) DAWN_BM_LAUNCH(1, 6, 8); else DAWN_BM_LAUNCH(0, 6, 8);
+            } else if (deep) {
+                if (rt) DAWN_BM_LAUNCH(1, 12, 4); else DAWN_BM_LAUNCH(0, 12, 4);
             } else {
-                if (deep)
-                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 12>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                       DAWN_BOUNDED_ARGS);
-                else
-                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 6>), dim3(n_lists), dim3(256), sizeof(BoundedMultiLds), stream,
-                                       DAWN_BOUNDED_ARGS);
+                if (rt) DAWN_BM_LAUNCH(1, 6, 4); else DAWN_BM_LAUNCH(0, 6, 4);
             }
+#undef DAWN_BM_LAUNCH
         }
 #undef DAWN_BOUNDED_ARGS
     }

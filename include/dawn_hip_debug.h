@@ -92,6 +92,8 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "bounded_seed"     1 (default): a demoted single query's bounded pass on the packed shadow (indexes of >= 40 Mi rows) starts from the
  *                      k-th exact distance of a packed-stream search over the first 1/32 of the rows (100 M topical rows: mean 4.98 ->
  *                      4.17 ms, p50 4.63 -> 3.71); 0: from no threshold; 2: also on small indexes (tests)
+ *   "bounded_multi_waves"  process-wide: waves per workgroup of the bounded pass of batches, 8 (default) or 4 (one workgroup per CU
+ *                      either way; 74.0 against 77.4 ms per topical batch of 256 at 100 M rows)
  *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
  *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows
