@@ -134,8 +134,9 @@ int ensure_workspace(dawn_index* idx, size_t B) {
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_tb, lists * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_s, n * sizeof(float)));
     DAWN_HIP_TRY(hipMalloc((void**)&idx->d_cand_p, n * sizeof(uint32_t)));
-    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, 2 * B * sizeof(uint32_t)));  // flags[B] | arrival counters of the exact pass[B]
-    DAWN_HIP_TRY(hipMemset(idx->d_flags, 0, 2 * B * sizeof(uint32_t)));
+    // flags[B] | arrival counters of the exact pass[B] | launch_i8_rerun's scratch: go word (+ 3 unused) + 256 "lost" marks
+    DAWN_HIP_TRY(hipMalloc((void**)&idx->d_flags, (2 * B + 4 + dawn::BATCH_QT) * sizeof(uint32_t)));
+    DAWN_HIP_TRY(hipMemset(idx->d_flags, 0, (2 * B + 4 + dawn::BATCH_QT) * sizeof(uint32_t)));
     DAWN_HIP_TRY(hipDeviceSynchronize());  // (searches run on non-blocking streams)
     idx->ws_B = B;
     idx->ws_lists = lists;
@@ -451,6 +452,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     } else if (batched && idx->i8_batched && i8_live(idx)) {
         // matrix-core path on the int8 shadow (v_mfma_i32_32x32x32_i8, upper-bound scores), BATCH_QT queries per pass
         dawn::BatchWorkspace bw = idx->bws;
+        bool rerun = false;  // the flagged queries of a batch get a second pass with exact-derived thresholds (scan_i8.hip: launch_i8_rerun)
         if (idx->ladder_feedback && idx->h_stats && !idx->force_fallback && n > (uint32_t)BATCH_CAP) {
             // batch feedback (index_internal.hpp): too many of this index's batched queries in the ladder -> deeper thresholds
             auto& fb = idx->bfb;
@@ -465,14 +467,20 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             if (fb.boosted) {
                 bw.target = std::max(bw.target, k > 32 ? kBatchBoostTargetWide : kBatchBoostTarget);
                 idx->n_deepened_batches += (B + BATCH_QT - 1) / BATCH_QT;
+                rerun = idx->batch_rerun != 0 && idx->bounded_pass;
             }
         }
+        if (idx->batch_rerun == 2 && n > (uint32_t)BATCH_CAP && idx->force_fallback != 1) rerun = true;  // (tests, A/B: every batch)
         for (size_t b0 = 0; b0 < B; b0 += BATCH_QT) {
             const size_t nb = std::min<size_t>(BATCH_QT, B - b0);
             launch_scan_batched_i8(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * EM, (int)nb,
                                    (uint32_t)k, bw, idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0,
                                    idx->d_flags + b0, idx->force_fallback, stream, b0 == 0 ? e0 : nullptr,
                                    b0 == 0 ? e1 : nullptr);
+            if (rerun)
+                launch_i8_rerun(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->d_ids, n, d_q + b0 * EM, (int)nb, (uint32_t)k, bw,
+                                idx->mfma_blocks, d_labels + b0 * k, d_dist + b0 * k, d_found + b0, idx->d_flags + b0,
+                                idx->d_flags + 2 * idx->ws_B, stream);
         }
     } else if (batched) {
         // matrix-core path on 16-bit rows: the f16 shadow of an f32 index, a bf16 index itself; an f32 index without a
@@ -1000,6 +1008,12 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
                                 // packed-stream search over the first 1/32 of the rows
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_seed must be 0, 1 or 2");
         idx->bounded_seed = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "batch_rerun") {  // the second pass of a batch's flagged queries with exact-derived thresholds: 0 never (default), 1 on an
+                               // index whose batch feedback has deepened its thresholds, 2 every batch (tests, A/B)
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "batch_rerun must be 0, 1 or 2");
+        idx->batch_rerun = (int)value;
         return DAWN_OK;
     }
     if (n == "bounded_multi_waves") {  // process-wide: waves per workgroup of the bounded pass of batches (4 or 8)
@@ -1657,12 +1671,20 @@ int dawn_index_stats_ladder(dawn_index* idx, uint64_t* bounded, uint64_t* packed
 
 // ... what the feedback of the batched paths did (debug header): batches (of <= 256 queries) the FP6 first filter took, batches
 // its feedback handed to the int8 pass instead, batches the int8 pass ran with the deeper thresholds of a ladder-heavy index
-int dawn_index_stats_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches) {
+int dawn_index_stats_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches,
+                                    uint64_t* rerun_answers) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
     if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "per-shard counters: ask the shards");
     if (f6_batches) *f6_batches = idx->n_f6_batches;
     if (f6_suspended) *f6_suspended = idx->n_f6_suspended;
     if (deepened_batches) *deepened_batches = idx->n_deepened_batches;
+    if (rerun_answers) {  // queries of batches answered by the second pass with exact-derived thresholds (FLAG_RERUN)
+        uint32_t st[dawn::N_STAT_SLOTS] = {};
+        DAWN_TRY(set_device(idx));
+        DAWN_HIP_TRY(hipDeviceSynchronize());
+        if (idx->d_stats) DAWN_HIP_TRY(hipMemcpy(st, idx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+        *rerun_answers = st[dawn::FLAG_RERUN];
+    }
     return DAWN_OK;
 }
 

@@ -181,6 +181,13 @@ struct dawn_index {
     size_t events_used = 0;
     uint64_t n_searches = 0;
     int force_fallback = 0;      // option "force_fallback": 1 = every query takes the exact pass, 2 = every certificate fails (ladder)
+    // option "batch_rerun": a second matrix-core pass for a batch's flagged queries with exact-derived thresholds (scan_i8.hip:
+    // launch_i8_rerun): 0 never (default), 1 on ladder-heavy indexes, 2 always.  Measured on 100 M topical rows
+    // (profiles/r04/batch_rerun_ab_100M.log): it settles 18-30 % of a batch at the default threshold depth (74 -> 69, 84 -> 72 ms) but
+    // only 4-19 % once the batch feedback has deepened the thresholds, which alone gets 63-72 ms — the second pass costs 12 ms, two
+    // bounded streams' worth, and ~35 % of such a batch (the near-tie shells) overflows any candidate buffer.  Kept for indexes where
+    // the split is different; off by default.
+    int batch_rerun = 0;
     int bounded_seed = 1;        // option "bounded_seed": a demoted query's packed bounded pass is seeded by a search over 1/32 of the rows
     int bounded_packed = 1;      // option "bounded_packed": the bounded pass of a single query streams the packed 5-bit shadow
                                  // (240 B/row): 0 never, 1 from 40 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)

@@ -65,6 +65,8 @@ constexpr uint32_t FLAG_FALLBACK = 1;  // certificate failed: the exact pass mus
 constexpr uint32_t FLAG_SECOND = 2;    // first certificate failed, the 1024-deep second one held: result is exact
 constexpr uint32_t FLAG_DEEP = 3;      // first certificate failed, a deeper round (128 .. 256 rows) held: result is exact
 constexpr uint32_t FLAG_BOUNDED = 4;   // every certificate failed, the bounded exact pass (scan_bounded.hip) answered: result is exact
+constexpr uint32_t FLAG_RERUN = 6;     // a batch's certificate failed at the sampled threshold; a second pass of the flagged queries with the
+                                       // threshold their own k-th exact distance gives answered: result is exact (scan_i8.hip: launch_i8_rerun)
 constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query ...
 constexpr int STAT_PACKED_FAIL = 5;    // ... and [5]: single-query searches whose packed-stream certificate failed (merge_exact_kernel)
 
@@ -165,7 +167,13 @@ BatchPlan plan_batched_tiles(uint32_t n_rows, uint32_t tile_rows, int target, ui
 void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_t dense_count, uint32_t m, hipStream_t stream);
 void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                                const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
-                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream);
+                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream, int rerun = 0);
+// (rerun = 1: only queries flagged FLAG_FALLBACK are looked at; the ones this tail settles become FLAG_RERUN)
+// The int8 matrix-core pass once more for the FLAGGED queries of a batch, each with the threshold its own k-th exact distance gives
+// (1 - d_k - margin: the bounded pass's arithmetic) instead of the sampled one; d_go: 4 + BATCH_QT device words (scratch).
+void launch_i8_rerun(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
+                     const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
+                     uint32_t* d_found, uint32_t* d_flags, uint32_t* d_go, hipStream_t stream);
 void launch_batched_full_pass_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, int B, const BatchWorkspace& ws, int grid,
                                  int iters, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_batched_dense_scores_i8(const void* d_i8, const void* d_meta, uint32_t n_rows, const float* d_q, int B,

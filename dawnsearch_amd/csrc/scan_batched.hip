@@ -1100,7 +1100,8 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
     const void* __restrict__ x, const uint64_t* __restrict__ ids, uint32_t n_rows, const float* __restrict__ q,
     const float* __restrict__ dense, const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt,
     const float* __restrict__ tau, uint32_t k, uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
-    uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags, int force_fallback, float eps) {
+    uint32_t* __restrict__ out_found, uint32_t* __restrict__ out_flags, int force_fallback, float eps, int rerun) {
+    if (rerun && out_flags[blockIdx.x] != FLAG_FALLBACK) return;  // (block-uniform: a second pass looks at the flagged queries only)
     __shared__ float sh_s[16][LIST];
     __shared__ uint32_t sh_p[16][LIST];
     __shared__ uint32_t sh_rows[LIST];
@@ -1142,7 +1143,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
         }
         if (lane == 0) {
             out_found[b] = found;
-            out_flags[b] = flag;
+            out_flags[b] = (rerun && flag != FLAG_FALLBACK) ? FLAG_RERUN : flag;
         }
     }
     if (!heavy) return;
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(
             out_labels[(size_t)b * k + lane] = ids[p2];
             out_dist[(size_t)b * k + lane] = -s2;
         }
-        if (lane == 0) out_flags[b] = FLAG_SECOND;
+        if (lane == 0) out_flags[b] = rerun ? FLAG_RERUN : FLAG_SECOND;
     }
 }
 
@@ -1419,7 +1420,7 @@ template <bool DENSE>
 static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q,
                                   int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
                                   uint32_t* d_found, uint32_t* d_flags, int force_fallback, hipStream_t stream,
-                                  float eps_override = 0.f) {
+                                  float eps_override = 0.f, int rerun = 0) {
     const float* dense = reinterpret_cast<const float*>(ws.cand);
     const uint2* cand = reinterpret_cast<const uint2*>(ws.cand);
     // the bf16-rounded rows may exceed the is_normalized band by 2^-8: scale the bound on sum|q_i x_i| accordingly
@@ -1427,22 +1428,22 @@ static void launch_select_rescore(const void* d_x, int dtype, const uint64_t* d_
     if (dtype == ROW_BF16)
         hipLaunchKernelGGL((select_rescore_kernel<DENSE, 1>), dim3(B), dim3(1024), RescoreStage<1>::BYTES, stream, d_x,
                            d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
-                           force_fallback, eps);
+                           force_fallback, eps, rerun);
     else
         hipLaunchKernelGGL((select_rescore_kernel<DENSE, 0>), dim3(B), dim3(1024), RescoreStage<0>::BYTES, stream, d_x,
                            d_ids, n_rows, d_q, dense, cand, ws.cnt, ws.tau, k, d_labels, d_dist, d_found, d_flags,
-                           force_fallback, eps);
+                           force_fallback, eps, rerun);
 }
 
 void launch_select_rescore_eps(bool dense_pass, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                                const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, uint64_t* d_labels, float* d_dist,
-                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream) {
+                               uint32_t* d_found, uint32_t* d_flags, int force_fallback, float eps, hipStream_t stream, int rerun) {
     if (dense_pass)
         launch_select_rescore<true>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, force_fallback,
-                                    stream, eps);
+                                    stream, eps, rerun);
     else
         launch_select_rescore<false>(d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, force_fallback,
-                                     stream, eps);
+                                     stream, eps, rerun);
 }
 
 void launch_tau_select(bool dense_pass, int B, const BatchWorkspace& ws, uint32_t dense_count, uint32_t m, hipStream_t stream) {

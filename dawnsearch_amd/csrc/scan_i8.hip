@@ -1167,7 +1167,9 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
                                                             uint32_t n_tiles, const i32x4_t* __restrict__ qi,
                                                             const float2* __restrict__ qmeta, int n_q,
                                                             const float* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                            uint2* __restrict__ cand, float* __restrict__ dense) {
+                                                            uint2* __restrict__ cand, float* __restrict__ dense,
+                                                            uint32_t* __restrict__ go) {
+    if (go != nullptr && go[0] == 0u) return;  // (launch_i8_rerun: no query of the batch is flagged — grid-uniform)
     constexpr int NW = 4, PD = 8, DPW = 48 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char img[3 * I8_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW * I16_ECAP * I16_EDW];  // 12 KiB beside the 144-KiB ring
@@ -1255,6 +1257,13 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
             uint32_t hits = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hits |= ((int)en[i] > th && row0 + (uint32_t)i < n_rows) ? (1u << i) : 0u;
+            // (a segment that has overflowed stays overflowed: its query goes to the ladder whatever else is appended, and a query
+            // inside a shell of a million near-ties would otherwise send a million atomics to its sixteen counters — ~8 M/s per
+            // address: 0.5 s per batch in the second pass of launch_i8_rerun before this test)
+            if (hits && cnt[qidx * BATCH_CAND_SEGS + seg] > I8_SEG_CAP) {
+                hits = 0;
+                if (go != nullptr) go[4 + qidx] = 1u;  // (second pass: the query is lost to the bounded pass — every wave may stop looking)
+            }
             uint32_t slot = hits ? atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], (uint32_t)__popc(hits)) : 0u;
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
@@ -1267,6 +1276,15 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
             }
         }
         wpos = 0;
+        if (go != nullptr) {
+            // second pass (launch_i8_rerun): a query one of whose segments has overflowed gets the padding columns' threshold in this
+            // wave from here on — inside a shell of a million near-ties every tile would otherwise stage hits for it to the end
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi_ = group_first(g) + (int)r16;
+                if (qi_ < n_q && __atomic_load_n(&go[4 + qi_], __ATOMIC_RELAXED) != 0u) c1[g] = 3.0e38f;
+            }
+        }
     };
     const uint32_t stage_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)stage;
     // slow path of one query group: mxl = the lane's maximum over its 4 accumulators, thr_lane its integer threshold,
@@ -1544,7 +1562,7 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
 // append pass; mfma_sched 41 / 42 / 44 / 47: timing experiments with parts switched off (results are wrong)
 static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t n_rows, uint32_t stride, uint32_t n_tiles,
                              const i32x4_t* qi, const float2* qm, int B, const BatchWorkspace& ws, uint32_t blocks,
-                             hipStream_t stream) {
+                             hipStream_t stream, uint32_t* go = nullptr) {
 #define DAWN_I8_PIPE(DBG_)                                                                                                   \
     hipLaunchKernelGGL((scan_i8_pipe_kernel<false, DBG_>), dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, \
                        qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand))
@@ -1561,7 +1579,7 @@ static void launch_i8_append(const unsigned char* xs, const float2* mt, uint32_t
         case 32: DAWN_I8_PIPE(0); break;  // the 32x32x32 form (option "mfma_sched" = 32)
         default:
             hipLaunchKernelGGL(scan_i8_pipe16_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles,
-                               qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+                               qi, qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), go);
             break;
     }
 #undef DAWN_I8_PIPE
@@ -1576,7 +1594,7 @@ static void launch_i8_dense(const unsigned char* xs, const float2* mt, uint32_t 
                            B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
     else
         hipLaunchKernelGGL(scan_i8_pipe16_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 0u, stride, n_tiles, qi,
-                           qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand));
+                           qm, B, ws.tau, ws.cnt, reinterpret_cast<uint2*>(ws.cand), reinterpret_cast<float*>(ws.cand), nullptr);
 }
 
 // Timing hook: the full append pass alone (thresholds ws.tau and query images as left by the last search), `iters` times
@@ -1626,6 +1644,54 @@ void launch_i8_sample_thresholds(const void* d_i8, const void* d_meta, uint32_t 
         launch_i8_append(xs, mt, n_rows, pl.s2_stride, pl.s2_tiles, reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, b2, stream);
         launch_tau_select(false, B, ws, 0u, pl.m2, stream);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A second pass for the FLAGGED queries of a batch.  The sampled threshold of a query aims at ~1024 (4096) candidates; on topical
+// rows it often lands ABOVE the query's k-th score and no certificate can hold — but the tail has rescored what it had, and the
+// k-th exact distance d_k it found bounds the final one from above: every row that can still matter has ub > (1 - d_k) - 1e-4 (the
+// bounded pass's arithmetic, scan_bounded.hip).  That is a threshold like any other: the matrix-core pass runs once more with it
+// (every other query: +inf, nothing appended), and the same tail decides again with ALL rows above it as candidates — exact by the
+// usual certificate when they fit the 8192 slots.  One 9-ms stream for all flagged queries of the batch instead of 7 ms per
+// sixteen of them in the bounded pass, which keeps the ones that overflow (the near-tie shells of the largest clusters).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void i8_rerun_prepare_kernel(const uint32_t* __restrict__ flags, const float* __restrict__ out_dist,
+                                                               const uint32_t* __restrict__ out_found, uint32_t k, int n_q,
+                                                               float* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                               uint32_t* __restrict__ go) {
+    const int b = threadIdx.x;  // BATCH_QT = 256 threads
+    bool fl = false;
+    float t = POS_INF;
+    if (b < n_q && flags[b] == FLAG_FALLBACK) {
+        const uint32_t found = out_found[b];
+        const float dk = found > 0 ? out_dist[(size_t)b * k + found - 1] : POS_INF;
+        if (found == k && dk < POS_INF) {  // (k real rows with exact distances: the first result of a flagged query)
+            t = __fsub_rn(__fsub_rn(1.0f, dk), 1.0e-4f);
+            fl = true;
+        }
+    }
+    tau[b] = t;
+    go[4 + b] = 0u;  // (the pass's "lost" marks)
+#pragma unroll
+    for (int sg = 0; sg < BATCH_CAND_SEGS; ++sg) cnt[(size_t)b * BATCH_CAND_SEGS + sg] = 0u;
+    const int any = __syncthreads_or(fl ? 1 : 0);
+    if (b == 0) go[0] = any ? 1u : 0u;
+}
+
+void launch_i8_rerun(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids, uint32_t n_rows,
+                     const float* d_q, int B, uint32_t k, const BatchWorkspace& ws, int grid, uint64_t* d_labels, float* d_dist,
+                     uint32_t* d_found, uint32_t* d_flags, uint32_t* d_go, hipStream_t stream) {
+    // (the default 16x16x64 pass only — the other forms, option "mfma_sched", do not take the go word; a dense-only index has no threshold)
+    if (n_rows <= (uint32_t)BATCH_CAP || ws.sched == 32 || (ws.sched >= 41 && ws.sched <= 50)) return;
+    const BatchPlan pl = plan_batched_tiles(n_rows, I8_TILE_ROWS, ws.target, k);
+    const signed char* qi = reinterpret_cast<const signed char*>(ws.qh);  // (the images of the first pass)
+    const float2* qm = reinterpret_cast<const float2*>(qi + (size_t)BATCH_QT * EM);
+    hipLaunchKernelGGL(i8_rerun_prepare_kernel, dim3(1), dim3(BATCH_QT), 0, stream, d_flags, d_dist, d_found, k, B, ws.tau, ws.cnt, d_go);
+    const uint32_t blocks = pl.n_tiles_total < (uint32_t)grid ? pl.n_tiles_total : (uint32_t)grid;
+    launch_i8_append(reinterpret_cast<const unsigned char*>(d_i8), reinterpret_cast<const float2*>(d_meta), n_rows, 1u, pl.n_tiles_total,
+                     reinterpret_cast<const i32x4_t*>(qi), qm, B, ws, blocks, stream, d_go);
+    launch_select_rescore_eps(false, d_x, dtype, d_ids, n_rows, d_q, B, k, ws, d_labels, d_dist, d_found, d_flags, 0, FILTER_EPS_I8,
+                              stream, 1);
 }
 
 void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const void* d_meta, const uint64_t* d_ids,

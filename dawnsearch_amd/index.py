@@ -149,9 +149,9 @@ class VectorIndex:
     def stats_batch_feedback(self):
         """Batches the FP6 first filter took / batches its feedback handed to the int8 pass / batches the int8 pass ran with the
         deeper thresholds of a ladder-heavy index (dawn_hip_debug.h)."""
-        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        check(lib.dawn_index_stats_batch_feedback(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"f6_batches": a.value, "f6_suspended": b.value, "deepened_batches": c.value}
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib.dawn_index_stats_batch_feedback(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"f6_batches": a.value, "f6_suspended": b.value, "deepened_batches": c.value, "rerun_answers": d.value}
 
     def stats_f6(self):
         s = self.stats_batch_feedback()

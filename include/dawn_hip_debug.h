@@ -31,8 +31,11 @@ int dawn_index_debug_f6_scores(dawn_index *idx, const float *queries, size_t B, 
  * to the int8 pass instead (an index whose FP6-filtered queries end in the ladder more than 30 % of the time — topical rows —
  * suspends it for 16 .. 1024 batches at a time); batches the int8 pass ran with thresholds four times as deep ("mfma_target" 4096
  * instead of 1024: an index that sent more than 10 % of a window of 1024 batched queries to the ladder keeps them until its rows
- * change).  Option "ladder_feedback" = 0 switches all of it off.  Not on a sharded handle. */
-int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended, uint64_t *deepened_batches);
+ * change); rerun_answers: queries of such batches whose failed certificate was settled by a SECOND matrix-core pass with the
+ * threshold their own k-th exact distance gives (option "batch_rerun"; the bounded pass keeps the rest).  Option "ladder_feedback" = 0
+ * switches all of it off.  Not on a sharded handle. */
+int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended, uint64_t *deepened_batches,
+                                    uint64_t *rerun_answers);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
@@ -92,6 +95,10 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "bounded_seed"     1 (default): a demoted single query's bounded pass on the packed shadow (indexes of >= 40 Mi rows) starts from the
  *                      k-th exact distance of a packed-stream search over the first 1/32 of the rows (100 M topical rows: mean 4.98 ->
  *                      4.17 ms, p50 4.63 -> 3.71); 0: from no threshold; 2: also on small indexes (tests)
+ *   "batch_rerun"      a second matrix-core pass for the flagged queries of a batch, each with the threshold its own k-th exact distance
+ *                      gives, before the bounded pass takes what is left: 0 never (default), 1 on indexes whose batch feedback has
+ *                      deepened the thresholds, 2 every batch.  100 M topical rows: settles 18-30 % of a batch at the default depth
+ *                      (74 -> 69 ms), 4-19 % at the deepened one, where it no longer pays for its 12 ms (63 -> 71 ms)
  *   "bounded_multi_waves"  process-wide: waves per workgroup of the bounded pass of batches, 8 (default) or 4 (one workgroup per CU
  *                      either way; 74.0 against 77.4 ms per topical batch of 256 at 100 M rows)
  *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no

@@ -301,7 +301,34 @@ def test_batch_feedback_deepens_the_thresholds_of_a_ladder_heavy_index(dawn, ora
     Qf = synth.unit_rows(2, 0, 256)
     for _ in range(8):
         flat.search_batch(Qf, 10)
-    assert flat.stats_batch_feedback()["deepened_batches"] == 0
+    assert flat.stats_batch_feedback()["deepened_batches"] == 0 and flat.stats_batch_feedback()["rerun_answers"] == 0
+
+
+@pytest.mark.parametrize("dist", [4, 5])
+@pytest.mark.parametrize("k", [10, 20])
+def test_batch_rerun_settles_flagged_queries(dawn, oracle, dist, k):
+    """The second pass of a batch's flagged queries (option "batch_rerun" = 2: every batch; by default only on a ladder-heavy
+    index): thresholds from the queries' own k-th exact distances, the same tail over ALL rows above them.  With the sampled
+    thresholds made far too shallow ("mfma_target" 64 on 400 k topical rows) most certificates fail at first; the second pass
+    settles those whose candidates fit, the bounded pass the rest — the oracle's answers, no exact pass."""
+    n = 400_000
+    idx = _topical_index(dawn, n, dist, packed=False)
+    idx.set_option("mfma_target", 64)
+    Q = np.concatenate([_topical_queries(dist, 40, clusters={0, 1, 2}), _topical_queries(dist, 24)])
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=dist)
+    base = idx.search_batch(Q, k)
+    b0 = idx.stats()["bounded"]
+    assert b0 >= 8  # (the premise)
+    idx.set_option("batch_rerun", 2)
+    lab, dist_, found = idx.search_batch(Q, k)
+    for b in range(len(Q)):
+        assert found[b] == k
+        _same(lab[b], dist_[b], want[0][b], want[1][b])
+        _same(base[0][b], base[1][b], want[0][b], want[1][b])
+    st = idx.stats()
+    fb = idx.stats_batch_feedback()
+    assert st["fallbacks"] == 0 and fb["rerun_answers"] >= 4, (st, fb)
+    assert fb["rerun_answers"] + (st["bounded"] - b0) == b0, (st, fb, b0)  # (the same queries failed at first both times)
 
 
 @pytest.mark.parametrize("n", [1, 31, 33, 64, 1000, 4097, 100_003])
