@@ -1257,12 +1257,13 @@ __global__ __launch_bounds__(256) void scan_i8_pipe16_kernel(const unsigned char
             uint32_t hits = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hits |= ((int)en[i] > th && row0 + (uint32_t)i < n_rows) ? (1u << i) : 0u;
-            // (a segment that has overflowed stays overflowed: its query goes to the ladder whatever else is appended, and a query
-            // inside a shell of a million near-ties would otherwise send a million atomics to its sixteen counters — ~8 M/s per
-            // address: 0.5 s per batch in the second pass of launch_i8_rerun before this test)
-            if (hits && cnt[qidx * BATCH_CAND_SEGS + seg] > I8_SEG_CAP) {
+            // (second pass, launch_i8_rerun: a segment that has overflowed stays overflowed — its query goes to the bounded pass
+            // whatever else is appended, and a query inside a shell of a million near-ties would otherwise send a million atomics to
+            // its sixteen counters, ~8 M/s per address: 0.5 s per batch before this test.  Not in the first pass: the extra load in
+            // front of every atomic cost 1 M rows x 256 queries 0.150 -> 0.204 ms.)
+            if (go != nullptr && hits && cnt[qidx * BATCH_CAND_SEGS + seg] > I8_SEG_CAP) {
                 hits = 0;
-                if (go != nullptr) go[4 + qidx] = 1u;  // (second pass: the query is lost to the bounded pass — every wave may stop looking)
+                go[4 + qidx] = 1u;  // (the query is lost to the bounded pass: every wave may stop looking)
             }
             uint32_t slot = hits ? atomicAdd(&cnt[qidx * BATCH_CAND_SEGS + seg], (uint32_t)__popc(hits)) : 0u;
 #pragma unroll 1
