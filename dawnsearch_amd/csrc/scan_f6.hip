@@ -777,15 +777,17 @@ __global__ __launch_bounds__(512) void scan_f6_pass_lds_kernel(const uint32_t* _
 __global__ __launch_bounds__(256) void f6_refine_kernel(const uint2* __restrict__ big, uint32_t* __restrict__ cnt_big, uint32_t seg_cap_big,
                                                          const unsigned char* __restrict__ x8, const float2* __restrict__ meta8,
                                                          const signed char* __restrict__ qi8, const float2* __restrict__ qm8,
-                                                         const float* __restrict__ tau, uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
+                                                         float* __restrict__ tau, uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
     __shared__ __attribute__((aligned(16))) signed char sh_img[EM];
     __shared__ uint32_t sh_cnt;
     const int b = blockIdx.x, seg = blockIdx.y;  // one block per (query, segment of the big buffer)
     for (int i = threadIdx.x; i < EM / 4; i += blockDim.x)
         reinterpret_cast<int*>(sh_img)[i] = reinterpret_cast<const int*>(qi8 + (size_t)b * EM)[i];
     if (threadIdx.x == 0) {
-        uint32_t c = cnt_big[(size_t)b * BATCH_CAND_SEGS + seg];
-        sh_cnt = c < seg_cap_big ? c : seg_cap_big;
+        // (a counter past the capacity: survivors were dropped — or a wave of the pass marked the query as lost, in which case the
+        // entries behind the ones it wrote are NOT survivors of this search: nothing of such a segment is read)
+        const uint32_t c = cnt_big[(size_t)b * BATCH_CAND_SEGS + seg];
+        sh_cnt = c <= seg_cap_big ? c : 0u;
     }
     __syncthreads();
     const uint32_t n = sh_cnt;
@@ -822,9 +824,10 @@ __global__ __launch_bounds__(256) void f6_refine_kernel(const uint2* __restrict_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // a big segment that overflowed lost candidates: make the query's ordinary counter say so
-        if (cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] > seg_cap_big)
-            atomicAdd(&cnt[(size_t)b * BATCH_CAND_SEGS + seg], (uint32_t)BATCH_CAP);
+        // a big segment that overflowed lost candidates: no certificate may hold for this query — its threshold becomes +inf ("rows that
+        // never became candidates score <= tau" is then never enough), the tail flags it and the ladder answers.  (Not by inflating
+        // the ordinary counter: the tail would read entries nobody wrote.)
+        if (cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] > seg_cap_big) tau[b] = POS_INF;
         cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] = 0u;
     }
 }
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(256) void f6_refine_kernel(const uint2* __restrict_
 // f32 dot product is within gamma_384 x 1.0201 = 2.34e-5 of the real one whatever the order of the sum: + 3e-5 makes it a bound.
 __global__ __launch_bounds__(256) void f6_refine_rows_kernel(const uint2* __restrict__ big, uint32_t* __restrict__ cnt_big,
                                                               uint32_t seg_cap_big, const f32x4* __restrict__ x,
-                                                              const float* __restrict__ q, const float* __restrict__ tau,
+                                                              const float* __restrict__ q, float* __restrict__ tau,
                                                               uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
     const int b = blockIdx.x, seg = blockIdx.y;
     const int part = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(256) void f6_refine_rows_kernel(const uint2* __rest
 #pragma unroll
     for (int j = 0; j < 6; ++j) qv[j] = reinterpret_cast<const f32x4*>(q + (size_t)b * EM)[part + 16 * j];
     const uint32_t c0 = cnt_big[(size_t)b * BATCH_CAND_SEGS + seg];
-    const uint32_t n = c0 < seg_cap_big ? c0 : seg_cap_big;
+    const uint32_t n = c0 <= seg_cap_big ? c0 : 0u;  // (past the capacity: dropped survivors or a "lost" mark — see f6_refine_kernel)
     const float t = tau[b];
     const uint2* src = big + ((size_t)b * BATCH_CAND_SEGS + seg) * seg_cap_big;
     constexpr uint32_t seg_small = (uint32_t)BATCH_CAP / (uint32_t)BATCH_CAND_SEGS;
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(256) void f6_refine_rows_kernel(const uint2* __rest
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (c0 > seg_cap_big) atomicAdd(&cnt[(size_t)b * BATCH_CAND_SEGS + seg], (uint32_t)BATCH_CAP);
+        if (c0 > seg_cap_big) tau[b] = POS_INF;  // (the query is flagged by the tail: see f6_refine_kernel)
         cnt_big[(size_t)b * BATCH_CAND_SEGS + seg] = 0u;
     }
 }

@@ -1,0 +1,105 @@
+"""Randomised cross-check of the search paths this round added or touched (GPU): random index sizes (around every tile boundary the
+kernels have: 16, 32, 128 rows, groups of 8 tiles), row kinds, k, batch sizes and option sets — FP6 first filter and its row /
+int8 re-scoring, the bounded pass on the packed shadow with and without its seed, the batch's second pass, forced ladders,
+demotion, deepened thresholds — every answer compared bit for bit with the CPU oracle's scan of the same rows
+(oracle/dawn_oracle.c: src/search/vector.rs:128-134 + exact top-k, ties to the lower position).  Seeds are fixed: a failure
+reproduces."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from dawnsearch_amd import synth  # noqa: E402
+
+from test_scan_gpu import _assert_same  # noqa: E402
+
+QROW0 = 1 << 40
+
+
+def _case(rng):
+    edges = [1, 15, 16, 17, 31, 32, 33, 127, 128, 129, 1023, 1024, 1025, 8191, 8192, 8193]
+    if rng.random() < 0.35:
+        n = int(rng.choice(edges)) * int(rng.choice([1, 1, 3, 8, 16]))
+    else:
+        n = int(rng.integers(1, 260_000))
+    n = max(1, min(n, 260_000))
+    dist = int(rng.choice([0, 0, 4, 5]))
+    dtype = "bf16" if (dist == 0 and rng.random() < 0.25) else "f32"
+    k = int(rng.choice([1, 5, 10, 20, 33, 64]))
+    B = int(rng.choice([1, 1, 3, 17, 64, 256]))
+    if n > 120_000 and B > 64:
+        B = 64  # (the oracle's side of the comparison: n x B x 384 on the host cores)
+    opts = {}
+    if rng.random() < 0.5:
+        opts["i6_min_rows"] = 0
+    if rng.random() < 0.5:
+        opts["f6_min_rows"] = 0
+        opts["f6_shadow"] = 1
+        if rng.random() < 0.4:
+            opts["f6_refine_rows"] = 0
+        if rng.random() < 0.3:
+            opts["f6_target"] = int(rng.choice([256, 1024, 24576]))
+        if rng.random() < 0.2:
+            opts["f6_stagger"] = int(rng.choice([0, 8]))
+    if rng.random() < 0.5:
+        opts["bounded_packed"] = int(rng.choice([0, 2]))
+    if rng.random() < 0.5:
+        opts["bounded_seed"] = int(rng.choice([0, 2]))
+    if rng.random() < 0.4:
+        opts["batch_rerun"] = 2
+    if rng.random() < 0.35:
+        opts["force_fallback"] = 2
+    if rng.random() < 0.4:
+        opts["ladder_feedback"] = int(rng.choice([0, 2]))
+    if rng.random() < 0.4:
+        opts["mfma_target"] = int(rng.choice([64, 256, 4096]))
+    if rng.random() < 0.3:
+        opts["bounded_multi_waves"] = int(rng.choice([4, 8]))
+    return n, dist, dtype, k, B, opts
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n, dist, dtype, k, B, opts = _case(rng)
+    idx = dawn.VectorIndex(0, dtype=dtype)
+    if dist:
+        idx.set_option("synth_dist", dist)
+    for name, v in opts.items():
+        idx.set_option(name, v)
+    idx.fill_synthetic(1, 0, n, 1)
+    if dist:
+        Q = np.concatenate([synth.unit_rows_topical(1, QROW0 + 256 * i, 1, runs=(dist == 5)) for i in range(B)])
+        want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=dist)
+        wl = [want[0][b][:min(k, n)] for b in range(B)]
+        wd = [want[1][b][:min(k, n)] for b in range(B)]
+    else:
+        x = oracle.unit_rows(1, 0, n)
+        if dtype == "bf16":
+            x = synth.round_bf16(x)
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        Q = synth.unit_rows(2 + seed, 0, B)
+        Q[0] = synth.planted_queries(1, [int(rng.integers(0, n))], 7)[0]
+        res = [oracle.scan_topk(x, ids, q, k, threads=8) for q in Q]
+        wl = [r[0] for r in res]
+        wd = [r[1] for r in res]
+    try:
+        for rep in range(2):  # (twice: the second call runs with whatever the feedback learned from the first)
+            if B == 1:
+                lab, dd = idx.search(Q[0], k)
+                _assert_same(lab, dd, wl[0], wd[0])
+            else:
+                lab, dd, found = idx.search_batch(Q, k)
+                for b in range(B):
+                    assert found[b] == min(k, n), (n, dist, dtype, k, B, opts, b)
+                    _assert_same(lab[b][:found[b]], dd[b][:found[b]], wl[b], wd[b])
+        st = idx.stats()
+        assert st["fallbacks"] == 0 or dtype == "bf16" or "force_fallback" in opts or n <= 64, (st, n, dist, dtype, k, B, opts)
+    finally:
+        idx.set_option("bounded_multi_waves", 8)  # (process-wide knob: back to the default for the tests that follow)
+        idx.close()
