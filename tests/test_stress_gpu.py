@@ -64,6 +64,46 @@ def _case(rng):
 
 
 @pytest.mark.parametrize("seed", list(range(40)))
+def test_random_configuration_with_adds_and_shards(dawn, oracle, seed):
+    """The same on indexes that GROW between searches (rows appended in two batches: every shadow re-quantises its last partial
+    tile) and on sharded handles (three logical shards on one device, rows dealt in chunks): uniform rows, f32."""
+    rng = np.random.default_rng(5000 + seed)
+    n, _, _, k, B, opts = _case(rng)
+    n = max(n, 200)
+    B = min(B, 64)
+    sharded = rng.random() < 0.5
+    idx = dawn.VectorIndex(devices=[0, 0, 0]) if sharded else dawn.VectorIndex(0)
+    if sharded:
+        idx.set_option("shard_chunk", int(rng.choice([64, 1024, 4096])))
+        opts.pop("bounded_multi_waves", None)
+    for name, v in opts.items():
+        idx.set_option(name, v)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    cuts = sorted({int(n * rng.uniform(0.3, 0.8)), int(n * rng.uniform(0.8, 0.999)), n})
+    Q = synth.unit_rows(9 + seed, 0, B)
+    Q[0] = synth.planted_queries(1, [n - 1], 7)[0]
+    try:
+        lo = 0
+        for hi in cuts:
+            if hi <= lo:
+                continue
+            idx.add_batch(ids[lo:hi], x[lo:hi])
+            lo = hi
+            if B == 1:
+                lab, dd = idx.search(Q[0], k)
+                _assert_same(lab, dd, *oracle.scan_topk(x[:hi], ids[:hi], Q[0], k, threads=8))
+            else:
+                lab, dd, found = idx.search_batch(Q, k)
+                for b in range(B):
+                    assert found[b] == min(k, hi)
+                    _assert_same(lab[b][:found[b]], dd[b][:found[b]], *oracle.scan_topk(x[:hi], ids[:hi], Q[b], k, threads=8))
+        assert idx.size() == n
+    finally:
+        idx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(160)))
 def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n, dist, dtype, k, B, opts = _case(rng)
