@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
                                                             uint32_t stride, uint32_t n_visits, const uint32_t* __restrict__ qf6,
                                                             const float2* __restrict__ qmeta, int n_q, const float* __restrict__ tau,
                                                             uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t seg_cap,
-                                                            float* __restrict__ dense, uint32_t stagger) {
+                                                            float* __restrict__ dense, uint32_t stagger, int mark_lost) {
     __shared__ uint32_t stage[4][F6_STAGE][3];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -492,7 +492,9 @@ __global__ __launch_bounds__(256) void scan_f6_pass_kernel(const uint32_t* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's last loads: nothing may be in flight when the wave ends)
 #undef DAWN_F6_LD4
 #undef DAWN_F6_LD2
-    if (!DENSE && __any(lost)) {  // (never on real data: see above)
+    // (a SAMPLING pass does not mark: hits dropped from a sample only move the threshold read from it, and an inflated counter
+    // would make tau_select read entries nobody wrote)
+    if (!DENSE && mark_lost && __any(lost)) {
         const uint32_t qi = (uint32_t)(64 * wave + lane);
         if ((int)qi < n_q) atomicAdd(&cnt[(size_t)qi * BATCH_CAND_SEGS + seg], seg_cap + 1u);
     }
@@ -963,14 +965,14 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     {
         const uint32_t blocks = pl.s1_tiles < (uint32_t)grid ? pl.s1_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<true>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, pl.s1_stride, pl.s1_tiles, qf6,
-                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u);
+                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u, 0);
         launch_tau_select(true, B, w6, pl.s1_tiles * 16u, pl.m1, stream);
     }
     {
         // (two workgroups per CU: the strided sample is bound by memory latency, 0.36 -> 0.2 ms per 100 M rows)
         const uint32_t blocks = pl.s2_tiles < 2u * (uint32_t)grid ? pl.s2_tiles : 2u * (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, pl.s2_stride, pl.s2_tiles, qf6,
-                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u);
+                           qm6, B, f6.tau6, ws.cnt, reinterpret_cast<uint2*>(ws.cand), seg_small, reinterpret_cast<float*>(ws.cand), 0u, 0);
         launch_tau_select(false, B, w6, 0u, pl.m2, stream);
     }
     hipLaunchKernelGGL(f6_merge_tau_kernel, dim3(1), dim3(256), 0, stream, ws.tau, f6.tau6, B, rows_refine ? 0 : 1);
@@ -994,7 +996,7 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
     } else {
         const uint32_t blocks = pl.n_tiles < (uint32_t)grid ? pl.n_tiles : (uint32_t)grid;
         hipLaunchKernelGGL(scan_f6_pass_kernel<false>, dim3(blocks), dim3(256), 0, stream, xs, mt, n_rows, 1u, pl.n_tiles, qf6, qm6, B,
-                           f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big, nullptr, (uint32_t)f6.stagger);
+                           f6.tau6, f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big, nullptr, (uint32_t)f6.stagger, 1);
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
     // 4. survivors -> int8 bound -> the ordinary candidate buffers
