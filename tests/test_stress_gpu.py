@@ -143,3 +143,56 @@ def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
     finally:
         idx.set_option("bounded_multi_waves", 8)  # (process-wide knob: back to the default for the tests that follow)
         idx.close()
+
+
+_TOGGLES = {
+    "i8_shadow": [0, 1], "i6_shadow": [0, 1], "i6_bits": [5, 6], "f16_shadow": [0, 1], "f16_shadow_b1": [0, 1], "f6_shadow": [0, 1],
+    "i8_batched": [0, 1], "mfma_min_batch": [2, 100000], "bounded_pass": [0, 1], "force_fallback": [0, 2], "ladder_feedback": [0, 1, 2],
+    "bounded_packed": [0, 1, 2], "bounded_seed": [0, 1, 2], "batch_rerun": [0, 1, 2], "mfma_target": [64, 1024, 4096],
+    "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
+}
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_option_walk_on_one_index(dawn, oracle, seed):
+    """One index, a random walk through its options between searches (shadows are built and released, kernels change, ladders are
+    forced and released): after every step a single query and a batch equal the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([5000, 33_333, 70_000, 150_001]))
+    dist = int(rng.choice([0, 4]))
+    k = int(rng.choice([10, 20, 64]))
+    idx = dawn.VectorIndex(0)
+    if dist:
+        idx.set_option("synth_dist", dist)
+    idx.set_option("i6_min_rows", 0)
+    idx.set_option("f6_min_rows", 0)
+    idx.fill_synthetic(1, 0, n, 1)
+    B = 24
+    if dist:
+        Q = np.concatenate([synth.unit_rows_topical(1, QROW0 + 256 * i, 1) for i in range(B)])
+        want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=dist)
+        wl, wd = list(want[0]), list(want[1])
+    else:
+        x = oracle.unit_rows(1, 0, n)
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        Q = synth.unit_rows(3 + seed, 0, B)
+        res = [oracle.scan_topk(x, ids, q, k, threads=8) for q in Q]
+        wl, wd = [r[0] for r in res], [r[1] for r in res]
+    names = sorted(_TOGGLES)
+    trail = []
+    try:
+        for step in range(10):
+            for _ in range(int(rng.integers(1, 4))):
+                name = names[int(rng.integers(0, len(names)))]
+                v = int(rng.choice(_TOGGLES[name]))
+                idx.set_option(name, v)
+                trail.append((name, v))
+            b = int(rng.integers(0, B))
+            lab, dd = idx.search(Q[b], k)
+            assert np.array_equal(lab, wl[b]) and np.array_equal(dd.view(np.uint32), np.asarray(wd[b]).view(np.uint32)), (n, dist, k, trail)
+            labs, dds, found = idx.search_batch(Q, k)
+            for j in range(B):
+                assert found[j] == k
+                assert np.array_equal(labs[j], wl[j]) and np.array_equal(dds[j].view(np.uint32), np.asarray(wd[j]).view(np.uint32)), (n, dist, k, j, trail)
+    finally:
+        idx.close()
