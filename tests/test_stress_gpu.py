@@ -154,7 +154,7 @@ _TOGGLES = {
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_random_option_walk_on_one_index(dawn, oracle, seed):
+def test_random_option_walk_on_one_index(dawn, oracle, seed, tmp_path):
     """One index, a random walk through its options between searches (shadows are built and released, kernels change, ladders are
     forced and released): after every step a single query and a batch equal the oracle."""
     rng = np.random.default_rng(9000 + seed)
@@ -194,5 +194,23 @@ def test_random_option_walk_on_one_index(dawn, oracle, seed):
             for j in range(B):
                 assert found[j] == k
                 assert np.array_equal(labs[j], wl[j]) and np.array_equal(dds[j].view(np.uint32), np.asarray(wd[j]).view(np.uint32)), (n, dist, k, j, trail)
+            if step % 3 == 1:
+                # a peer's search: only the hits with distance < limit (udp_service.rs:196-199)
+                limit = float(np.asarray(wd[b])[int(rng.integers(0, k))])
+                keep = int(np.sum(np.asarray(wd[b]) < np.float32(limit)))
+                lab, dd = idx.search_limited(Q[b], k, limit)
+                assert len(lab) == keep and np.array_equal(lab, wl[b][:keep]), (n, dist, k, b, limit, trail)
+            if step == 6:
+                # save -> load into a fresh index (its shadows are rebuilt from the rows): the same answers
+                path = os.path.join(tmp_path, "walk.dawn")
+                idx.save(path)
+                other = dawn.VectorIndex(0)
+                try:
+                    other.load(path)
+                    assert other.size() == n
+                    lab, dd = other.search(Q[b], k)
+                    assert np.array_equal(lab, wl[b]) and np.array_equal(dd.view(np.uint32), np.asarray(wd[b]).view(np.uint32)), (n, dist, k, trail)
+                finally:
+                    other.close()
     finally:
         idx.close()
