@@ -343,13 +343,22 @@ bool f6_live(const dawn_index* idx) {
 bool i8_live(const dawn_index* idx);
 // (its stream refines the listed rows on the int8 shadow: no int8 shadow, no packed stream)
 // The bounded pass of a single query on the packed 5-bit shadow instead of the int8 one: 240 instead of 384 B per row, but a bound
-// seven times as loose — more rows reach the exact scores, and a pass that starts without a threshold needs longer to find one.
-// Measured on topical rows (profiles/r04/bounded_packed_ab_*.log; mean ms per query, int8 -> packed): 12.5 M rows 0.89 -> 1.04,
-// 25 M 1.58 -> 1.69, 50 M 3.00 -> 2.80, 100 M 5.80 -> 4.98 (k = 20: 5.86 -> 5.35).  Option "bounded_packed": 0 never, 1 from
-// 40 Mi rows (default), 2 always (tests).
+// seven times as loose — more rows reach the exact scores, and a pass that starts without a threshold needs much longer to find
+// one.  With a first threshold (the failed packed stream's k-th distance, or the seed below) it wins at every size that keeps a
+// packed shadow; without one it loses below ~40 M rows.  Measured on topical rows, mean ms per demoted query (profiles/r04/
+// bounded_packed_ab_*.log; int8 / packed unseeded / packed seeded): 2.5 M rows 0.314 / 0.436 / 0.273, 5 M 0.463 / 0.608 / 0.382,
+// 12.5 M 0.881 / 1.055 / 0.684, 25 M 1.58 / 1.67 / 1.18, 100 M 5.79 / 4.97 / 4.17 (k = 20: 5.85 / 5.35 / 4.20).
+// Option "bounded_packed": 0 never, 1 (default) wherever the packed shadow is live from 2 Mi rows, 2 always (tests).
 static bool bounded_packed_wanted(const dawn_index* idx, uint32_t n) {
     if (idx->i6_bits != 5) return false;
-    return idx->bounded_packed == 2 || (idx->bounded_packed == 1 && n >= (40u << 20));
+    return idx->bounded_packed == 2 || (idx->bounded_packed == 1 && n >= (2u << 20));
+}
+// ... and the seed of a pass that would otherwise start without a threshold (a demoted query): the packed stream over the first 1/32
+// of the rows — its k-th exact distance bounds the final one from above whatever its own certificate says.  Option "bounded_seed":
+// 0 never (the packed form is then only used from 40 Mi rows), 1 (default) from 2 Mi rows, 2 from 32 Ki rows (tests).
+static bool bounded_seed_wanted(const dawn_index* idx, uint32_t n) {
+    if (!idx->bounded_seed || idx->debug_bad_threshold) return false;
+    return n / 32u >= (idx->bounded_seed == 2 ? 1024u : (64u << 10));
 }
 
 bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size && i8_live(idx); }
@@ -507,7 +516,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             if (fb.demote_left == 0 && fb.issued - fb.win_issued0 >= kFbWindow) {
                 const uint32_t now = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
                 const double rate = (double)(now - fb.win_fail0) / (double)(fb.issued - fb.win_issued0);
-                if (rate > (bounded_packed_wanted(idx, n) && idx->bounded_seed ? kFbDemotePacked : kFbDemote)) {
+                if (rate > (bounded_packed_wanted(idx, n) && idx->bounded_seed && n >= (40u << 20) ? kFbDemotePacked : kFbDemote)) {
                     fb.demote_left = fb.demote_len;
                     fb.demote_len = std::min(fb.demote_len * 2u, kFbDemoteMax);
                 } else {
@@ -528,13 +537,14 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         if (demoted) {
             // a demoted index: the bounded exact pass is the whole search (240 B/row on the packed shadow, no certificate to fail)
             ++idx->n_demoted;
-            const bool p5 = bounded_packed_wanted(idx, n);
+            // (unseeded, the packed form only pays on very large indexes)
+            const bool seed_ok = bounded_seed_wanted(idx, n);
+            const bool p5 = bounded_packed_wanted(idx, n) && (seed_ok || idx->bounded_packed == 2 || n >= (40u << 20));
             // A pass that starts without a threshold scores rows exactly until its waves have found k good ones each — with the
             // packed shadow's loose bound that costs ~0.75 ms of a 5-ms pass at 100 M rows (a pass behind a failed packed stream,
             // which hands over its k-th distance: 4.2 ms).  The packed stream over the first 1/32 of the rows (0.15 ms) finds a
             // k-th exact distance that bounds the final one from above just as well (option "bounded_seed").
-            const bool seed = p5 && idx->bounded_seed && !idx->debug_bad_threshold &&
-                              n / 32u >= (idx->bounded_seed == 2 ? 1024u : (1u << 20));  // (2: tests, any index of >= 32 Ki rows)
+            const bool seed = p5 && seed_ok;
             if (seed) {
                 ScanGeom g6 = idx->i6_geom();
                 launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
@@ -999,7 +1009,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->f6ws.stagger = (int)value;
         return DAWN_OK;
     }
-    if (n == "bounded_packed") {  // the bounded pass of a single query streams the packed 5-bit shadow: 0 never, 1 from 40 Mi rows, 2 always
+    if (n == "bounded_packed") {  // the bounded pass of a single query streams the packed 5-bit shadow: 0 never, 1 from 2 Mi rows, 2 always
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_packed must be 0, 1 or 2");
         idx->bounded_packed = (int)value;
         return DAWN_OK;

@@ -25,8 +25,8 @@ constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host b
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)
 constexpr uint32_t kFbWindow = 32;        // ladder feedback: packed single-query searches per window
 constexpr double kFbBoost = 0.05, kFbDemote = 0.35;  // failure rates that make the waves refine full lists / demote the index
-// ... an index whose bounded pass runs on the packed shadow, seeded (>= 40 Mi rows): packed stream 3.5 ms + 4.2 ms behind a failure
-// against 4.17 ms for the seeded pass alone on 100 M rows — break-even at a failure rate of 0.16
+// ... an index of >= 40 Mi rows (its bounded pass runs on the packed shadow, seeded): packed stream 3.5 ms + 4.2 ms behind a failure
+// against 4.17 ms for the seeded pass alone on 100 M rows — break-even at a failure rate of 0.16 (12.5 M rows: 0.30, 5 M: 0.37)
 constexpr double kFbDemotePacked = 0.18;
 constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
 constexpr uint32_t kBatchFbWindow = 1024;  // int8 batched pass: queries per feedback window
@@ -190,7 +190,7 @@ struct dawn_index {
     int batch_rerun = 0;
     int bounded_seed = 1;        // option "bounded_seed": a demoted query's packed bounded pass is seeded by a search over 1/32 of the rows
     int bounded_packed = 1;      // option "bounded_packed": the bounded pass of a single query streams the packed 5-bit shadow
-                                 // (240 B/row): 0 never, 1 from 40 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)
+                                 // (240 B/row): 0 never, 1 from 2 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)
     int bounded_pass = 1;        // option "bounded_pass": a failed certificate is answered from the int8 shadow (scan_bounded.hip)
     // Ladder feedback.  The packed stream (240 B/row) followed by the bounded pass (384 B/row) costs 2.6 x the packed stream
     // when its certificate fails; the bounded pass ALONE, started without a threshold, costs 1.6 x and cannot fail.  The index

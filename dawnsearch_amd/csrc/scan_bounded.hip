@@ -28,11 +28,11 @@
 // isotropic data, the dense part of a cluster on topical data — read at the exact pass's rate (lane-per-row walks, 4.6 TB/s with
 // every wave of the chip at it): it degrades towards the exact pass's cost as the data gets denser, never beyond it + 5.5 ms.
 // Predicated per query on d_flags[b] == FLAG_FALLBACK like the exact pass (launch-only searches: no host decision).
-// A SINGLE query of an index of >= 40 Mi rows with a packed 5-bit shadow (scan_i6.hip) streams THAT shadow instead (template
-// parameter SH = 5: 240 B per row, the packed stream's loads and unpacking, its bound E (1 + k2u) + k2c): 4.98 against 5.80 ms per
-// query on 100 M topical rows (k = 20: 5.35 against 5.86); its bound is seven times as loose, so more rows reach the exact scores
-// and a pass that starts without a threshold takes longer to find one — below ~40 M rows the int8 shadow wins
-// (dawn_index.cpp: bounded_packed_wanted; profiles/r04/bounded_packed_ab_*.log).
+// A SINGLE query of an index with a live packed 5-bit shadow (scan_i6.hip; >= 2 Mi rows) streams THAT shadow instead (template
+// parameter SH = 5: 240 B per row, the packed stream's loads and unpacking, its bound E (1 + k2u) + k2c).  Its bound is seven times
+// as loose, so more rows reach the exact scores and a pass that starts without a threshold takes much longer to find one: a demoted
+// query's pass is therefore SEEDED by a packed-stream search over 1/32 of the rows (dawn_index.cpp: bounded_packed_wanted /
+// bounded_seed_wanted; 100 M topical rows 5.79 -> 4.17 ms per query, 12.5 M 0.88 -> 0.68; profiles/r04/bounded_packed_ab_*.log).
 #include <type_traits>
 
 #include "kernels.hpp"

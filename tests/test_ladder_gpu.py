@@ -71,7 +71,7 @@ def test_topical_index_every_rung_equals_the_oracle(dawn, oracle, dist, k, bound
     8 entries, int8 stream 2 workgroups, 64 candidates per query in a batch.  Packed stream, int8 stream, a batch — all bit-equal
     to the oracle's scan of the same rows, no exact pass anywhere, the bounded pass counted where certificates failed.
     bounded_packed: the bounded pass of a single query streams the int8 shadow (0) or the packed 5-bit shadow (2: forced; by
-    default from 40 Mi rows)."""
+    default wherever the packed shadow is live, from 2 Mi rows)."""
     n = 400_000
     idx = _topical_index(dawn, n, dist)
     idx.set_option("bounded_packed", bounded_packed)
@@ -334,7 +334,7 @@ def test_batch_rerun_settles_flagged_queries(dawn, oracle, dist, k):
 @pytest.mark.parametrize("n", [1, 31, 33, 64, 1000, 4097, 100_003])
 @pytest.mark.parametrize("k", [1, 10, 64])
 def test_bounded_pass_on_the_packed_shadow_sizes(dawn, oracle, n, k):
-    """The bounded pass of a single query on the packed 5-bit shadow (option "bounded_packed" = 2: by default only from 40 Mi rows):
+    """The bounded pass of a single query on the packed 5-bit shadow (option "bounded_packed" = 2: by default only from 2 Mi rows):
     behind certificates that are made to fail (force_fallback = 2) and as the whole search of a demoted index (ladder_feedback =
     2: no first threshold), sizes around the sub-tile boundaries, k up to the list length, an f32 and a bf16 index."""
     for dtype in ("f32", "bf16"):
@@ -359,7 +359,7 @@ def test_bounded_pass_on_the_packed_shadow_sizes(dawn, oracle, n, k):
         st = idx.stats()
         assert st["bounded"] == 6 and st["fallbacks"] == 0 and st["demoted"] == 3, st
         if n >= 32 * 1024:
-            # ... seeded: the packed stream over the first 1/32 of the rows hands the pass its first threshold (by default from 32 Mi rows)
+            # ... seeded: the packed stream over the first 1/32 of the rows hands the pass its first threshold (by default from 2 Mi rows)
             idx.set_option("bounded_seed", 2)
             for q in Q:
                 _same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
