@@ -597,7 +597,8 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     // cannot fail, keeps the certificate counters and mirrors them to the host), the others with the exact pass over all rows.
     // force_fallback = 1 (tests of the exact pass) takes the second form; 2 forces the flags only.
     // (a single query of an index with a live packed 5-bit shadow streams that one: 240 instead of 384 B per row; option "bounded_packed")
-    const bool packed5 = bounded_packed_wanted(idx, n) && B == 1 && i6_live(idx);
+    // (a batch: the packed form of the multi kernel, option "bounded_multi_packed")
+    const bool packed5 = bounded_packed_wanted(idx, n) && i6_live(idx) && idx->i6_bits == 5;
     if (idx->bounded_pass && idx->force_fallback != 1 && i8_live(idx) && n > 0)
         launch_scan_bounded(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags,
                             idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
@@ -1024,6 +1025,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
                                // index whose batch feedback has deepened its thresholds, 2 every batch (tests, A/B)
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "batch_rerun must be 0, 1 or 2");
         idx->batch_rerun = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_multi_packed") {  // process-wide: the bounded pass of BATCHES streams the packed 5-bit shadow too (0 / 1)
+        if (value != 0 && value != 1) return fail(DAWN_ERR_INVALID_ARG, "bounded_multi_packed must be 0 or 1");
+        dawn::set_bounded_multi_packed((int)value);
         return DAWN_OK;
     }
     if (n == "bounded_multi_waves") {  // process-wide: waves per workgroup of the bounded pass of batches (4 or 8)

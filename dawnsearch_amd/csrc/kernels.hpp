@@ -228,6 +228,7 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 // the int8 shadow, scores exactly every row whose upper bound can still reach the k-th best distance known so far (d_dist of
 // the failed stage), sets FLAG_BOUNDED.  cand_s / cand_p [B][n_lists][64]; d_done [B] arrival counters (zero before and after).
 // It is the LAST launch of a search (no exact pass behind it): d_stats / stats_mirror as for launch_scan_exact.
+void set_bounded_multi_packed(int v);  // 1: the batch form of the bounded pass streams the packed 5-bit shadow where one is passed
 void set_bounded_multi_waves(int nw);  // 4 or 8 waves per workgroup of the batch form (process-wide; option "bounded_multi_waves")
 void set_bounded_ring(int pd);  // 6 or 12 fragments in flight per wave (process-wide; option "bounded_ring")
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,

@@ -472,14 +472,17 @@ struct BoundedMultiLds {
     float merge_s[NW][LIST];
     uint32_t merge_p[NW][LIST];
     float sq[BQ];
+    int sum[2][BQ];  // sums of the queries' int8 images (SH = 5: accumulator offsets)
     float d_in[BQ];
     uint32_t flagged[kBoundedMaxFlags];
     unsigned long long mask[kBoundedMaxFlags / 64];
     uint32_t last;
 };
 
-template <int RT, int PD, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+// SH = 5: the packed 5-bit shadow instead of the int8 one (as in scan_bounded_i8_kernel; PD = 4 or 8): every query of a batch's ladder
+// comes with a first threshold, which is what the looser bound needs
+template <int RT, int PD, int NW = 4, int SH = 8>
+__global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const void* __restrict__ xv, const float2* __restrict__ meta,
                                                                      const void* __restrict__ rows, const uint64_t* __restrict__ ids,
                                                                      uint32_t n_rows, const float* __restrict__ q, int n_q,
                                                                      uint32_t* __restrict__ flags, uint32_t* __restrict__ done,
@@ -487,7 +490,10 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
                                                                      uint32_t n_lists, uint32_t k, uint64_t* __restrict__ out_labels,
                                                                      float* __restrict__ out_dist, uint32_t* __restrict__ out_found,
                                                                      uint32_t* __restrict__ stats, uint32_t* __restrict__ mirror) {
-    static_assert(12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    static_assert(SH == 5 ? (PD == 4 || PD == 8) : 12 % PD == 0, "the ring must divide the 12 k-steps of a sub-tile");
+    const u32x4* x = reinterpret_cast<const u32x4*>(xv);        // SH = 8
+    const uint32_t* x5 = reinterpret_cast<const uint32_t*>(xv);  // SH = 5
+    constexpr int NH = SH == 5 ? PD / 4 : 1, NN = SH == 5 ? 3 * PD / 4 : 1, NA = SH == 5 ? 1 : PD;
     extern __shared__ __attribute__((aligned(16))) unsigned char bounded_lds[];
     BoundedMultiLds<NW>& S = *reinterpret_cast<BoundedMultiLds<NW>*>(bounded_lds);
     const int lane = threadIdx.x & 63;
@@ -519,11 +525,27 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
         const uint32_t ng = n_flagged - g0 < (uint32_t)BQ ? n_flagged - g0 : (uint32_t)BQ;
         uint32_t t = blockIdx.x * nwaves + wave;
         const u32x4* p = x + (size_t)(t < n_sub ? t : 0) * (12 * 64) + lane;
-        u32x4 a[PD];
+        const uint32_t* p5 = x5 + (size_t)(t < n_sub ? t : 0) * I5_SUB_DW;
+        [[maybe_unused]] u32x4 a[NA];
+        [[maybe_unused]] u32x3 hq[NH];
+        [[maybe_unused]] u32x4 nq[NN];
+        auto load_h = [&](const uint32_t* sub, int g) __attribute__((always_inline)) { return frag_load(sub + g * I5_HALF_DW + lane * 3); };
+        auto load_n = [&](const uint32_t* sub, int pr) __attribute__((always_inline)) {  // pr = fragment pair 0..5
+            return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sub + (pr / 3) * I5_HALF_DW + 192 + (pr % 3) * 256 + lane * 4));
+        };
         float2 mt = {0.f, 0.f};
         if (t < n_sub) {
+            if constexpr (SH == 5) {
 #pragma unroll
-            for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+                for (int g = 0; g < NH; ++g) {
+                    hq[g] = load_h(p5, g);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) nq[3 * g + m] = load_n(p5, 3 * g + m);
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) a[d] = __builtin_nontemporal_load(p + d * 64);
+            }
             mt = meta[t];
         }
         // the group's queries: f32 copies, int8 images (a wave per query), the failed stages' k-th distances
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
             const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+            int sumH = 0, sumL = 0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float tt = v[j] / sq;
@@ -552,8 +575,19 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
                 const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
                 S.img[0][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)H : (signed char)0;
                 S.img[1][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)L : (signed char)0;
+                sumH += sidx < ng ? (int)H : 0;
+                sumL += sidx < ng ? (int)L : 0;
             }
-            if (lane == 0) S.sq[sidx] = sq;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {  // (the packed codes are value + 16: the accumulators start from -16 x these sums)
+                sumH += __shfl_xor(sumH, o);
+                sumL += __shfl_xor(sumL, o);
+            }
+            if (lane == 0) {
+                S.sq[sidx] = sq;
+                S.sum[0][sidx] = sumH;
+                S.sum[1][sidx] = sumL;
+            }
         }
         for (int i = lane; i < BQ * LIST; i += 64) {  // the wave's exact lists start empty
             (&S.lists_s[wave][0][0])[i] = NEG_INF;
@@ -569,7 +603,12 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
             for (int f = 0; f < 12; ++f) qf[f] = slot < ng ? img[2 * f + h] : i32x4_t{0, 0, 0, 0};
         }
         const float sq_l = S.sq[slot];
-        const float sq254_l = sq_l / 254.0f, rsq254_l = 254.0f / sq_l, k2_l = I8_K2_PER_SQ * sq_l;
+        // ub = C g1 + g0(E): int8 shadow E + K2; packed shadow E (1 + k2u) + k2c (scan_bounded_i8_kernel)
+        const float sq254_l = sq_l / 254.0f, rsq254_l = 254.0f / sq_l;
+        const float k2u_l = I6_K2U_PER_SQ * sq_l;
+        const float k2_l = SH == 5 ? I6_XNORM * k2u_l : I8_K2_PER_SQ * sq_l;
+        const float emul_l = SH == 5 ? 1.0f + k2u_l : 1.0f, emul_thr_l = emul_l * 1.000001f;
+        const int acc0 = (SH == 5 && slot < ng) ? -PackedShadow<5>::OFFSET * S.sum[(c & 8u) ? 1 : 0][slot] : 0;
         const float d_in_l = S.d_in[slot];
         float tau_l = (tested && d_in_l < POS_INF) ? __fsub_rn(__fsub_rn(1.0f, d_in_l), BOUNDED_MARGIN) : NEG_INF;
         float tau_m = POS_INF;
@@ -652,7 +691,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
             int thr = 0, mx = 0;
 
             auto slow_path = [&]() __attribute__((always_inline)) {
-                const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l, g0 = pmt.y + k2_l;
+                const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l, g0 = __builtin_fmaf(pmt.y, emul_l, k2_l);
                 // (sixteen compares into scalar masks first: with 16 queries per stream some lane is over its threshold in most
                 // sub-tiles of a topical index, but in one or two of the sixteen accumulator registers only — the rest of the work
                 // is skipped by scalar branches)
@@ -674,7 +713,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
             };
             auto test_slice = [&](int s, const i32x16_t& pacc) __attribute__((always_inline)) {
                 if (s == 0) {
-                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m);
+                    const float u = __builtin_fmaf(-pmt.y, emul_thr_l, tau_m);
                     float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l, -2.0f);
                     thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
                     if (!tested) thr_f = 2.0e9f;
@@ -695,16 +734,49 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
                 const uint32_t tn = t + t_stride;
                 more = tn < n_sub;
                 const u32x4* pn = more ? x + (size_t)tn * (12 * 64) + lane : p;
+                const uint32_t* pn5 = more ? x5 + (size_t)tn * I5_SUB_DW : p5;
                 const float2 mtn = meta[more ? tn : t];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0;
+                for (int e = 0; e < 16; ++e) acc[e] = acc0;
+                if constexpr (SH == 5) {
 #pragma unroll
-                for (int f = 0; f < 12; ++f) {
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % PD]), qf[f], acc, 0, 0, 0);
-                    if (f + PD < 12) a[f % PD] = __builtin_nontemporal_load(p + (f + PD) * 64);
-                    else a[f % PD] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
-                    if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int pr = 0; pr < 6; ++pr) {  // (scan_filter_i6s_kernel's 5-bit loop)
+                        const int g = pr / 3, m = pr % 3;
+                        const u32x4 nw = nq[pr % NN];
+                        const u32x3 hw = hq[g % NH];
+                        const uint32_t H = m == 0 ? hw.x : m == 1 ? hw.y : hw.z;
+                        const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z, n3 = nw.w;
+                        i32x4_t av, bv;
+                        av[0] = (int)((n0 & 0x0F0F0F0Fu) | (H & 0x10101010u));
+                        av[1] = (int)(((n0 >> 4) & 0x0F0F0F0Fu) | ((H >> 1) & 0x10101010u));
+                        av[2] = (int)((n1 & 0x0F0F0F0Fu) | ((H >> 2) & 0x10101010u));
+                        av[3] = (int)(((n1 >> 4) & 0x0F0F0F0Fu) | ((H >> 3) & 0x10101010u));
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, qf[2 * pr], acc, 0, 0, 0);
+                        if constexpr (decltype(with_test)::value) test_slice(2 * pr, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bv[0] = (int)((n2 & 0x0F0F0F0Fu) | ((H << 4) & 0x10101010u));
+                        bv[1] = (int)(((n2 >> 4) & 0x0F0F0F0Fu) | ((H << 3) & 0x10101010u));
+                        bv[2] = (int)((n3 & 0x0F0F0F0Fu) | ((H << 2) & 0x10101010u));
+                        bv[3] = (int)(((n3 >> 4) & 0x0F0F0F0Fu) | ((H << 1) & 0x10101010u));
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bv, qf[2 * pr + 1], acc, 0, 0, 0);
+                        if (pr + NN < 6) nq[pr % NN] = load_n(p5, pr + NN);
+                        else nq[pr % NN] = load_n(pn5, pr + NN - 6);
+                        if (m == 2) {
+                            if (g + NH < 2) hq[g % NH] = load_h(p5, g + NH);
+                            else hq[g % NH] = load_h(pn5, g + NH - 2);
+                        }
+                        if constexpr (decltype(with_test)::value) test_slice(2 * pr + 1, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 12; ++f) {
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a[f % NA]), qf[f], acc, 0, 0, 0);
+                        if (f + PD < 12) a[f % NA] = __builtin_nontemporal_load(p + (f + PD) * 64);
+                        else a[f % NA] = __builtin_nontemporal_load(pn + (f + PD - 12) * 64);
+                        if constexpr (decltype(with_test)::value) test_slice(f, accs[1 - P]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if constexpr (decltype(with_test)::value)
                     if (__any(mx > thr)) slow_path();
@@ -712,6 +784,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
                 prow = t * 32u;
                 t = tn;
                 p = pn;
+                p5 = pn5;
                 mt = mtn;
             };
             using P0 = std::integral_constant<int, 0>;
@@ -802,6 +875,8 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const u3
 static int g_bounded_ring = 6;
 void set_bounded_ring(int pd) { g_bounded_ring = pd == 12 ? 12 : 6; }
 // waves per workgroup of the batch form (one workgroup per CU either way: its LDS); process-wide, option "bounded_multi_waves"
+static int g_bounded_multi_packed = 0;  // the batch form on the packed 5-bit shadow (process-wide; option "bounded_multi_packed")
+void set_bounded_multi_packed(int v) { g_bounded_multi_packed = v ? 1 : 0; }
 static int g_bounded_multi_waves = 8;  // (74.0 against 77.4 ms per topical batch of 256 at 100 M rows: profiles/r04/bounded_multi_waves_100M.log)
 void set_bounded_multi_waves(int nw) { g_bounded_multi_waves = nw == 8 ? 8 : 4; }
 
@@ -816,6 +891,10 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<NW_>));
         DAWN_BM_ATTR(0, 6, 4) DAWN_BM_ATTR(1, 6, 4) DAWN_BM_ATTR(0, 12, 4) DAWN_BM_ATTR(1, 12, 4) DAWN_BM_ATTR(0, 6, 8) DAWN_BM_ATTR(1, 6, 8)
 #undef DAWN_BM_ATTR
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<0, 8, 8, 5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<8>));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 8, 8, 5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<8>));
     });
     const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
     const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
@@ -849,7 +928,19 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<RT_, PD_, NW_>), dim3(n_lists), dim3(64 * NW_), sizeof(BoundedMultiLds<NW_>), stream, \
                        DAWN_BOUNDED_ARGS)
             const int rt = dtype == ROW_BF16 ? 1 : 0;
-            if (g_bounded_multi_waves == 8) {
+            if (d_i5 && d_i5meta && g_bounded_multi_packed) {  // the packed 5-bit shadow (eight waves)
+#define DAWN_BOUNDED_ARGS5M                                                                                                    \
+    d_i5, reinterpret_cast<const float2*>(d_i5meta), d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0,   \
+        cand_s + (size_t)b0 * n_lists * LIST, cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, \
+        d_dist + (size_t)b0 * k, d_found + b0, d_stats, stats_mirror
+                if (rt)
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<1, 8, 8, 5>), dim3(n_lists), dim3(512), sizeof(BoundedMultiLds<8>), stream,
+                                       DAWN_BOUNDED_ARGS5M);
+                else
+                    hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 8, 8, 5>), dim3(n_lists), dim3(512), sizeof(BoundedMultiLds<8>), stream,
+                                       DAWN_BOUNDED_ARGS5M);
+#undef DAWN_BOUNDED_ARGS5M
+            } else if (g_bounded_multi_waves == 8) {
                 if (rt) DAWN_BM_LAUNCH(1, 6, 8); else DAWN_BM_LAUNCH(0, 6, 8);
             } else if (deep) {
                 if (rt) DAWN_BM_LAUNCH(1, 12, 4); else DAWN_BM_LAUNCH(0, 12, 4);

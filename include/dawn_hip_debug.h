@@ -95,6 +95,15 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "bounded_seed"     1 (default): a demoted single query's bounded pass on the packed shadow starts from the k-th exact distance of a
  *                      packed-stream search over the first 1/32 of the rows (topical rows, mean ms per query, int8 form -> packed
  *                      seeded: 12.5 M rows 0.88 -> 0.68, 100 M 5.79 -> 4.17); 0: no seed; 2: also on indexes below 2 Mi rows (tests)
+ *   "batch_rerun"      a second matrix-core pass for the flagged queries of a batch, each with the threshold its own k-th exact distance
+ *                      gives, before the bounded pass takes what is left: 0 never (default), 1 on indexes whose batch feedback has
+ *                      deepened the thresholds, 2 every batch.  100 M topical rows: settles 18-30 % of a batch at the default depth
+ *                      (74 -> 69 ms), 4-19 % at the deepened one, where it no longer pays for its 12 ms (63 -> 71 ms)
+ *   "bounded_multi_waves"  process-wide: waves per workgroup of the bounded pass of batches, 8 (default) or 4 (one workgroup per CU
+ *                      either way; 74.0 against 77.4 ms per topical batch of 256 at 100 M rows)
+ *   "bounded_multi_packed" process-wide: 1: the bounded pass of BATCHES streams the packed 5-bit shadow too.  Slower (100 M topical
+ *                      rows: 80.9 against 73.9 ms per batch of 256: sixteen queries per stream turn the looser bound into several
+ *                      times the hits to queue and score); default 0
  *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
  *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows

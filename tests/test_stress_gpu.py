@@ -62,6 +62,8 @@ def _case(rng):
         opts["mfma_target"] = int(rng.choice([64, 256, 4096]))
     if rng.random() < 0.3:
         opts["bounded_multi_waves"] = int(rng.choice([4, 8]))
+    if rng.random() < 0.3:
+        opts["bounded_multi_packed"] = 1
     return n, dist, dtype, k, B, opts
 
 
@@ -78,6 +80,7 @@ def test_random_configuration_with_adds_and_shards(dawn, oracle, seed):
     if sharded:
         idx.set_option("shard_chunk", int(rng.choice([64, 1024, 4096])))
         opts.pop("bounded_multi_waves", None)
+        opts.pop("bounded_multi_packed", None)
     for name, v in opts.items():
         idx.set_option(name, v)
     x = oracle.unit_rows(1, 0, n)
@@ -143,7 +146,8 @@ def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
         st = idx.stats()
         assert st["fallbacks"] == 0 or dtype == "bf16" or "force_fallback" in opts or n <= 64, (st, n, dist, dtype, k, B, opts)
     finally:
-        idx.set_option("bounded_multi_waves", 8)  # (process-wide knob: back to the default for the tests that follow)
+        idx.set_option("bounded_multi_waves", 8)  # (process-wide knobs: back to the defaults for the tests that follow)
+        idx.set_option("bounded_multi_packed", 0)
         idx.close()
 
 
@@ -151,7 +155,7 @@ _TOGGLES = {
     "i8_shadow": [0, 1], "i6_shadow": [0, 1], "i6_bits": [5, 6], "f16_shadow": [0, 1], "f16_shadow_b1": [0, 1], "f6_shadow": [0, 1],
     "i8_batched": [0, 1], "mfma_min_batch": [2, 100000], "bounded_pass": [0, 1], "force_fallback": [0, 2], "ladder_feedback": [0, 1, 2],
     "bounded_packed": [0, 1, 2], "bounded_seed": [0, 1, 2], "batch_rerun": [0, 1, 2], "mfma_target": [64, 1024, 4096],
-    "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
+    "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "bounded_multi_packed": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
 }
 
 
@@ -215,4 +219,5 @@ def test_random_option_walk_on_one_index(dawn, oracle, seed, tmp_path):
                 finally:
                     other.close()
     finally:
+        idx.set_option("bounded_multi_packed", 0)
         idx.close()

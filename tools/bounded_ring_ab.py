@@ -30,8 +30,8 @@ blob = torch.zeros((dawn.result_blob_bytes(256, k),), dtype=torch.uint8, device=
 p = blob.data_ptr()
 ref = {}
 for r in range(rounds):
-    for ring in (4, 8):  # (waves per workgroup of the batch form; the fragment ring made no difference: 6 vs 12, earlier log)
-        idx.set_option("bounded_multi_waves", ring)
+    for ring in (0, 1):  # (the batch form on the int8 / the packed 5-bit shadow; earlier logs: fragment ring 6 vs 12, 4 vs 8 waves)
+        idx.set_option("bounded_multi_packed", ring)
         for name, B, fb, iters in (("batch 256", 256, 0, 6), ("single queries, bounded pass directly", 1, 2, 32)):
             idx.set_option("ladder_feedback", fb)
             for _ in range(2):
@@ -47,5 +47,5 @@ for r in range(rounds):
             s1 = idx.stats()
             raw = blob.cpu().numpy()[:B * k * 12].copy()
             same = np.array_equal(ref.setdefault(name, raw), raw)
-            print(f"rows={rows} multi_waves={ring:2d} {name:40s}: {el:8.3f} ms per search; bounded per query "
+            print(f"rows={rows} multi_packed={ring:2d} {name:40s}: {el:8.3f} ms per search; bounded per query "
                   f"{(s1['bounded'] - s0['bounded']) / (iters * B):.3f}; identical: {same}", flush=True)
