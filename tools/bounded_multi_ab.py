@@ -1,6 +1,9 @@
-"""Bounded exact pass: fragments in flight per wave (dev tool, option "bounded_ring" 6 / 12).  Topical rows (synth_dist 4), queries =
-further rows of the same stream; a batch of 256 (its flagged queries take the bounded pass sixteen per stream) and single queries
-sent to the bounded pass directly ("ladder_feedback" = 2).  python tools/bounded_ring_ab.py [rows=100000000] [rounds=2]"""
+"""Bounded exact pass of BATCHES, A/B of one process-wide knob at a time (dev tool; edit the loop for another knob): here option
+"bounded_multi_packed" 0 / 1 — the int8 or the packed 5-bit shadow (earlier runs of the same loop: fragment ring 6 / 12 with
+"bounded_ring", 4 / 8 waves per workgroup with "bounded_multi_waves": profiles/r04/bounded_ring_ab_100M.log,
+bounded_multi_waves_100M.log).  Topical rows (synth_dist 4), queries = further rows of the same stream; a batch of 256 without the
+batch feedback (equal ladder share in both arms) and single queries sent to the bounded pass directly ("ladder_feedback" = 2).
+python tools/bounded_multi_ab.py [rows=100000000] [rounds=2]"""
 import os
 import sys
 import time
