@@ -983,14 +983,20 @@ void launch_scan_batched_f6(const void* d_x, int dtype, const void* d_i8, const 
         once_per_device(attr_once, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
+#ifdef DAWN_EXPERIMENTS  // (make EXPERIMENTS=1: the timing forms are not in the release library)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f6_pass_lds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)sizeof(F6PassLds));
+#endif
         });
         const uint32_t n_groups = (pl.n_tiles + (uint32_t)F6L_GROUP - 1u) / (uint32_t)F6L_GROUP;
         const uint32_t blocks = n_groups < (uint32_t)grid ? n_groups : (uint32_t)grid;
+#ifdef DAWN_EXPERIMENTS
         auto kern = f6.stagger == -2 ? scan_f6_pass_lds_kernel<1> : f6.stagger == -4 ? scan_f6_pass_lds_kernel<4> : scan_f6_pass_lds_kernel<0>;
+#else
+        auto kern = scan_f6_pass_lds_kernel<0>;  // (f6_stagger -2 / -4: the timing forms of an EXPERIMENTS build; here the pass itself)
+#endif
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), sizeof(F6PassLds), stream, xs, mt, n_rows, pl.n_tiles, qf6, qm6, B, f6.tau6,
                            f6.cnt_big, reinterpret_cast<uint2*>(f6.cand_big), f6.seg_cap_big);
     } else {

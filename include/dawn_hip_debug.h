@@ -111,8 +111,8 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow
  *                      (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
  *                      that for count > 32); "f6_stagger" -1 (default): the pass staged through LDS, >= 0: the register-ring pass
- *                      with its waves that many tiles apart (A/B), -2 / -4: timing experiments of the LDS-staged pass (no threshold
- *                      tests: wrong results / a few waves print their cycle counts).  Default 0: 8.55 against 9.55 ms per batch of
+ *                      with its waves that many tiles apart (A/B), -2 / -4: timing experiments of the LDS-staged pass in a `make EXPERIMENTS=1`
+ *                      build (no threshold tests: wrong results / a few waves print their cycle counts; the release library runs the pass itself).  Default 0: 8.55 against 9.55 ms per batch of
  *                      256 on 100 M rows with it (profiles/r04/f6_ab_100M_v7_*.log) for 28.8 GB more HBM
  *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
  *                      the index's 64 best by the refined score (measured: a wash; default 0)
