@@ -358,7 +358,7 @@ static bool bounded_packed_wanted(const dawn_index* idx, uint32_t n) {
 // 0 never (the packed form is then only used from 40 Mi rows), 1 (default) from 2 Mi rows, 2 from 32 Ki rows (tests).
 static bool bounded_seed_wanted(const dawn_index* idx, uint32_t n) {
     if (!idx->bounded_seed || idx->debug_bad_threshold) return false;
-    return n / 32u >= (idx->bounded_seed == 2 ? 1024u : (64u << 10));
+    return (n >> idx->bounded_seed_shift) >= (idx->bounded_seed == 2 ? 1024u : (64u << 10));
 }
 
 bool i6_live(const dawn_index* idx) { return i6_wanted(idx) && idx->d_i6 && idx->i6_rows == idx->size && i8_live(idx); }
@@ -548,7 +548,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             if (seed) {
                 ScanGeom g6 = idx->i6_geom();
                 launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
-                               n / 32u, d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
+                               n >> idx->bounded_seed_shift, d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
                                idx->stream_dyn_tail ? idx->d_i6_pool : nullptr, g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
                                0, true, stream, nullptr, nullptr, nullptr, idx->i6_central_tail != 0);
             }
@@ -1013,6 +1013,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "bounded_packed") {  // the bounded pass of a single query streams the packed 5-bit shadow: 0 never, 1 from 2 Mi rows, 2 always
         if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "bounded_packed must be 0, 1 or 2");
         idx->bounded_packed = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_seed_shift") {  // the seed searches the first n >> shift rows (default 5: 1/32)
+        if (value < 2 || value > 8) return fail(DAWN_ERR_INVALID_ARG, "bounded_seed_shift must be 2..8");
+        idx->bounded_seed_shift = (int)value;
         return DAWN_OK;
     }
     if (n == "bounded_seed") {  // 1 (default): a demoted query's bounded pass on the packed shadow starts from the k-th distance of a

@@ -188,6 +188,7 @@ struct dawn_index {
     // bounded streams' worth, and ~35 % of such a batch (the near-tie shells) overflows any candidate buffer.  Kept for indexes where
     // the split is different; off by default.
     int batch_rerun = 0;
+    int bounded_seed_shift = 5;  // option "bounded_seed_shift": the seed searches the first n >> shift rows
     int bounded_seed = 1;        // option "bounded_seed": a demoted query's packed bounded pass is seeded by a search over 1/32 of the rows
     int bounded_packed = 1;      // option "bounded_packed": the bounded pass of a single query streams the packed 5-bit shadow
                                  // (240 B/row): 0 never, 1 from 2 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)

@@ -95,6 +95,9 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "bounded_seed"     1 (default): a demoted single query's bounded pass on the packed shadow starts from the k-th exact distance of a
  *                      packed-stream search over the first 1/32 of the rows (topical rows, mean ms per query, int8 form -> packed
  *                      seeded: 12.5 M rows 0.88 -> 0.68, 100 M 5.79 -> 4.17); 0: no seed; 2: also on indexes below 2 Mi rows (tests)
+ *   "bounded_seed_shift" the seed searches the first n >> shift rows, 2..8 (default 5 = 1/32: a flat optimum — 100 M topical rows, mean
+ *                      ms per query at shift 3 .. 7: 4.43 / 4.26 / 4.17 / 4.15 / 4.13 with the p95 rising again from 6,
+ *                      profiles/r04/bounded_seed_fraction_sweep_*.log)
  *   "batch_rerun"      a second matrix-core pass for the flagged queries of a batch, each with the threshold its own k-th exact distance
  *                      gives, before the bounded pass takes what is left: 0 never (default), 1 on indexes whose batch feedback has
  *                      deepened the thresholds, 2 every batch.  100 M topical rows: settles 18-30 % of a batch at the default depth
