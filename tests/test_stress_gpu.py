@@ -52,6 +52,8 @@ def _case(rng):
         opts["bounded_packed"] = int(rng.choice([0, 2]))
     if rng.random() < 0.5:
         opts["bounded_seed"] = int(rng.choice([0, 2]))
+        if rng.random() < 0.4:
+            opts["bounded_seed_shift"] = int(rng.choice([2, 4, 7, 8]))
     if rng.random() < 0.4:
         opts["batch_rerun"] = 2
     if rng.random() < 0.35:
@@ -154,7 +156,7 @@ def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
 _TOGGLES = {
     "i8_shadow": [0, 1], "i6_shadow": [0, 1], "i6_bits": [5, 6], "f16_shadow": [0, 1], "f16_shadow_b1": [0, 1], "f6_shadow": [0, 1],
     "i8_batched": [0, 1], "mfma_min_batch": [2, 100000], "bounded_pass": [0, 1], "force_fallback": [0, 2], "ladder_feedback": [0, 1, 2],
-    "bounded_packed": [0, 1, 2], "bounded_seed": [0, 1, 2], "batch_rerun": [0, 1, 2], "mfma_target": [64, 1024, 4096],
+    "bounded_packed": [0, 1, 2], "bounded_seed": [0, 1, 2], "bounded_seed_shift": [2, 5, 8], "batch_rerun": [0, 1, 2], "mfma_target": [64, 1024, 4096],
     "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "bounded_multi_packed": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
 }
 
