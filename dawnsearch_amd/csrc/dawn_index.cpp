@@ -1692,21 +1692,46 @@ int dawn_index_stats_ladder(dawn_index* idx, uint64_t* bounded, uint64_t* packed
 
 // ... what the feedback of the batched paths did (debug header): batches (of <= 256 queries) the FP6 first filter took, batches
 // its feedback handed to the int8 pass instead, batches the int8 pass ran with the deeper thresholds of a ladder-heavy index
+int dawn_index_debug_raw_stats(dawn_index* idx, uint64_t* out8);
 int dawn_index_stats_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches,
                                     uint64_t* rerun_answers) {
     if (!idx) return fail(DAWN_ERR_INVALID_ARG, "idx is NULL");
-    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "per-shard counters: ask the shards");
-    if (f6_batches) *f6_batches = idx->n_f6_batches;
-    if (f6_suspended) *f6_suspended = idx->n_f6_suspended;
-    if (deepened_batches) *deepened_batches = idx->n_deepened_batches;
+    if (f6_batches) *f6_batches = 0;
+    if (f6_suspended) *f6_suspended = 0;
+    if (deepened_batches) *deepened_batches = 0;
+    if (idx->shards) {  // a sharded handle: the sums over its shards
+        dawn::sharded_batch_feedback(idx, f6_batches, f6_suspended, deepened_batches);
+    } else {
+        if (f6_batches) *f6_batches = idx->n_f6_batches;
+        if (f6_suspended) *f6_suspended = idx->n_f6_suspended;
+        if (deepened_batches) *deepened_batches = idx->n_deepened_batches;
+    }
     if (rerun_answers) {  // queries of batches answered by the second pass with exact-derived thresholds (FLAG_RERUN)
-        uint32_t st[dawn::N_STAT_SLOTS] = {};
-        DAWN_TRY(set_device(idx));
-        DAWN_HIP_TRY(hipDeviceSynchronize());
-        if (idx->d_stats) DAWN_HIP_TRY(hipMemcpy(st, idx->d_stats, sizeof(st), hipMemcpyDeviceToHost));
-        *rerun_answers = st[dawn::FLAG_RERUN];
+        uint64_t raw[dawn::N_STAT_SLOTS] = {};
+        DAWN_TRY(dawn_index_debug_raw_stats(idx, raw));
+        *rerun_answers = raw[dawn::FLAG_RERUN];
     }
     return DAWN_OK;
+}
+
+// ... the device-side counters as they are (debug header): out[N_STAT_SLOTS = 8], indexed by final flag; [5] packed-stream failures,
+// [7] (row, query) pairs the bounded pass scored exactly.  A sharded handle sums its shards.
+int dawn_index_debug_raw_stats(dawn_index* idx, uint64_t* out8) {
+    if (!idx || !out8) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    return dawn::guarded([&] {
+        for (int i = 0; i < dawn::N_STAT_SLOTS; ++i) out8[i] = 0;
+        std::vector<dawn_index*> parts;
+        if (idx->shards) dawn::sharded_collect(idx, parts);
+        else parts.push_back(idx);
+        for (dawn_index* s : parts) {
+            uint32_t st[dawn::N_STAT_SLOTS] = {};
+            DAWN_TRY(set_device(s));
+            DAWN_HIP_TRY(hipDeviceSynchronize());
+            if (s->d_stats) DAWN_HIP_TRY(hipMemcpy(st, s->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+            for (int i = 0; i < dawn::N_STAT_SLOTS; ++i) out8[i] += st[i];
+        }
+        return (int)DAWN_OK;
+    });
 }
 
 // ... and, of the second chances, the ones a deeper round of the same certificate (128 .. 256 rows, ~10 us each) settled

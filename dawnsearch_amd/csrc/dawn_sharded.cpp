@@ -556,6 +556,19 @@ int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_
     return DAWN_OK;
 }
 
+void sharded_collect(dawn_index* idx, std::vector<dawn_index*>& out) {
+    for (dawn_index* sh : idx->shards->sh) out.push_back(sh);
+}
+
+// the batch feedback's host-side counters, summed over the shards (the sharded handle used to refuse)
+void sharded_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches) {
+    for (dawn_index* sh : idx->shards->sh) {
+        if (f6_batches) *f6_batches += sh->n_f6_batches;
+        if (f6_suspended) *f6_suspended += sh->n_f6_suspended;
+        if (deepened_batches) *deepened_batches += sh->n_deepened_batches;
+    }
+}
+
 int sharded_profile_enable(dawn_index* idx, int enable) {
     for (dawn_index* sh : idx->shards->sh) DAWN_TRY(index_profile_enable_single(sh, enable));
     return DAWN_OK;

@@ -313,6 +313,8 @@ int sharded_set_option(dawn_index* idx, const char* name, int64_t value);
 int sharded_memory(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);
 int sharded_stats(dawn_index* idx, uint64_t* searches, uint64_t* second, uint64_t* fallbacks, uint64_t* deepened,
                   uint64_t* bounded = nullptr, uint64_t* packed_failures = nullptr, uint64_t* demoted = nullptr);
+void sharded_collect(dawn_index* idx, std::vector<dawn_index*>& out);  // the shards' single-device indexes
+void sharded_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint64_t* f6_suspended, uint64_t* deepened_batches);
 int sharded_profile_enable(dawn_index* idx, int enable);
 int sharded_profile_read(dawn_index* idx, uint64_t* launches, double* total_ms);
 int sharded_dtype(const dawn_index* idx);

@@ -69,6 +69,7 @@ constexpr uint32_t FLAG_RERUN = 6;     // a batch's certificate failed at the sa
                                        // threshold their own k-th exact distance gives answered: result is exact (scan_i8.hip: launch_i8_rerun)
 constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query ...
 constexpr int STAT_PACKED_FAIL = 5;    // ... and [5]: single-query searches whose packed-stream certificate failed (merge_exact_kernel)
+constexpr int STAT_BOUNDED_EXACT = 7;  // ... and [7]: (row, query) pairs the bounded pass scored exactly (mod 2^32; scan_bounded.hip)
 
 // Function attributes (hipFuncSetAttribute: the dynamic-LDS limit of a kernel) belong to the CURRENT device's copy of the
 // kernel: a process that drives several devices (dawn_sharded.cpp) has to set them on each.  once_per_device(state, fn) runs fn

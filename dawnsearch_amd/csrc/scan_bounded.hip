@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const void* __rest
         };
         set_tau_m();
         uint32_t n_wait = 0;  // rows in the wave's queue (wave-uniform)
+        uint32_t n_exact = 0;  // rows this wave scored exactly (-> stats[STAT_BOUNDED_EXACT])
         uint32_t* queue = &sh_queue[wave][0];
 
         auto flush = [&]() __attribute__((always_inline)) {
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const void* __rest
                 if (d == d) key = -d;
                 else row = NO_POS;
             }
+            n_exact += n_wait;
             n_wait = 0;
             // rows arrive in ascending order (queue order = stream order), so a later row never displaces an equal key
             const float t64 = read_lane63(ls);
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_kernel(const void* __rest
             if (__any(mx > thr)) slow_path();
         }
         if (n_wait > 0u) flush();
+        if (stats && lane == 0 && n_exact) atomicAdd(&stats[STAT_BOUNDED_EXACT], n_exact);
 
         block_merge(ls, lp, sh_s, sh_p, wave, lane, nwaves);
         if (wave == 0) {
@@ -620,6 +623,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
         };
         set_tau_m();
         uint32_t n_wait = 0;  // entries in the wave's queue (wave-uniform)
+        uint32_t n_exact = 0;  // (row, query) pairs this wave scored exactly (-> stats[STAT_BOUNDED_EXACT])
         uint2* queue = &S.queue[wave][0];
 
         // the top (up to) 64 entries of the queue: exact scores, a lane per entry, into the lists of their queries
@@ -628,6 +632,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
             const uint32_t n = n_wait < 64u ? n_wait : 64u;
             const uint32_t base = n_wait - n;
             n_wait = base;
+            n_exact += n;
             float key = NEG_INF;
             uint32_t row = NO_POS, es = 0;
             if ((uint32_t)lane < n) {
@@ -808,6 +813,7 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
             if (__any(mx > thr)) slow_path();
         }
         while (n_wait > 0u) flush64();
+        if (stats && lane == 0 && n_exact) atomicAdd(&stats[STAT_BOUNDED_EXACT], n_exact);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // the workgroup's list of every query of the group

@@ -146,6 +146,13 @@ class VectorIndex:
         return {"searches": s.value, "fallbacks": f.value, "second_chances": c2.value, "deepened": dp.value,
                 "bounded": bd.value, "packed_failures": pf.value, "demoted": dm.value}
 
+    def stats_raw(self):
+        """The device-side counters as they are (dawn_hip_debug.h): 8 slots indexed by final flag; [5] packed-stream failures,
+        [7] (row, query) pairs the bounded pass scored exactly."""
+        out = (C.c_uint64 * 8)()
+        check(lib.dawn_index_debug_raw_stats(self._h, out))
+        return [int(v) for v in out]
+
     def stats_batch_feedback(self):
         """Batches the FP6 first filter took / batches its feedback handed to the int8 pass / batches the int8 pass ran with the
         deeper thresholds of a ladder-heavy index (dawn_hip_debug.h)."""

@@ -26,6 +26,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#endif
 
 #define DAWN_OK 0
 #define DAWN_ERR_INVALID_ARG (-1)
@@ -238,6 +241,9 @@ int dawn_tokenizer_encode(const dawn_tokenizer *t, const char *text_utf8, uint32
 int dawn_tokenizer_encode_batch(const dawn_tokenizer *t, const char *const *texts, size_t B, uint32_t *out_ids,
                                 size_t cap, int32_t *seq_offsets);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#endif
 
 /* Fill rows [size, size+n) with the synthetic unit rows of DESIGN.md §5 (stream `seed`, rows
  * first_row..) generated on the GPU, ids = first_id + i.  Bench / test input only. */
@@ -33,9 +36,13 @@ int dawn_index_debug_f6_scores(dawn_index *idx, const float *queries, size_t B, 
  * instead of 1024: an index that sent more than 10 % of a window of 1024 batched queries to the ladder keeps them until its rows
  * change); rerun_answers: queries of such batches whose failed certificate was settled by a SECOND matrix-core pass with the
  * threshold their own k-th exact distance gives (option "batch_rerun"; the bounded pass keeps the rest).  Option "ladder_feedback" = 0
- * switches all of it off.  Not on a sharded handle. */
+ * switches all of it off.  A sharded handle reports the sums over its shards. */
 int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint64_t *f6_suspended, uint64_t *deepened_batches,
                                     uint64_t *rerun_answers);
+/* The device-side counters of the index as they are: out8[8], indexed by a query's final flag (1 exact pass over all rows, 2 second
+ * chance, 3 deeper round, 4 bounded exact pass, 6 second matrix-core pass); [5] single queries whose packed-stream certificate failed;
+ * [7] (row, query) pairs the bounded pass scored exactly (mod 2^32).  A sharded handle reports the sums over its shards. */
+int dawn_index_debug_raw_stats(dawn_index *idx, uint64_t *out8);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
@@ -154,6 +161,9 @@ int dawn_embedder_debug_op(dawn_embedder *e, int op, const void *in, int T, floa
  * f32-MFMA tile kernel, 1 = the bf16x3 kernel (f32-accurate 3-way bf16 split on the bf16 matrix cores). */
 int dawn_embedder_debug_gemm_time(dawn_embedder *e, int T, int N, int K, int variant, int iters, double *mean_ms);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

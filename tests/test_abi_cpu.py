@@ -29,6 +29,14 @@ def test_library_exports_every_declared_symbol(dawn):
     assert sorted(_lib._SIGS) == names  # the ctypes table binds exactly the header
 
 
+def test_library_exports_nothing_but_the_declared_abi(dawn):
+    """-fvisibility=hidden + csrc/exports.map: no internal C++ symbol (namespace dawn, process-wide knobs) leaks out of the .so."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", dawn.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == _declared_symbols()
+
+
 def test_no_cpu_fallback_without_device(dawn):
     if dawn.device_count() > 0:
         pytest.skip("a GPU is present")
