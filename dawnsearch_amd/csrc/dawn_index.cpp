@@ -107,6 +107,11 @@ int ensure_workspace(dawn_index* idx, size_t B) {
         DAWN_HIP_TRY(hipHostMalloc((void**)&idx->h_stats, dawn::N_STAT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
         std::memset(idx->h_stats, 0, dawn::N_STAT_SLOTS * sizeof(uint32_t));
     }
+    if (!idx->bounded.wide_res) {  // the wide batch form of the bounded pass: appended exact results per query + their counters (zero between searches)
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bounded.wide_res, (size_t)dawn::BATCH_QT * dawn::BOUNDED_WIDE_CAP * sizeof(uint2)));
+        DAWN_HIP_TRY(hipMalloc((void**)&idx->bounded.wide_cnt, dawn::BATCH_QT * sizeof(uint32_t)));
+        DAWN_HIP_TRY(hipMemset(idx->bounded.wide_cnt, 0, dawn::BATCH_QT * sizeof(uint32_t)));
+    }
     if (!idx->d_i6_pool) {  // chunk counters of the packed stream: zero between searches (merge_exact_kernel resets them)
         DAWN_HIP_TRY(hipMalloc((void**)&idx->d_i6_pool, 32 * sizeof(uint32_t)));
         DAWN_HIP_TRY(hipMemset(idx->d_i6_pool, 0, 32 * sizeof(uint32_t)));
@@ -554,7 +559,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             }
             launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
                                        idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
-                                       d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats,
+                                       d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats, idx->bounded,
                                        idx->debug_bad_threshold ? -1.0f : __builtin_inff(), p5 ? idx->d_i6 : nullptr,
                                        p5 ? idx->d_i6meta : nullptr, seed);
             DAWN_HIP_TRY(hipGetLastError());
@@ -602,7 +607,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
     if (idx->bounded_pass && idx->force_fallback != 1 && i8_live(idx) && n > 0)
         launch_scan_bounded(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags,
                             idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k, d_labels,
-                            d_dist, d_found, stream, idx->d_stats, idx->h_stats, packed5 ? idx->d_i6 : nullptr,
+                            d_dist, d_found, stream, idx->d_stats, idx->h_stats, idx->bounded, packed5 ? idx->d_i6 : nullptr,
                             packed5 ? idx->d_i6meta : nullptr);
     else
         launch_scan_exact(idx->d_x, idx->dtype, idx->d_ids, n, d_q, (int)B, idx->d_flags, idx->d_flags + idx->ws_B, idx->d_stats,
@@ -672,7 +677,7 @@ void index_destroy_single(dawn_index* idx) {
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
     void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
-                    idx->d_flags, idx->d_stats, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->bws.pool, idx->d_q,
+                    idx->d_flags, idx->d_stats, idx->bounded.wide_res, idx->bounded.wide_cnt, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->bws.pool, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1032,19 +1037,24 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->batch_rerun = (int)value;
         return DAWN_OK;
     }
-    if (n == "bounded_multi_packed") {  // process-wide: the bounded pass of BATCHES streams the packed 5-bit shadow too (0 / 1)
+    if (n == "bounded_multi_packed") {  // the 16-query batch form of the bounded pass streams the packed 5-bit shadow too (0 / 1)
         if (value != 0 && value != 1) return fail(DAWN_ERR_INVALID_ARG, "bounded_multi_packed must be 0 or 1");
-        dawn::set_bounded_multi_packed((int)value);
+        idx->bounded.multi_packed = (int)value;
         return DAWN_OK;
     }
-    if (n == "bounded_multi_waves") {  // process-wide: waves per workgroup of the bounded pass of batches (4 or 8)
+    if (n == "bounded_multi_waves") {  // waves per workgroup of the 16-query batch form (4 or 8)
         if (value != 4 && value != 8) return fail(DAWN_ERR_INVALID_ARG, "bounded_multi_waves must be 4 or 8");
-        dawn::set_bounded_multi_waves((int)value);
+        idx->bounded.multi_waves = (int)value;
         return DAWN_OK;
     }
-    if (n == "bounded_ring") {  // process-wide: 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)
+    if (n == "bounded_ring") {  // 16-B fragments a wave of the bounded pass keeps in flight (6 or 12)
         if (value != 6 && value != 12) return fail(DAWN_ERR_INVALID_ARG, "bounded_ring must be 6 or 12");
-        dawn::set_bounded_ring((int)value);
+        idx->bounded.ring = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "bounded_wide") {  // a batch's flagged queries go through the wide form (64 per stream of the int8 shadow) first (0 / 1)
+        if (value != 0 && value != 1) return fail(DAWN_ERR_INVALID_ARG, "bounded_wide must be 0 or 1");
+        idx->bounded.wide = (int)value;
         return DAWN_OK;
     }
     if (n == "f6_refine_rows") {  // f32 index: re-score the FP6 survivors on the rows themselves (1, default) or on the int8 shadow (0)

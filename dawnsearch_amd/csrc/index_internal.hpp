@@ -193,6 +193,9 @@ struct dawn_index {
     int bounded_packed = 1;      // option "bounded_packed": the bounded pass of a single query streams the packed 5-bit shadow
                                  // (240 B/row): 0 never, 1 from 2 Mi rows, 2 always (dawn_index.cpp: bounded_packed_wanted)
     int bounded_pass = 1;        // option "bounded_pass": a failed certificate is answered from the int8 shadow (scan_bounded.hip)
+    // the pass's per-index choices and the result buffers of its wide batch form (options "bounded_ring", "bounded_multi_waves",
+    // "bounded_multi_packed", "bounded_wide"; buffers owned by ensure_workspace)
+    dawn::BoundedOpts bounded{};
     // Ladder feedback.  The packed stream (240 B/row) followed by the bounded pass (384 B/row) costs 2.6 x the packed stream
     // when its certificate fails; the bounded pass ALONE, started without a threshold, costs 1.6 x and cannot fail.  The index
     // therefore watches how often the packed certificate fails — the device mirrors its counters into h_stats at the end of

@@ -69,6 +69,7 @@ constexpr uint32_t FLAG_RERUN = 6;     // a batch's certificate failed at the sa
                                        // threshold their own k-th exact distance gives answered: result is exact (scan_i8.hip: launch_i8_rerun)
 constexpr int N_STAT_SLOTS = 8;        // device-side counters per index, indexed by the final flag of a query ...
 constexpr int STAT_PACKED_FAIL = 5;    // ... and [5]: single-query searches whose packed-stream certificate failed (merge_exact_kernel)
+constexpr int STAT_BOUNDED_WIDE = 0;   // ... [0] (no final flag is 0): queries the WIDE batch form of the bounded pass answered (a subset of [4])
 constexpr int STAT_BOUNDED_EXACT = 7;  // ... and [7]: (row, query) pairs the bounded pass scored exactly (mod 2^32; scan_bounded.hip)
 
 // Function attributes (hipFuncSetAttribute: the dynamic-LDS limit of a kernel) belong to the CURRENT device's copy of the
@@ -229,13 +230,22 @@ void launch_scan_exact(const void* d_x, int dtype, const uint64_t* d_ids, uint32
 // the int8 shadow, scores exactly every row whose upper bound can still reach the k-th best distance known so far (d_dist of
 // the failed stage), sets FLAG_BOUNDED.  cand_s / cand_p [B][n_lists][64]; d_done [B] arrival counters (zero before and after).
 // It is the LAST launch of a search (no exact pass behind it): d_stats / stats_mirror as for launch_scan_exact.
-void set_bounded_multi_packed(int v);  // 1: the batch form of the bounded pass streams the packed 5-bit shadow where one is passed
-void set_bounded_multi_waves(int nw);  // 4 or 8 waves per workgroup of the batch form (process-wide; option "bounded_multi_waves")
-void set_bounded_ring(int pd);  // 6 or 12 fragments in flight per wave (process-wide; option "bounded_ring")
+// Per-index choices of the pass (dawn_index::bounded; options "bounded_ring" / "bounded_multi_waves" / "bounded_multi_packed" /
+// "bounded_wide") and the workspace of its wide batch form.
+constexpr uint32_t BOUNDED_WIDE_CAP = 2048;  // exact results a query of the wide form may collect (more: the 16-query form answers it)
+struct BoundedOpts {
+    int ring = 6;          // 16-B fragments a wave keeps in flight ahead of its MFMAs: 6 (half a sub-tile) or 12
+    int multi_waves = 8;   // waves per workgroup of the 16-query batch form: 4 or 8 (one workgroup per CU either way: its LDS)
+    int multi_packed = 0;  // 1: the 16-query batch form streams the packed 5-bit shadow where one is passed
+    int wide = 1;          // 1: a batch's flagged queries go through the WIDE form first — 64 queries per stream of the int8 shadow
+    uint2* wide_res = nullptr;     // [kBoundedMaxFlags = 256][BOUNDED_WIDE_CAP] {distance bits, row}: exact results appended by the wide form
+    uint32_t* wide_cnt = nullptr;  // [256] entries appended per query; zero between searches
+};
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
-                         uint32_t* d_stats, uint32_t* stats_mirror, const void* d_i5 = nullptr, const void* d_i5meta = nullptr);
+                         uint32_t* d_stats, uint32_t* stats_mirror, const BoundedOpts& opts, const void* d_i5 = nullptr,
+                         const void* d_i5meta = nullptr);
 // (d_i5 / d_i5meta: the packed 5-bit shadow of the same rows, or NULL — a single query (B = 1) then streams it, 240 B per row,
 // instead of the int8 shadow)
 // ... as the WHOLE search of one query (a demoted index, dawn_index.cpp: ladder feedback): the flag is raised and the threshold
@@ -244,8 +254,8 @@ void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const vo
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold = __builtin_inff(), const void* d_i5 = nullptr, const void* d_i5meta = nullptr,
-                                bool seeded = false);
+                                const BoundedOpts& opts, float first_threshold = __builtin_inff(), const void* d_i5 = nullptr,
+                                const void* d_i5meta = nullptr, bool seeded = false);
 // (seeded: d_dist[k - 1] already holds the k-th exact distance of a search over PART of the rows — a valid first threshold; it is kept)
 
 // Stable G-way merge of per-shard results (multi-GPU).  pos_to_label != NULL: the incoming labels are global insertion

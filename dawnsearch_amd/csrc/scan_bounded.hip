@@ -874,22 +874,391 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The WIDE batch form (round 5): SIXTY-FOUR flagged queries per stream of the int8 shadow.  The 16-query form above is one HBM stream
+// per sixteen queries with the matrix pipe nearly idle: a topical batch that leaves 100-135 certificates open paid 7-9 streams
+// (profiles/r04: 348 GB read per batch = 9.07 x the shadow).  Here the H and L images of 32 queries each fill the 32 columns of
+// their own MFMAs — four MFMAs per k-step, 48 per 32-row sub-tile, C = 254 acc_H + acc_L formed by CHAINING (the L chain starts
+// from 254 x the finished H accumulator) — with all 192 query fragments resident in registers (one wave per SIMD, 512 registers),
+// and nothing per query lives in LDS but its f32 copy:
+//   * no lists.  A pair (row, query) whose int8 bound passes the query's threshold tau = (1 - D) - 1e-4 (D = the failed stage's
+//     k-th exact distance; fixed for the pass) is queued BY ROW — (row, 32-query mask) — and re-tested on the f32 row itself: one
+//     coalesced 1.5-KB read per row, an any-order f32 dot per hitting query (FILTER_EPS_F32 from the reference-order sum: the same
+//     tau and the same 1e-4 cover it).  Only what passes that too — the rows within 1e-4 of the k-th score and the better ones —
+//     is scored in the reference's order (vector.rs:128-134), and every pair at distance <= D is APPENDED to the query's result
+//     buffer (global, BOUNDED_WIDE_CAP entries); bounded_wide_finish_kernel sorts them by (distance, row) and writes the top k.
+//   * a query that overflows its buffer, or whose D is unusable, keeps its flag: the 16-query form, launched behind this one,
+//     answers it with its lists (and closes the search: counters, mirror).
+// ------------------------------------------------------------------------------------------------
+constexpr int WQ = 64;            // queries per stream
+constexpr int WQ_QSTRIDE = 388;   // floats per staged query (lanes reading different queries hit different banks)
+constexpr int WQ_HITCAP = 320;    // (row, mask, group) entries per wave: drained from 256 on, a sub-tile adds at most 64
+constexpr int WQ_DRAIN_AT = 24;   // entries that make a drain worth its row reads (8 rows in flight per round)
+struct BoundedWideLds {
+    float q[WQ][WQ_QSTRIDE];
+    union {
+        signed char img[2][WQ][EM];  // set-up only: the int8 images the waves load their fragments from
+        struct {
+            uint4 hit[4][WQ_HITCAP];  // {row, query mask, group, -}
+            uint2 ex[4][64];          // {row, query slot}: pairs awaiting their reference-order score
+        } w;
+    } u;
+    float sq[WQ];
+    float d_in[WQ];
+    float tau[WQ];
+    uint32_t flagged[kBoundedMaxFlags];
+    unsigned long long mask[kBoundedMaxFlags / 64];
+};
+
+template <int RT>
+__global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
+                                                                    const void* __restrict__ rows, uint32_t n_rows,
+                                                                    const float* __restrict__ q, int n_q,
+                                                                    const uint32_t* __restrict__ flags, uint32_t k,
+                                                                    const float* __restrict__ out_dist, uint2* __restrict__ res,
+                                                                    uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bounded_lds[];
+    BoundedWideLds& S = *reinterpret_cast<BoundedWideLds*>(bounded_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_sub = (n_rows + 31u) >> 5;
+    const uint32_t c = lane & 31, h = lane >> 5;
+    const uint32_t t_stride = gridDim.x * 4u;
+    const uint32_t found = n_rows < k ? n_rows : k;
+    {
+        const uint32_t myflag = (int)threadIdx.x < n_q ? flags[threadIdx.x] : FLAG_OK;
+        const bool fl = myflag == FLAG_FALLBACK;
+        const unsigned long long m = __ballot(fl);
+        if (lane == 0) S.mask[wave] = m;
+        __syncthreads();
+        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) rank += (uint32_t)__popcll(S.mask[w]);
+        if (fl) S.flagged[rank] = threadIdx.x;
+        __syncthreads();
+    }
+    uint32_t n_flagged = 0;
+    for (int w = 0; w < kBoundedMaxFlags / 64; ++w) n_flagged += (uint32_t)__popcll(S.mask[w]);
+    if (n_flagged == 0 || found == 0) return;  // (block-uniform)
+
+    uint32_t n_pairs = 0;  // (row, query) pairs past the int8 bound (-> stats[STAT_BOUNDED_EXACT])
+    for (uint32_t g0 = 0; g0 < n_flagged; g0 += WQ) {
+        const uint32_t ng = n_flagged - g0 < (uint32_t)WQ ? n_flagged - g0 : (uint32_t)WQ;
+        uint32_t t = blockIdx.x * 4u + wave;
+        auto tile_ptr = [&](uint32_t tt) __attribute__((always_inline)) { return x + (size_t)(tt < n_sub ? tt : 0u) * (12 * 64) + lane; };
+        // two sub-tiles of fragments in flight per wave (24 KiB): the pass is 48 MFMAs per sub-tile, a whole one ahead hides HBM
+        u32x4 A0[12], A1[12];
+        {
+            const u32x4* p0 = tile_ptr(t);
+            const u32x4* p1 = tile_ptr(t + t_stride);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) A0[f] = __builtin_nontemporal_load(p0 + f * 64);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) A1[f] = __builtin_nontemporal_load(p1 + f * 64);
+        }
+        // the group's queries: f32 copies, thresholds, int8 images (a wave per query)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)WQ * EM; i += blockDim.x) {
+            const uint32_t sidx = i / EM, e = i % EM;
+            S.q[sidx][e] = sidx < ng ? q[(size_t)S.flagged[g0 + sidx] * EM + e] : 0.f;
+        }
+        if (threadIdx.x < (uint32_t)WQ) {
+            const uint32_t sidx = threadIdx.x;
+            float d = POS_INF;
+            if (sidx < ng) d = out_dist[(size_t)S.flagged[g0 + sidx] * k + found - 1];
+            // a usable D is the k-th distance of k real rows: finite, and no wider than anything a unit-vector index holds.  Otherwise
+            // nothing passes for this query, it collects nothing and keeps its flag (the 16-query form takes it)
+            const bool ok = sidx < ng && d == d && d < 2.5f;
+            S.d_in[sidx] = ok ? d : NEG_INF;
+            S.tau[sidx] = ok ? __fsub_rn(__fsub_rn(1.0f, d), BOUNDED_MARGIN) : POS_INF;
+        }
+        for (uint32_t sidx = wave; sidx < (uint32_t)WQ; sidx += 4u) {
+            float v[6];
+            const float* qv = q + (size_t)S.flagged[g0 + (sidx < ng ? sidx : 0)] * EM;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = sidx < ng ? qv[lane + 64 * j] : 0.f;
+            rotate384_wave(v, lane);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) amax = fmaxf(amax, fabsf(v[j]));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+            const float sq = fmaxf(amax, 1e-20f) / 127.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float tt = v[j] / sq;
+                const float H = fminf(fmaxf(rintf(tt), -127.f), 127.f);
+                const float L = fminf(fmaxf(rintf((tt - H) * 254.0f), -127.f), 127.f);
+                S.u.img[0][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)H : (signed char)0;
+                S.u.img[1][sidx][lane + 64 * j] = sidx < ng ? (signed char)(int)L : (signed char)0;
+            }
+            if (lane == 0) S.sq[sidx] = sq;
+        }
+        __syncthreads();
+        // this lane's columns: query slots c (group 0) and 32 + c (group 1); fragments H0 | L0 | H1 | L1
+        i32x4_t qf[4][12];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const i32x4_t* img = reinterpret_cast<const i32x4_t*>(&S.u.img[gi & 1][32 * (gi >> 1) + c][0]);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) qf[gi][f] = img[2 * f + h];
+        }
+        bool tested[2];
+        float sq254_l[2], rsq254_l[2], k2_l[2], tau_l[2], tau_m[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t slot = 32u * g + c;
+            const float sq_l = S.sq[slot];
+            tau_l[g] = S.tau[slot];
+            tested[g] = slot < ng && tau_l[g] < POS_INF;
+            sq254_l[g] = sq_l / 254.0f;
+            rsq254_l[g] = 254.0f / sq_l;
+            k2_l[g] = I8_K2_PER_SQ * sq_l;
+            const float tk = tau_l[g] - k2_l[g];
+            tau_m[g] = tested[g] ? tk - fabsf(tk) * 1e-6f : POS_INF;
+        }
+        const unsigned long long tested_mask[2] = {__ballot(tested[0]), __ballot(tested[1])};
+        __syncthreads();  // the images are in registers: their LDS becomes the waves' queues
+        uint4* hitq = &S.u.w.hit[wave][0];
+        uint2* exq = &S.u.w.ex[wave][0];
+        uint32_t n_hit = 0, n_ex = 0;  // wave-uniform
+
+        // pairs that passed both bounds: reference-order scores, a lane per pair; what lies at distance <= D is appended
+        auto flush_exact = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((uint32_t)lane < n_ex) {
+                const uint2 ent = exq[lane];
+                const float dot = exact_dot_row<RT>(&S.q[ent.y][0], rows, ent.x);
+                const float d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+                if (d == d && d <= S.d_in[ent.y]) {
+                    const uint32_t b = S.flagged[g0 + ent.y];
+                    const uint32_t pos = atomicAdd(&res_cnt[b], 1u);
+                    if (pos < BOUNDED_WIDE_CAP) res[(size_t)b * BOUNDED_WIDE_CAP + pos] = uint2{__builtin_bit_cast(uint32_t, d), ent.x};
+                }
+            }
+            n_ex = 0;
+        };
+        // the queued rows against the queries that hit them: the f32 row read once, coalesced; an any-order dot per query
+        auto drain_hits = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int RB = 8;  // rows in flight per round
+            for (uint32_t i0 = 0; i0 < n_hit; i0 += RB) {
+                float xr[RB][RT == 1 ? 8 : 6];
+                uint32_t erow[RB], emask[RB], egrp[RB];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const uint4 ent = hitq[i0 + j < n_hit ? i0 + j : i0];
+                    erow[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.x);
+                    emask[j] = i0 + j < n_hit ? (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.y) : 0u;
+                    egrp[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.z);
+                    if constexpr (RT == 1) {  // bf16 rows in fragment order: 48 chunks of 8 values
+                        u32x4 w = {0u, 0u, 0u, 0u};
+                        if (lane < ROW_C8) w = reinterpret_cast<const u32x4*>(rows)[frag_chunk(erow[j], lane)];
+                        xr[j][0] = bf16_lo(w.x); xr[j][1] = bf16_hi(w.x); xr[j][2] = bf16_lo(w.y); xr[j][3] = bf16_hi(w.y);
+                        xr[j][4] = bf16_lo(w.z); xr[j][5] = bf16_hi(w.z); xr[j][6] = bf16_lo(w.w); xr[j][7] = bf16_hi(w.w);
+                    } else {  // f32 rows: lane l holds elements 2l + 128 m, + 1 (three coalesced 512-B reads)
+                        const float2* xp = reinterpret_cast<const float2*>(rows) + (size_t)erow[j] * (EM / 2) + lane;
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            const float2 v2 = xp[64 * m];
+                            xr[j][2 * m] = v2.x;
+                            xr[j][2 * m + 1] = v2.y;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    uint32_t m = emask[j];
+                    while (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1u;
+                        const uint32_t s_u = 32u * egrp[j] + b;  // wave-uniform query slot
+                        float p = 0.f;
+                        if constexpr (RT == 1) {
+                            if (lane < ROW_C8) {
+                                const f32x4 qa = *reinterpret_cast<const f32x4*>(&S.q[s_u][8 * lane]);
+                                const f32x4 qb = *reinterpret_cast<const f32x4*>(&S.q[s_u][8 * lane + 4]);
+                                p = xr[j][0] * qa.x;
+                                p = __builtin_fmaf(xr[j][1], qa.y, p);
+                                p = __builtin_fmaf(xr[j][2], qa.z, p);
+                                p = __builtin_fmaf(xr[j][3], qa.w, p);
+                                p = __builtin_fmaf(xr[j][4], qb.x, p);
+                                p = __builtin_fmaf(xr[j][5], qb.y, p);
+                                p = __builtin_fmaf(xr[j][6], qb.z, p);
+                                p = __builtin_fmaf(xr[j][7], qb.w, p);
+                            }
+                        } else {
+                            const float2* qs = reinterpret_cast<const float2*>(&S.q[s_u][0]) + lane;
+                            const float2 q0 = qs[0], q1 = qs[64], q2 = qs[128];
+                            p = xr[j][0] * q0.x;
+                            p = __builtin_fmaf(xr[j][1], q0.y, p);
+                            p = __builtin_fmaf(xr[j][2], q1.x, p);
+                            p = __builtin_fmaf(xr[j][3], q1.y, p);
+                            p = __builtin_fmaf(xr[j][4], q2.x, p);
+                            p = __builtin_fmaf(xr[j][5], q2.y, p);
+                        }
+                        const float tot = read_lane63(wave_sum_lane63(p));
+                        ++n_pairs;
+                        if (tot > S.tau[s_u]) {  // (a NaN passes nothing; the exact score would drop it as well)
+                            if (lane == 0) exq[n_ex] = uint2{erow[j], s_u};
+                            if (++n_ex == 64u) flush_exact();
+                        }
+                    }
+                }
+            }
+            n_hit = 0;
+        };
+
+        if (t < n_sub) {
+            // one sub-tile held in A: 48 MFMAs, both groups' tests, the hits queued by row; then A is refilled two sub-tiles ahead
+            auto tile = [&](u32x4 (&A)[12]) __attribute__((always_inline)) {
+                const float2 pmt = meta[t];
+                const uint32_t prow = t * 32u;
+                const uint32_t t2 = t + 2u * t_stride;
+                const u32x4* pn = tile_ptr(t2 < n_sub ? t2 : t);
+                int thr[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m[g]);
+                    float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l[g], -2.0f);
+                    thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
+                    if (!tested[g]) thr_f = 2.0e9f;
+                    thr[g] = (int)floorf(thr_f);
+                }
+                i32x16_t acc[2];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0;
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {  // H chain, group 0
+                    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[0][f], acc[0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {  // H chain, group 1; in its shadow group 0's finished H sums x 254 (|acc_H| <= 384 x 127^2 < 2^23)
+                    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[2][f], acc[1], 0, 0, 0);
+                    if (f >= 3 && f < 11) {
+                        acc[0][2 * (f - 3)] = __mul24(acc[0][2 * (f - 3)], 254);
+                        acc[0][2 * (f - 3) + 1] = __mul24(acc[0][2 * (f - 3) + 1], 254);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {  // L chain, group 0, on top of 254 x H; group 1's H sums x 254
+                    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[1][f], acc[0], 0, 0, 0);
+                    if (f >= 3 && f < 11) {
+                        acc[1][2 * (f - 3)] = __mul24(acc[1][2 * (f - 3)], 254);
+                        acc[1][2 * (f - 3) + 1] = __mul24(acc[1][2 * (f - 3) + 1], 254);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                int mx0 = 0;
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {  // L chain, group 1; the fragment is free afterwards: refill it; group 0's maximum
+                    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[3][f], acc[1], 0, 0, 0);
+                    A[f] = __builtin_nontemporal_load(pn + f * 64);
+                    if (f >= 3 && f < 11) {
+                        const int m2 = max(acc[0][2 * (f - 3)], acc[0][2 * (f - 3) + 1]);
+                        mx0 = f == 3 ? m2 : max(mx0, m2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    int mx = mx0;
+                    if (g == 1) {
+                        mx = acc[1][0];
+#pragma unroll
+                        for (int e = 1; e < 16; ++e) mx = max(mx, acc[1][e]);
+                    }
+                    if (!__any(mx > thr[g])) continue;
+                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l[g], gz = pmt.y + k2_l[g];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ce = acc[g][e];
+                        if ((__ballot(ce > thr[g]) & tested_mask[g]) == 0ull) continue;
+                        const uint32_t r0 = prow + (uint32_t)((e & 3) + 8 * (e >> 2));
+                        const bool hit = tested[g] && ce > thr[g] && r0 + 4u * h < n_rows && __builtin_fmaf((float)ce, g1, gz) > tau_l[g];
+                        const unsigned long long m = __ballot(hit);
+                        const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+                        if (lo) {
+                            if (lane == 0) hitq[n_hit] = uint4{r0, lo, (uint32_t)g, 0u};
+                            ++n_hit;
+                        }
+                        if (hi) {
+                            if (lane == 0) hitq[n_hit] = uint4{r0 + 4u, hi, (uint32_t)g, 0u};
+                            ++n_hit;
+                        }
+                    }
+                }
+                if (n_hit >= (uint32_t)WQ_DRAIN_AT) drain_hits();
+                t += t_stride;
+            };
+            while (true) {
+                tile(A0);
+                if (t >= n_sub) break;
+                tile(A1);
+                if (t >= n_sub) break;
+            }
+        }
+        if (n_hit > 0u) drain_hits();
+        if (n_ex > 0u) flush_exact();
+        __syncthreads();  // the shared state is reused by the next group
+    }
+    if (stats && lane == 0 && n_pairs) atomicAdd(&stats[STAT_BOUNDED_EXACT], n_pairs);
+}
+
+// One wave per query of the batch: the pairs the wide form appended -> the k best by (distance, row).  A query that collected fewer
+// than k pairs or more than the buffer holds keeps FLAG_FALLBACK (the 16-query form behind this launch answers it); the counters
+// go back to zero either way.  The final flag is COUNTED by the launch that closes the search (bounded_count_and_mirror).
+template <int DUMMY = 0>
+__global__ __launch_bounds__(64) void bounded_wide_finish_kernel(const uint64_t* __restrict__ ids, uint32_t n_rows, int n_q,
+                                                                 uint32_t* __restrict__ flags, uint32_t k,
+                                                                 const uint2* __restrict__ res, uint32_t* __restrict__ res_cnt,
+                                                                 uint64_t* __restrict__ out_labels, float* __restrict__ out_dist,
+                                                                 uint32_t* __restrict__ out_found, uint32_t* __restrict__ stats) {
+    const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if ((int)b >= n_q) return;
+    const uint32_t cnt = res_cnt[b];
+    if (cnt == 0u) return;  // (nothing appended: not a query of the wide form, or one without a usable threshold)
+    if (lane == 0) res_cnt[b] = 0u;
+    const uint32_t found = n_rows < k ? n_rows : k;
+    if (flags[b] != FLAG_FALLBACK || cnt > BOUNDED_WIDE_CAP || cnt < found) return;
+    float ls = NEG_INF;
+    uint32_t lp = NO_POS;
+    const uint2* r = res + (size_t)b * BOUNDED_WIDE_CAP;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
+        float d = POS_INF;
+        uint32_t pr = NO_POS;
+        if (i0 + lane < cnt) {
+            const uint2 e = r[i0 + lane];
+            d = __builtin_bit_cast(float, e.x);
+            pr = e.y;
+        }
+        sort64_asc(d, pr, lane);
+        const float os = -__shfl(d, 63 - lane);
+        const uint32_t op = __shfl(pr, 63 - lane);
+        merge64(ls, lp, os, op, lane);
+    }
+    if ((uint32_t)lane < found) {
+        out_labels[(size_t)b * k + lane] = ids[lp];
+        out_dist[(size_t)b * k + lane] = -ls;
+    }
+    if (lane == 0) {
+        out_found[b] = found;
+        flags[b] = FLAG_BOUNDED;
+        if (stats) atomicAdd(&stats[STAT_BOUNDED_WIDE], 1u);  // (of the FLAG_BOUNDED answers, the ones this form gave)
+    }
+}
+
 // Per query b < B with d_flags[b] == FLAG_FALLBACK: the exact top-k through the int8 shadow, flag -> FLAG_BOUNDED; every other
 // query is left alone (one nearly empty launch when no flag is set).  cand_s / cand_p: the per-workgroup lists [B][n_lists][64]
 // (the filter's own, free by now); d_done [B]: arrival counters, zero before and after.  B <= 256 per launch.
-// fragments a wave keeps in flight ahead of its MFMAs (6: half a sub-tile, 12: a whole one); process-wide, option "bounded_ring"
-static int g_bounded_ring = 6;
-void set_bounded_ring(int pd) { g_bounded_ring = pd == 12 ? 12 : 6; }
-// waves per workgroup of the batch form (one workgroup per CU either way: its LDS); process-wide, option "bounded_multi_waves"
-static int g_bounded_multi_packed = 0;  // the batch form on the packed 5-bit shadow (process-wide; option "bounded_multi_packed")
-void set_bounded_multi_packed(int v) { g_bounded_multi_packed = v ? 1 : 0; }
-static int g_bounded_multi_waves = 8;  // (74.0 against 77.4 ms per topical batch of 256 at 100 M rows: profiles/r04/bounded_multi_waves_100M.log)
-void set_bounded_multi_waves(int nw) { g_bounded_multi_waves = nw == 8 ? 8 : 4; }
-
+// opts (per index): fragments a wave keeps in flight ahead of its MFMAs (6: half a sub-tile, 12: a whole one), waves per workgroup of
+// the 16-query batch form (8: 74.0 against 77.4 ms per topical batch of 256 at 100 M rows with 4, profiles/r04/
+// bounded_multi_waves_100M.log), that form on the packed 5-bit shadow, and the wide form in front of it (round 5).
 void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x, int dtype, const uint64_t* d_ids, uint32_t n_rows,
                          const float* d_q, int B, uint32_t* d_flags, uint32_t* d_done, float* cand_s, uint32_t* cand_p,
                          int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found, hipStream_t stream,
-                         uint32_t* d_stats, uint32_t* stats_mirror, const void* d_i5, const void* d_i5meta) {
+                         uint32_t* d_stats, uint32_t* stats_mirror, const BoundedOpts& opts, const void* d_i5, const void* d_i5meta) {
     static OncePerDevice attr_once;
     once_per_device(attr_once, [] {
 #define DAWN_BM_ATTR(RT_, PD_, NW_)                                                                      \
@@ -901,6 +1270,10 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<8>));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_multi_kernel<1, 8, 8, 5>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedMultiLds<8>));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_wide_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedWideLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bounded_i8_wide_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BoundedWideLds));
     });
     const u32x4* x8 = reinterpret_cast<const u32x4*>(d_i8);
     const float2* mt = reinterpret_cast<const float2*>(d_i8meta);
@@ -910,7 +1283,7 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
     x8, mt, d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0, cand_s + (size_t)b0 * n_lists * LIST,       \
         cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0,   \
         d_stats, stats_mirror
-        const bool deep = g_bounded_ring == 12;
+        const bool deep = opts.ring == 12;
         if (B == 1 && d_i5 && d_i5meta) {  // one query, an index with a packed shadow: 240 B per row
 #define DAWN_BOUNDED_ARGS5                                                                                                     \
     d_i5, reinterpret_cast<const float2*>(d_i5meta), d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0,   \
@@ -929,12 +1302,24 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                 if (deep) hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 12>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
                 else hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
             }
-        } else {       // a batch: its flagged queries, sixteen per stream of the shadow
+        } else {       // a batch: its flagged queries, sixty-four per stream of the int8 shadow (wide form), then sixteen per stream
+            if (opts.wide && opts.wide_res && opts.wide_cnt && k <= (uint32_t)LIST) {
+                static_assert(sizeof(BoundedWideLds) <= 160 * 1024, "one workgroup per CU: all of its LDS");
+                const float* qb = d_q + (size_t)b0 * EM;
+                if (dtype == ROW_BF16)
+                    hipLaunchKernelGGL((scan_bounded_i8_wide_kernel<1>), dim3(n_lists), dim3(256), sizeof(BoundedWideLds), stream, x8, mt, d_x,
+                                       n_rows, qb, nb, d_flags + b0, k, d_dist + (size_t)b0 * k, opts.wide_res, opts.wide_cnt, d_stats);
+                else
+                    hipLaunchKernelGGL((scan_bounded_i8_wide_kernel<0>), dim3(n_lists), dim3(256), sizeof(BoundedWideLds), stream, x8, mt, d_x,
+                                       n_rows, qb, nb, d_flags + b0, k, d_dist + (size_t)b0 * k, opts.wide_res, opts.wide_cnt, d_stats);
+                hipLaunchKernelGGL((bounded_wide_finish_kernel<0>), dim3(nb), dim3(64), 0, stream, d_ids, n_rows, nb, d_flags + b0, k,
+                                   opts.wide_res, opts.wide_cnt, d_labels + (size_t)b0 * k, d_dist + (size_t)b0 * k, d_found + b0, d_stats);
+            }
 #define DAWN_BM_LAUNCH(RT_, PD_, NW_)                                                                                                  \
     hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<RT_, PD_, NW_>), dim3(n_lists), dim3(64 * NW_), sizeof(BoundedMultiLds<NW_>), stream, \
                        DAWN_BOUNDED_ARGS)
             const int rt = dtype == ROW_BF16 ? 1 : 0;
-            if (d_i5 && d_i5meta && g_bounded_multi_packed) {  // the packed 5-bit shadow (eight waves)
+            if (d_i5 && d_i5meta && opts.multi_packed) {  // the packed 5-bit shadow (eight waves)
 #define DAWN_BOUNDED_ARGS5M                                                                                                    \
     d_i5, reinterpret_cast<const float2*>(d_i5meta), d_x, d_ids, n_rows, d_q + (size_t)b0 * EM, nb, d_flags + b0, d_done + b0,   \
         cand_s + (size_t)b0 * n_lists * LIST, cand_p + (size_t)b0 * n_lists * LIST, (uint32_t)n_lists, k, d_labels + (size_t)b0 * k, \
@@ -946,7 +1331,7 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                     hipLaunchKernelGGL((scan_bounded_i8_multi_kernel<0, 8, 8, 5>), dim3(n_lists), dim3(512), sizeof(BoundedMultiLds<8>), stream,
                                        DAWN_BOUNDED_ARGS5M);
 #undef DAWN_BOUNDED_ARGS5M
-            } else if (g_bounded_multi_waves == 8) {
+            } else if (opts.multi_waves == 8) {
                 if (rt) DAWN_BM_LAUNCH(1, 6, 8); else DAWN_BM_LAUNCH(0, 6, 8);
             } else if (deep) {
                 if (rt) DAWN_BM_LAUNCH(1, 12, 4); else DAWN_BM_LAUNCH(0, 12, 4);
@@ -973,12 +1358,12 @@ void launch_scan_bounded_direct(const void* d_i8, const void* d_i8meta, const vo
                                 uint32_t n_rows, const float* d_q, uint32_t* d_flags, uint32_t* d_done, float* cand_s,
                                 uint32_t* cand_p, int n_lists, uint32_t k, uint64_t* d_labels, float* d_dist, uint32_t* d_found,
                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_stats, uint32_t* stats_mirror,
-                                float first_threshold, const void* d_i5, const void* d_i5meta, bool seeded) {
+                                const BoundedOpts& opts, float first_threshold, const void* d_i5, const void* d_i5meta, bool seeded) {
     const uint32_t found = n_rows < k ? n_rows : k;
     hipLaunchKernelGGL(bounded_prime_kernel, dim3(1), dim3(64), 0, stream, d_flags, d_dist, found, first_threshold, seeded ? 1 : 0);
     if (ev0) (void)hipEventRecord(ev0, stream);
     launch_scan_bounded(d_i8, d_i8meta, d_x, dtype, d_ids, n_rows, d_q, 1, d_flags, d_done, cand_s, cand_p, n_lists, k, d_labels,
-                        d_dist, d_found, stream, d_stats, stats_mirror, d_i5, d_i5meta);
+                        d_dist, d_found, stream, d_stats, stats_mirror, opts, d_i5, d_i5meta);
     if (ev1) (void)hipEventRecord(ev1, stream);
 }
 

@@ -41,7 +41,7 @@ int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint6
                                     uint64_t *rerun_answers);
 /* The device-side counters of the index as they are: out8[8], indexed by a query's final flag (1 exact pass over all rows, 2 second
  * chance, 3 deeper round, 4 bounded exact pass, 6 second matrix-core pass); [5] single queries whose packed-stream certificate failed;
- * [7] (row, query) pairs the bounded pass scored exactly (mod 2^32).  A sharded handle reports the sums over its shards. */
+ * [7] (row, query) pairs of the bounded pass that got past its int8 bound (mod 2^32); [0] queries the wide batch form of that pass answered.  A sharded handle reports the sums over its shards. */
 int dawn_index_debug_raw_stats(dawn_index *idx, uint64_t *out8);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
@@ -109,12 +109,16 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      gives, before the bounded pass takes what is left: 0 never (default), 1 on indexes whose batch feedback has
  *                      deepened the thresholds, 2 every batch.  100 M topical rows: settles 18-30 % of a batch at the default depth
  *                      (74 -> 69 ms), 4-19 % at the deepened one, where it no longer pays for its 12 ms (63 -> 71 ms)
- *   "bounded_multi_waves"  process-wide: waves per workgroup of the bounded pass of batches, 8 (default) or 4 (one workgroup per CU
+ *   "bounded_wide"     1 (default): the flagged queries of a BATCH go through the wide form of the bounded pass first — 64 queries per
+ *                      stream of the int8 shadow, no lists: pairs past the int8 bound are re-tested on the f32 row, the few that can still
+ *                      matter are scored in the reference's order and appended, a finish kernel sorts them; a query whose buffer
+ *                      (2048 results) overflows is answered by the 16-query form behind it; 0: the 16-query form only (A/B, tests)
+ *   "bounded_multi_waves"  waves per workgroup of the 16-query batch form of the bounded pass, 8 (default) or 4 (one workgroup per CU
  *                      either way; 74.0 against 77.4 ms per topical batch of 256 at 100 M rows)
- *   "bounded_multi_packed" process-wide: 1: the bounded pass of BATCHES streams the packed 5-bit shadow too.  Slower (100 M topical
+ *   "bounded_multi_packed" 1: the 16-query batch form streams the packed 5-bit shadow too.  Slower (100 M topical
  *                      rows: 80.9 against 73.9 ms per batch of 256: sixteen queries per stream turn the looser bound into several
  *                      times the hits to queue and score); default 0
- *   "bounded_ring"     process-wide: 16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
+ *   "bounded_ring"     16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
  *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
  *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows
  *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
