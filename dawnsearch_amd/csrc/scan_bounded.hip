@@ -878,8 +878,8 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
 // The WIDE batch form (round 5): SIXTY-FOUR flagged queries per stream of the int8 shadow.  The 16-query form above is one HBM stream
 // per sixteen queries with the matrix pipe nearly idle: a topical batch that leaves 100-135 certificates open paid 7-9 streams
 // (profiles/r04: 348 GB read per batch = 9.07 x the shadow).  Here the H and L images of 32 queries each fill the 32 columns of
-// their own MFMAs — four MFMAs per k-step, 48 per 32-row sub-tile, C = 254 acc_H + acc_L formed by CHAINING (the L chain starts
-// from 254 x the finished H accumulator) — with all 192 query fragments resident in registers (one wave per SIMD, 512 registers),
+// their own MFMAs — four MFMAs per k-step, 48 per 32-row sub-tile, C = 254 acc_H + acc_L —
+// with all 192 query fragments resident in registers (one wave per SIMD, 512 registers),
 // and nothing per query lives in LDS but its f32 copy:
 //   * no lists.  A pair (row, query) whose int8 bound passes the query's threshold tau = (1 - D) - 1e-4 (D = the failed stage's
 //     k-th exact distance; fixed for the pass) is queued BY ROW — (row, 32-query mask) — and re-tested on the f32 row itself: one
@@ -890,25 +890,29 @@ __global__ __launch_bounds__(64 * NW) void scan_bounded_i8_multi_kernel(const vo
 //   * a query that overflows its buffer, or whose D is unusable, keeps its flag: the 16-query form, launched behind this one,
 //     answers it with its lists (and closes the search: counters, mirror).
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBoundedWideMinRows = 4096;  // smaller indexes: the 16-query form (launch_scan_bounded)
 constexpr int WQ = 64;            // queries per stream
 constexpr int WQ_QSTRIDE = 388;   // floats per staged query (lanes reading different queries hit different banks)
-constexpr int WQ_HITCAP = 320;    // (row, mask, group) entries per wave: drained from 256 on, a sub-tile adds at most 64
+constexpr int WQ_HITCAP = 128;    // (row, mask, group) entries per wave: drained from WQ_DRAIN_AT on, a sub-tile adds at most 64
 constexpr int WQ_DRAIN_AT = 24;   // entries that make a drain worth its row reads (8 rows in flight per round)
+constexpr int WQ_EXCAP = 1024;    // pairs per wave and group that may await their reference-order score (scored when the stream is through)
 struct BoundedWideLds {
     float q[WQ][WQ_QSTRIDE];
     union {
         signed char img[2][WQ][EM];  // set-up only: the int8 images the waves load their fragments from
         struct {
             uint4 hit[4][WQ_HITCAP];  // {row, query mask, group, -}
-            uint2 ex[4][64];          // {row, query slot}: pairs awaiting their reference-order score
+            uint2 ex[4][WQ_EXCAP];    // {row, query slot}: pairs awaiting their reference-order score
         } w;
     } u;
     float sq[WQ];
     float d_in[WQ];
     float tau[WQ];
+    uint32_t lost[WQ];  // != 0: a wave ran out of room for this query's pairs — the query keeps its flag
     uint32_t flagged[kBoundedMaxFlags];
     unsigned long long mask[kBoundedMaxFlags / 64];
 };
+static_assert(sizeof(BoundedWideLds) <= 160 * 1024, "one workgroup per CU: all of its LDS");
 
 template <int RT>
 __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* __restrict__ x, const float2* __restrict__ meta,
@@ -944,17 +948,23 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
     for (uint32_t g0 = 0; g0 < n_flagged; g0 += WQ) {
         const uint32_t ng = n_flagged - g0 < (uint32_t)WQ ? n_flagged - g0 : (uint32_t)WQ;
         uint32_t t = blockIdx.x * 4u + wave;
-        auto tile_ptr = [&](uint32_t tt) __attribute__((always_inline)) { return x + (size_t)(tt < n_sub ? tt : 0u) * (12 * 64) + lane; };
         // two sub-tiles of fragments in flight per wave (24 KiB): the pass is 48 MFMAs per sub-tile, a whole one ahead hides HBM
+        // The fragments are loaded by inline asm under hand-counted vmcnt: the wave keeps two sub-tiles (2 x 12 fragments) in flight, and
+        // vmcnt retires loads in order.  hipcc's own waits came out as vmcnt(0) at the head of every sub-tile (registers shared with the
+        // drain path joined as "pending" at the loop header): 7.0 ms per stream of 100 M rows, the MFMAs idle half the time.
+        // Step f of a sub-tile needs its fragment f: the 11 - f behind it and the other sub-tile's 12 may stay out.  The fragments live
+        // in AGPRs that nothing but these loads and the MFMAs touch (tests/test_abi_cpu.py checks the ISA: a register copy between
+        // a load and its wait would read stale data).  The sub-tile's {scale, error bound} is a SCALAR load (its address is
+        // wave-uniform): lgkmcnt, not vmcnt.
         u32x4 A0[12], A1[12];
-        {
-            const u32x4* p0 = tile_ptr(t);
-            const u32x4* p1 = tile_ptr(t + t_stride);
+        auto load_tile = [&](u32x4 (&A)[12], uint32_t tt) __attribute__((always_inline)) {
+            const u32x4* pb = x + (size_t)(tt < n_sub ? tt : 0u) * (12 * 64) + lane;
 #pragma unroll
-            for (int f = 0; f < 12; ++f) A0[f] = __builtin_nontemporal_load(p0 + f * 64);
-#pragma unroll
-            for (int f = 0; f < 12; ++f) A1[f] = __builtin_nontemporal_load(p1 + f * 64);
-        }
+            for (int f = 0; f < 12; ++f)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=a"(A[f]) : "v"(pb + (f & ~3) * 64), "n"((f & 3) * 1024));
+        };
+        load_tile(A0, t);
+        load_tile(A1, t + t_stride);
         // the group's queries: f32 copies, thresholds, int8 images (a wave per query)
         for (uint32_t i = threadIdx.x; i < (uint32_t)WQ * EM; i += blockDim.x) {
             const uint32_t sidx = i / EM, e = i % EM;
@@ -969,6 +979,7 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
             const bool ok = sidx < ng && d == d && d < 2.5f;
             S.d_in[sidx] = ok ? d : NEG_INF;
             S.tau[sidx] = ok ? __fsub_rn(__fsub_rn(1.0f, d), BOUNDED_MARGIN) : POS_INF;
+            S.lost[sidx] = 0u;
         }
         for (uint32_t sidx = wave; sidx < (uint32_t)WQ; sidx += 4u) {
             float v[6];
@@ -1002,36 +1013,37 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
             for (int f = 0; f < 12; ++f) qf[gi][f] = img[2 * f + h];
         }
         bool tested[2];
-        float sq254_l[2], rsq254_l[2], k2_l[2], tau_l[2], tau_m[2];
+        float rsq254_l[2], k2_l[2], tau_l[2], tau_m[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const uint32_t slot = 32u * g + c;
             const float sq_l = S.sq[slot];
             tau_l[g] = S.tau[slot];
             tested[g] = slot < ng && tau_l[g] < POS_INF;
-            sq254_l[g] = sq_l / 254.0f;
             rsq254_l[g] = 254.0f / sq_l;
             k2_l[g] = I8_K2_PER_SQ * sq_l;
             const float tk = tau_l[g] - k2_l[g];
             tau_m[g] = tested[g] ? tk - fabsf(tk) * 1e-6f : POS_INF;
         }
-        const unsigned long long tested_mask[2] = {__ballot(tested[0]), __ballot(tested[1])};
         __syncthreads();  // the images are in registers: their LDS becomes the waves' queues
         uint4* hitq = &S.u.w.hit[wave][0];
         uint2* exq = &S.u.w.ex[wave][0];
         uint32_t n_hit = 0, n_ex = 0;  // wave-uniform
 
-        // pairs that passed both bounds: reference-order scores, a lane per pair; what lies at distance <= D is appended
+        // pairs that passed both bounds: reference-order scores, a lane per pair; what lies at distance <= D is appended.  Runs when the
+        // stream is through (hipcc-visible loads inside the stream loop would bring back its vmcnt(0) waits: see the fragment loads)
         auto flush_exact = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if ((uint32_t)lane < n_ex) {
-                const uint2 ent = exq[lane];
-                const float dot = exact_dot_row<RT>(&S.q[ent.y][0], rows, ent.x);
-                const float d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
-                if (d == d && d <= S.d_in[ent.y]) {
-                    const uint32_t b = S.flagged[g0 + ent.y];
-                    const uint32_t pos = atomicAdd(&res_cnt[b], 1u);
-                    if (pos < BOUNDED_WIDE_CAP) res[(size_t)b * BOUNDED_WIDE_CAP + pos] = uint2{__builtin_bit_cast(uint32_t, d), ent.x};
+            for (uint32_t i0 = 0; i0 < n_ex; i0 += 64u) {
+                if (i0 + (uint32_t)lane < n_ex) {
+                    const uint2 ent = exq[i0 + lane];
+                    const float dot = exact_dot_row<RT>(&S.q[ent.y][0], rows, ent.x);
+                    const float d = __fsub_rn(1.0f, dot);  // vector.rs:133  1.0 - result
+                    if (d == d && d <= S.d_in[ent.y]) {
+                        const uint32_t b = S.flagged[g0 + ent.y];
+                        const uint32_t pos = atomicAdd(&res_cnt[b], 1u);
+                        if (pos < BOUNDED_WIDE_CAP) res[(size_t)b * BOUNDED_WIDE_CAP + pos] = uint2{__builtin_bit_cast(uint32_t, d), ent.x};
+                    }
                 }
             }
             n_ex = 0;
@@ -1039,9 +1051,11 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
         // the queued rows against the queries that hit them: the f32 row read once, coalesced; an any-order dot per query
         auto drain_hits = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int RB = 8;  // rows in flight per round
+            constexpr int RB = RT == 1 ? 8 : 6;  // rows in flight per round
             for (uint32_t i0 = 0; i0 < n_hit; i0 += RB) {
-                float xr[RB][RT == 1 ? 8 : 6];
+                float xr[RT == 1 ? 8 : 6];
+                [[maybe_unused]] float2 x2[RB][3];
+                [[maybe_unused]] u32x4 xw[RB];
                 uint32_t erow[RB], emask[RB], egrp[RB];
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
@@ -1049,23 +1063,47 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
                     erow[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.x);
                     emask[j] = i0 + j < n_hit ? (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.y) : 0u;
                     egrp[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.z);
-                    if constexpr (RT == 1) {  // bf16 rows in fragment order: 48 chunks of 8 values
-                        u32x4 w = {0u, 0u, 0u, 0u};
-                        if (lane < ROW_C8) w = reinterpret_cast<const u32x4*>(rows)[frag_chunk(erow[j], lane)];
-                        xr[j][0] = bf16_lo(w.x); xr[j][1] = bf16_hi(w.x); xr[j][2] = bf16_lo(w.y); xr[j][3] = bf16_hi(w.y);
-                        xr[j][4] = bf16_lo(w.z); xr[j][5] = bf16_hi(w.z); xr[j][6] = bf16_lo(w.w); xr[j][7] = bf16_hi(w.w);
-                    } else {  // f32 rows: lane l holds elements 2l + 128 m, + 1 (three coalesced 512-B reads)
-                        const float2* xp = reinterpret_cast<const float2*>(rows) + (size_t)erow[j] * (EM / 2) + lane;
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) {
-                            const float2 v2 = xp[64 * m];
-                            xr[j][2 * m] = v2.x;
-                            xr[j][2 * m + 1] = v2.y;
-                        }
-                    }
+                }
+                // The round's row reads and their wait are ONE asm statement: hipcc must not see a loaded register before its data is there
+                // (hand-counted vmcnt as for the fragments; a copy it inserted between a load and the wait would read stale data).
+                if constexpr (RT == 1) {  // bf16 rows in fragment order: 48 chunks of 8 values (lanes >= 48 re-read chunk 47)
+                    const u32x4* xb = reinterpret_cast<const u32x4*>(rows);
+                    const int cl = lane < ROW_C8 ? lane : ROW_C8 - 1;
+                    const u32x4 *p0 = xb + frag_chunk(erow[0], cl), *p1 = xb + frag_chunk(erow[1], cl), *p2 = xb + frag_chunk(erow[2], cl),
+                                *p3 = xb + frag_chunk(erow[3], cl), *p4 = xb + frag_chunk(erow[4], cl), *p5 = xb + frag_chunk(erow[5], cl),
+                                *p6 = xb + frag_chunk(erow[6], cl), *p7 = xb + frag_chunk(erow[7], cl);
+                    asm volatile(
+                        "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %9, off\n\tglobal_load_dwordx4 %2, %10, off\n\t"
+                        "global_load_dwordx4 %3, %11, off\n\tglobal_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %13, off\n\t"
+                        "global_load_dwordx4 %6, %14, off\n\tglobal_load_dwordx4 %7, %15, off\n\ts_waitcnt vmcnt(0)"
+                        : "=&v"(xw[0]), "=&v"(xw[1]), "=&v"(xw[2]), "=&v"(xw[3]), "=&v"(xw[4]), "=&v"(xw[5]), "=&v"(xw[6]), "=&v"(xw[7])
+                        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+                } else {  // f32 rows: lane l holds elements 2l + 128 m, + 1 (three coalesced 512-B reads per row)
+                    const float2* xb = reinterpret_cast<const float2*>(rows) + lane;
+                    const float2 *p0 = xb + (size_t)erow[0] * (EM / 2), *p1 = xb + (size_t)erow[1] * (EM / 2), *p2 = xb + (size_t)erow[2] * (EM / 2),
+                                 *p3 = xb + (size_t)erow[3] * (EM / 2), *p4 = xb + (size_t)erow[4] * (EM / 2), *p5 = xb + (size_t)erow[5] * (EM / 2);
+                    asm volatile(
+                        "global_load_dwordx2 %0, %18, off\n\tglobal_load_dwordx2 %1, %18, off offset:512\n\tglobal_load_dwordx2 %2, %18, off offset:1024\n\t"
+                        "global_load_dwordx2 %3, %19, off\n\tglobal_load_dwordx2 %4, %19, off offset:512\n\tglobal_load_dwordx2 %5, %19, off offset:1024\n\t"
+                        "global_load_dwordx2 %6, %20, off\n\tglobal_load_dwordx2 %7, %20, off offset:512\n\tglobal_load_dwordx2 %8, %20, off offset:1024\n\t"
+                        "global_load_dwordx2 %9, %21, off\n\tglobal_load_dwordx2 %10, %21, off offset:512\n\tglobal_load_dwordx2 %11, %21, off offset:1024\n\t"
+                        "global_load_dwordx2 %12, %22, off\n\tglobal_load_dwordx2 %13, %22, off offset:512\n\tglobal_load_dwordx2 %14, %22, off offset:1024\n\t"
+                        "global_load_dwordx2 %15, %23, off\n\tglobal_load_dwordx2 %16, %23, off offset:512\n\tglobal_load_dwordx2 %17, %23, off offset:1024\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(x2[0][0]), "=&v"(x2[0][1]), "=&v"(x2[0][2]), "=&v"(x2[1][0]), "=&v"(x2[1][1]), "=&v"(x2[1][2]), "=&v"(x2[2][0]),
+                          "=&v"(x2[2][1]), "=&v"(x2[2][2]), "=&v"(x2[3][0]), "=&v"(x2[3][1]), "=&v"(x2[3][2]), "=&v"(x2[4][0]), "=&v"(x2[4][1]),
+                          "=&v"(x2[4][2]), "=&v"(x2[5][0]), "=&v"(x2[5][1]), "=&v"(x2[5][2])
+                        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5));
                 }
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
+                    if constexpr (RT == 1) {
+                        const u32x4 w = xw[j];
+                        xr[0] = bf16_lo(w.x); xr[1] = bf16_hi(w.x); xr[2] = bf16_lo(w.y); xr[3] = bf16_hi(w.y);
+                        xr[4] = bf16_lo(w.z); xr[5] = bf16_hi(w.z); xr[6] = bf16_lo(w.w); xr[7] = bf16_hi(w.w);
+                    } else {
+                        xr[0] = x2[j][0].x; xr[1] = x2[j][0].y; xr[2] = x2[j][1].x; xr[3] = x2[j][1].y; xr[4] = x2[j][2].x; xr[5] = x2[j][2].y;
+                    }
                     uint32_t m = emask[j];
                     while (m) {
                         const uint32_t b = (uint32_t)__builtin_ctz(m);
@@ -1076,30 +1114,34 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
                             if (lane < ROW_C8) {
                                 const f32x4 qa = *reinterpret_cast<const f32x4*>(&S.q[s_u][8 * lane]);
                                 const f32x4 qb = *reinterpret_cast<const f32x4*>(&S.q[s_u][8 * lane + 4]);
-                                p = xr[j][0] * qa.x;
-                                p = __builtin_fmaf(xr[j][1], qa.y, p);
-                                p = __builtin_fmaf(xr[j][2], qa.z, p);
-                                p = __builtin_fmaf(xr[j][3], qa.w, p);
-                                p = __builtin_fmaf(xr[j][4], qb.x, p);
-                                p = __builtin_fmaf(xr[j][5], qb.y, p);
-                                p = __builtin_fmaf(xr[j][6], qb.z, p);
-                                p = __builtin_fmaf(xr[j][7], qb.w, p);
+                                p = xr[0] * qa.x;
+                                p = __builtin_fmaf(xr[1], qa.y, p);
+                                p = __builtin_fmaf(xr[2], qa.z, p);
+                                p = __builtin_fmaf(xr[3], qa.w, p);
+                                p = __builtin_fmaf(xr[4], qb.x, p);
+                                p = __builtin_fmaf(xr[5], qb.y, p);
+                                p = __builtin_fmaf(xr[6], qb.z, p);
+                                p = __builtin_fmaf(xr[7], qb.w, p);
                             }
                         } else {
                             const float2* qs = reinterpret_cast<const float2*>(&S.q[s_u][0]) + lane;
                             const float2 q0 = qs[0], q1 = qs[64], q2 = qs[128];
-                            p = xr[j][0] * q0.x;
-                            p = __builtin_fmaf(xr[j][1], q0.y, p);
-                            p = __builtin_fmaf(xr[j][2], q1.x, p);
-                            p = __builtin_fmaf(xr[j][3], q1.y, p);
-                            p = __builtin_fmaf(xr[j][4], q2.x, p);
-                            p = __builtin_fmaf(xr[j][5], q2.y, p);
+                            p = xr[0] * q0.x;
+                            p = __builtin_fmaf(xr[1], q0.y, p);
+                            p = __builtin_fmaf(xr[2], q1.x, p);
+                            p = __builtin_fmaf(xr[3], q1.y, p);
+                            p = __builtin_fmaf(xr[4], q2.x, p);
+                            p = __builtin_fmaf(xr[5], q2.y, p);
                         }
                         const float tot = read_lane63(wave_sum_lane63(p));
                         ++n_pairs;
                         if (tot > S.tau[s_u]) {  // (a NaN passes nothing; the exact score would drop it as well)
-                            if (lane == 0) exq[n_ex] = uint2{erow[j], s_u};
-                            if (++n_ex == 64u) flush_exact();
+                            if (n_ex < (uint32_t)WQ_EXCAP) {
+                                if (lane == 0) exq[n_ex] = uint2{erow[j], s_u};
+                                ++n_ex;
+                            } else if (lane == 0) {
+                                S.lost[s_u] = 1u;  // no room: the query is left to the 16-query form
+                            }
                         }
                     }
                 }
@@ -1108,86 +1150,103 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
         };
 
         if (t < n_sub) {
-            // one sub-tile held in A: 48 MFMAs, both groups' tests, the hits queued by row; then A is refilled two sub-tiles ahead
+            // The hits of one group of a sub-tile: `bits` = this lane's 16 accumulator elements (rows (e & 3) + 8 (e >> 2) + 4 h of the
+            // sub-tile, column = the lane's query) over the integer threshold.  Queued BY ROW: one ballot per element any lane has set.
+            auto emit = [&](int g, uint32_t bits, uint32_t prow) __attribute__((always_inline)) {
+                if (prow + 32u > n_rows) {  // the last sub-tile: rows past the end never hit
+                    uint32_t vm = 0u;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (prow + (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h < n_rows) vm |= 1u << e;
+                    bits &= vm;
+                }
+                if (!tested[g]) bits = 0u;
+                if (!__any(bits != 0u)) return;
+                uint32_t u = bits;  // OR over the wave (DPP; the total lands in lane 63)
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true);
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, true);
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xf, 0xf, true);
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true);
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x142, 0xa, 0xf, false);
+                u |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x143, 0xc, 0xf, false);
+                uint32_t U = (uint32_t)__builtin_amdgcn_readlane((int)u, 63);
+                while (U) {
+                    const uint32_t e = (uint32_t)__builtin_ctz(U);
+                    U &= U - 1u;
+                    const unsigned long long m = __ballot(((bits >> e) & 1u) != 0u);
+                    const uint32_t r0 = prow + (e & 3u) + 8u * (e >> 2);
+                    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+                    if (lo) {
+                        if (lane == 0) hitq[n_hit] = uint4{r0, lo, (uint32_t)g, 0u};
+                        ++n_hit;
+                    }
+                    if (hi) {
+                        if (lane == 0) hitq[n_hit] = uint4{r0 + 4u, hi, (uint32_t)g, 0u};
+                        ++n_hit;
+                    }
+                }
+            };
+            // C = 254 acc_H + acc_L (|acc_H| <= 384 x 127^2 < 2^23) of elements e, e + 1 against the integer threshold.  The test is the
+            // conservative one of the streaming filters (thr sits 2 units below the bound's own crossing); what it lets through is
+            // re-tested on the f32 row anyway
+            auto post2 = [&](const i32x16_t& ahh, const i32x16_t& all_, int thr, uint32_t& bits, int e) __attribute__((always_inline)) {
+                const int c0 = __mul24(ahh[e], 254) + all_[e];
+                const int c1 = __mul24(ahh[e + 1], 254) + all_[e + 1];
+                bits |= (c0 > thr ? 1u : 0u) << e;
+                bits |= (c1 > thr ? 1u : 0u) << (e + 1);
+            };
+            auto thr_of = [&](int g, const float2 pmt) __attribute__((always_inline)) {
+                const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m[g]);
+                float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l[g], -2.0f);
+                thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
+                if (!tested[g]) thr_f = 2.0e9f;
+                return (int)floorf(thr_f);
+            };
+            // One sub-tile held in A, in two phases of 24 MFMAs: group 0 (H0 | L0 chains) with the PREVIOUS sub-tile's group-1 sums tested
+            // in its shadow, then group 1 (H1 | L1) with this sub-tile's group-0 sums tested in its shadow; a fragment is free after its
+            // group-1 MFMAs and refilled at once, two sub-tiles ahead.  (One wave per SIMD: what is not interleaved with the MFMAs is
+            // paid in full — a version that tested after all 48 MFMAs, one scalar branch per accumulator element, took 8.3 ms per
+            // stream of 100 M rows against the 5.6 ms the stream itself needs.)
+            i32x16_t ah[2], al[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ah[1][e] = al[1][e] = 0;
+            int prev_thr1 = 0x7fffffff;
+            uint32_t prev_prow = 0;
             auto tile = [&](u32x4 (&A)[12]) __attribute__((always_inline)) {
-                const float2 pmt = meta[t];
+                const float2 pmt = meta[t];  // (wave-uniform address: s_load_dwordx2)
                 const uint32_t prow = t * 32u;
                 const uint32_t t2 = t + 2u * t_stride;
-                const u32x4* pn = tile_ptr(t2 < n_sub ? t2 : t);
-                int thr[2];
+                const uint32_t tn = t2 < n_sub ? t2 : t;
+                const u32x4* pn = x + (size_t)tn * (12 * 64) + lane;
+                const int thr0 = thr_of(0, pmt), thr1 = thr_of(1, pmt);
+                uint32_t bits1p = 0u, bits0 = 0u;
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float u = __builtin_fmaf(-pmt.y, 1.000001f, tau_m[g]);
-                    float thr_f = __builtin_fmaf(u, pmt.x * rsq254_l[g], -2.0f);
-                    thr_f = fminf(fmaxf(thr_f, -2.0e9f), 2.0e9f);
-                    if (!tested[g]) thr_f = 2.0e9f;
-                    thr[g] = (int)floorf(thr_f);
-                }
-                i32x16_t acc[2];
+                for (int e = 0; e < 16; ++e) ah[0][e] = al[0][e] = 0;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0;
-#pragma unroll
-                for (int f = 0; f < 12; ++f) {  // H chain, group 0
-                    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[0][f], acc[0], 0, 0, 0);
+                for (int f = 0; f < 12; ++f) {
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+a"(A[f]) : "n"(23 - f));
+                    const i32x4_t af = __builtin_bit_cast(i32x4_t, A[f]);
+                    ah[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, qf[0][f], ah[0], 0, 0, 0);
+                    al[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, qf[1][f], al[0], 0, 0, 0);
+                    if (f >= 2 && f < 10) post2(ah[1], al[1], prev_thr1, bits1p, 2 * (f - 2));
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                emit(1, bits1p, prev_prow);
 #pragma unroll
-                for (int f = 0; f < 12; ++f) {  // H chain, group 1; in its shadow group 0's finished H sums x 254 (|acc_H| <= 384 x 127^2 < 2^23)
-                    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[2][f], acc[1], 0, 0, 0);
-                    if (f >= 3 && f < 11) {
-                        acc[0][2 * (f - 3)] = __mul24(acc[0][2 * (f - 3)], 254);
-                        acc[0][2 * (f - 3) + 1] = __mul24(acc[0][2 * (f - 3) + 1], 254);
-                    }
+                for (int e = 0; e < 16; ++e) ah[1][e] = al[1][e] = 0;
+#pragma unroll
+                for (int f = 0; f < 12; ++f) {
+                    const i32x4_t af = __builtin_bit_cast(i32x4_t, A[f]);
+                    ah[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, qf[2][f], ah[1], 0, 0, 0);
+                    al[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, qf[3][f], al[1], 0, 0, 0);
+                    // (the MFMAs above have read A[f] by the time the data of this load can arrive)
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=a"(A[f]) : "v"(pn + (f & ~3) * 64), "n"((f & 3) * 1024));
+                    if (f >= 2 && f < 10) post2(ah[0], al[0], thr0, bits0, 2 * (f - 2));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int f = 0; f < 12; ++f) {  // L chain, group 0, on top of 254 x H; group 1's H sums x 254
-                    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[1][f], acc[0], 0, 0, 0);
-                    if (f >= 3 && f < 11) {
-                        acc[1][2 * (f - 3)] = __mul24(acc[1][2 * (f - 3)], 254);
-                        acc[1][2 * (f - 3) + 1] = __mul24(acc[1][2 * (f - 3) + 1], 254);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                int mx0 = 0;
-#pragma unroll
-                for (int f = 0; f < 12; ++f) {  // L chain, group 1; the fragment is free afterwards: refill it; group 0's maximum
-                    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, A[f]), qf[3][f], acc[1], 0, 0, 0);
-                    A[f] = __builtin_nontemporal_load(pn + f * 64);
-                    if (f >= 3 && f < 11) {
-                        const int m2 = max(acc[0][2 * (f - 3)], acc[0][2 * (f - 3) + 1]);
-                        mx0 = f == 3 ? m2 : max(mx0, m2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    int mx = mx0;
-                    if (g == 1) {
-                        mx = acc[1][0];
-#pragma unroll
-                        for (int e = 1; e < 16; ++e) mx = max(mx, acc[1][e]);
-                    }
-                    if (!__any(mx > thr[g])) continue;
-                    const float g1 = __builtin_amdgcn_rcpf(pmt.x) * sq254_l[g], gz = pmt.y + k2_l[g];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int ce = acc[g][e];
-                        if ((__ballot(ce > thr[g]) & tested_mask[g]) == 0ull) continue;
-                        const uint32_t r0 = prow + (uint32_t)((e & 3) + 8 * (e >> 2));
-                        const bool hit = tested[g] && ce > thr[g] && r0 + 4u * h < n_rows && __builtin_fmaf((float)ce, g1, gz) > tau_l[g];
-                        const unsigned long long m = __ballot(hit);
-                        const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-                        if (lo) {
-                            if (lane == 0) hitq[n_hit] = uint4{r0, lo, (uint32_t)g, 0u};
-                            ++n_hit;
-                        }
-                        if (hi) {
-                            if (lane == 0) hitq[n_hit] = uint4{r0 + 4u, hi, (uint32_t)g, 0u};
-                            ++n_hit;
-                        }
-                    }
-                }
+                emit(0, bits0, prow);
+                prev_thr1 = thr1;
+                prev_prow = prow;
                 if (n_hit >= (uint32_t)WQ_DRAIN_AT) drain_hits();
                 t += t_stride;
             };
@@ -1197,9 +1256,19 @@ __global__ __launch_bounds__(256) void scan_bounded_i8_wide_kernel(const u32x4* 
                 tile(A1);
                 if (t >= n_sub) break;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the refills past the end: nothing of this group stays in flight)
+            {  // the last sub-tile's group 1
+                uint32_t bits1p = 0u;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) post2(ah[1], al[1], prev_thr1, bits1p, e);
+                emit(1, bits1p, prev_prow);
+            }
         }
         if (n_hit > 0u) drain_hits();
         if (n_ex > 0u) flush_exact();
+        __syncthreads();
+        // a query some wave ran out of room for: its count goes past the buffer's size, which makes the finish kernel leave it flagged
+        if (threadIdx.x < ng && S.lost[threadIdx.x] != 0u) atomicAdd(&res_cnt[S.flagged[g0 + threadIdx.x]], BOUNDED_WIDE_CAP + 1u);
         __syncthreads();  // the shared state is reused by the next group
     }
     if (stats && lane == 0 && n_pairs) atomicAdd(&stats[STAT_BOUNDED_EXACT], n_pairs);
@@ -1303,7 +1372,9 @@ void launch_scan_bounded(const void* d_i8, const void* d_i8meta, const void* d_x
                 else hipLaunchKernelGGL((scan_bounded_i8_kernel<0, 6>), dim3(n_lists), dim3(256), 0, stream, DAWN_BOUNDED_ARGS);
             }
         } else {       // a batch: its flagged queries, sixty-four per stream of the int8 shadow (wide form), then sixteen per stream
-            if (opts.wide && opts.wide_res && opts.wide_cnt && k <= (uint32_t)LIST) {
+            // (not on a tiny index: with k >= n every row of every query is a result — 64 queries x 32 rows of pairs per wave, more than
+            // its queue of pairs awaiting their exact score holds; nothing to win there either)
+            if (opts.wide && opts.wide_res && opts.wide_cnt && k <= (uint32_t)LIST && n_rows >= kBoundedWideMinRows) {
                 static_assert(sizeof(BoundedWideLds) <= 160 * 1024, "one workgroup per CU: all of its LDS");
                 const float* qb = d_q + (size_t)b0 * EM;
                 if (dtype == ROW_BF16)

@@ -153,6 +153,61 @@ def test_pipelined_kernels_keep_their_accumulators_out_of_agpr_spills(tmp_path):
     assert len(i16) == 2 and set(i16.values()) == {48}, i16
 
 
+def test_wide_bounded_kernel_keeps_its_hand_counted_loads_safe(tmp_path):
+    """scan_bounded_i8_wide_kernel loads its int8 fragments by inline asm under hand-counted vmcnt (two sub-tiles in flight per
+    wave; hipcc's own waits drained them at every sub-tile).  hipcc does not know those registers are in flight: a register copy or
+    any other use it placed between a load and its wait would read stale data.  Guard, on the shipped code object: the AGPRs the
+    fragment loads write are touched by nothing but those loads and the MFMAs; the stream loop holds no scratch access and no
+    vmcnt(0), and the kernel spills nothing (no private segment)."""
+    import glob
+    import shutil
+    import subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "dawnsearch_amd", "libdawn_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(lib)):
+        pytest.skip("ROCm binutils or the built library not present")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    checked = 0
+    for f in glob.glob(str(tmp_path / "lib.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
+        if "scan_bounded_i8_wide_kernel" not in notes:
+            continue
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            if "scan_bounded_i8_wide_kernel" in name:
+                assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
+                assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", f], capture_output=True, text=True, check=True).stdout
+        for fn in re.findall(r"^[0-9a-f]+ <(_ZN4dawn27scan_bounded_i8_wide_kernel\w+)>:$", dis, flags=re.M):
+            body = dis.split(f"<{fn}>:\n", 1)[1].split("\n\n", 1)[0]
+            ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+            frag = set()
+            for i in ins:
+                m = re.match(r"global_load_dwordx4 a\[(\d+):(\d+)\].* nt", i)
+                if m:
+                    frag.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            assert len(frag) == 96, (fn, sorted(frag))  # two sub-tiles of 12 fragments x 4 registers
+            mf = [n for n, i in enumerate(ins) if i.startswith("v_mfma")]
+            assert len(mf) == 96
+            for i in ins:
+                if i.startswith(("v_mfma", "s_waitcnt")) or re.match(r"global_load_dwordx4 a\[", i):
+                    continue
+                regs = set()
+                for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", i):
+                    regs.update(range(int(a), int(b) + 1))
+                regs.update(int(a) for a in re.findall(r"\ba(\d+)\b", i))
+                assert not (regs & frag), (fn, i)
+            # the first phase of each of the two unrolled sub-tiles: 24 MFMAs under the waits vmcnt(23) .. vmcnt(12), nothing else
+            for first in (mf[0], mf[48]):
+                waits = [i for i in ins[first - 8:first + 200] if "vmcnt" in i][:12]
+                assert waits == [f"s_waitcnt vmcnt({23 - f})" for f in range(12)], (fn, waits)
+            loop = ins[mf[0] - 8:mf[95] + 1]
+            assert not any("scratch_" in i for i in loop), fn
+            checked += 1
+    assert checked == 2  # f32 and bf16 rows
+
+
 def test_release_library_holds_no_experiment_kernels(tmp_path):
     """The timing-experiment variants of the pipelined kernels (DBG != 0: parts switched off, wrong results by design) and
     the stamped diagnostic kernel only exist in `make EXPERIMENTS=1` builds (libdawn_hip_exp.so); the shipped library must

@@ -40,13 +40,34 @@ def test_forced_ladder_batches_take_the_wide_form(dawn, oracle, n, B, k):
         assert found[b] == min(k, n)
         _same(lab[b][:found[b]], dist[b][:found[b]], *oracle.scan_topk(x, ids, Q[b], k))
     assert r1[4] - r0[4] == B and r1[1] == r0[1], (r0, r1)
-    assert r1[0] - r0[0] == B, (r0, r1)  # every one of them by the wide form
+    # every one of them by the wide form (an index below 4096 rows: by the 16-query form — with k >= n every row of every query is a result)
+    assert r1[0] - r0[0] == (B if n >= 4096 else 0), (r0, r1)
     # ... and the same answers with the wide form switched off (sixteen per stream)
     idx.set_option("bounded_wide", 0)
     lab2, dist2, found2 = idx.search_batch(Q, k)
     r2 = idx.stats_raw()
     assert np.array_equal(lab, lab2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32)) and np.array_equal(found, found2)
     assert r2[0] == r1[0] and r2[4] - r1[4] == B
+
+
+def test_a_wave_out_of_room_leaves_its_queries_to_the_sixteen_query_form(dawn, oracle):
+    """4200 identical rows: every query's k-th distance IS the tie, all 4200 rows pass both bounds, and a wave that holds 32 of them
+    collects 64 queries x 32 rows = 2048 pairs, more than its queue (1024): the queries it runs out of room for keep their flag
+    and the 16-query form answers them — first-inserted rows first (src/search/best_results.rs:56)."""
+    n = 4200
+    v = synth.unit_rows(7, 0, 1)[0]
+    idx = dawn.VectorIndex(0)
+    idx.add_batch(np.arange(1, n + 1, dtype=np.uint64), np.repeat(v[None, :], n, axis=0))
+    x = np.repeat(v[None, :], n, axis=0)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 64)
+    idx.set_option("force_fallback", 2)
+    r0 = idx.stats_raw()
+    lab, dist, found = idx.search_batch(Q, 10)
+    r1 = idx.stats_raw()
+    for b in range(0, 64, 5):
+        _same(lab[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10))
+    assert r1[4] - r0[4] == 64 and r1[1] == r0[1] and r1[0] - r0[0] < 64, (r0, r1)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
