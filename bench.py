@@ -99,6 +99,10 @@ def short_line(full: dict) -> dict:
         "embed_256_texts_ms": _get(ex, "e2e_1M_batch256", "embed_ms"),
         "bf16_index_batch1_ms": _get(ex, "bf16_index_batch1", "ms_per_step"),
         "fallbacks_all_legs": _get(full, "checks", "all_legs_on_this_index", "fallbacks"),
+        "topical_12p5M_batch1_ms": _get(ex, "rows_12p5M_clustered_topical", "k10_batch1", "ms_per_step"),
+        "topical_12p5M_batch256_ms": _get(ex, "rows_12p5M_clustered_topical", "k10_batch256", "ms_per_step"),
+        "predicted_speedup_8gpu_batch1": _get(ex, "predicted_scaling", "predicted_speedup", 8, "batch1"),
+        "predicted_speedup_8gpu_batch256": _get(ex, "predicted_scaling", "predicted_speedup", 8, "batch256"),
     }
     line["extra"] = {k: _r(v) for k, v in heads.items() if v is not None}
     if full.get("mfma_busy_frac"):
@@ -435,6 +439,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def settle(seconds=2.0):
+        """After anything that RELEASES tens of GB of HBM (an option that drops a shadow, an index closed): every stream on the device
+        runs ~3 % slower behind such a hipFree until the device has idled for a second or two (profiles/r05/stream_after_free_probe.log;
+        rounds 3 and 4 timed their f32-row and int8 stream legs right behind the release of the packed shadow and read it as a
+        regression of the kernels).  The library itself only releases shadows on option changes."""
+        torch.cuda.synchronize()
+        time.sleep(seconds)
+
     def scan_passes(Bq):
         """Passes over the index rows made by the dominant kernel for a batch of Bq queries."""
         if Bq >= 2:
@@ -579,18 +591,20 @@ def main():
                 pass
         return res
 
-    def realistic_leg(dist_id):
+    def realistic_leg(dist_id, rows=None, ks=(10, 20), ablations=True):
         """100 M rows of another distribution (option synth_dist), k = 10 / 20, batch 1 / 256: ms per search and which rung of
         the ladder answered.  dist 1-3: isotropic rows with realistic tails, random queries of the same distribution.  dist 4 / 5:
         the TOPICAL mixture (Zipf-sized clusters, cosine 0.5-0.95 inside a cluster; 5: runs of 256 consecutive rows per cluster) with
         queries that are further rows of the same stream — new pages on the same topics, most of them inside a large cluster:
         the data certificates fail on."""
         topical = dist_id >= 4
+        rows = args.rows if rows is None else rows
         ix = dawn.VectorIndex(local_rank)
         ix.set_option("synth_dist", dist_id)
         t0 = time.perf_counter()
-        ix.fill_synthetic(1, 0, args.rows, 1)
-        res = {"rows": args.rows, "fill_seconds": time.perf_counter() - t0}
+        ix.fill_synthetic(1, 0, rows, 1)
+        res = {"rows": rows, "fill_seconds": time.perf_counter() - t0}
+        settle()  # (the previous leg's index was closed just before)
         qi = dawn.VectorIndex(local_rank)
         qi.set_option("synth_dist", dist_id)
         if topical:
@@ -600,17 +614,17 @@ def main():
             qi.fill_synthetic(2, 0, 256, 1)
             Qh, _ = qi.get_rows(0, 256)
         qi.close()
-        Qh[0] = ix.get_rows(4242 % args.rows, 1)[0][0]  # a row of the index itself: its label must come out first
+        Qh[0] = ix.get_rows(4242 % rows, 1)[0][0]  # a row of the index itself: its label must come out first
         d_q = torch.from_numpy(Qh).to(dev)
         rates = {"second_chances": "second_chance_rate", "deepened": "deepened_rate", "fallbacks": "fallback_rate",
                  "bounded": "bounded_rate", "packed_failures": "packed_failure_rate", "demoted": "demoted_rate"}
-        for kk in (10, 20):
+        for kk in ks:
             for Bq in (1, 256):
                 nb = dawn.result_blob_bytes(Bq, kk)
                 blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
                 p = blob.data_ptr()
-                steps = (96 if topical else 16) if Bq == 1 else 4
-                warm = 2
+                steps = (96 if topical else 16) if Bq == 1 else 6
+                warm = 2 if Bq == 1 else 5  # (batches: the batch feedback deepens a ladder-heavy index's thresholds after its first window of 1024 queries)
                 per = []
                 for it in range(steps + warm):
                     if it == warm:
@@ -636,8 +650,11 @@ def main():
                                                                   float(pa.max()))
                 res[f"k{kk}_batch{Bq}"] = leg
         lab, _ = ix.search(Qh[0], 10)
-        res["planted_top1_ok"] = bool(len(lab) and lab[0] == 1 + 4242 % args.rows)
+        res["planted_top1_ok"] = bool(len(lab) and lab[0] == 1 + 4242 % rows)
         if topical:
+            r = ix.stats_raw()
+            res["wide_form_answers"], res["bounded_answers"] = r[0], r[4]
+        if topical and ablations:
             # the same single queries with the ladder's pieces switched off: what round 3 did (exact pass over all rows behind a
             # failed certificate), and the ladder without its feedback
             for name, opts in (("k10_batch1_no_feedback", {"ladder_feedback": 0}),
@@ -660,7 +677,63 @@ def main():
                              "bounded_rate": (s1["bounded"] - s0["bounded"]) / nst}
                 ix.set_option("ladder_feedback", 1)
                 ix.set_option("bounded_pass", 1)
+            # the batch of 256 with the wide form of the bounded pass switched off (round 4: sixteen flagged queries per stream)
+            ix.set_option("bounded_wide", 0)
+            nb = dawn.result_blob_bytes(256, 10)
+            blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+            p = blob.data_ptr()
+            ix.search_device(d_q.data_ptr(), 256, 10, p, p + 256 * 80, p + 256 * 120, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ix.search_device(d_q.data_ptr(), 256, 10, p, p + 256 * 80, p + 256 * 120, stream)
+            torch.cuda.synchronize()
+            res["k10_batch256_round4_sixteen_per_stream"] = {"ms_per_step": (time.perf_counter() - t0) / 3 * 1e3}
+            ix.set_option("bounded_wide", 1)
         ix.close()
+        return res
+
+    def shard_overhead(G, Bq, kk, calls=120):
+        """What the sharded handle adds to its slowest shard: p50 of one synchronised dawn_index_search_device call on G logical shards
+        of 4096 rows each (the scans are negligible: issue on G streams + gather + merge remain) minus the same on one index of 4096
+        rows.  All shards on THIS device: the copies are device-local, an xGMI hop and RCCL's launch are not in it."""
+        def p50(ix):
+            qh = synth.unit_rows(3, 0, Bq)
+            dq = torch.from_numpy(qh).to(dev)
+            blob = torch.zeros((dawn.result_blob_bytes(Bq, kk),), dtype=torch.uint8, device=dev)
+            pp = blob.data_ptr()
+            ts = []
+            for i in range(calls + 20):
+                t0 = time.perf_counter()
+                ix.search_device(dq.data_ptr(), Bq, kk, pp, pp + Bq * kk * 8, pp + Bq * kk * 12, stream)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return float(np.percentile(np.array(ts[20:]) * 1e3, 50))
+        one = dawn.VectorIndex(local_rank)
+        one.fill_synthetic(1, 0, 4096, 1)
+        sh = dawn.VectorIndex(devices=[local_rank] * G)
+        sh.set_option("shard_chunk", 1024)
+        sh.fill_synthetic(1, 0, 4096 * G, 1)
+        r = p50(sh) - p50(one)
+        sh.close()
+        one.close()
+        return r
+
+    def predicted_scaling(extra, head, kk):
+        """A prediction the first real 1 / 2 / 4 / 8-GPU run can be held against: ms per search = the measured single-GPU search of the
+        shard size (100 M / N rows) + the sharded handle's own overhead measured with logical shards."""
+        shard_ms = {1: {"batch1": head["ms_per_step"], "batch256": extra["batch256"]["ms_per_step"]},
+                    2: {"batch1": extra["rows_50M_batch1"]["ms_per_step"], "batch256": extra["rows_50M_batch256"]["ms_per_step"]},
+                    4: {"batch1": extra["rows_25M_batch1"]["ms_per_step"], "batch256": extra["rows_25M_batch256"]["ms_per_step"]},
+                    8: {"batch1": extra["rows_12p5M_batch1"]["ms_per_step"], "batch256": extra["rows_12p5M_batch256"]["ms_per_step"]}}
+        res = {"per_shard_ms": shard_ms, "overhead_ms": {}, "predicted_ms": {}, "predicted_speedup": {},
+               "what": "predicted_ms[N] = per_shard_ms[N] + overhead_ms[N]; overhead: G logical shards of 4096 rows on one device, p50 of "
+                       "a synchronised call minus a single index's (no xGMI hop, no RCCL launch in it: add ~0.02-0.05 ms on real devices)"}
+        for G in (2, 4, 8):
+            res["overhead_ms"][G] = {"batch1": shard_overhead(G, 1, kk), "batch256": shard_overhead(G, 256, kk)}
+        for G in (1, 2, 4, 8):
+            res["predicted_ms"][G] = {b: shard_ms[G][b] + (res["overhead_ms"][G][b] if G > 1 else 0.0) for b in ("batch1", "batch256")}
+            res["predicted_speedup"][G] = {b: shard_ms[1][b] / res["predicted_ms"][G][b] for b in ("batch1", "batch256")}
         return res
 
     # ---- headline leg ------------------------------------------------------------------------
@@ -751,6 +824,7 @@ def main():
         # the same batch-1 search streaming the f32 rows themselves (1536 B/row; shadow filter off): the f32-stream
         # roofline of DESIGN.md §4.1
         idx.set_option("f16_shadow_b1", 0)
+        settle()
         legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="f32")
         idx.set_option("f16_shadow_b1", 1)
         extra["batch1_streaming_f32_rows"] = legf
@@ -762,13 +836,16 @@ def main():
             idx.set_option("i6_bits", 5)
             extra["batch1_streaming_i6_shadow"] = legf
             idx.set_option("i6_shadow", 0)
+            settle()
             legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="i8")
             idx.set_option("i6_shadow", 1)
             extra["batch1_streaming_i8_shadow"] = legf
         # ... and streaming the f16 shadow (768 B/row; both integer shadows off)
         idx.set_option("i8_shadow", 0)
+        settle()
         legf, _ = run_leg(idx, 1, max(5, args.steps // 2), 2, check_planted=True, rows_read="f16")
         idx.set_option("i8_shadow", 1)
+        settle()
         extra["batch1_streaming_f16_shadow"] = legf
         # batch-256 on the same index: one pass of the matrix-core kernel serves all 256 queries
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
@@ -783,11 +860,14 @@ def main():
             legf6["f6_shadow_bytes"] = int(idx.memory()["shadows"] - sh0)  # (0: not enough free HBM — the int8 pass answered)
             legf6["vs_int8_pass"] = legf6["queries_per_s"] / leg["queries_per_s"]
             idx.set_option("f6_shadow", 0)
+            settle()
             extra["batch256_f6_first_filter"] = legf6
         # ... and on the f16 shadow (scan_f16_pipe_kernel; int8 shadow off)
         idx.set_option("i8_shadow", 0)
+        settle()
         leg, _ = run_leg(idx, 256, max(3, b256_steps // 2), 1, seed=3, rows_read="f16")
         idx.set_option("i8_shadow", 1)
+        settle()
         extra["batch256_f16_shadow"] = leg
         if world == 1:
             # host-API latency (host buffers in/out: includes H2D of the query and D2H of k results)
@@ -836,6 +916,7 @@ def main():
                 extra[name] = lg
             extra["fallbacks_12p5M"] = idx12.stats()["fallbacks"]
             idx12.close()
+            settle(1.0)
             for nm in ("rows_1M_batch1", "rows_1M_batch256"):
                 extra[nm]["tail_ms"] = extra[nm]["ms_per_step"] - extra[nm]["scan_kernel_ms"]
                 extra[nm]["hbm_floor_ms"] = 1_000_000 * extra[nm]["row_bytes_streamed"] / (HBM_PEAK_GBS * 1e9) * 1e3
@@ -873,6 +954,7 @@ def main():
             # parity of this path: tests/test_scan_bf16_gpu.py (oracle over the bf16-rounded rows)
             idx1.close()
             idx.close()
+            settle()
             idxh = dawn.VectorIndex(local_rank, dtype="bf16")
             idxh.fill_synthetic(1, 0, args.rows, 1)
             legh, _ = run_leg(idxh, 1, max(5, args.steps // 2), 3, check_planted=True)
@@ -881,11 +963,30 @@ def main():
             extra["bf16_index_batch256"] = legh2
             # ... filtering on the bf16 rows themselves (no int8 shadow: 76.8 GB in total instead of 115.2 GB)
             idxh.set_option("i8_shadow", 0)
+            settle()
             legh, _ = run_leg(idxh, 1, 5, 2, check_planted=True, rows_read="f16")
             extra["bf16_index_batch1_own_rows"] = legh
             legh2, _ = run_leg(idxh, 256, 3, 1, seed=3, rows_read="f16")
             extra["bf16_index_batch256_own_rows"] = legh2
             idxh.close()
+            settle()
+            # ---- the shard sizes of 2 / 4 GPUs (50 M / 25 M rows; 8 GPUs: rows_12p5M_* above) and what they predict for the 1 -> 8 curve
+            for name, nrows in (("rows_50M", 50_000_000), ("rows_25M", 25_000_000)):
+                ixs = dawn.VectorIndex(local_rank)
+                ixs.fill_synthetic(1, 0, nrows, 1)
+                for Bq, st, wu, sd in ((1, 60, 6, 2), (256, 15, 3, 3)):
+                    lg, _ = run_leg(ixs, Bq, st, wu, seed=sd)
+                    lg["tail_ms"] = lg["ms_per_step"] - lg["scan_kernel_ms"]
+                    lg["hbm_floor_ms"] = nrows * lg["row_bytes_streamed"] / (HBM_PEAK_GBS * 1e9) * 1e3
+                    extra[f"{name}_batch{Bq}"] = lg
+                extra["fallbacks_" + name[5:]] = ixs.stats()["fallbacks"]
+                ixs.close()
+                settle()
+            try:
+                extra["predicted_scaling"] = predicted_scaling(extra, head, k)
+            except Exception as e:
+                extra["predicted_scaling"] = {"error": repr(e)}
+            extra["rows_12p5M_clustered_topical"] = realistic_leg(4, rows=12_500_000, ks=(10,), ablations=False)
             # ---- realistic score distributions (dawn_index_set_option "synth_dist"): Gaussian rows and heavy-tailed rows
             # (4 dimensions x5, as sentence embeddings have); k = 10 and the service's k = 20; certificate counters
             for name, dist_id in (("gaussian", 1), ("heavy_tailed_4dims_x5", 2), ("clustered_topical", 4),

@@ -37,7 +37,7 @@ def test_result_line_fits_and_keeps_the_contract():
     cb = line["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and "note" not in cb and "rust_probe" not in cb
     assert len(line["config"]["workload"]) <= 200 and "model" not in line["config"]
-    assert all(not isinstance(v, (dict, list)) for v in line["extra"].values()) and len(line["extra"]) <= 24
+    assert all(not isinstance(v, (dict, list)) for v in line["extra"].values()) and len(line["extra"]) <= 32
 
 
 def test_emit_puts_the_result_line_last_and_everything_else_before_it(tmp_path, monkeypatch):

@@ -29,9 +29,17 @@ blob = torch.zeros((dawn.result_blob_bytes(1, k),), dtype=torch.uint8, device=de
 p = blob.data_ptr()
 
 
+SETTLE = float(os.environ.get("SETTLE", "2.0"))  # seconds of idle after an option that may release a shadow (0: as rounds 3 / 4 measured)
+
+
 def opt(name, v):
+    """An option that releases tens of GB (the packed shadow goes when it is not wanted) leaves every stream ~3 % slower until the device
+    has idled for a second or two (tools/stream_alloc_probe.py: any hipFree of 24 GB does) — settle before timing."""
     try:
         idx.set_option(name, v)
+        torch.cuda.synchronize()
+        if SETTLE > 0:
+            time.sleep(SETTLE)
         return True
     except Exception:
         return False
