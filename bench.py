@@ -82,6 +82,8 @@ def short_line(full: dict) -> dict:
         "batch256_ms": _get(ex, "batch256", "ms_per_step"),
         "batch256_qps": _get(ex, "batch256", "queries_per_s"),
         "batch256_p50_ms_host_api": _get(ex, "host_api_batch256", "p50_ms"),
+        "batch256_first_filter": _get(ex, "batch256", "first_filter") or "int8",
+        "batch256_int8_first_filter_ms": _get(ex, "batch256_int8_first_filter", "ms_per_step"),
         "f32_row_stream_hbm_frac": _get(ex, "batch1_streaming_f32_rows", "hbm_frac"),
         "i8_stream_hbm_frac": _get(ex, "batch1_streaming_i8_shadow", "hbm_frac"),
         "topical_batch1_ms": _get(ex, "rows_clustered_topical", "k10_batch1", "ms_per_step"),
@@ -231,14 +233,15 @@ def rust_probe(sample_rows: int):
 
 def read_ceiling_probe(timeout_s: float = 120.0):
     """The bare-read ceiling of THIS chip, measured in this run: tools/probes/hbm_read (the headline kernel's stream with
-    nothing but the loads: same grid, 16 B/lane nt loads, 24-48 KiB in flight per CU) over a 38.4 GB buffer, as a child
+    nothing but the loads: same grid, 16 B/lane nt loads, 24-48 KiB in flight per CU) over a 19.2 GB buffer, as a child
     process beside the resident index.  None if the binary is not built (python -c 'import __graft_entry__ as g; g.build()')."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "probes", "hbm_read")
     if not os.path.exists(exe):
         return None
     try:
-        out = subprocess.run([exe, "38.4", "4", "quick"], capture_output=True, text=True, timeout=timeout_s).stdout
+        # (19.2 GB: far beyond the 256 MiB Infinity Cache, and it fits beside a 100 M-row index that keeps all four shadows)
+        out = subprocess.run([exe, "19.2", "4", "quick"], capture_output=True, text=True, timeout=timeout_s).stdout
         lines = [ln for ln in out.splitlines() if ln.strip()]
         js = json.loads(lines[-1])
         best = js["hbm_read_ceiling_GBps"]
@@ -246,7 +249,7 @@ def read_ceiling_probe(timeout_s: float = 120.0):
                 "GBps_packed_stream_pattern": js.get("hbm_read_ceiling_i5_pattern_GBps"),
                 "lines": [ln for ln in lines if "GB/s" in ln],
                 "what": "tools/probes/hbm_read.hip quick mode: best of the bare 16 B/lane nt read streams (2 / 4 / 8 waves per CU, "
-                        "rings of 6 and 12 fragments, chip-wide window and per-XCD ranges) over 38.4 GB, 4 launches each; "
+                        "rings of 6 and 12 fragments, chip-wide window and per-XCD ranges) over 19.2 GB, 4 launches each; "
                         "GBps_12B_per_lane: the same for 12 B/lane loads (global_load_dwordx3, 768-B "
                         "fragments, 3 / 4 / 8 waves per CU); GBps_packed_stream_pattern: the headline kernel's own mix of loads (per "
                         "7680-B sub-tile two dwordx3 and six dwordx4 loads, rings of 4 and 8) with nothing but the loads"}
@@ -457,6 +460,7 @@ def main():
         """`steps` timed searches of a Bq-query batch.  Returns qps (max over ranks), ms/step and the mean
         duration of the dominant scan kernel measured with HIP events on its launch stream."""
         step, result = make_step(index, Bq, seed)
+        f6_before = index.stats_batch_feedback()["f6_batches"] if Bq >= 2 else 0
         index.profile_enable(True)
         for _ in range(warmup):
             step()
@@ -486,6 +490,9 @@ def main():
         #         (scan_i6.hip; "i6" 288.25: its 6-bit form, option i6_bits = 6)
         if rows_read == "default":
             rows_read = "i5" if (Bq == 1 and rows_here >= I6_MIN_ROWS) else "i8"
+            if Bq >= 2 and index.stats_batch_feedback()["f6_batches"] > f6_before:
+                rows_read = "f6"  # (the FP6 first filter took the batches: "f6_shadow" = auto on an index of >= 64 Mi rows)
+                leg["first_filter"] = "fp6"
         #   "f6"  288.5: the FP6 shadow (+ 8 B of scale/bound per 16 rows)
         row_bytes = {"i5": 240.25, "i6": 288.25, "f6": 288.5, "i8": ROW_BYTES / 4 + 0.25, "f16": ROW_BYTES // 2,
                      "f32": ROW_BYTES}[rows_read]
@@ -851,17 +858,18 @@ def main():
         b256_steps = max(3, min(args.steps, 10 if rows_local > 20_000_000 else 30))
         leg, _ = run_leg(idx, 256, b256_steps, 2, seed=3)
         extra["batch256"] = leg
-        # ... with the optional FP6 (e2m3) first filter (option "f6_shadow": + 288 B per row; scan_f6.hip): the 6-bit floating-point
-        # shadow through v_mfma_scale_f32_16x16x128_f8f6f4, survivors re-scored on the f32 rows, the same tail and certificates
-        if world == 1 and rows_local >= (64 << 20):
+        # ... the same with the FP6 (e2m3) first filter switched off ("f6_shadow" = 0; the default is auto: an index of >= 64 Mi rows keeps the
+        # FP6 shadow — + 288 B per row — where it leaves 24 GiB of HBM free; scan_f6.hip: v_mfma_scale_f32_16x16x128_f8f6f4, survivors
+        # re-scored on the f32 rows, the same tail and certificates)
+        if world == 1 and leg.get("first_filter") == "fp6":
             sh0 = idx.memory()["shadows"]
-            idx.set_option("f6_shadow", 1)
-            legf6, _ = run_leg(idx, 256, b256_steps, 2, seed=3, rows_read="f6")
-            legf6["f6_shadow_bytes"] = int(idx.memory()["shadows"] - sh0)  # (0: not enough free HBM — the int8 pass answered)
-            legf6["vs_int8_pass"] = legf6["queries_per_s"] / leg["queries_per_s"]
             idx.set_option("f6_shadow", 0)
             settle()
-            extra["batch256_f6_first_filter"] = legf6
+            leg8, _ = run_leg(idx, 256, b256_steps, 2, seed=3)
+            leg["f6_shadow_bytes"] = int(sh0 - idx.memory()["shadows"])
+            leg["vs_int8_first_filter"] = leg["queries_per_s"] / leg8["queries_per_s"]
+            extra["batch256_int8_first_filter"] = leg8
+            idx.set_option("f6_shadow", 2)
         # ... and on the f16 shadow (scan_f16_pipe_kernel; int8 shadow off)
         idx.set_option("i8_shadow", 0)
         settle()

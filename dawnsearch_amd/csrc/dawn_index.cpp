@@ -221,7 +221,7 @@ bool i8_shadow_sync(dawn_index* idx) {
         idx->i8_cap = idx->cap_phys;  // (re-quantised from the rows: 0.03 ms per million rows)
     }
     if (idx->i8_rows < idx->size) {
-        dawn::launch_rows_to_i8s(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size, stream);
+        dawn::launch_rows_to_i8s(idx->d_x, idx->dtype, idx->d_i8, idx->d_i8meta, idx->i8_rows, idx->size, stream, idx->i8_levels);
         idx->i8_rows = idx->size;
     }
     return true;
@@ -322,7 +322,12 @@ bool f6_shadow_sync(dawn_index* idx) {
         idx->f6_cap = idx->f6_rows = 0;
         char* ns = nullptr;
         float* nm = nullptr;
-        if (!enough_free(bytes + mbytes) || hipMalloc((void**)&ns, bytes) != hipSuccess || hipMalloc((void**)&nm, mbytes) != hipSuccess) {
+        // auto (the default): the FP6 shadow is an OPTIONAL accelerator of batches (+ 288 B per row for ~ -10 % per batch) — it is only built
+        // where it leaves dawn::kF6AutoHeadroom of HBM free for whatever else the caller keeps on the card (other indexes, the embedder);
+        // the order when HBM runs out is therefore: FP6 shadow first to go, then packed shadow -> int8 shadow -> f16 shadow -> the rows
+        const size_t spare = idx->use_f6 == 2 ? dawn::kF6AutoHeadroom : 0;
+        if ((idx->debug_fail_alloc & 8) || !enough_free(bytes + mbytes + spare) || hipMalloc((void**)&ns, bytes) != hipSuccess ||
+            hipMalloc((void**)&nm, mbytes) != hipSuccess) {
             (void)hipGetLastError();
             if (ns) (void)hipFree(ns);
             idx->f6_failed = true;
@@ -392,12 +397,19 @@ namespace dawn {
 
 // Which filter source the searches of this index will read, given its options (mirrors index_search_on_device), built on
 // idx->stream.  An option that needs a shadow the index does not hold yet builds it here — never inside a search.
-int index_prepare_search(dawn_index* idx) {
+int index_prepare_search(dawn_index* idx, bool appended) {
     DAWN_TRY(ensure_workspace(idx, std::max(idx->ws_B, kMaxBatch)));
-    idx->fb = dawn_index::LadderFeedback{};  // the rows (or the options) changed: what the certificates did before says nothing
-    idx->f6fb = dawn_index::F6Feedback{};
-    idx->bfb = dawn_index::BatchFeedback{};
-    if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
+    // The feedback (what the certificates of this index did lately) starts over when the options change or the contents are replaced.
+    // Appends keep it — the reference crawls while it serves (src/search/search_service.rs:158-171: an insert per extracted page between
+    // searches), and an index whose windows are reset by every flush of staged adds never demotes or deepens — until the
+    // index has grown by an eighth since the feedback last started over: by then the rows it was learnt on are not the index any more.
+    if (!appended || idx->size < 1024 || idx->size - idx->fb_rows0 > idx->fb_rows0 / 8) {
+        idx->fb = dawn_index::LadderFeedback{};
+        idx->f6fb = dawn_index::F6Feedback{};
+        idx->bfb = dawn_index::BatchFeedback{};
+        idx->fb_rows0 = idx->size;
+        if (idx->h_stats) idx->fb.win_fail0 = reinterpret_cast<volatile uint32_t*>(idx->h_stats)[STAT_PACKED_FAIL];
+    }
     if (idx->size == 0) return DAWN_OK;
     bool i8_ok = false;
     if (idx->use_i8 && !idx->i8_failed && (idx->i8_batched || idx->shadow_small_batches)) i8_ok = i8_shadow_sync(idx);
@@ -555,11 +567,11 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
                 launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
                                n >> idx->bounded_seed_shift, d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
                                idx->stream_dyn_tail ? idx->d_i6_pool : nullptr, g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
-                               0, true, stream, nullptr, nullptr, nullptr, idx->i6_central_tail != 0);
+                               0, true, stream, e0, nullptr, nullptr, idx->i6_central_tail != 0);  // (the profile of a demoted search includes its seed)
             }
             launch_scan_bounded_direct(idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q, idx->d_flags,
                                        idx->d_flags + idx->ws_B, idx->d_cand_s, idx->d_cand_p, idx->geom_i8.blocks, (uint32_t)k,
-                                       d_labels, d_dist, d_found, stream, e0, e1, idx->d_stats, idx->h_stats, idx->bounded,
+                                       d_labels, d_dist, d_found, stream, seed ? nullptr : e0, e1, idx->d_stats, idx->h_stats, idx->bounded,
                                        idx->debug_bad_threshold ? -1.0f : __builtin_inff(), p5 ? idx->d_i6 : nullptr,
                                        p5 ? idx->d_i6meta : nullptr, seed);
             DAWN_HIP_TRY(hipGetLastError());
@@ -628,6 +640,7 @@ int index_create_single(int dtype, int device, dawn_index** out) {
     if (const char* e = getenv("DAWN_I6_SHADOW")) idx->use_i6 = atoi(e) != 0;  // default of the "i6_shadow" option
     if (const char* e = getenv("DAWN_I6_BITS")) idx->i6_bits = atoi(e) == 6 ? 6 : 5;
     if (const char* e = getenv("DAWN_I6_MIN_ROWS")) idx->i6_min_rows = (size_t)std::max(0ll, atoll(e));
+    if (const char* e = getenv("DAWN_F6_SHADOW")) idx->use_f6 = std::min(2, std::max(0, atoi(e)));  // default of the "f6_shadow" option
     hipDeviceProp_t prop{};
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         idx->geom.blocks = prop.multiProcessorCount;  // one block per CU
@@ -782,7 +795,7 @@ int index_append_finish(dawn_index* idx, bool keep) {
     }
     idx->size += idx->pending;
     idx->pending = 0;
-    DAWN_TRY(index_prepare_search(idx));
+    DAWN_TRY(index_prepare_search(idx, true));
     DAWN_HIP_TRY(hipStreamSynchronize(idx->stream));
     return DAWN_OK;
 }
@@ -815,6 +828,7 @@ int index_clear(dawn_index* idx) {
     idx->i8_rows = 0;
     idx->i6_rows = 0;
     idx->f6_rows = 0;
+    idx->fb_rows0 = 0;  // (whatever comes next is a new index: its feedback starts over)
     return DAWN_OK;
 }
 
@@ -947,6 +961,10 @@ int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_
     if (idx->bws.cand) other += (uint64_t)BATCH_QT * (EM * 2 + 4 + BATCH_CAND_SEGS * 4 + (uint64_t)BATCH_CAP * 8);
     other += idx->stage_bytes;
     other += kMaxBatch * (EM * 4 + DAWN_MAX_K * 12 + 4) + 4;  // host-API staging
+    if (idx->f6ws.cand_big)  // the FP6 first filter's workspaces: survivors, their counters, query images, thresholds
+        other += (uint64_t)BATCH_QT * BATCH_CAND_SEGS * idx->f6ws.seg_cap_big * 8 + (uint64_t)BATCH_QT * BATCH_CAND_SEGS * 4 + 16 * 3 * 64 * 6 * 4 +
+                 (uint64_t)BATCH_QT * 12;
+    if (idx->bounded.wide_res) other += (uint64_t)BATCH_QT * BOUNDED_WIDE_CAP * 8 + BATCH_QT * 4;  // the bounded pass's wide form
     if (rows_bytes) *rows_bytes = rows;
     if (shadow_bytes) *shadow_bytes = shadows;
     if (other_bytes) *other_bytes = other;
@@ -1000,8 +1018,10 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }
-    if (n == "f6_shadow") {  // 1: batches of an index of >= f6_min_rows rows filter on the FP6 shadow first (scan_f6.hip)
-        idx->use_f6 = value != 0;
+    if (n == "f6_shadow") {  // batches of an index of >= f6_min_rows rows filter on the FP6 shadow first (scan_f6.hip): 0 never, 1 whenever
+                             // it can be allocated, 2 (default) auto: when it fits with kF6AutoHeadroom of HBM to spare
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "f6_shadow must be 0, 1 or 2");
+        idx->use_f6 = (int)value;
         if (value) idx->f6_failed = false;
         return reprepare();
     }
@@ -1149,10 +1169,10 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         idx->i8_batched = value != 0;
         return reprepare();
     }
-    if (n == "debug_i8_levels") {  // experiment hook: quantise the int8 shadow to +-value levels (127 = normal); process-wide
+    if (n == "debug_i8_levels") {  // experiment hook: quantise this index's int8 shadow to +-value levels (127 = normal)
         if (value < 3 || value > 127) return fail(DAWN_ERR_INVALID_ARG, "debug_i8_levels must be 3..127");
         DAWN_HIP_TRY(hipDeviceSynchronize());
-        dawn::g_i8_levels = (float)value;
+        idx->i8_levels = (float)value;
         idx->i8_rows = 0;  // re-quantise everything
         return reprepare();
     }
@@ -1160,8 +1180,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         // test hook for the out-of-memory order (int8 shadow -> f16 shadow -> the f32 rows themselves): bit 0 makes the
         // next int8-shadow allocation fail, bit 1 the next f16-shadow allocation; the shadows held now are dropped so that
         // the allocation is attempted again.  0 restores normal behaviour (and retries).
-        if (value < 0 || value > 7) return fail(DAWN_ERR_INVALID_ARG, "debug_fail_alloc is a 3-bit mask");
+        // bit 3: the FP6 shadow's allocation
+        if (value < 0 || value > 15) return fail(DAWN_ERR_INVALID_ARG, "debug_fail_alloc is a 4-bit mask");
         DAWN_HIP_TRY(hipDeviceSynchronize());
+        f6_release(idx);
+        idx->f6_failed = false;
         void* drop[] = {idx->d_i8, idx->d_i8meta, idx->d_shadow, idx->d_i6, idx->d_i6meta};
         for (void* p : drop)
             if (p) (void)hipFree(p);

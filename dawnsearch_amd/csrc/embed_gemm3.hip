@@ -464,12 +464,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const uint16_t* __
     }
 }
 
-int g_gemm3_persistent = 256;  // tuning: blocks of the 128 x 128 kernel (a multiple of 8; 0 = one per tile)
-int g_gemm3_pingpong = 1;  // tuning: 1 = the two waves of a SIMD run half a step apart (see the kernel)
 
 template <int PP>
 static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
-                            uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+                            uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s, const Gemm3Opts& o) {
     static OncePerDevice attr;  // (the attribute belongs to the current device's copy of the kernel: kernels.hpp)
     once_per_device(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<0, G3B_STAGES, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B_LDS);
@@ -478,7 +476,7 @@ static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* 
     });
     const int n_tiles = (N / G3B) * ((M + G3B - 1) / G3B);
     int blocks = (n_tiles + 7) / 8 * 8;
-    if (g_gemm3_persistent > 0 && blocks > g_gemm3_persistent) blocks = g_gemm3_persistent;  // one block per CU walks the tiles
+    if (o.persistent > 0 && blocks > o.persistent) blocks = o.persistent;  // one block per CU walks the tiles
     dim3 grid(blocks), block(512);
     const size_t lds = G3B_LDS;
     if (act == 1) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<1, G3B_STAGES, PP>), grid, block, lds, s, Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K);
@@ -487,9 +485,9 @@ static void launch_g3_big_v(const uint16_t* Ap, size_t a_plane, const uint16_t* 
 }
 
 static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
-                          uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
-    if (g_gemm3_pingpong) return launch_g3_big_v<1>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
-    return launch_g3_big_v<0>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+                          uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s, const Gemm3Opts& o) {
+    if (o.pingpong) return launch_g3_big_v<1>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s, o);
+    return launch_g3_big_v<0>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s, o);
 }
 
 // The 128 x 128 kernel is used when the GEMM has at least this many of its tiles: below that the chip is better filled by four
@@ -499,9 +497,7 @@ static void launch_g3_big(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp
 // form): the round-2 threshold of 512 tiles (two per CU) kept every GEMM of a 4708-token batch and the N = 384 GEMMs of a 9174-token
 // batch on the small form; from ~190 tiles (three quarters of the CUs busy with one persistent workgroup each) the big form
 // wins: 256 queries / 4708 tokens 0.965 -> 0.90 ms, 512 queries / 9174 tokens 1.71 -> 1.50 ms, 64 pages 1.44 -> 1.40 ms;
-// at 111 tiles it loses (1.00 ms).  0 = always.
-int g_gemm3_big_min_m = 190;
-int g_gemm3_stages = 2;  // tuning: ring depth of the bf16x3 kernel (2 .. 4)
+// at 111 tiles it loses (1.00 ms).  0 = always.  (Gemm3Opts::big_min_tiles, embed_kernels.hpp)
 
 template <int STAGES>
 static void launch_g3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
@@ -527,11 +523,11 @@ static void launch_g3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, si
 }
 
 void launch_gemm_bf16x3(const uint16_t* Ap, size_t a_plane, const uint16_t* Wp, size_t w_plane, const float* bias, float* Y,
-                        uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s) {
+                        uint16_t* Yp, size_t y_plane, int M, int N, int K, int act, hipStream_t s, const Gemm3Opts& o) {
     if (M <= 0) return;
-    if (N % G3B == 0 && (long long)((M + G3B - 1) / G3B) * (N / G3B) >= g_gemm3_big_min_m) return launch_g3_big(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
-    if (g_gemm3_stages == 2) launch_g3<2>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
-    else if (g_gemm3_stages == 4) launch_g3<4>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    if (N % G3B == 0 && (long long)((M + G3B - 1) / G3B) * (N / G3B) >= o.big_min_tiles) return launch_g3_big(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s, o);
+    if (o.stages == 2) launch_g3<2>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
+    else if (o.stages == 4) launch_g3<4>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
     else launch_g3<3>(Ap, a_plane, Wp, w_plane, bias, Y, Yp, y_plane, M, N, K, act, s);
 }
 

@@ -258,7 +258,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 // Lane (r = l&15, kq = l>>4) loads A[m0+r][kb + 4kq .. +3] and W[n0+r][same] as one 16-B load per
 // 16-wide k-step; MFMA j consumes element j of every lane (k = kb + 4kq + j).
 // ------------------------------------------------------------------------------------------------
-int g_skinny_max_m = 640;  // rows up to which launch_gemm_nt takes the skinny form (measured crossover with the 64x64 tile kernel: ~768 tokens)
 
 template <int ACT, int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __restrict__ A,
@@ -395,12 +394,12 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
 // Y = act(LN(a + r) . W^T + bias), x_out = LN(a + r); false: this shape does not take the fused form (the caller then
 // runs add_ln + gemm)
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
-                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s) {
+                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s, int skinny_max_m) {
     if (M <= 0) return true;
     // measured (tools/embed_latency.py, device-resident loop): 12 tokens 0.170 -> 0.164 ms, 27 tokens 0.194 -> 0.189 ms per
     // forward; at 128 tokens the N/16 blocks of a strip each redoing its statistics cost more than the launch saves
     // (0.290 -> 0.310 ms): fused up to 64 rows only
-    if (K != H || M > 64 || M > g_skinny_max_m || N % 16 != 0) return false;
+    if (K != H || M > 64 || M > skinny_max_m || N % 16 != 0) return false;
     dim3 grid(N / 16, (M + 15) / 16), block(512);
     if (act == 1) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<1>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
     else if (act == 2) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<2>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
@@ -419,9 +418,9 @@ static void launch_skinny16(const float* A, const float* W, const float* bias, f
 }
 
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                    hipStream_t s, bool tile_only) {
+                    hipStream_t s, bool tile_only, int skinny_max_m) {
     if (M <= 0) return;
-    if (!tile_only && M <= g_skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
+    if (!tile_only && M <= skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
         if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
         if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
     }
@@ -941,11 +940,10 @@ void launch_add_ln(const float* a, const float* r, int T, const float* g, const 
     hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride);
 }
 
-int g_attn_wave = 0;  // tuning: 1 = sequences of up to 64 tokens always take attention_wave_kernel (0: only with planes — for ONE
-                      // text the block kernel is as fast: 12 tokens 0.160 vs 0.173 ms per forward, 27 tokens 0.184 vs 0.181)
-
+// attn_wave (embedder option "attention_wave"): 1 = sequences of up to 64 tokens always take attention_wave_kernel (0: only with planes
+// — for ONE text the block kernel is as fast: 12 tokens 0.160 vs 0.173 ms per forward, 27 tokens 0.184 vs 0.181)
 bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s, uint16_t* ctxp,
-                      size_t plane_stride) {
+                      size_t plane_stride, int attn_wave) {
     if (B <= 0) return false;
     if (max_len > 64 && max_len <= ATM_S) {
         // (with planes asked for, only the planes are written: the dense layer that follows reads nothing else)
@@ -958,7 +956,7 @@ bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_l
         hipLaunchKernelGGL(attention_rows_kernel, dim3(NH, B), dim3(128), lds, s, qkv, seq_offsets, ctx);
         return false;
     }
-    if (ctxp || g_attn_wave) {  // the wave-per-sequence form (planes asked for: the throughput path)
+    if (ctxp || attn_wave) {  // the wave-per-sequence form (planes asked for: the throughput path)
         if (max_len <= 32)
             hipLaunchKernelGGL(attention_wave_kernel<1>, dim3(NH, (B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctx, ctxp, plane_stride);
         else

@@ -64,6 +64,9 @@ struct dawn_embedder {
     uint16_t* d_wplanes = nullptr;
     uint16_t *xp = nullptr, *ctxp = nullptr, *attnp = nullptr, *ffp = nullptr;
     int use_bf16x3 = 1;  // option "gemm_bf16x3"
+    int skinny_max_m = dawn::kSkinnyMaxM;  // option "skinny_max_rows": tokens up to which the GEMMs take the split-K latency form
+    int attn_wave = 0;                     // option "attention_wave"
+    dawn::Gemm3Opts g3{};                  // options "gemm3_*"
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
@@ -119,7 +122,7 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
         DAWN_HIP_TRY(hipMalloc((void**)&e->tmp2, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->attn, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ff, cap * I * 4));
-        if (cap > dawn::g_skinny_max_m) {  // planes are only used by the tile path
+        if (cap > e->skinny_max_m) {  // planes are only used by the tile path
             DAWN_HIP_TRY(hipMalloc((void**)&e->xp, (size_t)3 * cap * H * 2));
             DAWN_HIP_TRY(hipMalloc((void**)&e->ctxp, (size_t)3 * cap * H * 2));
             DAWN_HIP_TRY(hipMalloc((void**)&e->attnp, (size_t)3 * cap * H * 2));
@@ -157,7 +160,7 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
         dawn::launch_tok_pos(d_off, B, e->d_pos, s);
         d_pos = e->d_pos;
     }
-    if (e->use_bf16x3 && T > dawn::g_skinny_max_m && e->xp && e->d_wplanes) {
+    if (e->use_bf16x3 && T > e->skinny_max_m && e->xp && e->d_wplanes) {
         // Throughput form: the dense layers run f32-accurately on the bf16 matrix cores (embed_gemm3.hip: 3-way bf16 split,
         // 6 products).  Whatever feeds a dense layer is produced as three bf16 planes by the kernel that computes it (the
         // LayerNorms beside their f32 output — the residual —, FFN1's GELU epilogue and the page attention instead of it; the
@@ -165,13 +168,13 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
         const size_t ps = (size_t)e->cap_T * H, psi = (size_t)e->cap_T * I;  // plane strides
         dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, e->xp, ps, d_off, B);
         for (const LayerW& L : e->layers) {
-            dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s);
-            if (!dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, e->ctxp, ps))
+            dawn::launch_gemm_bf16x3(e->xp, ps, L.qkv_p, (size_t)3 * H * H, L.qkv_b, e->qkv, nullptr, 0, T, 3 * H, H, 0, s, e->g3);
+            if (!dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, e->ctxp, ps, e->attn_wave))
                 dawn::launch_split_planes(e->ctx, e->ctxp, T, H, (size_t)e->cap_T, s);
-            dawn::launch_gemm_bf16x3(e->ctxp, ps, L.ao_p, (size_t)H * H, L.ao_b, e->tmp, nullptr, 0, T, H, H, 0, s);
+            dawn::launch_gemm_bf16x3(e->ctxp, ps, L.ao_p, (size_t)H * H, L.ao_b, e->tmp, nullptr, 0, T, H, H, 0, s, e->g3);
             dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s, e->attnp, ps);
-            dawn::launch_gemm_bf16x3(e->attnp, ps, L.i_p, (size_t)I * H, L.i_b, nullptr, e->ffp, psi, T, I, H, c.act, s);
-            dawn::launch_gemm_bf16x3(e->ffp, psi, L.o_p, (size_t)H * I, L.o_b, e->tmp2, nullptr, 0, T, H, I, 0, s);
+            dawn::launch_gemm_bf16x3(e->attnp, ps, L.i_p, (size_t)I * H, L.i_b, nullptr, e->ffp, psi, T, I, H, c.act, s, e->g3);
+            dawn::launch_gemm_bf16x3(e->ffp, psi, L.o_p, (size_t)H * I, L.o_b, e->tmp2, nullptr, 0, T, H, I, 0, s, e->g3);
             dawn::launch_add_ln(e->tmp2, e->attn, T, L.o_g, L.o_beta, eps, e->x, s, e->xp, ps);
         }
         return false;
@@ -184,18 +187,18 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
     for (const LayerW& L : e->layers) {  // BertLayer::forward model.rs:487-498
         // :327-329 (Q|K|V fused)
         if (!(pending && dawn::launch_gemm_ln_nt(e->tmp2, e->attn, pending->o_g, pending->o_beta, eps, e->x, L.qkv_w, L.qkv_b,
-                                                 e->qkv, T, 3 * H, H, 0, s))) {
+                                                 e->qkv, T, 3 * H, H, 0, s, e->skinny_max_m))) {
             if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
-            dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s);
+            dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s, false, e->skinny_max_m);
         }
-        dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s);                      // :331-346
-        dawn::launch_gemm_nt(e->ctx, L.ao_w, L.ao_b, e->tmp, T, H, H, 0, s);               // :376
+        dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, nullptr, 0, e->attn_wave);                      // :331-346
+        dawn::launch_gemm_nt(e->ctx, L.ao_w, L.ao_b, e->tmp, T, H, H, 0, s, false, e->skinny_max_m);               // :376
         // :378 LayerNorm(dense + x) -> attn, then :427-428 intermediate dense + activation
-        if (!dawn::launch_gemm_ln_nt(e->tmp, e->x, L.ao_g, L.ao_beta, eps, e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s)) {
+        if (!dawn::launch_gemm_ln_nt(e->tmp, e->x, L.ao_g, L.ao_beta, eps, e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s, e->skinny_max_m)) {
             dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s);
-            dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s);
+            dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s, false, e->skinny_max_m);
         }
-        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s);                 // :460
+        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s, false, e->skinny_max_m);                 // :460
         pending = &L;                                                                      // :462 LayerNorm(dense + attn)
     }
     if (pending && d_pool_out && B <= 64) {  // (a block per sequence: few sequences only)
@@ -338,7 +341,7 @@ static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t 
     if (!e || !name) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (std::string(name) == "skinny_max_rows") {  // token count up to which the GEMMs take the split-K skinny form
         if (value < 0 || value > 4096) return fail(DAWN_ERR_INVALID_ARG, "skinny_max_rows out of range");
-        dawn::g_skinny_max_m = (int)value;
+        e->skinny_max_m = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "gemm_bf16x3") {  // 0: batches use the f32-MFMA tile kernel instead of the bf16x3 kernels
@@ -348,27 +351,27 @@ static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t 
     }
     if (std::string(name) == "gemm3_big_min_tiles") {  // 128 x 128 tiles from which that form of the bf16x3 kernel is used
         if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "gemm3_big_min_tiles out of range");
-        dawn::g_gemm3_big_min_m = (int)std::min<int64_t>(value, 1 << 30);
+        e->g3.big_min_tiles = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }
     if (std::string(name) == "attention_wave") {  // sequences of up to 64 tokens: 1 = always the wave-per-sequence kernel (tuning)
         if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "attention_wave must be 0 or 1");
-        dawn::g_attn_wave = (int)value;
+        e->attn_wave = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "gemm3_persistent") {  // 128 x 128 kernel: blocks that walk the tile list (0 = a block per tile)
         if (value < 0 || value > 4096 || value % 8) return fail(DAWN_ERR_INVALID_ARG, "gemm3_persistent must be a multiple of 8 in 0..4096");
-        dawn::g_gemm3_persistent = (int)value;
+        e->g3.persistent = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "gemm3_pingpong") {  // 128 x 128 kernel: waves of a SIMD half a step apart (tuning; default 1)
         if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "gemm3_pingpong must be 0 or 1");
-        dawn::g_gemm3_pingpong = (int)value;
+        e->g3.pingpong = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "gemm3_stages") {  // ring depth of the bf16x3 kernel (tuning)
         if (value < 2 || value > 4) return fail(DAWN_ERR_INVALID_ARG, "gemm3_stages must be 2..4");
-        dawn::g_gemm3_stages = (int)value;
+        e->g3.stages = (int)value;
         return DAWN_OK;
     }
     if (std::string(name) == "graphs") {  // 0: never replay hipGraphs (every forward is ~45 plain launches)
@@ -502,7 +505,7 @@ static int debug_op_impl(dawn_embedder* e, int op, const void* in, int T, float*
         dawn::launch_add_ln(e->tmp, e->attn, T, L.ao_g, L.ao_beta, eps, e->x, s);
     } else if (op == 2 || op == 3) {
         DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
-        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s, op == 3);
+        dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, (int)I, (int)H, c.act, s, op == 3, e->skinny_max_m);
         out_elems = (size_t)T * I;
     } else if (op == 4 || op == 5) {
         // 4: the same dense layer through the bf16x3 kernel (embed_gemm3.hip): planes made here from the f32 input / weights
@@ -515,7 +518,7 @@ static int debug_op_impl(dawn_embedder* e, int op, const void* in, int T, float*
         DAWN_HIP_TRY(hipMemcpyAsync(e->attn, in, (size_t)T * H * 4, hipMemcpyHostToDevice, s));
         dawn::launch_split_planes(e->attn, ap, T, (int)H, (size_t)T, s);
         dawn::launch_split_planes(L.i_w, wp, (int)I, (int)H, (size_t)I, s);
-        dawn::launch_gemm_bf16x3(ap, (size_t)T * H, wp, (size_t)I * H, L.i_b, e->ff, yp, (size_t)T * I, T, (int)I, (int)H, c.act, s);
+        dawn::launch_gemm_bf16x3(ap, (size_t)T * H, wp, (size_t)I * H, L.i_b, e->ff, yp, (size_t)T * I, T, (int)I, (int)H, c.act, s, e->g3);
         out_elems = (size_t)T * I;
         if (op == 5) {
             std::vector<uint16_t> hp((size_t)3 * T * I);
@@ -584,8 +587,8 @@ static int debug_gemm_time_impl(dawn_embedder* e, int T, int N, int K, int varia
     for (int it = -2; it < iters; ++it) {
         if (it == 0) DAWN_HIP_TRY(hipEventRecord(e0, s));
         if (variant == 0) dawn::launch_gemm_nt(a, W, bias, y, T, N, K, 0, s, true);
-        else if (variant == 1) dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s);
-        else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, nullptr, yp, (size_t)T * N, T, N, K, variant == 3 ? 1 : 0, s);
+        else if (variant == 1) dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, y, nullptr, 0, T, N, K, 0, s, e->g3);
+        else dawn::launch_gemm_bf16x3(ap, (size_t)T * K, wp, (size_t)N * K, bias, nullptr, yp, (size_t)T * N, T, N, K, variant == 3 ? 1 : 0, s, e->g3);
     }
     DAWN_HIP_TRY(hipEventRecord(e1, s));
     DAWN_HIP_TRY(hipStreamSynchronize(s));

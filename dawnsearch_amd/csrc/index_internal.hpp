@@ -32,6 +32,7 @@ constexpr uint32_t kFbDemoteMin = 256, kFbDemoteMax = 8192;
 constexpr uint32_t kBatchFbWindow = 1024;  // int8 batched pass: queries per feedback window
 constexpr double kBatchFbBoost = 0.10;
 constexpr int kBatchBoostTarget = 4096, kBatchBoostTargetWide = 3072;  // (k > 32 doubles the target: 2 x 3072 stays inside the 8192 slots)
+constexpr size_t kF6AutoHeadroom = (size_t)24 << 30;  // "f6_shadow" = auto: HBM that must stay free once the FP6 shadow is built
 constexpr uint32_t kF6FbWindow = 1024;  // FP6 feedback: queries per window
 constexpr double kF6FbSuspend = 0.30;
 constexpr uint32_t kF6FbSuspendMin = 16, kF6FbSuspendMax = 1024;
@@ -88,6 +89,7 @@ struct dawn_index {
     int use_i8 = 1;              // option "i8_shadow"
     int i8_batched = 1;          // option "i8_batched": batches of mfma_min_batch and more also filter on it
     bool i8_failed = false;
+    float i8_levels = 127.0f;    // option "debug_i8_levels" (experiments on coarser shadows)
     // Packed shadow (ROW_I6S, scan_i6.hip: 5 bits per component = 240 B/row, or 6 = 288 B/row, + 8 B per 32 rows) read by the
     // single-query stream of an index of at least i6_min_rows rows instead of the int8 shadow (which the matrix-core pass keeps
     // using): the stream is HBM-bound, fewer bytes per row are the only thing that makes it faster.  Kept current by the
@@ -122,11 +124,12 @@ struct dawn_index {
     const dawn::ScanGeom& i6_geom() const { return (!geom_i6_pinned && size < dawn::kI6SmallRows) ? geom_i6_small : geom_i6; }
     // FP6 (e2m3) shadow (ROW_F6S, scan_f6.hip: 288 B/row + 8 B per 16 rows): the FIRST filter of batches on a large index —
     // 1.5 x the int8 matrix rate under the chip's power envelope; its survivors are re-scored on the int8 shadow.  Option
-    // "f6_shadow" (default 0: measured in bench legs, not the default path yet); kept current by the mutations like the others.
+    // "f6_shadow" (default 2 = auto: built from f6_min_rows rows where it leaves kF6AutoHeadroom of HBM free; its feedback suspends it on an
+    // index whose FP6-filtered queries end in the ladder); kept current by the mutations like the others.
     char* d_f6 = nullptr;
     float* d_f6meta = nullptr;
     size_t f6_cap = 0, f6_rows = 0;
-    int use_f6 = 0;              // option "f6_shadow"
+    int use_f6 = 2;              // option "f6_shadow": 0 never, 1 always, 2 auto (default): from f6_min_rows rows, where it fits with kF6AutoHeadroom to spare
     // option "f6_min_rows": batches of smaller indexes take the int8 pass.  The re-scoring of the filter's ~12 k survivors per
     // query costs 0.8 ms per batch of 256 whatever the index size: a tie at 50 M rows (4.79 ms both), -10 % at 100 M, + 55 % at
     // 12.5 M (2.00 against 1.29 ms; profiles/r04/f6_ab_12p5M_v8.log)
@@ -202,7 +205,7 @@ struct dawn_index {
     // every search (scan_exact_kernel; pinned memory, no synchronisation, the host reads whatever has landed) — in windows of
     // kFbWindow single-query searches: above kFbBoost the waves refine full lists (n_refine = 64), above kFbDemote the next
     // demote_len single queries go to the bounded pass directly (doubling while the next probe window fails again, back to
-    // kFbDemoteMin once one passes).  Results never depend on it.  Reset by every mutation and option (index_prepare_search).
+    // kFbDemoteMin once one passes).  Results never depend on it.  Reset by options, load / clear and growth by an eighth (index_prepare_search).
     uint32_t* h_stats = nullptr;   // [N_STAT_SLOTS] pinned, device-visible
     int ladder_feedback = 1;       // option "ladder_feedback": 0 off, 1 adaptive, 2 every single query goes to the bounded pass directly
     int debug_bad_threshold = 0;   // option "debug_bad_threshold" (tests)
@@ -212,6 +215,7 @@ struct dawn_index {
         uint32_t demote_left = 0, demote_len = 256;
         bool boosted = false;
     } fb;
+    size_t fb_rows0 = 0;           // rows when the feedback last started over (appends keep it until the index has grown by an eighth)
     uint64_t n_demoted = 0;        // single queries answered by the bounded pass directly
     // The same for the FP6 first filter of batches ("f6_shadow"): its looser bound sends MORE queries of a batch to the ladder than
     // the int8 pass on topical rows (81-90 % against 53-68 % at 100 M rows: 133 against 80 ms per batch, profiles/r04/
@@ -286,7 +290,7 @@ int index_clear(dawn_index* idx);           // size = 0 (load replaces the conte
 int index_fill_async(dawn_index* idx, uint64_t seed, uint64_t first_row, size_t n, uint64_t first_id, bool ids_are_positions,
                      uint64_t first_pos);
 // Workspaces + filter shadows for the current rows and options, on idx->stream (callers synchronise).
-int index_prepare_search(dawn_index* idx);
+int index_prepare_search(dawn_index* idx, bool appended = false);  // appended: rows were added, nothing else changed
 int index_set_option_single(dawn_index* idx, const char* name, int64_t value);
 int index_get_rows_single(dawn_index* idx, size_t first, size_t n, float* out_rows, uint64_t* out_ids);
 int index_memory_single(dawn_index* idx, uint64_t* rows_bytes, uint64_t* shadow_bytes, uint64_t* other_bytes);

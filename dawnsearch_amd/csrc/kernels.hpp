@@ -129,9 +129,9 @@ void launch_scan_filter_f16s(const void* d_rows, int rt, uint32_t n_rows, const 
 // int8 shadow (scan_i8.hip): d_meta = float2 {scale, error bound} per 32-row sub-tile
 void launch_scan_filter_i8s(const void* d_shadow, const void* d_meta, uint32_t n_rows, const float* d_q, int B, float* cand_s,
                             uint32_t* cand_p, const ScanGeom& geom, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-extern float g_i8_levels;  // quantiser levels of the int8 shadow (127; "debug_i8_levels": fewer, experiments on coarser shadows)
+// levels: quantiser levels of the int8 shadow (127; index option "debug_i8_levels": fewer, experiments on coarser shadows)
 void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
-                        hipStream_t stream);
+                        hipStream_t stream, float levels = 127.0f);
 // Packed shadow of 5 or 6 bits per component (scan_i6.hip): conversion, and the whole single-query search on it (stream with
 // exact rescoring of every workgroup's shortlist(s) in its epilogue, merge of the exact lists + certificate; merge = false:
 // the stream alone).  d_i8 / d_i8meta: the int8 shadow, which refines the bounds of the listed rows; tb [blocks].

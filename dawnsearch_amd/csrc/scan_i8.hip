@@ -139,20 +139,19 @@ __global__ __launch_bounds__(256) void rows_to_i8s_kernel(const void* __restrict
     }
 }
 
-float g_i8_levels = 127.0f;  // option "debug_i8_levels"
 
 // rt: ROW_F32 (f32 rows) or ROW_BF16 (fragment-ordered bf16 rows)
 void launch_rows_to_i8s(const void* d_rows, int rt, void* d_shadow, void* d_meta, size_t first_row, size_t n_valid,
-                        hipStream_t stream) {
+                        hipStream_t stream, float levels) {
     const uint32_t first_sub = (uint32_t)(first_row / 32);  // the sub-tile holding first_row is re-quantised whole
     const uint32_t end_sub = (uint32_t)((n_valid + 31) / 32);
     if (end_sub <= first_sub) return;
     if (rt == ROW_BF16)
         hipLaunchKernelGGL(rows_to_i8s_kernel<1>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, g_i8_levels);
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, levels);
     else
         hipLaunchKernelGGL(rows_to_i8s_kernel<0>, dim3(end_sub - first_sub), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, g_i8_levels);
+                           reinterpret_cast<uint32_t*>(d_shadow), reinterpret_cast<float2*>(d_meta), first_sub, (uint32_t)n_valid, levels);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,23 +120,25 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      times the hits to queue and score); default 0
  *   "bounded_ring"     16-B fragments a wave of the bounded pass (int8 shadow) keeps in flight, 6 (default) or 12 — no
  *                      measurable difference (profiles/r04/bounded_ring_ab_100M.log)
- *   "f6_shadow"        1: batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than the pass saves) filter on an FP6 (e2m3) shadow of the rows
- *                      first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the int8 matrix rate under the chip's power
- *                      envelope), its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8 shadow
- *                      (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
+ *   "f6_shadow"        batches of an index of at least "f6_min_rows" rows (default 64 Mi: below ~50 M rows the survivors' re-scoring costs more than
+ *                      the pass saves) filter on an FP6 (e2m3) shadow of the rows first (288 B/row; v_mfma_scale_f32_16x16x128_f8f6f4: 1.5 x the
+ *                      int8 matrix rate under the chip's power envelope): 0 never, 1 whenever it can be allocated, 2 (DEFAULT, or env
+ *                      DAWN_F6_SHADOW at creation) auto — only where it leaves 24 GiB of HBM free once built (it is an optional accelerator:
+ *                      the first shadow to go when HBM runs out), and its feedback suspends it on an index whose FP6-filtered queries end in
+ *                      the ladder (topical rows).  Its survivors are re-scored on the f32 rows ("f6_refine_rows" 1, default) or on the int8
+ *                      shadow (0; always for a bf16 index); "f6_target" = survivors per query its threshold aims for (12288; twice
  *                      that for count > 32); "f6_stagger" -1 (default): the pass staged through LDS, >= 0: the register-ring pass
  *                      with its waves that many tiles apart (A/B), -2 / -4: timing experiments of the LDS-staged pass in a `make EXPERIMENTS=1`
- *                      build (no threshold tests: wrong results / a few waves print their cycle counts; the release library runs the pass itself).  Default 0: 8.55 against 9.55 ms per batch of
- *                      256 on 100 M rows with it (profiles/r04/f6_ab_100M_v7_*.log) for 28.8 GB more HBM
+ *                      build.  100 M rows x 256 queries: 8.4-8.5 against 9.3-9.6 ms per batch for 28.8 GB more HBM
  *   "i6_central_tail"  1: the packed stream's workgroups do not rescore their own 64 rows exactly; merge_rescore_kernel rescores
  *                      the index's 64 best by the refined score (measured: a wash; default 0)
  *   "i6_dyn_chunk" / "i6_dyn_share"   the packed stream's dynamically assigned tail: sub-tiles per chunk (default 16; 8 below 32 Mi
  *                      rows) and sixteenths of the index it covers (2; 3)
- *   "debug_i8_levels"  experiment hook (process-wide): quantise the int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
+ *   "debug_i8_levels"  experiment hook: quantise this index's int8 shadow to +-N levels, 3..127 (127 = normal), bytes unchanged —
  *                      what a coarser shadow would cost the certificates (tools/coarse_shadow_probe.py); results stay exact
- *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (6-bit shadow -> int8 shadow -> f16 shadow -> the
- *                      rows themselves): bit 0 / bit 1 / bit 2 make the int8 / f16 / 6-bit shadow allocation fail as if the card
- *                      were full; 0 = normal
+ *   "debug_fail_alloc" test hook for the out-of-HBM order of the filter sources (FP6 shadow -> 6-bit shadow -> int8 shadow -> f16 shadow ->
+ *                      the rows themselves): bit 0 / bit 1 / bit 2 / bit 3 make the int8 / f16 / 6-bit / FP6 shadow allocation fail as if
+ *                      the card were full; 0 = normal
  *   "synth_dist"       rows made by dawn_index_fill_synthetic: 0 the spec's uniform rows (default), 1 Gaussian, 2 heavy-tailed
  *                      (4 fixed dimensions x5), 3 heavy-tailed (4 dimensions per row x5) — bench legs on realistic tails; 4 topical mixture
  *                      (Zipf-sized clusters, cosine 0.5 .. 0.95 inside a cluster; restated on the CPU: dawnsearch_amd/synth.py),

@@ -122,6 +122,7 @@ def test_100m_batch256_all_paths_agree(dawn, big):
     k = 20
     Q = synth.unit_rows(3, 0, 256)
     Q[:10] = _queries()[0][6:16]  # the planted ones
+    idx.set_option("f6_shadow", 0)  # (the default is auto — an index of this size keeps the FP6 shadow: first the int8 pass alone)
     before = idx.stats()
     labels, dist, found = idx.search_batch(Q, k)
     assert np.all(found == k) and np.all(np.diff(dist, axis=1) >= 0) and labels.min() >= 1 and labels.max() <= N
@@ -132,7 +133,7 @@ def test_100m_batch256_all_paths_agree(dawn, big):
         l6, d6, _ = idx.search_batch(Q, k)
         assert idx.stats_f6()["f6_batches"] == f6_before + 1  # (it did run: the shadow found its memory)
     finally:
-        idx.set_option("f6_shadow", 0)
+        idx.set_option("f6_shadow", 0)  # (the int8 pass for what follows: its counters are compared below)
     assert np.array_equal(l6, labels) and np.array_equal(d6.view(np.uint32), dist.view(np.uint32))
     idx.set_option("mfma_min_batch", 100000)  # the streaming filter, 8 queries per pass over the int8 shadow
     try:

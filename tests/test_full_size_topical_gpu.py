@@ -72,6 +72,7 @@ def test_100m_topical_batches_through_the_ladder_equal_the_exact_pass(dawn, topi
     idx = topical
     Q = _queries(256)
     k = 10
+    idx.set_option("f6_shadow", 0)  # (the default is auto: first the int8 pass and its own feedback alone)
     idx.set_option("force_fallback", 1)
     wl, wd, _ = idx.search_batch(Q[:64], k)  # (64 exact passes of 33 ms)
     idx.set_option("force_fallback", 0)
@@ -100,5 +101,5 @@ def test_100m_topical_batches_through_the_ladder_equal_the_exact_pass(dawn, topi
         f2 = idx.stats_batch_feedback()
         assert f2["f6_batches"] >= 4 and f2["f6_suspended"] >= 1, f2
     finally:
-        idx.set_option("f6_shadow", 0)
+        idx.set_option("f6_shadow", 2)
     assert idx.stats()["fallbacks"] == s0["fallbacks"]

@@ -222,20 +222,25 @@ def test_ladder_feedback_demotes_and_recovers(dawn, oracle):
             _same(*idx.search(q, 10), want[0][b], want[1][b])
     st = idx.stats()
     assert st["fallbacks"] == 0 and st["bounded"] == 96 and st["packed_failures"] == 32 and st["demoted"] == 64, st
-    # a mutation resets the feedback: the packed stream is tried again
+    # a trickle of adds (the reference inserts a page between searches: src/search/search_service.rs:158-171) does NOT start the feedback
+    # over — the index stays demoted; an option change (or growth by an eighth, a load, a clear) does: the packed stream is tried again
     extra = synth.unit_rows(9, 0, 1)
     idx.add(n + 1, extra[0])
-    _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(
-        np.concatenate([oracle.unit_rows_topical(1, 0, n), extra]), np.arange(1, n + 2, dtype=np.uint64), Qbad[0], 10, threads=8))
+    grown = (np.concatenate([oracle.unit_rows_topical(1, 0, n), extra]), np.arange(1, n + 2, dtype=np.uint64))
+    _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(*grown, Qbad[0], 10, threads=8))
     st2 = idx.stats()
-    assert st2["packed_failures"] == 33 and st2["demoted"] == 64
+    assert st2["packed_failures"] == 32 and st2["demoted"] == 65, st2
+    idx.set_option("i6_refine", 8)
+    _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(*grown, Qbad[0], 10, threads=8))
+    st2 = idx.stats()
+    assert st2["packed_failures"] == 33 and st2["demoted"] == 65, st2
     # feedback off: every search tries the packed stream first
     idx.set_option("ladder_feedback", 0)
     for it in range(6):
         for q in Qbad:
             idx.search(q, 10)
     st3 = idx.stats()
-    assert st3["demoted"] == 64 and st3["packed_failures"] == 33 + 48
+    assert st3["demoted"] == 65 and st3["packed_failures"] == 33 + 48
     # queries that certify are never demoted
     idx2 = dawn.VectorIndex(0)
     idx2.set_option("i6_min_rows", 0)

@@ -203,3 +203,51 @@ def test_f6_behind_a_sharded_handle(dawn, oracle):
     sh.set_option("f6_shadow", 0)
     assert sh.memory()["shadows"] <= m0
     assert sh.stats()["fallbacks"] == 0
+
+
+def test_f6_auto_policy_and_out_of_hbm_order(dawn, oracle):
+    """"f6_shadow" = 2 (the default): an index of at least f6_min_rows rows builds the FP6 shadow by itself when that leaves 24 GiB of HBM free —
+    and not otherwise ("f6_shadow" = 1 still does); when its allocation fails the int8 pass answers the same bits (the FP6 shadow is
+    the first to go when HBM runs out: debug_fail_alloc bit 3)."""
+    import torch
+    n = 70_000
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    Q = synth.unit_rows(2, 0, 40)
+    idx = dawn.VectorIndex(0)
+    idx.set_option("f6_min_rows", 0)  # (default 64 Mi rows; the option's own default stays auto)
+    idx.fill_synthetic(1, 0, n, 1)
+    m_auto = idx.memory()["shadows"]
+    b0 = idx.stats_f6()["f6_batches"]
+    lab, dist, found = idx.search_batch(Q, 10)
+    assert idx.stats_f6()["f6_batches"] == b0 + 1  # auto built it and the batch went through it
+    for b in range(0, 40, 3):
+        _assert_same(lab[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10))
+    # the allocation fails: no FP6 shadow, the int8 pass answers
+    idx.set_option("debug_fail_alloc", 8)
+    assert idx.memory()["shadows"] < m_auto - n * 280
+    lab2, dist2, _ = idx.search_batch(Q, 10)
+    assert idx.stats_f6()["f6_batches"] == b0 + 1
+    assert np.array_equal(lab, lab2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32))
+    idx.set_option("debug_fail_alloc", 0)
+    assert idx.memory()["shadows"] == m_auto
+    idx.close()
+    # less than 24 GiB would stay free: auto declines, 1 insists
+    free, _tot = torch.cuda.mem_get_info()
+    ballast = torch.empty((max(free - (20 << 30), 1),), dtype=torch.uint8, device="cuda:0")
+    try:
+        idx = dawn.VectorIndex(0)
+        idx.set_option("f6_min_rows", 0)
+        idx.fill_synthetic(1, 0, n, 1)
+        b0 = idx.stats_f6()["f6_batches"]
+        lab3, dist3, _ = idx.search_batch(Q, 10)
+        assert idx.stats_f6()["f6_batches"] == b0 and idx.memory()["shadows"] < m_auto - n * 280
+        idx.set_option("f6_shadow", 1)
+        lab4, dist4, _ = idx.search_batch(Q, 10)
+        assert idx.stats_f6()["f6_batches"] == b0 + 1 and idx.memory()["shadows"] == m_auto
+        for l_, d_ in ((lab3, dist3), (lab4, dist4)):
+            assert np.array_equal(lab, l_) and np.array_equal(dist.view(np.uint32), d_.view(np.uint32))
+        idx.close()
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
