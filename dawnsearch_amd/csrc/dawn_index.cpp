@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -483,17 +484,33 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             // batch feedback (index_internal.hpp): too many of this index's batched queries in the ladder -> deeper thresholds
             auto& fb = idx->bfb;
             const volatile uint32_t* hs = reinterpret_cast<volatile uint32_t*>(idx->h_stats);
-            if (!fb.boosted && fb.issued >= kBatchFbWindow) {
+            if (fb.issued >= kBatchFbWindow) {
                 const uint32_t now = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
-                if ((double)(now - fb.ladder0) > kBatchFbBoost * (double)fb.issued) fb.boosted = true;
+                const double per_pass = (double)(now - fb.ladder0) / (double)std::max<uint64_t>(fb.passes, 1);
+                auto streams = [](double flagged) { return flagged <= 0.0 ? 0.0 : std::ceil(flagged / 64.0 - 0.02); };  // (wide form: 64 per stream)
+                if (fb.level == 1) {
+                    fb.base_per_pass = per_pass;
+                    if ((double)(now - fb.ladder0) > kBatchFbBoost * (double)fb.issued && !fb.tried_deep) fb.level = 2;  // a trial window
+                    else if (now == fb.ladder0 && !fb.no_shallow) fb.level = 0;
+                } else if (fb.level == 2 && !fb.tried_deep) {
+                    fb.tried_deep = true;  // keep the deeper thresholds only where they save the ladder a stream
+                    if (!(streams(per_pass) < streams(fb.base_per_pass))) fb.level = 1;
+                } else if (fb.level == 0 && now != fb.ladder0) {
+                    fb.level = 1;
+                    fb.no_shallow = true;
+                }
                 fb.issued = 0;
+                fb.passes = 0;
             }
             if (fb.issued == 0) fb.ladder0 = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
             fb.issued += B;
-            if (fb.boosted) {
+            fb.passes += (B + BATCH_QT - 1) / BATCH_QT;
+            if (fb.level == 2) {
                 bw.target = std::max(bw.target, k > 32 ? kBatchBoostTargetWide : kBatchBoostTarget);
                 idx->n_deepened_batches += (B + BATCH_QT - 1) / BATCH_QT;
                 rerun = idx->batch_rerun != 0 && idx->bounded_pass;
+            } else if (fb.level == 0) {
+                bw.target = std::max(bw.target / 2, 256);
             }
         }
         if (idx->batch_rerun == 2 && n > (uint32_t)BATCH_CAP && idx->force_fallback != 1) rerun = true;  // (tests, A/B: every batch)

@@ -231,11 +231,18 @@ struct dawn_index {
     // the fastest pass on well-spread rows, 8.82 ms per 100 M x 256 against 9.21 at 4096).  On topical rows a threshold that shallow
     // often sits ABOVE the k-th score inside a shell of near-ties and no certificate can hold: 53 % of a batch ended in the ladder
     // at 1024, 39 % at 4096 (79 -> 67 ms per batch at 100 M rows, profiles/r04/topical_target_sweep_100M.log).  Above
-    // kBatchFbBoost of a window's queries in the ladder, the index's batches aim four times as deep until its rows change.
+    // kBatchFbBoost of a window's queries in the ladder, the index TRIES four times as deep for a window, and keeps that depth only if it
+    // saves the ladder a whole stream: with the wide form of the bounded pass (round 5: 64 flagged queries per stream of the int8 shadow)
+    // a batch's ladder costs ceil(flagged / 64) streams — 135 -> 100 flagged is 3 -> 2 streams at 100 M rows (33 -> 28 ms per batch), but
+    // 102 -> 74 at 12.5 M rows is 2 -> 2 and the deeper pass only costs (4.14 -> 5.19 ms: profiles/r05/operating_point_sweep.log).  An index
+    // whose batches never reach the ladder aims half as deep instead (-3 % per batch on well-spread rows), and goes back at the first
+    // sign of one.
     struct BatchFeedback {
-        uint64_t issued = 0;
-        uint32_t ladder0 = 0;
-        bool boosted = false;
+        uint64_t issued = 0, passes = 0;  // batched queries / passes (of <= 256 queries) of this window
+        uint32_t ladder0 = 0;             // h_stats[FLAG_BOUNDED] + h_stats[FLAG_FALLBACK] at its start
+        int level = 1;                    // 0: half as deep (a quiet index), 1: "mfma_target", 2: four times as deep
+        bool tried_deep = false, no_shallow = false;
+        double base_per_pass = 0.0;       // queries per pass the ladder answered at level 1 (the window before a trial of level 2)
     } bfb;
     uint64_t n_f6_batches = 0, n_f6_suspended = 0, n_deepened_batches = 0;  // batches (of <= 256 queries) the FP6 filter took / handed to the int8 pass
     int synth_dist = 0;  // option "synth_dist": distribution of dawn_index_fill_synthetic rows (bench / tests)

@@ -125,9 +125,16 @@ int dawn_index_load_page_entries(dawn_index *idx, const char *emb_path, uint64_t
 /* d_queries [B][384] f32, d_labels [B][count] u64, d_distances [B][count] f32, d_found [B] u32 are
  * DEVICE pointers on the index's (root) device; `stream` is a hipStream_t (NULL = default stream).
  * Queries are assumed validated.  For B <= 256 on a single-device index this is kernel launches only — no allocation, no
- * synchronisation, no host decision on device data: graph-capturable.  (Workspaces and the filter shadow of the current rows
- * are prepared by create / add / load / reserve / set_option, which synchronise; a caller searching on its own stream
- * must have that stream idle before it mutates the index.  B > 256 in one call grows the workspaces once.) */
+ * synchronisation — and every rung of the ladder behind a failed certificate is a launch PREDICATED on the query's flag on the
+ * device: the sequence can be captured into a hipGraph and replayed, and a replay is exact for any query, whatever rung it needs.
+ * What is decided on the HOST, per call, is only which of two exact sequences is issued — the filter stream first, or (an index
+ * whose certificates fail often: the ladder feedback, read from counters the device mirrors into pinned memory; never a
+ * synchronisation) the bounded pass directly, and how deep the batched pass aims.  A captured graph therefore FREEZES the sequence
+ * chosen at capture: it stays exact, but it no longer adapts — capture with option "ladder_feedback" = 0 (always the filter stream
+ * first) or = 2 (always the bounded pass directly) to choose it explicitly, or re-capture now and then.
+ * (Workspaces and the filter shadows of the current rows are prepared by create / add / load / reserve / set_option, which
+ * synchronise; a caller searching on its own stream must have that stream idle before it mutates the index.  B > 256 in one call
+ * grows the workspaces once.) */
 int dawn_index_search_device(dawn_index *idx, const float *d_queries, size_t B, size_t count,
                              uint64_t *d_labels, float *d_distances, uint32_t *d_found, void *stream);
 /* Stable G-way merge of per-shard results (each ascending by (distance, shard-local order)) —

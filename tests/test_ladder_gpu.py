@@ -230,7 +230,7 @@ def test_ladder_feedback_demotes_and_recovers(dawn, oracle):
     _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(*grown, Qbad[0], 10, threads=8))
     st2 = idx.stats()
     assert st2["packed_failures"] == 32 and st2["demoted"] == 65, st2
-    idx.set_option("i6_refine", 8)
+    idx.set_option("i6_shadow", 1)  # (an option that re-prepares the searches)
     _same(*idx.search(Qbad[0], 10), *oracle.scan_topk(*grown, Qbad[0], 10, threads=8))
     st2 = idx.stats()
     assert st2["packed_failures"] == 33 and st2["demoted"] == 65, st2
@@ -278,29 +278,36 @@ def test_bounded_pass_notices_an_impossible_threshold(dawn, oracle):
 
 def test_batch_feedback_deepens_the_thresholds_of_a_ladder_heavy_index(dawn, oracle):
     """Batches on topical rows whose queries sit in the largest clusters end in the ladder often; after one window of 1024 batched
-    queries above 10 % the index's batches aim four times as deep ("mfma_target" 4096 instead of 1024) — fewer of them reach the
-    ladder, the answers stay the oracle's; an index of well-spread rows never deepens; "ladder_feedback" = 0 switches it off."""
+    queries above 10 % the index's batches TRY four times as deep ("mfma_target" 4096 instead of 1024) for a window, and keep that
+    depth only if it saves the ladder a whole stream of its wide form (64 flagged queries per stream: ceil(flagged / 64) per batch);
+    the answers stay the oracle's; an index of well-spread rows never deepens; "ladder_feedback" = 0 switches it off."""
+    import math
     n = 400_000
     idx = _topical_index(dawn, n, 4, packed=False)
     Q = np.concatenate([_topical_queries(4, 192, clusters={0, 1, 2}), _topical_queries(4, 64)])
     want = oracle.scan_topk_synth(1, 0, n, 1, Q[::16], 10, dist=4)
     rates = []
-    for it in range(8):
+    for it in range(12):
         s0 = idx.stats()
         lab, dist, found = idx.search_batch(Q, 10)
         s1 = idx.stats()
         rates.append((s1["bounded"] - s0["bounded"]) / 256.0)
         for j, b in enumerate(range(0, 256, 16)):
             _same(lab[b], dist[b], want[0][j], want[1][j])
-    fbk = idx.stats_batch_feedback()
+        if it == 7:
+            fbk = idx.stats_batch_feedback()
+            assert fbk["deepened_batches"] == 4, (fbk, rates)  # batches 5 .. 8: the trial window behind the first window of 4 x 256 queries
     assert rates[0] > 0.10, rates                     # (the premise: this index is ladder-heavy)
-    assert fbk["deepened_batches"] == 4, (fbk, rates)  # batches 5 .. 8, after the window of 4 x 256 queries
-    assert min(rates[4:]) <= max(rates[:4]), rates
+    assert min(rates[4:8]) <= max(rates[:4]), rates
+    streams = lambda r: math.ceil(sum(r) / len(r) * 256 / 64.0 - 0.02)
+    kept = streams(rates[4:8]) < streams(rates[:4])
+    assert idx.stats_batch_feedback()["deepened_batches"] == (8 if kept else 4), (rates, kept)
     assert idx.stats()["fallbacks"] == 0
+    deep_now = idx.stats_batch_feedback()["deepened_batches"]
     idx.set_option("ladder_feedback", 0)
     for _ in range(6):
         idx.search_batch(Q, 10)
-    assert idx.stats_batch_feedback()["deepened_batches"] == 4
+    assert idx.stats_batch_feedback()["deepened_batches"] == deep_now
     flat = dawn.VectorIndex(0)
     flat.fill_synthetic(1, 0, 300_000, 1)
     Qf = synth.unit_rows(2, 0, 256)
@@ -391,3 +398,48 @@ def test_seeded_bounded_pass_on_topical_rows(dawn, oracle, dist):
             _same(*idx.search(q, k), want[0][b], want[1][b])
     st = idx.stats()
     assert st["fallbacks"] == 0 and st["bounded"] == 24 and st["demoted"] == 24, st
+
+
+@pytest.mark.parametrize("feedback", [0, 1, 2])
+def test_search_captured_into_a_hipgraph_on_a_topical_index(dawn, oracle, feedback):
+    """dawn_index_search_device is launches only, every rung of the ladder predicated on the device: captured into a hipGraph and
+    replayed 200 times with changing queries (certifying ones and ones that need the bounded pass), every replay returns the
+    oracle's bits.  The host's only decision — filter stream first, or the bounded pass directly — is frozen at capture
+    (include/dawn_hip.h): with "ladder_feedback" = 0 / 2 it is chosen explicitly, with 1 it is whatever the feedback said then;
+    dawn_index_stats_ladder shows which rungs ran."""
+    import torch
+    n = 200_000
+    idx = _topical_index(dawn, n, 4)
+    idx.set_option("i6_scan_blocks", 4)  # (lists as short of this index's clusters as the full grid is of a 100 M-row index's)
+    idx.set_option("i6_refine", 8)
+    idx.set_option("ladder_feedback", feedback)
+    Q = np.concatenate([_topical_queries(4, 6, clusters={0, 1, 2}), _topical_queries(4, 6), synth.unit_rows(2, 0, 4)])
+    k = 10
+    want = oracle.scan_topk_synth(1, 0, n, 1, Q, k, dist=4)
+    dev = torch.device("cuda", 0)
+    d_q = torch.zeros((384,), dtype=torch.float32, device=dev)
+    blob = torch.zeros((dawn.result_blob_bytes(1, k),), dtype=torch.uint8, device=dev)
+    p = blob.data_ptr()
+    side = torch.cuda.Stream(device=dev)
+    d_q.copy_(torch.from_numpy(Q[0]))
+    with torch.cuda.stream(side):  # warm-up on the capture stream
+        idx.search_device(d_q.data_ptr(), 1, k, p, p + k * 8, p + k * 12, side.cuda_stream)
+    side.synchronize()
+    s0 = idx.stats()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        idx.search_device(d_q.data_ptr(), 1, k, p, p + k * 8, p + k * 12, torch.cuda.current_stream().cuda_stream)
+    for it in range(200):
+        b = it % len(Q)
+        d_q.copy_(torch.from_numpy(Q[b]))
+        g.replay()
+        torch.cuda.synchronize()
+        raw = blob.cpu().numpy()
+        lab = raw[:k * 8].view(np.uint64)
+        dist = raw[k * 8:k * 12].view(np.float32)
+        _same(lab, dist, want[0][b], want[1][b])
+    s1 = idx.stats()
+    assert s1["fallbacks"] == s0["fallbacks"]
+    assert s1["bounded"] - s0["bounded"] >= (200 if feedback == 2 else 40), (s0, s1)  # the ladder's rungs ran inside the replays
+    if feedback == 0:
+        assert s1["packed_failures"] - s0["packed_failures"] >= 40
