@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
                                                     int T, const float* __restrict__ g,
                                                     const float* __restrict__ b, float eps,
                                                     float* __restrict__ out, uint16_t* __restrict__ outp,
-                                                    size_t plane_stride) {
+                                                    size_t plane_stride, int a_parts, size_t a_part_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -134,7 +134,13 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int d = lane + 64 * i;
-        v[i] = a[(size_t)t * H + d] + r[(size_t)t * H + d];
+        float av = a[(size_t)t * H + d];
+        if (a_parts == 4) {  // (a split-K producer's partial sums, in order; all requested up front)
+            const float p1 = a[a_part_stride + (size_t)t * H + d], p2 = a[2 * a_part_stride + (size_t)t * H + d],
+                        p3 = a[3 * a_part_stride + (size_t)t * H + d];
+            av = ((av + p1) + p2) + p3;
+        }
+        v[i] = av + r[(size_t)t * H + d];
     }
     row_layer_norm(v, g, b, eps, lane, out + (size_t)t * H, outp, plane_stride, (size_t)t);
 }
@@ -264,12 +270,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 float* __restrict__ Y, int M, int N, int K) {
+    // gridDim.z > 1: split K — block z takes K / gridDim.z values of k and writes its partial sums to Y + z M N (the bias goes
+    // with z = 0, no activation); the consumer adds the parts up in order (launch_gemm_ln_nt / launch_add_ln*: a_parts).  The
+    // FFN-down layer of a one-text forward (K = 1536) took 7.6 us as 24 workgroups of 16 waves; as 4 x 24 of 8 it is a 4.8-us launch
+    // like the K = 384 layers.
     extern __shared__ __attribute__((aligned(16))) float part[];  // [NWV][4][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const int r = lane & 15, kq = lane >> 4;
-    const int kw = K / NWV;
-    const int k_begin = wave * kw;
+    const int kz = K / gridDim.z;
+    const int kw = kz / NWV;
+    const int k_begin = blockIdx.z * kz + wave * kw;
     constexpr int MAXS = 6;
     const int steps = kw / 16;
     f32x4 av[MAXS], bv[MAXS];
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
         for (int w = 1; w < NWV; ++w) sum += part[(w * 4 + e) * 64 + l];
         const int row = m0 + 4 * (l >> 4) + e;
         const int n = n0 + (l & 15);
-        if (row < M) Y[(size_t)row * N + n] = act_apply(sum + bias[n], ACT);
+        if (row < M) Y[blockIdx.z * (size_t)M * N + (size_t)row * N + n] = act_apply(blockIdx.z == 0 ? sum + bias[n] : sum, ACT);
     }
 }
 
@@ -315,12 +326,13 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
 // dependent launches of a one-text forward (model.rs:374-379, 458-463 + :86-104 arithmetic: mean = sum / H; xc = x - mean;
 // var = sum xc^2 / H; xc / sqrt(var + eps) * gamma + beta — the sums run over the block's lanes and waves in a fixed
 // order of their own, f32 throughout).
-template <int ACT>
+template <int ACT, int PARTS>
 __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __restrict__ Aa, const float* __restrict__ Ar,
                                                               const float* __restrict__ gam, const float* __restrict__ bet,
                                                               float eps, float* __restrict__ Xout,
                                                               const float* __restrict__ W, const float* __restrict__ bias,
-                                                              float* __restrict__ Y, int M, int N) {
+                                                              float* __restrict__ Y, int M, int N, size_t a_part_stride) {
+    // PARTS > 1: `a` is a split-K producer's partial sums, PARTS arrays a_part_stride apart, added up in order (all requested up front)
     constexpr int NWV = 8, K = H, STEPS = K / NWV / 16;  // 48 k-values per wave and row: 3 steps of 16
     __shared__ __attribute__((aligned(16))) float part[NWV * 4 * 64];
     __shared__ float red[NWV][16];
@@ -334,8 +346,15 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const size_t o = (size_t)(m0 + r) * K + k_begin + 16 * st;
-        av[st] = a_ok ? *reinterpret_cast<const f32x4*>(Aa + o) + *reinterpret_cast<const f32x4*>(Ar + o)
-                      : f32x4{0.f, 0.f, 0.f, 0.f};
+        const size_t oc = a_ok ? o : (size_t)(k_begin + 16 * st);  // (rows past M: row 0, discarded)
+        f32x4 ap[PARTS];
+#pragma unroll
+        for (int z = 0; z < PARTS; ++z) ap[z] = *reinterpret_cast<const f32x4*>(Aa + z * a_part_stride + oc);
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(Ar + oc);
+        f32x4 asum = ap[0];
+#pragma unroll
+        for (int z = 1; z < PARTS; ++z) asum = asum + ap[z];
+        av[st] = a_ok ? asum + rr : f32x4{0.f, 0.f, 0.f, 0.f};
         bv[st] = *reinterpret_cast<const f32x4*>(wrow + 16 * st);
     }
     // row statistics: this lane holds 12 of row r's 384 values; lanes r, r+16, r+32, r+48 of the 8 waves hold the rest
@@ -394,23 +413,30 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
 // Y = act(LN(a + r) . W^T + bias), x_out = LN(a + r); false: this shape does not take the fused form (the caller then
 // runs add_ln + gemm)
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
-                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s, int skinny_max_m) {
+                       const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s, int skinny_max_m,
+                       int a_parts, size_t a_part_stride) {
     if (M <= 0) return true;
     // measured (tools/embed_latency.py, device-resident loop): 12 tokens 0.170 -> 0.164 ms, 27 tokens 0.194 -> 0.189 ms per
     // forward; at 128 tokens the N/16 blocks of a strip each redoing its statistics cost more than the launch saves
     // (0.290 -> 0.310 ms): fused up to 64 rows only
     if (K != H || M > 64 || M > skinny_max_m || N % 16 != 0) return false;
     dim3 grid(N / 16, (M + 15) / 16), block(512);
-    if (act == 1) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<1>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
-    else if (act == 2) hipLaunchKernelGGL(gemm_skinny16_ln_kernel<2>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
-    else hipLaunchKernelGGL(gemm_skinny16_ln_kernel<0>, grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N);
+    if (a_parts != 1 && a_parts != 4) return false;
+#define DAWN_SKINNY_LN(ACT_, PARTS_) \
+    hipLaunchKernelGGL((gemm_skinny16_ln_kernel<ACT_, PARTS_>), grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N, a_part_stride)
+    if (a_parts == 4) {
+        if (act == 1) DAWN_SKINNY_LN(1, 4); else if (act == 2) DAWN_SKINNY_LN(2, 4); else DAWN_SKINNY_LN(0, 4);
+    } else {
+        if (act == 1) DAWN_SKINNY_LN(1, 1); else if (act == 2) DAWN_SKINNY_LN(2, 1); else DAWN_SKINNY_LN(0, 1);
+    }
+#undef DAWN_SKINNY_LN
     return true;
 }
 
 template <int NWV>
 static void launch_skinny16(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                            hipStream_t s) {
-    dim3 grid(N / 16, (M + 15) / 16), block(NWV * 64);
+                            hipStream_t s, int splits = 1) {
+    dim3 grid(N / 16, (M + 15) / 16, splits), block(NWV * 64);
     const size_t lds = (size_t)NWV * 4 * 64 * sizeof(float);
     if (act == 1) hipLaunchKernelGGL((gemm_skinny16_kernel<1, NWV>), grid, block, lds, s, A, W, bias, Y, M, N, K);
     else if (act == 2) hipLaunchKernelGGL((gemm_skinny16_kernel<2, NWV>), grid, block, lds, s, A, W, bias, Y, M, N, K);
@@ -418,10 +444,11 @@ static void launch_skinny16(const float* A, const float* W, const float* bias, f
 }
 
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                    hipStream_t s, bool tile_only, int skinny_max_m) {
+                    hipStream_t s, bool tile_only, int skinny_max_m, int splits) {
     if (M <= 0) return;
     if (!tile_only && M <= skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
         if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
+        if (K == 1536 && splits == 4 && act == 0) return launch_skinny16<8>(A, W, bias, Y, M, N, K, 0, s, 4);  // 4 parts at Y + z M N
         if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
     }
     const int n_tiles = (N / GT) * ((M + GT - 1) / GT);
@@ -804,6 +831,92 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE TEXT (round 5): attention of sequences of up to 32 tokens in REGISTERS — one wave per (head, sequence), no LDS, no barrier.
+// model.rs:325-347: softmax(Q K^T / sqrt(32)) V.  The block kernel above spends 7.3 us on one 27-token text (twelve workgroups, three
+// barrier-separated phases through LDS) next to dense layers of 4.7 us.  Here both products run TRANSPOSED so that nothing has to change
+// lanes in between:
+//   S^T = K Q^T   (v_mfma_f32_32x32x2_f32; accumulator: lane = QUERY ROW (+ 32: the other half of the keys), registers = 16 keys)
+//   softmax over a row's keys = over the lane's 16 registers + one exchange with lane ^ 32
+//   O^T = V^T P^T (the MFMA's k index is summed over: step e feeds key kappa(e, lane >> 5) = 8 (e >> 2) + (e & 3) + 4 (lane >> 5) — the
+//                  key whose probability the lane holds in register e; the V fragment is loaded from global memory in that order)
+// and a lane ends up with 16 context values of ITS row in four runs of four consecutive dimensions: four 16-B stores.
+// (Also built and dropped: this + the attention-output dense layer in one launch, wave = head, the dense layer's K slice = the head's
+// dimensions, twelve partial tiles summed through LDS — correct, and exactly as long as the two launches it replaced, 12.2 us: the
+// workgroup's 576 f32 MFMAs of 64 cycles share one CU's four matrix pipes, 3.8 us that twelve CUs otherwise do side by side.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attention_regs_kernel(const float* __restrict__ qkv /*[T][1152]*/, const int* __restrict__ seq_offsets,
+                                                            float* __restrict__ ctx /*[T][384]*/) {
+    const int lane = threadIdx.x;
+    const int c = lane & 31, hh = lane >> 5;
+    const int w = blockIdx.x, b = blockIdx.y;  // head, sequence
+    const int start = seq_offsets[b];
+    const int S = seq_offsets[b + 1] - start;  // <= 32 (the launcher's condition)
+    // row c of Q and of K (clamped: rows past the sequence are masked below), elements 2 kk + hh
+    float qb[16], ka[16];
+    {
+        const float* qr = qkv + (size_t)(start + (c < S ? c : 0)) * (3 * H) + w * DH;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 tq = *reinterpret_cast<const f32x4*>(qr + 4 * j);
+            const f32x4 tk = *reinterpret_cast<const f32x4*>(qr + H + 4 * j);
+            qb[2 * j] = hh ? tq[1] : tq[0];
+            qb[2 * j + 1] = hh ? tq[3] : tq[2];
+            ka[2 * j] = hh ? tk[1] : tk[0];
+            ka[2 * j + 1] = hh ? tk[3] : tk[2];
+        }
+    }
+    float va[16];  // V^T fragment of step e: V[key kappa(e, hh)][dim c]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int key = 8 * (e >> 2) + (e & 3) + 4 * hh;
+        va[e] = qkv[(size_t)(start + (key < S ? key : 0)) * (3 * H) + 2 * H + w * DH + c];
+    }
+    // S^T[key][row]: A = K (m = key), B = Q (n = row)
+    f32x16 st, st1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = st1[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk], qb[kk], st, 0, 0, 0);
+        st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk + 1], qb[kk + 1], st1, 0, 0, 0);
+    }
+    const float inv_scale = (float)(1.0 / 5.656854249492381);  // 1/sqrt(32) as f32 (affine(1/rhs, 0))
+    float p[16];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int key = 8 * (e >> 2) + (e & 3) + 4 * hh;
+        p[e] = key < S ? (st[e] + st1[e]) * inv_scale : -__builtin_inff();
+        mx = fmaxf(mx, p[e]);
+    }
+    mx = fmaxf(mx, lane_xor_f32<32>(mx, lane));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        p[e] = __expf(p[e] - mx);  // exp(-inf) = 0 for the masked keys
+        sum += p[e];
+    }
+    sum += lane_xor_f32<32>(sum, lane);
+    // O^T[dim][row]: A = V^T (m = dim, k = key kappa(e, .)), B = P^T (n = row)
+    f32x16 o, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = o1[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], p[e], o, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e + 1], p[e + 1], o1, 0, 0, 0);
+    }
+    // register e = context[row c][dim kappa(e, hh)]: dims 4 hh + 8 j + {0, 1, 2, 3}
+    if (c < S) {
+        float* dst = ctx + (size_t)(start + c) * H + w * DH + 4 * hh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(dst + 8 * j) = f32x4{(o[4 * j] + o1[4 * j]) / sum, (o[4 * j + 1] + o1[4 * j + 1]) / sum,
+                                                            (o[4 * j + 2] + o1[4 * j + 2]) / sum, (o[4 * j + 3] + o1[4 * j + 3]) / sum};
+    }
+}
+
 // Long sequences (max_len > 64: pages): one THREAD per query row, two passes over the keys (max, then exp/sum/PV);
 // K and V unpadded in LDS (every thread reads the same key row: broadcasts).  At S = 128 this keeps two full waves
 // busy per block; up to 64 tokens the three-phase kernel above is used.
@@ -888,7 +1001,7 @@ __global__ __launch_bounds__(384) void pool_norm_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void add_ln_pool_norm_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                                 const int* __restrict__ seq_offsets, const float* __restrict__ g,
                                                                 const float* __restrict__ bta, float eps, float* __restrict__ x,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, int a_parts, size_t a_part_stride) {
     __shared__ float red[6];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = seq_offsets[b];
@@ -899,7 +1012,12 @@ __global__ __launch_bounds__(1024) void add_ln_pool_norm_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int d = lane + 64 * j;
-            v[j] = a[t * H + d] + r[t * H + d];
+            float av = a[t * H + d];
+            if (a_parts == 4) {  // (all requested up front)
+                const float p1 = a[a_part_stride + t * H + d], p2 = a[2 * a_part_stride + t * H + d], p3 = a[3 * a_part_stride + t * H + d];
+                av = ((av + p1) + p2) + p3;
+            }
+            v[j] = av + r[t * H + d];
         }
         row_layer_norm(v, g, bta, eps, lane, x + t * H);
     }
@@ -929,18 +1047,19 @@ void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float
 }
 
 void launch_add_ln_pool_norm(const float* a, const float* r, const int* seq_offsets, int B, const float* g, const float* b,
-                             float eps, float* x, float* out, hipStream_t s) {
+                             float eps, float* x, float* out, hipStream_t s, int a_parts, size_t a_part_stride) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(add_ln_pool_norm_kernel, dim3(B), dim3(1024), 0, s, a, r, seq_offsets, g, b, eps, x, out);
+    hipLaunchKernelGGL(add_ln_pool_norm_kernel, dim3(B), dim3(1024), 0, s, a, r, seq_offsets, g, b, eps, x, out, a_parts, a_part_stride);
 }
 
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
-                   hipStream_t s, uint16_t* outp, size_t plane_stride) {
+                   hipStream_t s, uint16_t* outp, size_t plane_stride, int a_parts, size_t a_part_stride) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride);
+    hipLaunchKernelGGL(add_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, r, T, g, b, eps, out, outp, plane_stride, a_parts, a_part_stride);
 }
 
-// attn_wave (embedder option "attention_wave"): 1 = sequences of up to 64 tokens always take attention_wave_kernel (0: only with planes
+// attn_wave (embedder option "attention_wave"): 2 = sequences of up to 32 tokens take the three-phase block kernel instead of the register
+// form (A/B, tests); 1 = sequences of up to 64 tokens always take attention_wave_kernel (0: only with planes
 // — for ONE text the block kernel is as fast: 12 tokens 0.160 vs 0.173 ms per forward, 27 tokens 0.184 vs 0.181)
 bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_len, float* ctx, hipStream_t s, uint16_t* ctxp,
                       size_t plane_stride, int attn_wave) {
@@ -963,7 +1082,8 @@ bool launch_attention(const float* qkv, const int* seq_offsets, int B, int max_l
             hipLaunchKernelGGL(attention_wave_kernel<2>, dim3(NH, (2 * B + 3) / 4), dim3(256), 0, s, qkv, seq_offsets, B, ctx, ctxp, plane_stride);
         return ctxp != nullptr;
     }
-    if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
+    if (max_len <= 32 && attn_wave != 2) hipLaunchKernelGGL(attention_regs_kernel, dim3(NH, B), dim3(64), 0, s, qkv, seq_offsets, ctx);
+    else if (max_len <= 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3(NH, B), dim3(256), 0, s, qkv, seq_offsets, ctx);
     return false;
 }

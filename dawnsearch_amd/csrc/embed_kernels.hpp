@@ -14,18 +14,19 @@ void launch_embed_ln(const uint32_t* ids, const int* tok_pos, int T, const float
                      uint16_t* xp = nullptr, size_t plane_stride = 0, const int* seq_offsets = nullptr, int B = 0);
 // x = LayerNorm(a + r) and out[b] = normalise(mean over the tokens of sequence b of x) in one launch (a block per sequence)
 void launch_add_ln_pool_norm(const float* a, const float* r, const int* seq_offsets, int B, const float* g, const float* b,
-                             float eps, float* x, float* out, hipStream_t s);
+                             float eps, float* x, float* out, hipStream_t s, int a_parts = 1, size_t a_part_stride = 0);
 void launch_add_ln(const float* a, const float* r, int T, const float* g, const float* b, float eps, float* out,
-                   hipStream_t s, uint16_t* outp = nullptr, size_t plane_stride = 0);
+                   hipStream_t s, uint16_t* outp = nullptr, size_t plane_stride = 0, int a_parts = 1, size_t a_part_stride = 0);
 // Y[M,N] = X[M,K]·W[N,K]^T + bias ; act: 0 none, 1 tanh-GELU, 2 ReLU.  N % 64 == 0, K % 32 == 0.  tile_only: never the
 // split-K latency form (test / timing hooks ask for the 64x64 tile kernel whatever M is)
 void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                    hipStream_t s, bool tile_only = false, int skinny_max_m = kSkinnyMaxM);
+                    hipStream_t s, bool tile_only = false, int skinny_max_m = kSkinnyMaxM, int splits = 1);
+// (splits = 4, K = 1536, act = 0, latency form only: four partial sums at Y + z M N, to be added up by the consumer — a_parts below)
 // Y = act(LN(a + r) . W^T + bias) and x_out = LN(a + r) in ONE launch (latency form: M <= skinny limit, K = 384); false =
 // not applicable to this shape
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s,
-                       int skinny_max_m = kSkinnyMaxM);
+                       int skinny_max_m = kSkinnyMaxM, int a_parts = 1, size_t a_part_stride = 0);
 // Planes (embed_gemm3.hip) are K-BLOCKED: element (row, k) of one plane of a [rows_alloc x width] operand sits at
 // ((k / 32) * rows_alloc + row) * 32 + k % 32 — the 32 values of k that one K-step of the dense kernels consumes are 64
 // contiguous bytes, and the rows of a tile follow each other: a tile's K-step slice of a plane is ONE contiguous run (8 KiB

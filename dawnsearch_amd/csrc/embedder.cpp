@@ -67,6 +67,7 @@ struct dawn_embedder {
     int skinny_max_m = dawn::kSkinnyMaxM;  // option "skinny_max_rows": tokens up to which the GEMMs take the split-K latency form
     int attn_wave = 0;                     // option "attention_wave"
     dawn::Gemm3Opts g3{};                  // options "gemm3_*"
+    int ffn2_split = 1;                    // option "ffn2_split": one text — the FFN-down layer as four K-slices (partials summed by the next LayerNorm)
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
@@ -119,7 +120,7 @@ int ensure_ws(dawn_embedder* e, int T, int B) {
         DAWN_HIP_TRY(hipMalloc((void**)&e->qkv, cap * 3 * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->tmp, cap * H * 4));
-        DAWN_HIP_TRY(hipMalloc((void**)&e->tmp2, cap * H * 4));
+        DAWN_HIP_TRY(hipMalloc((void**)&e->tmp2, 4 * cap * H * 4));  // (up to four split-K partial sums of the FFN-down layer)
         DAWN_HIP_TRY(hipMalloc((void**)&e->attn, cap * H * 4));
         DAWN_HIP_TRY(hipMalloc((void**)&e->ff, cap * I * 4));
         if (cap > e->skinny_max_m) {  // planes are only used by the tile path
@@ -184,11 +185,14 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
     // layer that consumes them (launch_gemm_ln_nt) — `pending` = the output LayerNorm of the previous layer not applied
     // yet: x = LN(tmp2 + attn) is produced by this layer's Q|K|V launch.
     const LayerW* pending = nullptr;
+    // one text: the FFN-down layer (K = 1536) as four K-slices whose partial sums the next LayerNorm adds up (option "ffn2_split")
+    const int parts = (e->ffn2_split && T <= 64 && T <= e->skinny_max_m) ? 4 : 1;
+    const size_t part_stride = (size_t)T * H;
     for (const LayerW& L : e->layers) {  // BertLayer::forward model.rs:487-498
         // :327-329 (Q|K|V fused)
         if (!(pending && dawn::launch_gemm_ln_nt(e->tmp2, e->attn, pending->o_g, pending->o_beta, eps, e->x, L.qkv_w, L.qkv_b,
-                                                 e->qkv, T, 3 * H, H, 0, s, e->skinny_max_m))) {
-            if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
+                                                 e->qkv, T, 3 * H, H, 0, s, e->skinny_max_m, parts, part_stride))) {
+            if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s, nullptr, 0, parts, part_stride);
             dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s, false, e->skinny_max_m);
         }
         dawn::launch_attention(e->qkv, d_off, B, max_len, e->ctx, s, nullptr, 0, e->attn_wave);                      // :331-346
@@ -198,14 +202,14 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
             dawn::launch_add_ln(e->tmp, e->x, T, L.ao_g, L.ao_beta, eps, e->attn, s);
             dawn::launch_gemm_nt(e->attn, L.i_w, L.i_b, e->ff, T, I, H, c.act, s, false, e->skinny_max_m);
         }
-        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s, false, e->skinny_max_m);                 // :460
+        dawn::launch_gemm_nt(e->ff, L.o_w, L.o_b, e->tmp2, T, H, I, 0, s, false, e->skinny_max_m, parts);          // :460
         pending = &L;                                                                      // :462 LayerNorm(dense + attn)
     }
     if (pending && d_pool_out && B <= 64) {  // (a block per sequence: few sequences only)
-        dawn::launch_add_ln_pool_norm(e->tmp2, e->attn, d_off, B, pending->o_g, pending->o_beta, eps, e->x, d_pool_out, s);
+        dawn::launch_add_ln_pool_norm(e->tmp2, e->attn, d_off, B, pending->o_g, pending->o_beta, eps, e->x, d_pool_out, s, parts, part_stride);
         return true;
     }
-    if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s);
+    if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s, nullptr, 0, parts, part_stride);
     return false;
 }
 
@@ -344,6 +348,11 @@ static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t 
         e->skinny_max_m = (int)value;
         return DAWN_OK;
     }
+    if (std::string(name) == "ffn2_split") {  // 0: the FFN-down layer of a one-text forward in one piece (A/B, tests)
+        e->ffn2_split = value != 0;
+        e->drop_graphs();
+        return DAWN_OK;
+    }
     if (std::string(name) == "gemm_bf16x3") {  // 0: batches use the f32-MFMA tile kernel instead of the bf16x3 kernels
         e->use_bf16x3 = value != 0;
         e->drop_graphs();
@@ -355,8 +364,9 @@ static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t 
         return DAWN_OK;
     }
     if (std::string(name) == "attention_wave") {  // sequences of up to 64 tokens: 1 = always the wave-per-sequence kernel (tuning)
-        if (value < 0 || value > 1) return fail(DAWN_ERR_INVALID_ARG, "attention_wave must be 0 or 1");
+        if (value < 0 || value > 2) return fail(DAWN_ERR_INVALID_ARG, "attention_wave must be 0, 1 or 2");
         e->attn_wave = (int)value;
+        e->drop_graphs();
         return DAWN_OK;
     }
     if (std::string(name) == "gemm3_persistent") {  // 128 x 128 kernel: blocks that walk the tile list (0 = a block per tile)

@@ -150,7 +150,10 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  * "gemm3_big_min_tiles" = number of 128 x 128 tiles from which that form is used, "gemm3_stages" = ring depth of its 64 x 64 form,
  * "gemm3_pingpong" 0 = the 128 x 128 form's waves in lockstep, "gemm3_persistent" = its workgroups (default 256, one per CU, walking
  * the tile list; 0 = one per tile)); "attention_wave" 1 = sequences of up to 64 tokens always take the wave-per-sequence
- * attention kernel (default 0: only where the dense layers read planes);
+ * attention kernel (default 0: only where the dense layers read planes), 2 = sequences of up to 32 tokens of a latency-form call take the
+ * three-phase block kernel instead of the register form (attention_regs_kernel: one wave per head, no LDS; one 27-token text 0.183 -> 0.169 ms);
+ * "ffn2_split" 0 = the FFN-down layer of a latency-form call (<= 64 tokens) in one piece (default 1: four K-slices, their partial sums added
+ * up by the next LayerNorm: 0.169 -> 0.158 ms);
  * "skinny_max_rows" = total tokens up to which the GEMMs use the split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
  * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
 
