@@ -910,7 +910,7 @@ void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* 
 }  // namespace dawn
 
 #ifdef DAWN_EXPERIMENTS
-extern "C" int dawn_debug_read_ts_i6(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int dawn_debug_read_ts_i6(unsigned long long* out, int n) {
     static unsigned long long h[2048 * 5];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_i6), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < n && i < 2048 * 5; ++i) out[i] = h[i];

@@ -1736,13 +1736,13 @@ void launch_scan_batched_i8(const void* d_x, int dtype, const void* d_i8, const 
 }  // namespace dawn
 
 #ifdef DAWN_EXPERIMENTS
-extern "C" int dawn_debug_read_ts_pass(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int dawn_debug_read_ts_pass(unsigned long long* out, int n) {
     unsigned long long h[1024];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_pass), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < n && i < 1024; ++i) out[i] = h[i];
     return 0;
 }
-extern "C" int dawn_debug_read_ts_i8(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int dawn_debug_read_ts_i8(unsigned long long* out, int n) {
     unsigned long long h[64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts_i8), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < n && i < 64; ++i) out[i] = h[i];

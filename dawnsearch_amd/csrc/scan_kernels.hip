@@ -991,7 +991,7 @@ void launch_iota_u64(uint64_t* d_out, uint64_t first, uint32_t n, hipStream_t st
 }  // namespace dawn
 
 #ifdef DAWN_EXPERIMENTS
-extern "C" int dawn_debug_read_ts(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int dawn_debug_read_ts(unsigned long long* out, int n) {
     unsigned long long h[16];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dawn_ts), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];

@@ -208,6 +208,40 @@ def test_wide_bounded_kernel_keeps_its_hand_counted_loads_safe(tmp_path):
     assert checked == 2  # f32 and bf16 rows
 
 
+def test_ladder_and_fp6_kernels_stay_out_of_scratch(tmp_path):
+    """Round-4 verdict: the ladder kernels were the first of the library with scratch, and nothing stopped the next edit from spilling into
+    a hot loop.  Guard on the shipped code objects (readelf notes): the kernels on the DEFAULT paths — the bounded pass of a single query
+    (int8 and packed shadows), its wide batch form, the FP6 first filter and its refine kernels — spill no VGPR; their private segment is
+    0, or the 16 bytes of the one out-of-line call they hold (block_exact_scan: the safety net behind an impossible threshold, never
+    taken by this library's producers).  The 16-query batch form (now only what the wide form leaves over) may spill a few VGPRs in its
+    prologue: bounded here so that it cannot grow unnoticed."""
+    import glob
+    import shutil
+    import subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "dawnsearch_amd", "libdawn_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(lib)):
+        pytest.skip("ROCm binutils or the built library not present")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    seen = {}
+    for f in glob.glob(str(tmp_path / "lib.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            if "scan_bounded" in name or "scan_f6" in name or "f6_refine" in name:
+                seen[name] = (int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)),
+                              int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    assert len(seen) >= 20, sorted(seen)
+    for name, (spill, priv) in seen.items():
+        if "scan_bounded_i8_multi_kernel" in name:
+            assert spill <= 32 and priv <= 160, (name, spill, priv)
+        elif "scan_bounded_i8_kernel" in name:
+            assert spill == 0 and priv <= 16, (name, spill, priv)
+        else:  # the wide form, the FP6 pass and its refine kernels
+            assert spill == 0 and priv == 0, (name, spill, priv)
+
+
 def test_release_library_holds_no_experiment_kernels(tmp_path):
     """The timing-experiment variants of the pipelined kernels (DBG != 0: parts switched off, wrong results by design) and
     the stamped diagnostic kernel only exist in `make EXPERIMENTS=1` builds (libdawn_hip_exp.so); the shipped library must
