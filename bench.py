@@ -611,6 +611,8 @@ def main():
         t0 = time.perf_counter()
         ix.fill_synthetic(1, 0, rows, 1)
         res = {"rows": rows, "fill_seconds": time.perf_counter() - t0}
+        if topical:
+            res["data"] = "synthetic topical mixture (DESIGN.md 5): a guess at page vectors, unvalidated against real embeddings"
         settle()  # (the previous leg's index was closed just before)
         qi = dawn.VectorIndex(local_rank)
         qi.set_option("synth_dist", dist_id)
