@@ -7,7 +7,7 @@ cd $R
 if [ "$1" != "noprofile" ]; then
 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
 fi
-python bench.py > gpurun_out/prof/bench_100M_n1.json 2> gpurun_out/bench_n1.err; tail -c 600 gpurun_out/prof/bench_100M_n1.json; echo
+python bench.py > gpurun_out/prof/bench_100M_n1.json 2> gpurun_out/bench_n1.err; cp bench_extra.json gpurun_out/prof/bench_extra.json; tail -c 600 gpurun_out/prof/bench_100M_n1.json; echo
 [ "$1" == "noprofile" ] && exit 0
 export TMPDIR=/tmp
 cd /tmp
