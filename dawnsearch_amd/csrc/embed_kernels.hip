@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
             const float p1 = a[a_part_stride + (size_t)t * H + d], p2 = a[2 * a_part_stride + (size_t)t * H + d],
                         p3 = a[3 * a_part_stride + (size_t)t * H + d];
             av = ((av + p1) + p2) + p3;
+        } else if (a_parts == 2) {
+            av += a[a_part_stride + (size_t)t * H + d];
         }
         v[i] = av + r[(size_t)t * H + d];
     }
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
                                                               const float* __restrict__ gam, const float* __restrict__ bet,
                                                               float eps, float* __restrict__ Xout,
                                                               const float* __restrict__ W, const float* __restrict__ bias,
-                                                              float* __restrict__ Y, int M, int N, size_t a_part_stride) {
-    // PARTS > 1: `a` is a split-K producer's partial sums, PARTS arrays a_part_stride apart, added up in order (all requested up front)
+                                                              float* __restrict__ Y, int M, int N, size_t a_part_stride, EmbSrc emb) {
+    // PARTS > 1: `a` is a split-K producer's partial sums, PARTS arrays a_part_stride apart, added up in order (all requested up front).
+    // PARTS == 0: the rows are BertEmbeddings (model.rs:266-281: word[ids] + type[0] + pos, the sum LayerNorm'ed with Aa / Ar unused) —
+    // the first layer's Q|K|V of a one-text forward takes the embedding launch with it
     constexpr int NWV = 8, K = H, STEPS = K / NWV / 16;  // 48 k-values per wave and row: 3 steps of 16
     __shared__ __attribute__((aligned(16))) float part[NWV * 4 * 64];
     __shared__ float red[NWV][16];
@@ -347,14 +351,25 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
     for (int st = 0; st < STEPS; ++st) {
         const size_t o = (size_t)(m0 + r) * K + k_begin + 16 * st;
         const size_t oc = a_ok ? o : (size_t)(k_begin + 16 * st);  // (rows past M: row 0, discarded)
-        f32x4 ap[PARTS];
+        if constexpr (PARTS == 0) {
+            const int t = a_ok ? m0 + r : 0;
+            int b = 0;
+            while (b + 1 < emb.B && emb.seq_offsets[b + 1] <= t) ++b;
+            const int kk = k_begin + 16 * st;
+            const f32x4 we = *reinterpret_cast<const f32x4*>(emb.word + (size_t)emb.ids[t] * K + kk);
+            const f32x4 ty = *reinterpret_cast<const f32x4*>(emb.type0 + kk);
+            const f32x4 pe = *reinterpret_cast<const f32x4*>(emb.pos + (size_t)(t - emb.seq_offsets[b]) * K + kk);
+            av[st] = a_ok ? (we + ty) + pe : f32x4{0.f, 0.f, 0.f, 0.f};  // model.rs:269-276 order
+        } else {
+            f32x4 ap[PARTS > 0 ? PARTS : 1];
 #pragma unroll
-        for (int z = 0; z < PARTS; ++z) ap[z] = *reinterpret_cast<const f32x4*>(Aa + z * a_part_stride + oc);
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(Ar + oc);
-        f32x4 asum = ap[0];
+            for (int z = 0; z < PARTS; ++z) ap[z] = *reinterpret_cast<const f32x4*>(Aa + z * a_part_stride + oc);
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(Ar + oc);
+            f32x4 asum = ap[0];
 #pragma unroll
-        for (int z = 1; z < PARTS; ++z) asum = asum + ap[z];
-        av[st] = a_ok ? asum + rr : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int z = 1; z < PARTS; ++z) asum = asum + ap[z];
+            av[st] = a_ok ? asum + rr : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         bv[st] = *reinterpret_cast<const f32x4*>(wrow + 16 * st);
     }
     // row statistics: this lane holds 12 of row r's 384 values; lanes r, r+16, r+32, r+48 of the 8 waves hold the rest
@@ -414,18 +429,24 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
 // runs add_ln + gemm)
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s, int skinny_max_m,
-                       int a_parts, size_t a_part_stride) {
+                       int a_parts, size_t a_part_stride, const EmbSrc* emb) {
     if (M <= 0) return true;
     // measured (tools/embed_latency.py, device-resident loop): 12 tokens 0.170 -> 0.164 ms, 27 tokens 0.194 -> 0.189 ms per
     // forward; at 128 tokens the N/16 blocks of a strip each redoing its statistics cost more than the launch saves
     // (0.290 -> 0.310 ms): fused up to 64 rows only
     if (K != H || M > 64 || M > skinny_max_m || N % 16 != 0) return false;
     dim3 grid(N / 16, (M + 15) / 16), block(512);
-    if (a_parts != 1 && a_parts != 4) return false;
+    if (a_parts != 1 && a_parts != 2 && a_parts != 4) return false;
+    const EmbSrc es = emb ? *emb : EmbSrc{};
 #define DAWN_SKINNY_LN(ACT_, PARTS_) \
-    hipLaunchKernelGGL((gemm_skinny16_ln_kernel<ACT_, PARTS_>), grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N, a_part_stride)
-    if (a_parts == 4) {
+    hipLaunchKernelGGL((gemm_skinny16_ln_kernel<ACT_, PARTS_>), grid, block, 0, s, a, r, g, b, eps, x_out, W, bias, Y, M, N, a_part_stride, es)
+    if (emb) {  // BertEmbeddings as the prologue (act 0: the first layer's Q|K|V)
+        if (act != 0 || emb->B > 16) return false;
+        DAWN_SKINNY_LN(0, 0);
+    } else if (a_parts == 4) {
         if (act == 1) DAWN_SKINNY_LN(1, 4); else if (act == 2) DAWN_SKINNY_LN(2, 4); else DAWN_SKINNY_LN(0, 4);
+    } else if (a_parts == 2) {
+        if (act == 1) DAWN_SKINNY_LN(1, 2); else if (act == 2) DAWN_SKINNY_LN(2, 2); else DAWN_SKINNY_LN(0, 2);
     } else {
         if (act == 1) DAWN_SKINNY_LN(1, 1); else if (act == 2) DAWN_SKINNY_LN(2, 1); else DAWN_SKINNY_LN(0, 1);
     }
@@ -448,7 +469,7 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
     if (M <= 0) return;
     if (!tile_only && M <= skinny_max_m && N % 16 == 0) {  // one text per call: latency form (16-row strips x split K)
         if (K == 384) return launch_skinny16<8>(A, W, bias, Y, M, N, K, act, s);
-        if (K == 1536 && splits == 4 && act == 0) return launch_skinny16<8>(A, W, bias, Y, M, N, K, 0, s, 4);  // 4 parts at Y + z M N
+        if (K == 1536 && (splits == 4 || splits == 2) && act == 0) return launch_skinny16<8>(A, W, bias, Y, M, N, K, 0, s, splits);  // parts at Y + z M N
         if (K == 1536) return launch_skinny16<16>(A, W, bias, Y, M, N, K, act, s);
     }
     const int n_tiles = (N / GT) * ((M + GT - 1) / GT);
@@ -1016,6 +1037,8 @@ __global__ __launch_bounds__(1024) void add_ln_pool_norm_kernel(const float* __r
             if (a_parts == 4) {  // (all requested up front)
                 const float p1 = a[a_part_stride + t * H + d], p2 = a[2 * a_part_stride + t * H + d], p3 = a[3 * a_part_stride + t * H + d];
                 av = ((av + p1) + p2) + p3;
+            } else if (a_parts == 2) {
+                av += a[a_part_stride + t * H + d];
             }
             v[j] = av + r[t * H + d];
         }

@@ -24,9 +24,18 @@ void launch_gemm_nt(const float* A, const float* W, const float* bias, float* Y,
 // (splits = 4, K = 1536, act = 0, latency form only: four partial sums at Y + z M N, to be added up by the consumer — a_parts below)
 // Y = act(LN(a + r) . W^T + bias) and x_out = LN(a + r) in ONE launch (latency form: M <= skinny limit, K = 384); false =
 // not applicable to this shape
+// emb != NULL: the rows are BertEmbeddings of the token ids (a, r unused; <= 16 sequences; act 0) — g / b the embeddings' LayerNorm
+struct EmbSrc {
+    const uint32_t* ids = nullptr;
+    const int* seq_offsets = nullptr;
+    int B = 0;
+    const float* word = nullptr;
+    const float* pos = nullptr;
+    const float* type0 = nullptr;
+};
 bool launch_gemm_ln_nt(const float* a, const float* r, const float* g, const float* b, float eps, float* x_out,
                        const float* W, const float* bias, float* Y, int M, int N, int K, int act, hipStream_t s,
-                       int skinny_max_m = kSkinnyMaxM, int a_parts = 1, size_t a_part_stride = 0);
+                       int skinny_max_m = kSkinnyMaxM, int a_parts = 1, size_t a_part_stride = 0, const EmbSrc* emb = nullptr);
 // Planes (embed_gemm3.hip) are K-BLOCKED: element (row, k) of one plane of a [rows_alloc x width] operand sits at
 // ((k / 32) * rows_alloc + row) * 32 + k % 32 — the 32 values of k that one K-step of the dense kernels consumes are 64
 // contiguous bytes, and the rows of a tile follow each other: a tile's K-step slice of a plane is ONE contiguous run (8 KiB

@@ -67,7 +67,8 @@ struct dawn_embedder {
     int skinny_max_m = dawn::kSkinnyMaxM;  // option "skinny_max_rows": tokens up to which the GEMMs take the split-K latency form
     int attn_wave = 0;                     // option "attention_wave"
     dawn::Gemm3Opts g3{};                  // options "gemm3_*"
-    int ffn2_split = 1;                    // option "ffn2_split": one text — the FFN-down layer as four K-slices (partials summed by the next LayerNorm)
+    int fused_embed = 1;                   // option "fused_embed": one text — BertEmbeddings as the prologue of the first Q|K|V launch
+    int ffn2_split = 4;                    // option "ffn2_split": one text — the FFN-down layer as 4 (or 2) K-slices (partials summed by the next LayerNorm); 0 / 1: whole
     uint32_t* d_ids = nullptr;
     int *d_off = nullptr, *d_pos = nullptr;
     float* d_out = nullptr;
@@ -180,17 +181,27 @@ bool encoder_forward(dawn_embedder* e, const uint32_t* d_ids, const int* d_off, 
         }
         return false;
     }
-    dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, nullptr, 0, d_off, B);
+    // one text (<= 64 tokens, <= 16 sequences): BertEmbeddings is the prologue of the first layer's Q|K|V (option "fused_embed")
+    bool emb_pending = e->fused_embed && T <= 64 && T <= e->skinny_max_m && B <= 16 && !e->layers.empty();
+    if (!emb_pending) dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, nullptr, 0, d_off, B);
     // Latency form (few tokens: the reference's one text per call): the residual LayerNorms run as the prologue of the dense
     // layer that consumes them (launch_gemm_ln_nt) — `pending` = the output LayerNorm of the previous layer not applied
     // yet: x = LN(tmp2 + attn) is produced by this layer's Q|K|V launch.
     const LayerW* pending = nullptr;
     // one text: the FFN-down layer (K = 1536) as four K-slices whose partial sums the next LayerNorm adds up (option "ffn2_split")
-    const int parts = (e->ffn2_split && T <= 64 && T <= e->skinny_max_m) ? 4 : 1;
+    const int parts = (e->ffn2_split && T <= 64 && T <= e->skinny_max_m) ? e->ffn2_split : 1;
     const size_t part_stride = (size_t)T * H;
     for (const LayerW& L : e->layers) {  // BertLayer::forward model.rs:487-498
         // :327-329 (Q|K|V fused)
-        if (!(pending && dawn::launch_gemm_ln_nt(e->tmp2, e->attn, pending->o_g, pending->o_beta, eps, e->x, L.qkv_w, L.qkv_b,
+        if (emb_pending) {
+            const dawn::EmbSrc es{d_ids, d_off, B, e->word, e->pos, e->type0};
+            emb_pending = false;
+            if (!dawn::launch_gemm_ln_nt(nullptr, nullptr, e->emb_g, e->emb_b, eps, e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s,
+                                         e->skinny_max_m, 1, 0, &es)) {
+                dawn::launch_embed_ln(d_ids, d_pos, T, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x, s, nullptr, 0, d_off, B);
+                dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s, false, e->skinny_max_m);
+            }
+        } else if (!(pending && dawn::launch_gemm_ln_nt(e->tmp2, e->attn, pending->o_g, pending->o_beta, eps, e->x, L.qkv_w, L.qkv_b,
                                                  e->qkv, T, 3 * H, H, 0, s, e->skinny_max_m, parts, part_stride))) {
             if (pending) dawn::launch_add_ln(e->tmp2, e->attn, T, pending->o_g, pending->o_beta, eps, e->x, s, nullptr, 0, parts, part_stride);
             dawn::launch_gemm_nt(e->x, L.qkv_w, L.qkv_b, e->qkv, T, 3 * H, H, 0, s, false, e->skinny_max_m);
@@ -348,8 +359,14 @@ static int embedder_set_option_impl(dawn_embedder* e, const char* name, int64_t 
         e->skinny_max_m = (int)value;
         return DAWN_OK;
     }
+    if (std::string(name) == "fused_embed") {  // 0: BertEmbeddings as a launch of its own (A/B, tests)
+        e->fused_embed = value != 0;
+        e->drop_graphs();
+        return DAWN_OK;
+    }
     if (std::string(name) == "ffn2_split") {  // 0: the FFN-down layer of a one-text forward in one piece (A/B, tests)
-        e->ffn2_split = value != 0;
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(DAWN_ERR_INVALID_ARG, "ffn2_split must be 0, 1, 2 or 4");
+        e->ffn2_split = value == 1 ? 4 : (int)value;  // (1: the default split)
         e->drop_graphs();
         return DAWN_OK;
     }

@@ -327,16 +327,17 @@ def test_register_attention_and_split_ffn_down_of_one_text(provider, oracle):
     """Round 5, one text per call (the reference's only call shape, embedding_service.rs:161-163): attention of sequences of up
     to 32 tokens in registers, one wave per head (attention_regs_kernel: both products transposed so that nothing changes lanes; option
     "attention_wave" = 2 brings the three-phase block kernel back), and the FFN-down layer as four K-slices whose partial sums the next
-    LayerNorm adds up (option "ffn2_split").  Every combination within the bar of the oracle, hidden states and embeddings, for every
+    LayerNorm adds up (option "ffn2_split"), BertEmbeddings as the prologue of the first layer's Q|K|V launch (option "fused_embed").  Every combination within the bar of the oracle, hidden states and embeddings, for every
     length 1 .. 32, a few texts per call, and 33 .. 64 tokens (two key tiles: the block kernel; still the split FFN-down)."""
     sb = oracle.SynthBert(3)
     cases = [synth.token_sequences(40 + n, 1, n, n) for n in (1, 2, 3, 7, 15, 16, 17, 27, 31, 32)]
     cases += [synth.token_sequences(61, 5, 2, 12), synth.token_sequences(62, 1, 33, 33), synth.token_sequences(63, 1, 64, 64),
               synth.token_sequences(64, 3, 20, 21)]
     base = None
-    for aw, split in ((0, 1), (2, 1), (0, 0), (2, 0)):
+    for aw, split, femb in ((0, 1, 1), (2, 1, 1), (0, 0, 0), (2, 0, 1), (0, 2, 0)):
         provider.set_option("attention_wave", aw)
         provider.set_option("ffn2_split", split)
+        provider.set_option("fused_embed", femb)
         try:
             got = []
             for seqs in cases:
@@ -353,6 +354,7 @@ def test_register_attention_and_split_ffn_down_of_one_text(provider, oracle):
         finally:
             provider.set_option("attention_wave", 0)
             provider.set_option("ffn2_split", 1)
+            provider.set_option("fused_embed", 1)
 
 
 def test_dense_kernel_forms_are_bit_identical(provider):

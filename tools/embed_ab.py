@@ -18,8 +18,10 @@ for rnd in range(2):
         d_off = torch.from_numpy(np.array([0, L], dtype=np.int32)).to(dev)
         d_out = torch.zeros((1, 384), dtype=torch.float32, device=dev)
         row = []
-        for name, opts in (("round 4", {"attention_wave": 2, "ffn2_split": 0}), ("register attention", {"attention_wave": 0, "ffn2_split": 0}),
-                           ("+ FFN-down split 4", {"attention_wave": 0, "ffn2_split": 1})):
+        for name, opts in (("round 4", {"attention_wave": 2, "ffn2_split": 0, "fused_embed": 0}),
+                           ("register attention", {"attention_wave": 0, "ffn2_split": 0, "fused_embed": 0}),
+                           ("+ FFN-down split 4", {"attention_wave": 0, "ffn2_split": 4, "fused_embed": 0}),
+                           ("+ embeddings in Q|K|V", {"attention_wave": 0, "ffn2_split": 4, "fused_embed": 1})):
             for o, v in opts.items():
                 ep.set_option(o, v)
             for _ in range(10):
