@@ -447,16 +447,23 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         // FP6 feedback (index_internal.hpp): does this index send too many of its FP6-filtered queries to the ladder?
         auto& fb = idx->f6fb;
         const volatile uint32_t* hs = reinterpret_cast<volatile uint32_t*>(idx->h_stats);
-        if (fb.suspend_left == 0 && fb.issued >= kF6FbWindow) {
+        // (a window of kF6FbWindow queries; or, from 256 queries on, as soon as MORE THAN HALF of them ended in the ladder — a topical
+        // index: an FP6-filtered batch there costs several times an int8-filtered one, the verdict need not wait for four of them)
+        if (fb.suspend_left == 0 && fb.issued >= 256) {
             const uint32_t now = hs[FLAG_BOUNDED] + hs[FLAG_FALLBACK];
-            if ((double)(now - fb.ladder0) > kF6FbSuspend * (double)fb.issued) {
+            const double in_ladder = (double)(now - fb.ladder0);
+            if (in_ladder > 0.5 * (double)fb.issued || (fb.issued >= kF6FbWindow && in_ladder > kF6FbSuspend * (double)fb.issued)) {
                 fb.suspend_left = fb.suspend_len;
                 fb.suspend_len = std::min(fb.suspend_len * 2u, kF6FbSuspendMax);
-            } else {
+                fb.issued = 0;
+            } else if (fb.issued >= kF6FbWindow) {
                 fb.suspend_len = kF6FbSuspendMin;
+                fb.issued = 0;
             }
-            fb.issued = 0;
         }
+        // ... and no probe while the int8 pass's own batches are ladder-heavy: the FP6 bound is the looser one by construction, it can
+        // only send more of a batch there (the batch feedback's last full window at its base depth, measured while this filter is suspended)
+        if (fb.suspend_left == 1 && idx->bfb.base_per_pass > kBatchFbBoost * (double)BATCH_QT) fb.suspend_left = fb.suspend_len;
         if (fb.suspend_left > 0) {
             --fb.suspend_left;
             ++idx->n_f6_suspended;

@@ -99,7 +99,7 @@ def test_100m_topical_batches_through_the_ladder_equal_the_exact_pass(dawn, topi
             lab, dist, _ = idx.search_batch(Q, k)
             assert np.array_equal(lab, first[0]) and np.array_equal(dist.view(np.uint32), first[1].view(np.uint32)), it
         f2 = idx.stats_batch_feedback()
-        assert f2["f6_batches"] >= 4 and f2["f6_suspended"] >= 1, f2
+        assert 1 <= f2["f6_batches"] <= 4 and f2["f6_suspended"] >= 2, f2  # (more than half of its first batch in the ladder: suspended at once)
     finally:
         idx.set_option("f6_shadow", 2)
     assert idx.stats()["fallbacks"] == s0["fallbacks"]

@@ -151,8 +151,8 @@ def test_f6_variants_answer_alike(dawn, oracle, opts):
 
 def test_f6_feedback_suspends_the_filter_where_it_loses(dawn, oracle):
     """An index whose FP6-filtered queries mostly end in the ladder (here: a threshold that is far too tight; in the field: topical
-    rows at 100 M) hands its batches back to the int8 pass after one window of 1024 queries, probes again later, and answers alike
-    throughout; with "ladder_feedback" = 0 it never does."""
+    rows at 100 M) hands its batches back to the int8 pass — after one window of 1024 queries above 30 %, or as soon as more than half of
+    at least 256 queries ended there —, probes again later, and answers alike throughout; with "ladder_feedback" = 0 it never does."""
     n = 120_000
     idx = _mk(dawn, n)
     idx.set_option("f6_target", 256)
@@ -166,8 +166,8 @@ def test_f6_feedback_suspends_the_filter_where_it_loses(dawn, oracle):
         lab, dist, _ = idx.search_batch(Q, 10)
         assert np.array_equal(lab, first[0]) and np.array_equal(dist.view(np.uint32), first[1].view(np.uint32))
     s = idx.stats_f6()
-    assert s["f6_batches"] >= 4 and s["f6_suspended"] >= 4 and s["f6_batches"] + s["f6_suspended"] == 10, s
-    assert idx.stats()["bounded"] >= 512
+    assert 1 <= s["f6_batches"] <= 4 and s["f6_suspended"] >= 4 and s["f6_batches"] + s["f6_suspended"] == 10, s
+    assert idx.stats()["bounded"] >= 128
     idx.set_option("ladder_feedback", 0)
     for _ in range(8):
         idx.search_batch(Q, 10)
