@@ -146,3 +146,5 @@ def test_wide_form_on_a_sharded_handle(dawn, oracle):
         _same(lab[b], dist[b], *oracle.scan_topk(x, ids, Q[b], 10))
     r = sh.stats_raw()
     assert r[0] == 140 and r[4] == 140 and r[1] == 0, r
+    fb = sh.stats_batch_feedback()  # (a sharded handle reports the sums over its shards: ADVICE r4)
+    assert fb["f6_batches"] == 0 and fb["deepened_batches"] == 0 and sh.stats_f6()["f6_suspended"] == 0
