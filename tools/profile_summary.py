@@ -90,5 +90,18 @@ def main():
         for k, v in groups.items():
             print(k, "launches", len(v), "mean HBM read bytes/launch", sum(v) / len(v))
 
+    if mode == "timeline":  # the kernels of the last `window_ms` of the trace, one line each (a batch's anatomy)
+        window_ns = float(sys.argv[4]) * 1e6 if len(sys.argv) > 4 else 60e6
+        ours = [d for d in disp if short(d["name"]) is not None]
+        t_end = max(d["end"] for d in ours)
+        last = [d for d in ours if d["start"] >= t_end - window_ns]
+        t0 = last[0]["start"]
+        with open(os.path.join(out, "timeline.txt"), "w") as f:
+            for d in last:
+                line = (f"{(d['start'] - t0) / 1e3:10.1f} us  +{(d['end'] - d['start']) / 1e3:9.1f} us  {short(d['name'])}  "
+                        f"grid={d.get('grid_x')} wg={d.get('workgroup_x')}")
+                print(line)
+                f.write(line + "\n")
+
 
 main()
