@@ -108,7 +108,9 @@ def short_line(full: dict) -> dict:
     }
     line["extra"] = {k: _r(v) for k, v in heads.items() if v is not None}
     if full.get("mfma_busy_frac"):
-        line["extra"]["batch256_mfma_busy_frac_pmc"] = _get(full, "mfma_busy_frac", "value")
+        line["extra"]["int8_pass_mfma_busy_frac_pmc"] = _get(full, "mfma_busy_frac", "value")
+        if _get(full, "mfma_busy_frac", "fp6_pass") is not None:
+            line["extra"]["fp6_pass_mfma_busy_frac_pmc"] = _get(full, "mfma_busy_frac", "fp6_pass")
     line["extra_file"] = os.path.basename(EXTRA_FILE)
     for k in ("value", "ms_per_step"):
         line[k] = _r(line[k], 6)
@@ -819,6 +821,7 @@ def main():
             if "mfma_busy_frac_12500000x256" in tj:
                 # matrix-pipe utilisation of the batched pass (north_star: "MFMA utilisation ... vs chip peak"): from the committed PMC run
                 out["mfma_busy_frac"] = {"value": tj["mfma_busy_frac_12500000x256"], "kernel": "scan_i8_pipe16_kernel<false>",
+                                         "fp6_pass": tj.get("mfma_busy_frac_12500000x256_f6"), "fp6_kernel": "scan_f6_pass_lds_kernel",
                                          "workload": "12.5 M rows x 256 queries", "source": tj.get("_note_mfma_busy")}
             if key in tj:
                 out["roofline"]["traffic"] = tj[key]
