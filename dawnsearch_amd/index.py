@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EM_LEN, MAX_K, check, lib
+from ._lib import EM_LEN, check, lib
 
 
 def _ptr(a: np.ndarray) -> C.c_void_p:

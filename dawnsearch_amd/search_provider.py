@@ -8,7 +8,7 @@ The Rust shim in INTEGRATION.md is this file written against `extern "C"`.
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 

@@ -12,7 +12,7 @@ single-index answer bit for bit.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

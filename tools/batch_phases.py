@@ -21,7 +21,6 @@ check(lib.dawn_index_debug_read_diag(idx._h, C.c_void_p(out.ctypes.data), 256))
 idx.set_option("mfma_sched", 0)
 names = ["wait loads + convert + issue", "barrier", "contract sub0", "epilogue sub0", "contract sub1", "epilogue sub1"]
 tiles = -(-rows // 64) / 256.0
-if mode == 4:
 tot = out[:, :, :6].sum(axis=2).mean()
 print(f"{dtype} rows={rows} B={B}: {tiles:.0f} tiles per workgroup, {tot / tiles:.0f} stamped cycles per tile per wave")
 for k, n in enumerate(names):

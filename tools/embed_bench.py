@@ -1,7 +1,6 @@
 """Embedder timing on the GPU box (dev tool): python tools/embed_bench.py"""
 import sys, os, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import dawnsearch_amd as dawn
 from dawnsearch_amd import synth
 

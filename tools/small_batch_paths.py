@@ -1,7 +1,6 @@
 """Dev tool: batches of 2..8 queries through the streaming filter vs the matrix-core path: python tools/small_batch_paths.py [rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import dawnsearch_amd as dawn
 from dawnsearch_amd import synth
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
