@@ -273,6 +273,25 @@ bool i6_shadow_sync(dawn_index* idx) {
     if (idx->i6_rows < idx->size) {
         dawn::launch_rows_to_i6s(idx->d_x, idx->dtype, idx->i6_bits, idx->d_i6, idx->d_i6meta, idx->i6_rows, idx->size, stream);
         idx->i6_rows = idx->size;
+        idx->i6_slack_dirty = true;
+    }
+    if (idx->i6_slack_dirty && idx->i6_slack_model) {
+        // what the conversion measured (E per sub-tile) sizes the waves' lists: 256 B back to the host, one wait per change of the shadow
+        uint32_t h[64] = {};
+        if ((idx->d_i6hist || hipMalloc((void**)&idx->d_i6hist, sizeof(h)) == hipSuccess)) {
+            dawn::launch_i6_slack_hist(idx->d_i6meta, (uint32_t)((idx->size + 31) / 32), idx->d_i6hist, stream);
+            if (hipMemcpyAsync(h, idx->d_i6hist, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                hipStreamSynchronize(stream) == hipSuccess) {
+                double total = 0.0;
+                for (uint32_t v : h) total += v;
+                if (total > 0.0) {
+                    for (int b = 0; b < 64; ++b) idx->i6_slack.frac[b] = (float)(h[b] / total);
+                    ++idx->i6_slack.version;
+                    idx->i6_slack_dirty = false;
+                }
+            }
+        }
+        (void)hipGetLastError();  // (a failure leaves the model on its constants)
     }
     return true;
 }
@@ -549,7 +568,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         }
     } else if (B == 1 && i6_live(idx) &&
                (idx->i6_geom().refine > 0 ||
-                i6_refine_count(n, (uint32_t)k, idx->i6_bits, idx->i6_geom().blocks * (idx->i6_geom().threads / 64)) > 0)) {
+                i6_refine_count(n, (uint32_t)k, idx->i6_bits, idx->i6_geom().blocks * (idx->i6_geom().threads / 64), idx->i6_slack_ptr()) > 0)) {
         // ladder feedback (index_internal.hpp): how often did the packed certificate fail lately?
         bool demoted = false;
         if (idx->ladder_feedback && idx->bounded_pass && !idx->force_fallback && idx->h_stats) {
@@ -588,6 +607,9 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
             const bool seed = p5 && seed_ok;
             if (seed) {
                 ScanGeom g6 = idx->i6_geom();
+                if (g6.refine == 0)
+                    g6.refine = std::max(0, i6_refine_count(n >> idx->bounded_seed_shift, (uint32_t)k, idx->i6_bits, g6.blocks * (g6.threads / 64),
+                                                            idx->i6_slack_ptr()));
                 launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids,
                                n >> idx->bounded_seed_shift, d_q, idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb,
                                idx->stream_dyn_tail ? idx->d_i6_pool : nullptr, g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
@@ -605,6 +627,7 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         // stream's epilogue, one merge + certificate (scan_i6.hip)
         ScanGeom g6 = idx->i6_geom();
         if (idx->fb.boosted && g6.refine == 0) g6.refine = LIST;
+        if (g6.refine == 0) g6.refine = i6_refine_count(n, (uint32_t)k, idx->i6_bits, g6.blocks * (g6.threads / 64), idx->i6_slack_ptr());
         launch_scan_i6(idx->d_i6, idx->d_i6meta, idx->i6_bits, idx->d_i8, idx->d_i8meta, idx->d_x, idx->dtype, idx->d_ids, n, d_q,
                        idx->d_cand_s, idx->d_cand_p, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->stream_dyn_tail ? idx->d_i6_pool : nullptr,
                        g6, (uint32_t)k, d_labels, d_dist, d_found, idx->d_flags,
@@ -713,7 +736,7 @@ void index_destroy_single(dawn_index* idx) {
     }
     for (hipEvent_t ev : idx->ev_slot)
         if (ev) (void)hipEventDestroy(ev);
-    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
+    void* ptrs[] = {idx->d_x, idx->d_shadow, idx->d_i8, idx->d_i8meta, idx->d_i6, idx->d_i6meta, idx->d_cand_es, idx->d_cand_ep, idx->d_cand_tb, idx->d_i6_pool, idx->d_i6hist, idx->d_stage, idx->d_ids, idx->d_cand_s, idx->d_cand_p,
                     idx->d_flags, idx->d_stats, idx->bounded.wide_res, idx->bounded.wide_cnt, idx->bws.qh, idx->bws.tau, idx->bws.cnt, idx->bws.cand, idx->bws.diag, idx->bws.pool, idx->d_q,
                     idx->d_labels, idx->d_dist, idx->d_found, idx->d_bad};
     for (void* p : ptrs)
@@ -1120,6 +1143,12 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         if (value < 1 || value > 15) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_share must be 1..15");
         idx->geom_i6.dyn_share = idx->geom_i6_small.dyn_share = (int)value;
         return DAWN_OK;
+    }
+    if (n == "i6_slack_model") {  // 1 (default): the packed stream's lists are sized from the shadow's measured error bounds; 0: from constants
+        if (value != 0 && value != 1) return fail(DAWN_ERR_INVALID_ARG, "i6_slack_model must be 0 or 1");
+        idx->i6_slack_model = (int)value;
+        idx->i6_slack_dirty = true;
+        return index_prepare_search(idx);
     }
     if (n == "i6_central_tail") {  // 1: the packed stream's workgroups do not rescore their own 64 rows exactly; one merge_rescore_kernel
                                    // rescores the index's 64 best by the refined score (deeper rounds, second chance behind it)
@@ -1773,6 +1802,25 @@ int dawn_index_stats_batch_feedback(dawn_index* idx, uint64_t* f6_batches, uint6
 
 // ... the device-side counters as they are (debug header): out[N_STAT_SLOTS = 8], indexed by final flag; [5] packed-stream failures,
 // [7] (row, query) pairs the bounded pass scored exactly.  A sharded handle sums its shards.
+int dawn_index_debug_i6_refine(dawn_index* idx, size_t count, int* n_refine, float* frac64) {
+    if (!idx || !n_refine) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
+    if (idx->shards) return fail(DAWN_ERR_UNSUPPORTED, "single-device handles only");
+    return dawn::guarded([&] {
+        DAWN_TRY(flush_adds(idx));
+        const dawn::I6Slack* sl = idx->i6_slack_ptr();
+        if (frac64)
+            for (int b = 0; b < 64; ++b) frac64[b] = sl ? sl->frac[b] : 0.f;
+        if (!i6_live(idx)) {
+            *n_refine = -1;
+            return (int)DAWN_OK;
+        }
+        const dawn::ScanGeom g6 = idx->i6_geom();
+        *n_refine = g6.refine > 0 ? g6.refine
+                                  : dawn::i6_refine_count((uint32_t)idx->size, (uint32_t)count, idx->i6_bits, g6.blocks * (g6.threads / 64), sl);
+        return (int)DAWN_OK;
+    });
+}
+
 int dawn_index_debug_raw_stats(dawn_index* idx, uint64_t* out8) {
     if (!idx || !out8) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     return dawn::guarded([&] {

@@ -102,6 +102,13 @@ struct dawn_index {
     size_t i6_row_bytes() const { return i6_bits == 6 ? 288 : 240; }
     size_t i6_min_rows = dawn::kI6MinRows;  // option "i6_min_rows" (tests: 0)
     bool i6_failed = false;
+    // The shadow's own error bounds, measured: histogram of its sub-tiles' E, re-read whenever the shadow changes (i6_shadow_sync);
+    // i6_refine_count sizes the waves' lists from it.  Option "i6_slack_model" = 0: the constants of rounds 3-4 (A/B).
+    dawn::I6Slack i6_slack;
+    uint32_t* d_i6hist = nullptr;
+    bool i6_slack_dirty = true;
+    int i6_slack_model = 1;
+    const dawn::I6Slack* i6_slack_ptr() const { return i6_slack_model && i6_slack.version ? &i6_slack : nullptr; }
     // its stream: `threads` / 64 waves per CU, `unroll` = loads in flight per wave (options "i6_scan_threads", "i6_scan_ring");
     // exact lists of the workgroups' epilogues [lists][64].  6-bit form, tools/stream_i6_ab.py, 100 M rows, three boxes
     // (profiles/r03/stream_i6_ab_100M_*.log, stream_i6_parts_off_100M.log; us per launch, the int8 stream on the same box

@@ -139,7 +139,17 @@ void launch_rows_to_i6s(const void* d_rows, int rt, int bits, void* d_shadow, vo
                         hipStream_t stream);
 // entries of its coarse list a wave keeps (8 .. 64), chosen from the index size and k; 0: the packed stream cannot certify this
 // search (too many rows above the bound for a 64-entry list: large k on a very large index) — stream the int8 shadow instead
-int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves);
+// slack: the packed shadow's own error bounds, measured (I6Slack below); nullptr: the constants of an unmeasured shadow
+struct I6Slack {
+    // share of the shadow's sub-tiles whose E (their bound on ||x' - s X||_2, the coarse score's offset above the true one) lies in
+    // [b, b + 1) x I6_SLACK_STEP; the last bin holds everything above.  version: bumped whenever the histogram is re-read.
+    uint32_t version = 0;
+    float frac[64] = {};
+};
+constexpr float I6_SLACK_STEP = 0.004f;
+// histogram of E over the n_sub sub-tiles of a packed shadow's meta array -> hist [64] (zeroed here)
+void launch_i6_slack_hist(const void* d_meta, uint32_t n_sub, uint32_t* d_hist, hipStream_t stream);
+int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves, const I6Slack* slack = nullptr);
 void launch_scan_i6(const void* d_i6, const void* d_meta, int bits, const void* d_i8, const void* d_i8meta, const void* d_rows,
                     int dtype, const uint64_t* d_ids, uint32_t n_rows, const float* d_q, float* ub_s, uint32_t* ub_p, float* ex_s,
                     uint32_t* ex_p, float* tb, uint32_t* pool, const ScanGeom& g,

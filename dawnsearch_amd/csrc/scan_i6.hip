@@ -812,11 +812,32 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
 // wider gaps) a wave holds Poisson(lambda) such rows, lambda = (N / waves) * (1 - Phi(z_k - (E + margin) sqrt(384))); n is the
 // smallest list length that all waves together exceed with probability < 1 % (0: no list length does).  A wrong guess costs
 // time (the certificate fails, the exact pass answers), never correctness.
-int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
+__global__ __launch_bounds__(256) void i6_slack_hist_kernel(const float2* __restrict__ meta, uint32_t n_sub, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[64];
+    if (threadIdx.x < 64) sh[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sub; i += gridDim.x * blockDim.x) {
+        const float e = meta[i].y;
+        int b = e == e ? (int)(e / I6_SLACK_STEP) : 63;  // (a NaN bound: the last bin)
+        b = b < 0 ? 0 : (b > 63 ? 63 : b);
+        atomicAdd(&sh[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+void launch_i6_slack_hist(const void* d_meta, uint32_t n_sub, uint32_t* d_hist, hipStream_t stream) {
+    (void)hipMemsetAsync(d_hist, 0, 64 * sizeof(uint32_t), stream);
+    if (n_sub == 0) return;
+    const uint32_t blocks = (n_sub + 255u) / 256u < 1024u ? (n_sub + 255u) / 256u : 1024u;
+    hipLaunchKernelGGL(i6_slack_hist_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float2*>(d_meta), n_sub, d_hist);
+}
+
+int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves, const I6Slack* sl) {
     // (the last answer is kept per thread: a sharded handle issues its shards' searches from worker threads)
-    thread_local uint32_t c_n = 0, c_k = 0;
+    thread_local uint32_t c_n = 0, c_k = 0, c_ver = 0;
     thread_local int c_bits = 0, c_waves = 0, c_out = LIST;
-    if (n_rows == c_n && k == c_k && bits == c_bits && waves == c_waves) return c_out;
+    thread_local const I6Slack* c_sl = nullptr;
+    if (n_rows == c_n && k == c_k && bits == c_bits && waves == c_waves && sl == c_sl && (sl == nullptr || sl->version == c_ver)) return c_out;
     auto tail = [](double z) { return 0.5 * std::erfc(z / 1.4142135623730951); };
     const double kk = k < 1 ? 1.0 : (double)k;
     int n = LIST;
@@ -827,10 +848,20 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
             if (tail(mid) * n_rows > kk) lo = mid;
             else hi = mid;
         }
-        const double slack = (bits == 6 ? 0.040 : 0.082) + 0.012;
         const double n_sub = std::ceil(n_rows / 32.0);  // (a small index does not reach every wave)
         const double holders = n_sub < (double)waves ? n_sub : (double)(waves > 0 ? waves : 1);
-        const double lambda = tail(lo - slack * 19.5959) * n_rows / holders;
+        // rows of a wave's share whose coarse bound reaches the k-th score: true score within the sub-tile's slack E + K2 of it.
+        // A measured shadow (I6Slack: the histogram of its sub-tiles' E, upper bin edges, + 0.004 for K2 and the packed score's own
+        // scatter, ~||dx|| / sqrt(384)) — or the constants of rounds 3-4, which predate the clipped scales and sit ~0.015 above
+        // what uniform rows measure (three times the lambda: profiles/r05/refine_sweep.log).
+        double share = 0.0;
+        if (sl != nullptr) {
+            for (int b = 0; b < 64; ++b)
+                if (sl->frac[b] > 0.f) share += (double)sl->frac[b] * tail(lo - ((double)(b + 1) * I6_SLACK_STEP + 0.004) * 19.5959);
+        } else {
+            share = tail(lo - ((bits == 6 ? 0.040 : 0.082) + 0.012) * 19.5959);
+        }
+        const double lambda = share * n_rows / holders;
         const double allowed = 0.01 / holders;
         double term = std::exp(-lambda), cdf = term;  // P(X <= 0)
         n = 0;
@@ -843,14 +874,17 @@ int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves) {
         // 64-row certificate has deeper rounds to fall back on, instead of paying an exact pass for a certificate that must fail
         if (1.0 - cdf > 0.05) n = -1;
     }
-    // + 8, and never fewer than 40: real rows cluster — the pages of one site arrive together and fill a 32-row sub-tile, which
-    // is ONE wave's — and a wave has to be able to keep such a sub-tile whole on top of its ordinary share; a refined entry
-    // costs ~1 us per list position of the whole grid (a 3-KB scatter per row): 12.5 M rows, k = 10: 40 instead of 64 = -24 us
-    // of a 0.5-ms search
+    // + 8, and a floor: real rows cluster — the pages of one site arrive together and fill a 32-row sub-tile, which is ONE wave's —
+    // and a wave should be able to keep most of such a sub-tile on top of its ordinary share.  A refined entry costs ~0.8 us per
+    // list position of the whole grid (a 1.5-KB row per entry and wave: 3 MB per position), so the floor is what the small indexes
+    // pay: 40 on an unmeasured shadow; 24 on a measured one — 12.5 M rows, k = 10: 0.487 instead of 0.500 ms, no certificate lost
+    // on uniform rows, 30 instead of 27 of 64 on the topical mixture (profiles/r05/refine_sweep.log) — an index that loses more
+    // than one certificate in twenty has its lists raised to 64 by the ladder feedback (dawn_index.cpp: kFbBoost).
+    const int floor_n = sl != nullptr ? 24 : 40;
     if (n < 0) n = 0;
-    else n = (n + 8 < 40) ? 40 : ((n + 8 + 7) & ~7);
+    else n = (n + 8 < floor_n) ? floor_n : ((n + 8 + 7) & ~7);
     if (n > LIST) n = LIST;
-    c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n;
+    c_n = n_rows, c_k = k, c_bits = bits, c_waves = waves, c_out = n, c_sl = sl, c_ver = sl ? sl->version : 0u;
     return n;
 }
 

@@ -153,6 +153,14 @@ class VectorIndex:
         check(lib.dawn_index_debug_raw_stats(self._h, out))
         return [int(v) for v in out]
 
+    def i6_refine(self, k: int = 10):
+        """(entries of its coarse list a wave of the packed stream refines for a top-k search — 0: the int8 stream is used, -1: no
+        packed shadow —, the measured histogram of the shadow's error bounds in bins of 0.004): dawn_hip_debug.h."""
+        n = C.c_int(0)
+        frac = (C.c_float * 64)()
+        check(lib.dawn_index_debug_i6_refine(self._h, k, C.byref(n), frac))
+        return n.value, [float(v) for v in frac]
+
     def stats_batch_feedback(self):
         """Batches the FP6 first filter took / batches its feedback handed to the int8 pass / batches the int8 pass ran with the
         deeper thresholds of a ladder-heavy index (dawn_hip_debug.h)."""

@@ -43,6 +43,11 @@ int dawn_index_stats_batch_feedback(dawn_index *idx, uint64_t *f6_batches, uint6
  * chance, 3 deeper round, 4 bounded exact pass, 6 second matrix-core pass); [5] single queries whose packed-stream certificate failed;
  * [7] (row, query) pairs of the bounded pass that got past its int8 bound (mod 2^32); [0] queries the wide batch form of that pass answered.  A sharded handle reports the sums over its shards. */
 int dawn_index_debug_raw_stats(dawn_index *idx, uint64_t *out8);
+/* The packed stream's list sizing (scan_i6.hip: i6_refine_count): *n_refine = entries of its coarse list a wave refines for a search of
+ * `count` results on this index (0: the packed stream would not certify, the int8 stream is used; -1: no packed shadow), frac64[64]
+ * (may be NULL) = the measured histogram of the shadow's error bounds E in bins of 0.004 (all zero: not measured, option
+ * "i6_slack_model" = 0).  Single-device handles. */
+int dawn_index_debug_i6_refine(dawn_index *idx, size_t count, int *n_refine, float *frac64);
 /* Diagnostic: per-wave phase cycle sums ([blocks][8 waves][8 phases]) of the last batched full pass run with the
  * "mfma_sched" option = 2 (s_memtime-stamped build of the kernel; tools/batch_phases.py prints the shares). */
 int dawn_index_debug_read_diag(dawn_index *idx, unsigned long long *out, size_t blocks);
@@ -71,9 +76,12 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "i6_shadow"        0: no packed shadow: single queries stream the int8 shadow (its memory is released; 1 rebuilds it).
  *                      Default 1, or env DAWN_I6_SHADOW at creation
  *   "i6_refine"        entries of its coarse list a wave of the packed stream keeps and refines: 1..64, or 0 = chosen from the
- *                      index size and k (default); too few cost a failed certificate (the bounded pass answers), never a result;
+ *                      index size, k and the shadow's measured error bounds (default; dawn_index_debug_i6_refine reads the choice);
+ *                      too few cost a failed certificate (the bounded pass answers), never a result;
  *                      -1 (tests): full lists that are NOT refined — dawn_index_debug_stream_lists then returns the packed
  *                      shadow's own bounds
+ *   "i6_slack_model"   1 (default): that choice uses the histogram of the shadow's own error bounds E, re-read whenever the shadow
+ *                      changes; 0: the constants of rounds 3-4 (deeper lists: A/B)
  *   "i6_bits"          bits per component of the packed shadow: 5 (240 B/row, default; env DAWN_I6_BITS) or 6 (288 B/row)
  *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 2 Mi, or env
  *                      DAWN_I6_MIN_ROWS at creation; below it the fixed costs of a search dominate and the shadow is not kept)

@@ -502,3 +502,43 @@ def test_i6_central_tail_and_tail_geometry_options_agree(dawn, oracle, n):
         idx.set_option("i6_central_tail", 0)
     st = idx.stats()
     assert st["fallbacks"] == 0
+
+
+def test_list_depth_follows_the_shadows_measured_error_bounds(dawn, oracle, bits):
+    """The waves' list depth (scan_i6.hip: i6_refine_count) is sized from the histogram of the shadow's own E (re-read when the shadow
+    changes), not from constants: shallower lists on uniform rows, the same answers; one-hot rows next to them (E of their sub-tiles
+    is several times larger) move the histogram and the depth with it; "i6_slack_model" = 0 is the round-4 sizing."""
+    n = 300_001
+    idx = _mk(dawn, n)
+    x = oracle.unit_rows(1, 0, n)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    n10, frac = idx.i6_refine(10)
+    assert abs(sum(frac) - 1.0) < 1e-4 and n10 == 24, (n10, sum(frac))
+    lo = min(b for b, f in enumerate(frac) if f > 0) * 0.004
+    mean = sum((b + 0.5) * 0.004 * f for b, f in enumerate(frac))
+    # (clipped scales on near-Gaussian rows: E ~0.074 at 5 bits, ~0.037 at 6)
+    assert (0.04 < lo and 0.05 < mean < 0.10) if bits == 5 else (0.02 < lo and 0.025 < mean < 0.05), (lo, mean)
+    Q = np.concatenate([synth.unit_rows(2, 0, 6), synth.planted_queries(1, [n // 2], 4)])
+    for k in (1, 10, 20, 64):
+        assert 24 <= idx.i6_refine(k)[0] <= 64
+        for q in Q:
+            _assert_same(*idx.search(q, k), *oracle.scan_topk(x, ids, q, k))
+    idx.set_option("i6_slack_model", 0)
+    n10c, fracc = idx.i6_refine(10)
+    assert n10c == 40 and sum(fracc) == 0.0
+    for q in Q:
+        _assert_same(*idx.search(q, 10), *oracle.scan_topk(x, ids, q, 10))
+    idx.set_option("i6_slack_model", 1)
+    assert idx.i6_refine(10)[0] == 24
+    # 4096 one-hot rows: their sub-tiles quantise badly (one component at the scale's end, 383 at zero is exact, but mixed with
+    # ordinary rows the sub-tile's scale is the one-hot's) -> the histogram grows a tail, re-read by the add's flush
+    hot = np.zeros((4096, 384), dtype=np.float32)
+    hot[np.arange(4096), np.arange(4096) % 384] = 1.0
+    idx.add_batch(np.arange(n + 1, n + 4097, dtype=np.uint64), hot)
+    n10h, frach = idx.i6_refine(10)
+    assert abs(sum(frach) - 1.0) < 1e-4 and frach != frac
+    x2 = np.concatenate([x, hot])
+    ids2 = np.arange(1, n + 4097, dtype=np.uint64)
+    for q in list(Q[:3]) + [hot[5]]:
+        _assert_same(*idx.search(q, 10), *oracle.scan_topk(x2, ids2, q, 10))
+    assert idx.stats()["fallbacks"] == 0
