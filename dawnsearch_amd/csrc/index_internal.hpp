@@ -18,8 +18,10 @@ constexpr size_t kMaxBatch = 256;        // queries per internal pass of the hos
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
 constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
 constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
-constexpr size_t kI6MinRows = 2u << 20;        // indexes of at least this many rows keep the packed shadow for their single queries
-                                               // (1 M rows: 0.130 ms per search against the int8 stream's 0.124; 3 M: 0.199 / 0.234)
+constexpr size_t kI6MinRows = 3u << 18;        // indexes of at least this many rows keep the packed shadow for their single queries
+                                               // (768 Ki; round 5, lists of 24: 0.5 M rows 0.076 ms per search against the int8 stream's 0.071,
+                                               // 1 M 0.094 / 0.100, 2 M 0.133 / 0.156, 3 M 0.164 / 0.211: profiles/r05/i6_min_rows_probe.log;
+                                               // rounds 3-4, lists of 40-64: 2 Mi)
 constexpr size_t kI6SmallRows = 32u << 20;     // below this the packed stream uses geom_i6_small
 constexpr size_t kAddStageRows = 1024;   // single-row adds staged on the host before they travel together
 constexpr size_t kStageChunk = 1u << 18;  // rows of device staging at most (bf16 adds / PageEntry records / get_rows)

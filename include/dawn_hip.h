@@ -175,7 +175,7 @@ int dawn_index_stats_deep(dawn_index *idx, uint64_t *deepened);
  * Any pointer may be NULL. */
 int dawn_index_stats_ladder(dawn_index *idx, uint64_t *bounded, uint64_t *packed_failures, uint64_t *demoted);
 /* HBM held by the index, in bytes: its rows (reserve()'d capacity; usearch: memory_usage()), the filter shadows built
- * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 2 Mi rows; f16: 768 B/row),
+ * so far (int8: 384 B/row + 8 B per 32 rows; packed 5- / 6-bit: 240 / 288 B/row + 8 B per 32 rows, indexes of >= 768 Ki rows; f16: 768 B/row),
  * everything else (labels, search workspaces, staging). */
 int dawn_index_memory(dawn_index *idx, uint64_t *rows_bytes, uint64_t *shadow_bytes, uint64_t *other_bytes);
 /* Per-index options (name, value).  A caller that binds this header needs none of them: the defaults are the tuned values and

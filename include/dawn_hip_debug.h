@@ -83,7 +83,7 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *   "i6_slack_model"   1 (default): that choice uses the histogram of the shadow's own error bounds E, re-read whenever the shadow
  *                      changes; 0: the constants of rounds 3-4 (deeper lists: A/B)
  *   "i6_bits"          bits per component of the packed shadow: 5 (240 B/row, default; env DAWN_I6_BITS) or 6 (288 B/row)
- *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 2 Mi, or env
+ *   "i6_min_rows"      single queries of an index of at least this many rows stream the packed shadow (default 768 Ki, or env
  *                      DAWN_I6_MIN_ROWS at creation; below it the fixed costs of a search dominate and the shadow is not kept)
  *   "i6_scan_blocks" / "i6_scan_threads" / "i6_scan_ring"   geometry of the packed stream: workgroups, 64..512 threads, loads in
  *                      flight per wave (6 bits: 12 / 6 / 4 / 3 / 2 fragments of 768 B; 5 bits: 8 or 4 loads of 768 B - 1 KiB); same

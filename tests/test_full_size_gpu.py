@@ -45,7 +45,7 @@ def test_100m_paths_agree_and_planted_rows_win(dawn, oracle, big):
     idx = big
     Q, planted = _queries()
     assert idx.size() == N
-    # (1) batch-1 stream over the packed shadow (default from 2 Mi rows up: scan_i6.hip)
+    # (1) batch-1 stream over the packed shadow (default from 768 Ki rows up: scan_i6.hip)
     assert idx.memory()["shadows"] > N * (384 + 240)  # both integer shadows are resident
     res1 = [idx.search(q, K) for q in Q]
     for lab, dist in res1:

@@ -1,6 +1,6 @@
 """GPU parity tests of the packed (5- or 6-bit) filter shadow and its single-query stream (dawnsearch_amd/csrc/scan_i6.hip).
 
-The default single-query search of an index of >= 2 Mi rows streams a 5-bit copy of the rows (240 B per row; 6 bits = 288 B
+The default single-query search of an index of >= 768 Ki rows streams a 5-bit copy of the rows (240 B per row; 6 bits = 288 B
 selectable), rescoring every workgroup's 64-row shortlists exactly in the kernel's epilogue and merging the exact lists under
 one certificate.  Here the path is forced on small indexes (option "i6_min_rows" = 0), in both widths (fixture `bits`: env
 DAWN_I6_BITS, read when an index is created), and held against the CPU oracle (oracle/dawn_oracle.c, a restatement
@@ -54,7 +54,7 @@ def test_i6_stream_matches_oracle_sizes(dawn, oracle, n, k):
 
 
 def test_i6_is_the_default_of_large_indexes_only(dawn, oracle, bits):
-    """Below i6_min_rows (2 Mi by default) no 6-bit shadow is built; the option / the size crossing the limit builds it, and
+    """Below i6_min_rows (768 Ki by default) no packed shadow is built; the option / the size crossing the limit builds it, and
     switching it off gives the memory back.  Same results either way."""
     n = 200_000
     idx = dawn.VectorIndex(0)
