@@ -806,12 +806,7 @@ __global__ __launch_bounds__(1024) void merge_exact_kernel(const uint64_t* __res
     }
 }
 
-// How many entries of its coarse list a wave keeps and refines.  The certificate needs the bound on every unlisted row — an
-// exact score plus the packed shadow's slack E — below the k-th best score s_k, i.e. no wave may drop a row scoring above
-// s_k - E - margin.  With scores ~ N(0, 1/384) (the thinnest top an index can have: uniform or Gaussian rows; clustered data has
-// wider gaps) a wave holds Poisson(lambda) such rows, lambda = (N / waves) * (1 - Phi(z_k - (E + margin) sqrt(384))); n is the
-// smallest list length that all waves together exceed with probability < 1 % (0: no list length does).  A wrong guess costs
-// time (the certificate fails, the exact pass answers), never correctness.
+// histogram of the sub-tiles' error bounds E (kernels.hpp: I6Slack) for the sizing below
 __global__ __launch_bounds__(256) void i6_slack_hist_kernel(const float2* __restrict__ meta, uint32_t n_sub, uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[64];
     if (threadIdx.x < 64) sh[threadIdx.x] = 0u;
@@ -832,6 +827,12 @@ void launch_i6_slack_hist(const void* d_meta, uint32_t n_sub, uint32_t* d_hist, 
     hipLaunchKernelGGL(i6_slack_hist_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float2*>(d_meta), n_sub, d_hist);
 }
 
+// How many entries of its coarse list a wave keeps and refines.  The certificate needs the bound on every unlisted row — an
+// exact score plus the packed shadow's slack E — below the k-th best score s_k, i.e. no wave may drop a row scoring above
+// s_k - E - margin.  With scores ~ N(0, 1/384) (the thinnest top an index can have: uniform or Gaussian rows; clustered data has
+// wider gaps) a wave holds Poisson(lambda) such rows, lambda = (N / waves) * (1 - Phi(z_k - (E + margin) sqrt(384))); n is the
+// smallest list length that all waves together exceed with probability < 1 % (0: no list length does).  A wrong guess costs
+// time (the certificate fails, the exact pass answers), never correctness.
 int i6_refine_count(uint32_t n_rows, uint32_t k, int bits, int waves, const I6Slack* sl) {
     // (the last answer is kept per thread: a sharded handle issues its shards' searches from worker threads)
     thread_local uint32_t c_n = 0, c_k = 0, c_ver = 0;
