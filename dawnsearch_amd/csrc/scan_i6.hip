@@ -21,7 +21,7 @@
 //     form holds whatever the rows and the chosen scale are: tests/test_scan_i6_gpu.py::test_k2_covers_the_worst_sub_tile.)
 // E is four times the int8 shadow's (~0.037 on unit vectors; eight times at 5 bits), which a 64-row shortlist cannot absorb (the
 // gap between the 10th and the 64th best score of 100 M rows is 0.017; tools/coarse_shadow_probe.py).  The stream therefore
-// does not hand a 64-row shortlist to a one-workgroup tail.  Every WAVE keeps the best 40-64 rows of its share by the packed
+// does not hand a 64-row shortlist to a one-workgroup tail.  Every WAVE keeps the best 24-64 rows of its share by the packed
 // bound and re-scores them tightly (f32 index: on the f32 rows, a wave per row; bf16 index: on the int8 shadow), every
 // WORKGROUP merges its waves' lists by that score and rescores its own 64 best rows exactly (reference order,
 // src/search/vector.rs:128-134) in its epilogue — a shortlist up to 131 072 rows deep by the packed bound, 16 384 by the tight
