@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -286,7 +287,9 @@ bool i6_shadow_sync(dawn_index* idx) {
                 for (uint32_t v : h) total += v;
                 if (total > 0.0) {
                     for (int b = 0; b < 64; ++b) idx->i6_slack.frac[b] = (float)(h[b] / total);
-                    ++idx->i6_slack.version;
+                    // (unique across indexes: i6_refine_count remembers its last answer by this number)
+                    static std::atomic<uint32_t> next_version{0};
+                    idx->i6_slack.version = ++next_version;
                     idx->i6_slack_dirty = false;
                 }
             }
