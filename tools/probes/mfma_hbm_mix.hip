@@ -31,12 +31,14 @@ __global__ void fill_kernel(uint32_t* p, size_t n) {
 }
 
 // MODE 0: int8, MODE 1: fp6.  M: MFMAs per fragment.  Wave w takes fragments w, w + W, ...
-template <int MODE, int M>
+// SHARE: that many consecutive waves of a workgroup stream the SAME fragments (a pass whose waves split the queries, not the rows:
+// one read from HBM, the others from L2); NT: non-temporal loads
+template <int MODE, int M, int SHARE = 1, bool NT = true>
 __global__ __launch_bounds__(256) void mix_kernel(const uint32_t* __restrict__ buf, uint32_t n_frag, float* __restrict__ out) {
     constexpr int PD = 8;
     constexpr uint32_t FRAG_DW = MODE == 0 ? 256 : 384;  // dwords per fragment
     const int lane = threadIdx.x & 63;
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t w = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) / SHARE, W = ((gridDim.x * blockDim.x) >> 6) / SHARE;
     i32x8 b8[4];
     for (int c = 0; c < 4; ++c)
         for (int j = 0; j < 8; ++j) b8[c][j] = (int)mix((w * 64 + lane) * 257u + c * 29u + j + 7u);
@@ -50,8 +52,13 @@ __global__ __launch_bounds__(256) void mix_kernel(const uint32_t* __restrict__ b
     u32x2 rb[PD];
     auto load = [&](int d, uint32_t f) __attribute__((always_inline)) {
         const uint32_t* p = buf + (size_t)(f < n_frag ? f : w) * FRAG_DW;
-        ra[d] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + lane);
-        if constexpr (MODE == 1) rb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 256) + lane);
+        if constexpr (NT) {
+            ra[d] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + lane);
+            if constexpr (MODE == 1) rb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 256) + lane);
+        } else {
+            ra[d] = reinterpret_cast<const u32x4*>(p)[lane];
+            if constexpr (MODE == 1) rb[d] = reinterpret_cast<const u32x2*>(p + 256)[lane];
+        }
     };
     uint32_t f = w;
 #pragma unroll
@@ -86,7 +93,83 @@ __global__ __launch_bounds__(256) void mix_kernel(const uint32_t* __restrict__ b
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int MODE, int M>
+// The register-resident form of a 256-query FP6 pass: every wave holds ALL 48 query operands (16 groups x 3 k-steps x 6 dwords = 288
+// registers), streams its own tiles (3 fragments = 16 rows) and runs 16 MFMAs per fragment into 16 accumulators that are folded
+// (a max per group: the pass's threshold test costs about that) and cleared per tile.  One wave per SIMD.
+template <int PDT>
+__global__ __launch_bounds__(256) void fp6_resident_kernel(const uint32_t* __restrict__ buf, uint32_t n_tiles, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
+    i32x8 bq[16][3];
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[g][ks][j] = j < 6 ? (int)mix((w * 64 + lane) * 257u + g * 29u + ks * 7u + j + 7u) : 0;
+    u32x4 ra[PDT][3];
+    u32x2 rb[PDT][3];
+    auto load = [&](int d, uint32_t t) __attribute__((always_inline)) {
+        const uint32_t* p = buf + (size_t)(t < n_tiles ? t : w) * (3 * 384);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            ra[d][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + ks * 384) + lane);
+            rb[d][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + ks * 384 + 256) + lane);
+        }
+    };
+    float best = 0.f;
+    uint32_t t = w;
+#pragma unroll
+    for (int d = 0; d < PDT; ++d) load(d, t + d * W);
+    for (; t < n_tiles; t += PDT * W) {
+#pragma unroll
+        for (int d = 0; d < PDT; ++d) {
+            f32x4 acc[16];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const i32x8 av = {(int)ra[d][ks].x, (int)ra[d][ks].y, (int)ra[d][ks].z, (int)ra[d][ks].w, (int)rb[d][ks].x, (int)rb[d][ks].y, 0, 0};
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bq[g][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g], 2, 2, 0,
+                                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
+            }
+            load(d, t + (PDT + d) * W);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) best = fmaxf(best, fmaxf(fmaxf(acc[g][0], acc[g][1]), fmaxf(acc[g][2], acc[g][3])));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = best;
+    for (int d = 0; d < PDT; ++d) s += (float)(ra[d][0].x & 1u);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int PDT>
+void run_resident(const uint32_t* buf, double rows, float* out, const char* name) {
+    const uint32_t n_tiles = (uint32_t)(rows / 16.0);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    double best = 1e30, sum = 0;
+    const int reps = 4;
+    for (int r = 0; r < reps + 1; ++r) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((fp6_resident_kernel<PDT>), dim3(256), dim3(256), 0, 0, buf, n_tiles, out);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r == 0) continue;
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    const double bytes = (double)n_tiles * 4608.0, ops = (double)n_tiles * 48 * 2.0 * 16 * 16 * 128;
+    printf("%-34s PDT=%d: best %7.3f mean %7.3f ms per %.0f M rows -> %5.2f TB/s, %5.2f Pop/s\n", name, PDT, best, sum / reps, rows / 1e6,
+           bytes / (best * 1e-3) / 1e12, ops / (best * 1e-3) / 1e15);
+    fflush(stdout);
+}
+
+template <int MODE, int M, int SHARE = 1, bool NT = true>
 void run(const uint32_t* buf, double rows, float* out, const char* name) {
     const double row_bytes = MODE == 0 ? 384.0 : 288.0;
     const uint32_t n_frag = (uint32_t)(rows * row_bytes / (MODE == 0 ? 1024.0 : 1536.0));
@@ -97,7 +180,7 @@ void run(const uint32_t* buf, double rows, float* out, const char* name) {
     const int reps = 4;
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((mix_kernel<MODE, M>), dim3(256), dim3(256), 0, 0, buf, n_frag, out);
+        hipLaunchKernelGGL((mix_kernel<MODE, M, SHARE, NT>), dim3(256), dim3(256), 0, 0, buf, n_frag, out);
         hipEventRecord(e1, 0);
         hipDeviceSynchronize();
         float ms = 0;
@@ -107,7 +190,7 @@ void run(const uint32_t* buf, double rows, float* out, const char* name) {
         sum += ms;
     }
     const double bytes = (double)n_frag * (MODE == 0 ? 1024.0 : 1536.0);
-    const double ops = (double)n_frag * M * 2.0 * 16 * 16 * (MODE == 0 ? 64 : 128);
+    const double ops = (double)n_frag * M * SHARE * 2.0 * 16 * 16 * (MODE == 0 ? 64 : 128);
     printf("%-34s M=%2d : best %7.3f mean %7.3f ms per %.0f M rows -> %5.2f TB/s, %5.2f Pop/s\n", name, M, best, sum / reps, rows / 1e6,
            bytes / (best * 1e-3) / 1e12, ops / (best * 1e-3) / 1e15);
     fflush(stdout);
@@ -131,6 +214,15 @@ int main(int argc, char** argv) {
         run<1, 0>(buf, rows, out, "fp6 rows (288 B), stream only");
         run<1, 8>(buf, rows, out, "fp6 16x16x128, 128 queries");
         run<1, 16>(buf, rows, out, "fp6 16x16x128, 256 queries");
+        run_resident<2>(buf, rows, out, "fp6 256 q resident operands");
+        run_resident<3>(buf, rows, out, "fp6 256 q resident operands");
+        run_resident<4>(buf, rows, out, "fp6 256 q resident operands");
+        run<1, 8, 2, true>(buf, rows, out, "fp6 256 q, 2 waves share, nt");
+        run<1, 8, 2, false>(buf, rows, out, "fp6 256 q, 2 waves share");
+        run<1, 4, 4, true>(buf, rows, out, "fp6 256 q, 4 waves share, nt");
+        run<1, 4, 4, false>(buf, rows, out, "fp6 256 q, 4 waves share");
+        run<0, 8, 2, false>(buf, rows, out, "int8 256 q, 2 waves share");
+        run<0, 4, 4, false>(buf, rows, out, "int8 256 q, 4 waves share");
     }
     return 0;
 }
