@@ -96,6 +96,7 @@ _SIGS = {
     "dawn_index_debug_raw_stats": (_i32, [_vp, _vp]),
     "dawn_index_debug_i6_refine": (_i32, [_vp, _sz, _vp, _vp]),
     "dawn_vec_is_normalized": (_i32, [_vp]),
+    "dawn_vec_first_not_normalized": (_sz, [_vp, _sz]),
     "dawn_vec_normalize": (None, [_vp, _sz]),
     "dawn_vec_to24": (None, [_vp, _vp]),
     "dawn_vec_from24": (_i32, [_vp, _vp]),

@@ -463,7 +463,14 @@ int index_search_on_device(dawn_index* idx, const float* d_q, size_t B, size_t k
         idx->events_used++;
     }
     const uint32_t n = (uint32_t)idx->size;
-    const bool batched = (int)B >= idx->mfma_min_batch;
+    // (mfma_min_batch = 0, the default: by size — the matrix-core pass costs the same for 2 queries as for 256, the streaming filter
+    // takes up to 8 queries through ONE stream of the int8 shadow but keeps per-wave lists per query: on large indexes it wins up
+    // to 4 queries — 12.5 M rows x 2: 0.84 against 1.23 ms, 100 M x 4: 5.7 against 6.5 —, on small ones the pass does from 2:
+    // profiles/r05/small_batch_paths.log)
+    bool batched = idx->mfma_min_batch > 0 ? (int)B >= idx->mfma_min_batch : B >= 2;
+    if (idx->mfma_min_batch == 0 && batched && idx->shadow_small_batches && i8_live(idx) &&
+        ((B <= 4 && (size_t)n >= (B - 1) * (size_t)1250000) || (B <= 6 && n >= (64u << 20))))
+        batched = false;
     bool use_f6 = batched && idx->i8_batched && i8_live(idx) && f6_live(idx) && n > (uint32_t)BATCH_CAP;
     if (use_f6 && idx->ladder_feedback && idx->h_stats && !idx->force_fallback) {
         // FP6 feedback (index_internal.hpp): does this index send too many of its FP6-filtered queries to the ladder?
@@ -1064,7 +1071,7 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
         return reprepare();  // candidate buffers are sized by the grid
     }
     if (n == "mfma_min_batch") {
-        if (value < 1) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 1");
+        if (value < 0) return fail(DAWN_ERR_INVALID_ARG, "mfma_min_batch must be >= 0");
         idx->mfma_min_batch = (int)std::min<int64_t>(value, 1 << 30);
         return DAWN_OK;
     }
@@ -1145,6 +1152,11 @@ int index_set_option_single(dawn_index* idx, const char* name, int64_t value) {
     if (n == "i6_dyn_share") {  // sixteenths of the index the packed stream hands out dynamically (default 2)
         if (value < 1 || value > 15) return fail(DAWN_ERR_INVALID_ARG, "i6_dyn_share must be 1..15");
         idx->geom_i6.dyn_share = idx->geom_i6_small.dyn_share = (int)value;
+        return DAWN_OK;
+    }
+    if (n == "zero_copy_batch") {  // host API: batches of up to this many queries have their results stored straight into pinned host memory
+        if (value < 0 || value > (long long)dawn::kMaxBatch) return fail(DAWN_ERR_INVALID_ARG, "zero_copy_batch must be 0..%zu", dawn::kMaxBatch);
+        idx->zero_copy_batch = (size_t)value;
         return DAWN_OK;
     }
     if (n == "i6_slack_model") {  // 1 (default): the packed stream's lists are sized from the shadow's measured error bounds; 0: from constants
@@ -1513,9 +1525,8 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
                             float* distances, size_t* found) {
     if (!idx || !queries || !labels || !distances || !found) return fail(DAWN_ERR_INVALID_ARG, "NULL argument");
     if (count == 0 || count > DAWN_MAX_K) return fail(DAWN_ERR_UNSUPPORTED, "count must be 1..%d", DAWN_MAX_K);
-    for (size_t b = 0; b < B; ++b)  // search_provider.rs:206-208
-        if (!dawn::host_is_normalized(queries + b * dawn::EM))
-            return fail(DAWN_ERR_NOT_NORMALIZED, "Search vector is not normalized");
+    if (dawn::host_first_not_normalized(queries, B) != B)  // search_provider.rs:206-208
+        return fail(DAWN_ERR_NOT_NORMALIZED, "Search vector is not normalized");
     if (idx->staged) {
         const int rc = dawn::guarded([&] { return flush_adds(idx); });
         if (rc != DAWN_OK) return rc;
@@ -1534,7 +1545,7 @@ int dawn_index_search_batch(dawn_index* idx, const float* queries, size_t B, siz
         std::memcpy(hq, queries + b0 * dawn::EM, nb * dawn::EM * sizeof(float));
         DAWN_HIP_TRY(hipMemcpyAsync(idx->d_q, hq, nb * dawn::EM * sizeof(float), hipMemcpyHostToDevice, idx->stream));
         idx->n_searches += nb;
-        if (nb <= dawn::kZeroCopyBatch) {
+        if (nb <= idx->zero_copy_batch) {
             // few queries: the tail kernels store the results straight into the pinned host block (coherent,
             // device-visible): no copy commands between the last kernel and the host's wake-up
             DAWN_TRY(dawn::index_search_on_device(idx, idx->d_q, nb, count, hl, hd, hf, idx->stream));

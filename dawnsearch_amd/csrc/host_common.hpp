@@ -47,5 +47,6 @@ int guarded(F&& f) noexcept {
 
 // vector.rs host restatements used by the ABI-side validation
 bool host_is_normalized(const float* v);
+size_t host_first_not_normalized(const float* v, size_t B);  // the same predicate, B vectors: the first that fails it, or B
 
 }  // namespace dawn

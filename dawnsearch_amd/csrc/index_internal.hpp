@@ -16,7 +16,8 @@ struct ShardSet;  // dawn_sharded.cpp
 
 constexpr size_t kMaxBatch = 256;        // queries per internal pass of the host API
 constexpr size_t kMaxProfile = 4096;     // kept event pairs
-constexpr size_t kZeroCopyBatch = 8;     // host API: up to this many queries get their results by zero-copy stores
+constexpr size_t kZeroCopyBatch = 256;   // host API: up to this many queries get their results by zero-copy stores (option "zero_copy_batch";
+                                         // 8 until round 5: three copy commands behind the last kernel cost a 256-batch ~20 us)
 constexpr size_t kShadowSmallRows = 6u << 20;  // below this the shadow stream uses geom_h_small
 constexpr size_t kI6MinRows = 3u << 18;        // indexes of at least this many rows keep the packed shadow for their single queries
                                                // (768 Ki; round 5, lists of 24: 0.5 M rows 0.076 ms per search against the int8 stream's 0.071,
@@ -104,6 +105,7 @@ struct dawn_index {
     size_t i6_row_bytes() const { return i6_bits == 6 ? 288 : 240; }
     size_t i6_min_rows = dawn::kI6MinRows;  // option "i6_min_rows" (tests: 0)
     bool i6_failed = false;
+    size_t zero_copy_batch = dawn::kZeroCopyBatch;  // option "zero_copy_batch" (0: results always come back by copy commands)
     // The shadow's own error bounds, measured: histogram of its sub-tiles' E, re-read whenever the shadow changes (i6_shadow_sync);
     // i6_refine_count sizes the waves' lists from it.  Option "i6_slack_model" = 0: the constants of rounds 3-4 (A/B).
     dawn::I6Slack i6_slack;
@@ -178,7 +180,8 @@ struct dawn_index {
     // streaming filter keeps per-wave top-64 lists, whose warm-up grows with every extra query
     // int8 shadow (tools/small_batch_paths.py, stream / matrix-core ms): 1M rows B=1 0.136 / 0.166, B=2 0.199 / 0.170,
     // B=3 0.251 / 0.169; 40M rows B=1 2.27 / 2.33, B=2 2.36 / 2.35, B=3 2.42 / 2.34: two queries and more take the pass
-    int mfma_min_batch = 2;
+    // (round 5: 0 = by index size, index_search_on_device; the table above is round 2's)
+    int mfma_min_batch = 0;
     // host-API staging
     float* d_q = nullptr;
     uint64_t* d_labels = nullptr;

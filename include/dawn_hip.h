@@ -187,6 +187,8 @@ int dawn_index_set_option(dawn_index *idx, const char *name, int64_t value);
 /* src/search/vector.rs + best_results.rs host helpers (bit-compatible with the reference)      */
 /* ------------------------------------------------------------------------------------------ */
 int dawn_vec_is_normalized(const float *v /*[384]*/);       /* vector.rs:185-192 -> 1/0 */
+/* the same predicate over n vectors [n][384]: index of the first that fails it, or n (what dawn_index_search_batch runs on its queries) */
+size_t dawn_vec_first_not_normalized(const float *v, size_t n);
 void dawn_vec_normalize(float *v, size_t n);                /* vector.rs:194-197 */
 void dawn_vec_to24(const float *v, uint8_t *out /*[1152]*/);/* vector.rs:74-86  */
 int dawn_vec_from24(const uint8_t *in, float *out);         /* vector.rs:57-72; DAWN_ERR_NOT_NORMALIZED */

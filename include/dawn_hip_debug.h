@@ -60,7 +60,8 @@ int dawn_index_debug_stream_lists(dawn_index *idx, const float *query, float *ou
  * dawn_index_debug_stream_lists call: every row that is in no list scores <= T. */
 int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
 /* Option catalogue of dawn_index_set_option (dawn_hip.h) — tuning knobs (tests and tools sweep them; the defaults are the tuned values):
- *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path (default 2)
+ *   "mfma_min_batch"   batches of at least this many queries take the matrix-core path; 0 (default): 2 on small indexes, up to 5 / 7
+ *                      on large ones, where up to 4 / 6 queries are cheaper as one stream of the int8 shadow
  *   "mfma_blocks"      workgroups of the matrix-core kernels (default: one per CU)
  *   "mfma_sched"       4 = default kernel choice, 5 = pipelined 4-wave kernel for every pass, 1 = 8-wave kernel only,
  *                      0 = lockstep converting kernel on the f32 rows, 32 = the int8 filter on v_mfma_i32_32x32x32_i8 (default:

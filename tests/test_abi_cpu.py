@@ -80,6 +80,23 @@ def test_host_vector_helpers_match_oracle(dawn, oracle):
         assert dawn.is_normalized(v) == bool(L.orc_is_normalized(v))
     with pytest.raises(dawn.NotNormalizedError):
         dawn.from24(bytes(1152))
+    # the batch form of the gate (eight interleaved sequential sums): the same verdict per vector, ragged counts, vectors on the
+    # boundary of the predicate (scaled so that their length straddles 0.99 / 1.01 by a few ulp)
+    from dawnsearch_amd._lib import lib as dl
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 8, 9, 16, 37):
+        V = synth.unit_rows(6, 0, max(n, 1))[:n].copy()
+        assert dl.dawn_vec_first_not_normalized(V.ctypes.data, n) == n
+        for bad in range(n):
+            for scale in (1.0099999, 1.0100001, 0.9900001, 0.9899999, np.nan, np.inf, 0.0):
+                W = V.copy()
+                W[bad] = (W[bad] * np.float32(scale)).astype(np.float32)
+                want = next((i for i in range(n) if not L.orc_is_normalized(W[i])), n)
+                assert dl.dawn_vec_first_not_normalized(W.ctypes.data, n) == want, (n, bad, scale)
+    V = synth.unit_rows(7, 0, 64).copy()
+    V *= rng.uniform(0.9895, 0.9905, size=(64, 1)).astype(np.float32)
+    want = next((i for i in range(64) if not L.orc_is_normalized(V[i])), 64)
+    assert dl.dawn_vec_first_not_normalized(V.ctypes.data, 64) == want
 
 
 def test_host_best_results_matches_oracle(dawn, oracle):
