@@ -81,6 +81,8 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  *                      too few cost a failed certificate (the bounded pass answers), never a result;
  *                      -1 (tests): full lists that are NOT refined — dawn_index_debug_stream_lists then returns the packed
  *                      shadow's own bounds
+ *   "zero_copy_batch"  host API: batches of up to this many queries get their results by zero-copy stores into pinned host memory
+ *                      (default 256 = all; 0: by copy commands)
  *   "i6_slack_model"   1 (default): that choice uses the histogram of the shadow's own error bounds E, re-read whenever the shadow
  *                      changes; 0: the constants of rounds 3-4 (deeper lists: A/B)
  *   "i6_bits"          bits per component of the packed shadow: 5 (240 B/row, default; env DAWN_I6_BITS) or 6 (288 B/row)

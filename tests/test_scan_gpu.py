@@ -591,6 +591,30 @@ def test_stream_filter_takes_up_to_8_queries_per_pass(dawn, oracle, n, B, dtype)
     assert idx.stats()["fallbacks"] == 0
 
 
+def test_small_batches_choose_their_path_by_index_size(dawn, oracle):
+    """"mfma_min_batch" = 0 (the default): 2-4 queries on an index of (B - 1) x 1.25 M rows and more take ONE stream of the int8 shadow,
+    smaller indexes and larger batches the matrix-core pass (dawn_index.cpp: index_search_on_device).  Same answers either way, and
+    the oracle's; which path ran shows in the profile: the streaming filter is one launch per search, the pass runs behind its
+    sampling passes."""
+    n = 1_400_000
+    idx = dawn.VectorIndex(0)
+    idx.fill_synthetic(1, 0, n, 1)
+    Q = synth.unit_rows(2, 0, 5)
+    Q[1] = synth.planted_queries(1, [n // 3], 6)[0]
+    for B in (2, 3, 5):
+        want = oracle.scan_topk_synth(1, 0, n, 1, Q[:B], 10)
+        got = {}
+        for mmb in (0, 2, 100000):
+            idx.set_option("mfma_min_batch", mmb)
+            got[mmb] = idx.search_batch(Q[:B], 10)
+            for b in range(B):
+                _assert_same(got[mmb][0][b], got[mmb][1][b], want[0][b], want[1][b])
+        assert got[0][0][1][0] == n // 3 + 1
+    assert idx.stats()["fallbacks"] == 0
+    with pytest.raises(dawn.DawnError):
+        idx.set_option("mfma_min_batch", -1)
+
+
 def test_batched_duplicates_second_certificate_then_exact_pass(dawn, oracle, shadow):
     base = synth.unit_rows(1, 0, 3000)
     rows = np.concatenate([base, np.repeat(base[11:12], 300, axis=0), base[:50]])
