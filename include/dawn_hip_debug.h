@@ -166,7 +166,9 @@ int dawn_index_debug_stream_bound(dawn_index *idx, float *bound);
  * "ffn2_split" 0 = the FFN-down layer of a latency-form call (<= 64 tokens) in one piece (default 1: four K-slices, their partial sums added
  * up by the next LayerNorm: 0.169 -> 0.158 ms);
  * "skinny_max_rows" = total tokens up to which the GEMMs use the split-K latency form; "graphs" 0 = never replay hipGraphs (default 1: forwards of up to "graph_max_tokens" = 512
- * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed). */
+ * tokens are captured at the second sighting of their (B, tokens, longest sequence, buffers) shape and replayed);
+ * "host_io" 0 = dawn_embedder_forward moves ids / offsets / vectors with three copy commands (default 1: offsets | ids staged in one
+ * pinned block and copied once, the vectors stored by the last kernel straight into pinned host memory). */
 
 /* BertModel::forward hidden states (model.rs:565-570) for tests: out [total_tokens][384]. */
 int dawn_embedder_hidden_states(dawn_embedder *e, const uint32_t *token_ids, const int32_t *seq_offsets,
