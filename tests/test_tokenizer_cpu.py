@@ -157,6 +157,37 @@ def test_truncation_and_batch_packing(setup):
         assert flat[offs[b]:offs[b + 1]].tolist() == hf.encode(t.replace("\x00", "")).ids
 
 
+def test_large_batches_are_encoded_by_the_pool_with_the_same_ids(setup):
+    """Batches of 32 texts and more are split over the tokenizer's worker threads (tokenizer.cpp: EncodePool): the same ids in the same
+    order as one by one, whatever the batch size and however often the pool is reused; two callers at once (the second finds the
+    pool busy and encodes on its own thread); a tokenizer destroyed with its workers idle."""
+    import threading
+    dawn, hf, tj, vt, texts = setup
+    tk = dawn.Tokenizer(tj)
+    pool = (texts + _fuzz_texts(3, 400)) * 2
+    one_by_one = [tk.encode(t).tolist() for t in pool]
+    for B in (31, 32, 33, 64, 257, len(pool)):
+        for rep in range(2):
+            flat, offs = tk.encode_batch(pool[:B])
+            assert len(offs) == B + 1 and offs[0] == 0
+            assert all(flat[offs[b]:offs[b + 1]].tolist() == one_by_one[b] for b in range(B)), B
+    results = [None, None]
+
+    def call(i):
+        results[i] = tk.encode_batch(pool[:300])
+
+    th = [threading.Thread(target=call, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for flat, offs in results:
+        assert all(flat[offs[b]:offs[b + 1]].tolist() == one_by_one[b] for b in range(300))
+    tk.close()
+    tk4 = dawn.Tokenizer(vt)  # (never used for a large batch: no workers to join)
+    tk4.close()
+
+
 def test_errors(setup, tmp_path):
     dawn = setup[0]
     with pytest.raises(dawn.DawnError):
