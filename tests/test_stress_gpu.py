@@ -155,9 +155,9 @@ def test_random_configuration_equals_the_oracle(dawn, oracle, seed):
 
 _TOGGLES = {
     "i8_shadow": [0, 1], "i6_shadow": [0, 1], "i6_bits": [5, 6], "f16_shadow": [0, 1], "f16_shadow_b1": [0, 1], "f6_shadow": [0, 1],
-    "i8_batched": [0, 1], "mfma_min_batch": [2, 100000], "bounded_pass": [0, 1], "force_fallback": [0, 2], "ladder_feedback": [0, 1, 2],
+    "i8_batched": [0, 1], "mfma_min_batch": [0, 2, 100000], "bounded_pass": [0, 1], "force_fallback": [0, 2], "ladder_feedback": [0, 1, 2],
     "bounded_packed": [0, 1, 2], "bounded_seed": [0, 1, 2], "bounded_seed_shift": [2, 5, 8], "batch_rerun": [0, 1, 2], "mfma_target": [64, 1024, 4096],
-    "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "bounded_multi_packed": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
+    "i6_slack_model": [0, 1], "zero_copy_batch": [0, 8, 256], "i6_central_tail": [0, 1], "stream_dynamic_tail": [0, 1], "bounded_multi_packed": [0, 1], "i6_refine": [0, 8, 64], "f6_refine_rows": [0, 1], "f6_target": [256, 12288],
 }
 
 
