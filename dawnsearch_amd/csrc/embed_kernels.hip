@@ -289,6 +289,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
     const float* arow = A + (size_t)(m0 + r) * K + k_begin + 4 * kq;
     const float* wrow = W + (size_t)(n0 + r) * K + k_begin + 4 * kq;
     const bool a_ok = m0 + r < M;
+    // (requested with the operands: behind the barrier it is one more dependent round trip of a 4-us launch)
+    const float bias_v = bias[n0 + r];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
         if (s < steps) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny16_kernel(const float* __
         for (int w = 1; w < NWV; ++w) sum += part[(w * 4 + e) * 64 + l];
         const int row = m0 + 4 * (l >> 4) + e;
         const int n = n0 + (l & 15);
-        if (row < M) Y[blockIdx.z * (size_t)M * N + (size_t)row * N + n] = act_apply(blockIdx.z == 0 ? sum + bias[n] : sum, ACT);
+        if (row < M) Y[blockIdx.z * (size_t)M * N + (size_t)row * N + n] = act_apply(blockIdx.z == 0 ? sum + bias_v : sum, ACT);
     }
 }
 
@@ -345,8 +347,16 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
     const int r = lane & 15, kq = lane >> 4;
     const int k_begin = wave * (K / NWV) + 4 * kq;
     const bool a_ok = m0 + r < M;
-    f32x4 av[STEPS], bv[STEPS];
+    f32x4 av[STEPS], bv[STEPS], g4[STEPS], b4[STEPS];
     const float* wrow = W + (size_t)(n0 + r) * K + k_begin;
+    // gamma, beta and the bias are requested with the operands: loaded where they are used — behind the reductions' barriers —
+    // they were three more dependent round trips (hipcc does not move a load across a barrier), ~2 us of a 6-8-us launch
+    const float bias_v = bias[n0 + r];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        g4[st] = *reinterpret_cast<const f32x4*>(gam + k_begin + 16 * st);
+        b4[st] = *reinterpret_cast<const f32x4*>(bet + k_begin + 16 * st);
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const size_t o = (size_t)(m0 + r) * K + k_begin + 16 * st;
@@ -399,8 +409,7 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const int k = k_begin + 16 * st;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam + k), b4 = *reinterpret_cast<const f32x4*>(bet + k);
-        av[st] = (av[st] / den) * g4 + b4;
+        av[st] = (av[st] / den) * g4[st] + b4[st];
         if (blockIdx.x == 0 && a_ok) *reinterpret_cast<f32x4*>(Xout + (size_t)(m0 + r) * K + k) = av[st];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(512) void gemm_skinny16_ln_kernel(const float* __re
         for (int w = 1; w < NWV; ++w) sum += part[(w * 4 + e) * 64 + l];
         const int row = m0 + 4 * (l >> 4) + e;
         const int n = n0 + (l & 15);
-        if (row < M) Y[(size_t)row * N + n] = act_apply(sum + bias[n], ACT);
+        if (row < M) Y[(size_t)row * N + n] = act_apply(sum + bias_v, ACT);
     }
 }
 
@@ -874,24 +883,32 @@ __global__ __launch_bounds__(64) void attention_regs_kernel(const float* __restr
     const int start = seq_offsets[b];
     const int S = seq_offsets[b + 1] - start;  // <= 32 (the launcher's condition)
     // row c of Q and of K (clamped: rows past the sequence are masked below), elements 2 kk + hh
+    // Every load of the launch is requested before anything is computed: left to itself hipcc sinks the loads between the MFMAs
+    // (request two, wait, multiply, request two ...) — eight memory round trips in a row instead of one, 4.7-5.2 us for a launch
+    // whose arithmetic is 32 MFMAs.
     float qb[16], ka[16];
+    f32x4 tq[8], tk[8];
+    float va[16];  // V^T fragment of step e: V[key kappa(e, hh)][dim c]
     {
         const float* qr = qkv + (size_t)(start + (c < S ? c : 0)) * (3 * H) + w * DH;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const f32x4 tq = *reinterpret_cast<const f32x4*>(qr + 4 * j);
-            const f32x4 tk = *reinterpret_cast<const f32x4*>(qr + H + 4 * j);
-            qb[2 * j] = hh ? tq[1] : tq[0];
-            qb[2 * j + 1] = hh ? tq[3] : tq[2];
-            ka[2 * j] = hh ? tk[1] : tk[0];
-            ka[2 * j + 1] = hh ? tk[3] : tk[2];
+            tq[j] = *reinterpret_cast<const f32x4*>(qr + 4 * j);
+            tk[j] = *reinterpret_cast<const f32x4*>(qr + H + 4 * j);
         }
     }
-    float va[16];  // V^T fragment of step e: V[key kappa(e, hh)][dim c]
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int key = 8 * (e >> 2) + (e & 3) + 4 * hh;
         va[e] = qkv[(size_t)(start + (key < S ? key : 0)) * (3 * H) + 2 * H + w * DH + c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        qb[2 * j] = hh ? tq[j][1] : tq[j][0];
+        qb[2 * j + 1] = hh ? tq[j][3] : tq[j][2];
+        ka[2 * j] = hh ? tk[j][1] : tk[j][0];
+        ka[2 * j + 1] = hh ? tk[j][3] : tk[j][2];
     }
     // S^T[key][row]: A = K (m = key), B = Q (n = row)
     f32x16 st, st1;
