@@ -13,7 +13,12 @@ if len(sys.argv) > 1 and sys.argv[1].endswith(".db"):
         m = re.search(r"dawn::(\w+(<[^>]*>)?)", n)
         return m.group(1) if m else n[:40]
     seq = [(short(r["name"]), r["start"], r["end"]) for r in rows]
-    starts = [i for i, s in enumerate(seq) if s[0].startswith("embed_ln")]
+    # a forward starts with BertEmbeddings: a launch of its own, or (option "fused_embed", the default) the PARTS = 0 form of the
+    # first layer's Q|K|V launch; it ends with the pooling launch
+    starts = [i for i, s in enumerate(seq) if s[0].startswith("embed_ln") or s[0].startswith("gemm_skinny16_ln_kernel<0, 0>")]
+    if len(starts) < 3:
+        ends = [i for i, s in enumerate(seq) if "pool_norm" in s[0]]
+        starts = [i + 1 for i in ends[:-1]]
     i0, i1 = starts[-3], starts[-2]  # one whole forward near the end
     tot = (seq[i1][1] - seq[i0][1]) / 1e3
     print(f"one forward: {i1 - i0} launches, {tot:.1f} us start to start")
