@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t t_stride = gridDim.x * nwaves, t_end = n_sub;
     const int n_refine = n_refine_arg < 0 ? LIST : n_refine_arg;
     DAWN_TS6(0);
-    // Work assignment.  Static and interleaved — wave w takes sub-tiles w, w + W, w + 2W, ... — for the first 7/8 of the index;
+    // Work assignment (indexes of ~3.7 M rows and more; smaller ones: static throughout).  Static and interleaved — wave w takes
+    // sub-tiles w, w + W, w + 2W, ... — for the first 7/8 of the index;
     // the last eighth is handed out in CHUNKS of 16 sub-tiles on demand.  The waves' shares of a static assignment are equal,
     // their speeds are not: the first wave of a 100 M-row launch is done 260-340 us before the last (tools/stream_i5_ts.py,
     // profiles/r03/stream_i5_wave_timestamps_100M_static.log) — 4 % of the kernel during which the memory system runs half empty.
@@ -287,7 +288,9 @@ __global__ __launch_bounds__(512) void scan_filter_i6s_kernel(const uint32_t* __
     const uint32_t n_pools = ((gridDim.x + 7u) >> 3) < POOLS ? ((gridDim.x + 7u) >> 3) : POOLS;
     const uint32_t pool_id = (blockIdx.x >> 3) % n_pools;
     uint32_t* my_pool = nullptr;
-    if (pool != nullptr && n_sub / t_stride >= 16u) {
+    // (from 56 rounds of the grid on, ~3.7 M rows: below that the static interleave alone is faster — 1.5 M rows 0.111 against 0.116 ms,
+    // 2 M 0.129 / 0.131, a tie at 4 M: profiles/r05/dyn_small_probe.log; 16 rounds until round 5)
+    if (pool != nullptr && n_sub / t_stride >= 56u) {
         const uint32_t rounds = n_sub / t_stride, i_static = rounds - rounds * SHARE16 / 16u;
         dyn0 = t_stride * i_static;
         n_chunks = (n_sub - dyn0 + CHUNK - 1u) / CHUNK;
